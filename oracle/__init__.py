@@ -1,0 +1,333 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY (never imported by spconv_amd/).
+
+Python half of the CPU restatement of the reference's ``ConvAlgo.Native`` CPU
+path (traveller59/spconv v2.3.8).  The rulebook loops and the gather /
+scatter-add helpers live in ``oracle.cpp`` (C++, ``std::unordered_map`` like the
+reference); the per-offset ``torch.mm`` driver loops live here because in the
+reference they are Python too (``spconv/pytorch/ops.py:888-988,1164-1253``).
+
+Allowed importers: ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py``.
+
+Parity status: numerics pinned by the reference's own test
+oracle -- dense ``torch.nn.functional.conv3d`` (``test/test_conv.py:247-357``)
+and its numpy per-offset formula (``test/test_all_algo.py:222-288``); rulebook
+*order* is "parity unpinned" by the reference's tests and is defined by the
+restated CPU loops.
+"""
+from __future__ import annotations
+
+import ctypes
+import functools
+import os
+import subprocess
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_I32P = ctypes.POINTER(ctypes.c_int32)
+_IP = ctypes.POINTER(ctypes.c_int)
+
+
+def build(force: bool = False) -> str:
+    """Compile oracle.cpp with g++ (see oracle/Makefile)."""
+    src = os.path.join(_HERE, "oracle.cpp")
+    if (force or not os.path.exists(_LIB_PATH)
+            or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+@functools.lru_cache(maxsize=None)
+def lib() -> ctypes.CDLL:
+    build()
+    L = ctypes.CDLL(_LIB_PATH)
+    L.orc_conv_out_shape.argtypes = [ctypes.c_int] + [_IP] * 6 + [ctypes.c_int, _IP]
+    L.orc_conv_out_shape.restype = None
+    L.orc_subm_rulebook.argtypes = [_I32P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                    _IP, _IP, _IP, _I32P, ctypes.c_int, _I32P]
+    L.orc_subm_rulebook.restype = ctypes.c_int
+    L.orc_conv_rulebook.argtypes = [_I32P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                    _IP, _IP, _IP, _IP, _IP, _IP, ctypes.c_int,
+                                    _I32P, ctypes.c_int, _I32P, _I32P]
+    L.orc_conv_rulebook.restype = ctypes.c_int
+    for name in ("orc_gather", "orc_gather_omp"):
+        fn = getattr(L, name)
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, _I32P, ctypes.c_int,
+                       ctypes.c_int, ctypes.c_int]
+        fn.restype = None
+    for name in ("orc_scatter_add_f32", "orc_scatter_add_f64", "orc_scatter_add_f32_omp"):
+        fn = getattr(L, name)
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, _I32P, ctypes.c_int, ctypes.c_int]
+        fn.restype = None
+    return L
+
+
+def _ints(v: Sequence[int]):
+    return (ctypes.c_int * len(v))(*[int(x) for x in v])
+
+
+def _i32p(a: np.ndarray):
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_I32P)
+
+
+# --------------------------------------------------------------------------
+# output size (spconv/pytorch/ops.py:73-96)
+# --------------------------------------------------------------------------
+def conv_out_shape(in_shape, ksize, stride, padding, dilation, out_padding=None,
+                   transposed: bool = False) -> List[int]:
+    ndim = len(in_shape)
+    if out_padding is None:
+        out_padding = [0] * ndim
+    out = (ctypes.c_int * ndim)()
+    lib().orc_conv_out_shape(ndim, _ints(in_shape), _ints(ksize), _ints(stride),
+                             _ints(padding), _ints(dilation), _ints(out_padding),
+                             int(transposed), out)
+    return [int(v) for v in out]
+
+
+# --------------------------------------------------------------------------
+# rulebook = ops.get_indice_pairs CPU branch (ops.py:171-326) which calls
+# SparseConvIndicesCPU (csrc/sparse/indices.py:1639-1778)
+# --------------------------------------------------------------------------
+def get_indice_pairs(indices: np.ndarray, batch_size: int, spatial_shape,
+                     ksize, stride, padding, dilation, out_padding=None,
+                     subm: bool = False, transpose: bool = False
+                     ) -> Tuple[np.ndarray, np.ndarray, np.ndarray, List[int]]:
+    """Returns (out_inds [N_out, ndim+1], pair [2, kv, N_in], num_per_loc [kv],
+    out_spatial_shape).  ``pair`` is -1 filled, like ops.py:191-197."""
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    n, ndim = indices.shape[0], indices.shape[1] - 1
+    kv = int(np.prod(ksize))
+    if out_padding is None:
+        out_padding = [0] * ndim
+    if subm:
+        out_shape = [int(v) for v in spatial_shape]
+    else:
+        out_shape = conv_out_shape(spatial_shape, ksize, stride, padding, dilation,
+                                   out_padding, transpose)
+    if any(x <= 0 for x in out_shape):
+        raise ValueError(f"your out spatial shape {out_shape} reach zero!!! "
+                         f"input shape: {list(spatial_shape)}")      # ops.py:182-185
+    pair = np.full((2, kv, n), -1, dtype=np.int32)
+    num = np.zeros((kv,), dtype=np.int32)
+    if subm:
+        r = lib().orc_subm_rulebook(_i32p(indices), n, ndim, batch_size,
+                                    _ints(spatial_shape), _ints(ksize), _ints(dilation),
+                                    _i32p(pair), n, _i32p(num))
+        if r < 0:
+            raise ValueError("subm only support odd ksize")
+        return indices, pair, num, out_shape
+    out_inds = np.empty((max(kv * n, 1), ndim + 1), dtype=np.int32)
+    num_act = lib().orc_conv_rulebook(_i32p(indices), n, ndim, batch_size,
+                                      _ints(out_shape), _ints(spatial_shape),
+                                      _ints(ksize), _ints(stride), _ints(padding),
+                                      _ints(dilation), int(transpose), _i32p(pair), n,
+                                      _i32p(out_inds), _i32p(num))
+    return out_inds[:num_act].copy(), pair, num, out_shape
+
+
+# --------------------------------------------------------------------------
+# canonical implicit-GEMM artefacts derived from the Native lists
+# (layout semantics: indices.py:806-874 SubM, :599-676 regular conv)
+# --------------------------------------------------------------------------
+def native_counts(num_per_loc: np.ndarray, kv: int, subm: bool, n_in: int) -> List[int]:
+    """Effective list length per offset (SubM mirror rule, ops.py:962-968)."""
+    out = []
+    for k in range(kv):
+        if subm and k == kv // 2:
+            out.append(n_in)
+        elif subm and k > kv // 2:
+            out.append(int(num_per_loc[kv - 1 - k]))
+        else:
+            out.append(int(num_per_loc[k]))
+    return out
+
+
+def dense_tables(pair: np.ndarray, num_per_loc: np.ndarray, n_in: int, n_out: int,
+                 subm: bool):
+    """(pair_fwd [kv,N_out], pair_bwd [kv,N_in], mask_fwd [N_out,W], mask_bwd [N_in,W])
+
+    pair_fwd[k,o] = input index feeding output o through offset k (or -1);
+    pair_bwd[k,i] = output index fed by input i through offset k (or -1);
+    mask bit k set iff the entry is valid (uint32 words, W = ceil(kv/32))."""
+    kv = pair.shape[1]
+    words = (kv + 31) // 32
+    fwd = np.full((kv, n_out), -1, dtype=np.int32)
+    bwd = np.full((kv, n_in), -1, dtype=np.int32)
+    mfwd = np.zeros((n_out, words), dtype=np.uint32)
+    mbwd = np.zeros((n_in, words), dtype=np.uint32)
+    counts = native_counts(num_per_loc, kv, subm, n_in)
+    for k in range(kv):
+        c = counts[k]
+        i_idx = pair[0, k, :c]
+        o_idx = pair[1, k, :c]
+        # first entry wins on duplicates, as written order in the CPU lists
+        fwd[k, o_idx[::-1]] = i_idx[::-1]
+        bwd[k, i_idx[::-1]] = o_idx[::-1]
+        bit = np.uint32(1 << (k % 32))
+        np.bitwise_or.at(mfwd[:, k // 32], o_idx, bit)
+        np.bitwise_or.at(mbwd[:, k // 32], i_idx, bit)
+    return fwd, bwd, mfwd, mbwd
+
+
+# --------------------------------------------------------------------------
+# Native conv forward / backward, CPU branch
+# (ops.indice_conv ops.py:811-988, ops.indice_conv_backward ops.py:1103-1253;
+#  C++ twin convops.py:1540-1633,1775-1860 + cppcore.py:232-348)
+# --------------------------------------------------------------------------
+def _gather(buf: torch.Tensor, src: torch.Tensor, inds: np.ndarray, omp: bool):
+    fn = lib().orc_gather_omp if omp else lib().orc_gather
+    fn(buf.data_ptr(), src.data_ptr(), _i32p(inds), len(inds), src.shape[1],
+       src.element_size())
+
+
+def _scatter_add(dst: torch.Tensor, buf: torch.Tensor, inds: np.ndarray, omp: bool):
+    if dst.dtype == torch.float32:
+        fn = lib().orc_scatter_add_f32_omp if omp else lib().orc_scatter_add_f32
+    elif dst.dtype == torch.float64:
+        fn = lib().orc_scatter_add_f64
+    else:
+        raise TypeError(dst.dtype)
+    fn(dst.data_ptr(), buf.data_ptr(), _i32p(inds), len(inds), dst.shape[1])
+
+
+def indice_conv(features: torch.Tensor, filters: torch.Tensor, pair: np.ndarray,
+                num_per_loc: np.ndarray, num_act_out: int, inverse: bool = False,
+                subm: bool = False, omp: bool = False) -> torch.Tensor:
+    """filters: KRSC [K, *ksize, C] (ALL_WEIGHT_IS_KRSC, ops.py:888-894)."""
+    assert features.dtype in (torch.float32, torch.float64)
+    features = features.contiguous()
+    K = filters.shape[0]
+    w = filters.reshape(K, -1, filters.shape[-1])
+    kv = w.shape[1]
+    center = kv // 2
+    if subm:
+        out = torch.mm(features, w[:, center].T)             # ops.py:908
+    else:
+        out = torch.zeros((num_act_out, K), dtype=features.dtype)
+    if kv == 1 and subm:
+        return out
+    nums = [int(v) for v in num_per_loc]
+    if subm and all(v == 0 for v in nums):
+        return out
+    maxnhot = max(nums)
+    pair_in, pair_out = pair[int(inverse)], pair[int(not inverse)]
+    inp_buf = torch.empty((maxnhot, features.shape[1]), dtype=features.dtype)
+    out_buf = torch.empty((maxnhot, K), dtype=features.dtype)
+    for i, nhot in enumerate(nums):                            # ops.py:962-986
+        if subm and i == center:
+            continue
+        if subm and i > center:
+            nhot = nums[kv - i - 1]
+        if nhot <= 0:
+            continue
+        ii = np.ascontiguousarray(pair_in[i, :nhot])
+        oi = np.ascontiguousarray(pair_out[i, :nhot])
+        _gather(inp_buf, features, ii, omp)
+        torch.mm(inp_buf[:nhot], w[:, i].T, out=out_buf[:nhot])
+        _scatter_add(out, out_buf, oi, omp)
+    return out
+
+
+def indice_conv_backward(features: torch.Tensor, filters: torch.Tensor,
+                         out_bp: torch.Tensor, pair: np.ndarray,
+                         num_per_loc: np.ndarray, inverse: bool = False,
+                         subm: bool = False, omp: bool = False
+                         ) -> Tuple[torch.Tensor, torch.Tensor]:
+    features = features.contiguous()
+    out_bp = out_bp.contiguous()
+    fshape = filters.shape
+    K = fshape[0]
+    w = filters.reshape(K, -1, fshape[-1]).contiguous()
+    kv = w.shape[1]
+    center = kv // 2
+    dw = torch.zeros_like(w)
+    if subm:
+        torch.mm(out_bp.T, features, out=dw[:, center])      # ops.py:1185
+        din = torch.mm(out_bp, w[:, center])                   # ops.py:1187
+    else:
+        din = torch.zeros_like(features)
+    if kv == 1 and subm:
+        return din, dw.reshape(fshape)
+    nums = [int(v) for v in num_per_loc]
+    if subm and all(v == 0 for v in nums):
+        return din, dw.reshape(fshape)
+    maxnhot = max(nums)
+    pair_in, pair_out = pair[int(inverse)], pair[int(not inverse)]
+    inp_buf = torch.empty((maxnhot, features.shape[1]), dtype=features.dtype)
+    out_buf = torch.empty((maxnhot, K), dtype=out_bp.dtype)
+    for i, nhot in enumerate(nums):                            # ops.py:1225-1252
+        if subm and i == center:
+            continue
+        if subm and i > center:
+            nhot = nums[kv - i - 1]
+        if nhot <= 0:
+            continue
+        ii = np.ascontiguousarray(pair_in[i, :nhot])
+        oi = np.ascontiguousarray(pair_out[i, :nhot])
+        _gather(inp_buf, features, ii, omp)
+        _gather(out_buf, out_bp, oi, omp)
+        torch.mm(out_buf[:nhot].T, inp_buf[:nhot], out=dw[:, i])   # overwrite
+        torch.mm(out_buf[:nhot], w[:, i], out=inp_buf[:nhot])
+        _scatter_add(din, inp_buf, ii, omp)
+    return din, dw.reshape(fshape)
+
+
+# --------------------------------------------------------------------------
+# int8 inference epilogue (test/test_all_algo.py:272-287,
+# quantization/quantized/conv.py:368-378)
+# --------------------------------------------------------------------------
+def int8_conv_ref(feat_i8: np.ndarray, w_i8: np.ndarray, pair: np.ndarray,
+                  num_per_loc: np.ndarray, num_act_out: int, subm: bool,
+                  scale: np.ndarray, bias: np.ndarray,
+                  add: Optional[np.ndarray] = None, add_scale: float = 0.0,
+                  relu: bool = False) -> np.ndarray:
+    """q_out = clip(round(act(acc_i32*scale[k] + bias[k] + add*add_scale)), -128, 127)."""
+    K = w_i8.shape[0]
+    w = w_i8.reshape(K, -1, w_i8.shape[-1]).astype(np.int32)
+    kv = w.shape[1]
+    acc = np.zeros((num_act_out, K), dtype=np.int32)
+    counts = native_counts(num_per_loc, kv, subm, feat_i8.shape[0])
+    for k in range(kv):
+        c = counts[k]
+        a = feat_i8[pair[0, k, :c]].astype(np.int32)
+        np.add.at(acc, pair[1, k, :c], a @ w[:, k].T)
+    r = acc.astype(np.float32) * scale.astype(np.float32) + bias.astype(np.float32)
+    if add is not None:
+        r = r + add.astype(np.float32) * np.float32(add_scale)
+    if relu:
+        r = np.maximum(r, 0)
+    return np.clip(np.round(r), -128, 127).astype(np.int8)
+
+
+# --------------------------------------------------------------------------
+# the reference's own test oracle: dense conv on the scattered dense input
+# (test/test_conv.py:83-109,286-357)
+# --------------------------------------------------------------------------
+def dense_conv_reference(features: torch.Tensor, indices: np.ndarray, batch_size: int,
+                         spatial_shape, weight_krsc: torch.Tensor, stride, padding,
+                         dilation, transposed: bool = False, out_padding=None):
+    """Returns the dense NC[D]HW output of torch conv{1,2,3}d on the densified input."""
+    import torch.nn.functional as F
+    ndim = len(spatial_shape)
+    C = features.shape[1]
+    dense = torch.zeros((batch_size, C, *spatial_shape), dtype=features.dtype)
+    idx = torch.from_numpy(indices.astype(np.int64))
+    dense[(idx[:, 0], slice(None), *[idx[:, i + 1] for i in range(ndim)])] = features
+    # KRSC -> K C R S (torch layout)
+    perm = [0, ndim + 1] + list(range(1, ndim + 1))
+    w = weight_krsc.permute(*perm).contiguous()
+    conv = {1: F.conv1d, 2: F.conv2d, 3: F.conv3d}[ndim]
+    convt = {1: F.conv_transpose1d, 2: F.conv_transpose2d, 3: F.conv_transpose3d}[ndim]
+    if transposed:
+        # conv_transpose weight layout is [C_in, C_out, ...]
+        wt = w.transpose(0, 1).contiguous()
+        return convt(dense, wt, None, stride, padding,
+                     out_padding if out_padding is not None else 0, 1, dilation)
+    return conv(dense, w, None, stride, padding, dilation)
