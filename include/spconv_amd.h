@@ -1,0 +1,184 @@
+/* spconv_amd -- C ABI of the MI355X (gfx950) sparse-convolution hot path.
+ *
+ * This header is the drop-in boundary: every entry point takes plain device
+ * pointers, sizes and a HIP stream (no torch / tensorview types) and replaces
+ * one native call that traveller59/spconv's Python layer makes into its
+ * pybind module `spconv.core_cc` (classes SpconvOps / ConvGemmOps, signatures in
+ * spconv/core_cc/csrc/sparse/all/__init__.pyi and convops/spops.pyi).  The
+ * reference interface each function replaces is cited as file:line relative to
+ * the reference tree.  INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers unless the name ends in `_h` (host).
+ *  - All functions return 0 on success and a negative value on error; the
+ *    message is available from spx_last_error() (thread local).  This replaces
+ *    the C++ exceptions TV_ASSERT_RT_ERR / TV_THROW_RT_ERR of the reference.
+ *  - No function allocates device memory: outputs and scratch ("ws") are
+ *    supplied by the caller, exactly like the reference's ExternalAllocator
+ *    contract (spconv/csrc/sparse/alloc.py:38-189, pytorch/cppcore.py:112-223).
+ *    spx_*_ws_bytes() give the required scratch size (cf. all.py:1580-1605).
+ *  - Work is enqueued on `stream` (a hipStream_t passed as void*; the reference
+ *    passes the CUDA stream as an integer, pytorch/cppcore.py:98-99).  Nothing
+ *    synchronises except spx_conv_rulebook_count (one D->H read of N_out, the
+ *    same unavoidable read as indices.py:1454-1455).
+ *  - indices: int32 [N, ndim+1] rows (batch, z, y, x), 1 <= ndim <= 4
+ *    (pytorch/core.py:148,163).  Offsets are numbered k = (r0*K1 + r1)*K2 + r2,
+ *    last spatial dim fastest (indices.py:114-136).
+ *  - weight: KRSC [K, *ksize, C] contiguous (pytorch/conv.py:136-139).
+ */
+#ifndef SPCONV_AMD_H_
+#define SPCONV_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPX_MAX_NDIM 4
+
+typedef void *spx_stream_t; /* hipStream_t */
+
+enum spx_dtype { SPX_F32 = 0, SPX_F16 = 1, SPX_BF16 = 2, SPX_I8 = 3 };
+
+/* tv::gemm::Activation subset used by the path (csrc/sparse/inference.py:26-146) */
+enum spx_act { SPX_ACT_NONE = 0, SPX_ACT_RELU = 1, SPX_ACT_SIGMOID = 2, SPX_ACT_LEAKY_RELU = 3 };
+
+/* Error text of the last failing call on this thread ("" if none). */
+const char *spx_last_error(void);
+
+/* Library ABI version (major*1000 + minor). */
+int spx_version(void);
+
+/* ops.get_conv_output_size / get_deconv_output_size (pytorch/ops.py:73-96). Host only. */
+int spx_conv_out_shape(int ndim, const int *in_shape, const int *ksize, const int *stride,
+                       const int *padding, const int *dilation, const int *out_padding,
+                       int transposed, int *out_shape);
+
+/* ------------------------------------------------------------------ rulebook */
+
+/* Scratch bytes for spx_subm_rulebook (hash table + compaction counters). */
+size_t spx_subm_rulebook_ws_bytes(int n, int kv);
+
+/* SubM rulebook.  Replaces SpconvOps.generate_subm_conv_inds[_cpu]
+ * (csrc/sparse/indices.py:1495-1599 GPU, :1639-1708 CPU; drivers all.py:628-660,
+ * pytorch/ops.py:202-233,505-565).
+ *   pair_fwd  [kv, n]  out: pair_fwd[k][o] = input index feeding output o through
+ *                      offset k, or -1 (implicit-GEMM layout, indices.py:806-874)
+ *   pair_bwd  [kv, n]  or NULL: pair_bwd[k][i] = output index fed by input i
+ *   mask      [n, ceil(kv/32)] uint32: bit k set iff pair_fwd[k][o] >= 0
+ *                      (centre bit always set, indices.py:1576-1577)
+ *   pair_native [2, kv, n] or NULL: ConvAlgo.Native lists, identical (including
+ *                      order and -1 fill) to the CPU path indices.py:1639-1708
+ *   num_per_loc [kv]   or NULL: counts for k < kv/2 only, like the CPU path
+ * Duplicate coordinates: the smallest index wins (CPU unordered_map::insert). */
+int spx_subm_rulebook(const int32_t *indices, int n, int ndim, int batch_size,
+                      const int *spatial_shape, const int *ksize, const int *dilation,
+                      int32_t *pair_fwd, int32_t *pair_bwd, uint32_t *mask,
+                      int32_t *pair_native, int32_t *num_per_loc,
+                      void *ws, size_t ws_bytes, spx_stream_t stream);
+
+/* Scratch bytes for the two-phase regular/transposed conv rulebook. */
+size_t spx_conv_rulebook_ws_bytes(int n_in, int ndim, const int *ksize, const int *stride,
+                                  int transposed);
+
+/* Regular / transposed conv rulebook, phase 1: hash the candidate output
+ * coordinates and count the distinct ones.  Replaces stage1 + unique
+ * (indices.py:501-597,997-1016,1118-1455; pytorch/ops.py:566-642).
+ * Writes the count to *n_out_h after synchronising `stream` (the one D->H read).
+ * `ws` must be passed unchanged to spx_conv_rulebook_fill. */
+int spx_conv_rulebook_count(const int32_t *indices, int n_in, int ndim, int batch_size,
+                            const int *in_shape, const int *out_shape, const int *ksize,
+                            const int *stride, const int *padding, const int *dilation,
+                            int transposed, void *ws, size_t ws_bytes, int *n_out_h,
+                            spx_stream_t stream);
+
+/* Phase 2: number the outputs in the CPU path's first-seen order (k-major,
+ * then input-major, indices.py:1742-1771) and fill every artefact.  Replaces
+ * assign_output + stage2 (indices.py:417-499,599-721; ops.py:646-714).
+ *   out_indices [n_out, ndim+1]
+ *   pair_fwd [kv, n_out], pair_bwd [kv, n_in]  (-1 = absent)
+ *   mask_fwd [n_out, W], mask_bwd [n_in, W] (or NULL)
+ *   pair_native [2, kv, n_in] (or NULL), num_per_loc [kv] (or NULL): identical
+ *   to SparseConvIndicesCPU::generate_conv_inds (indices.py:1710-1778). */
+int spx_conv_rulebook_fill(const int32_t *indices, int n_in, int ndim, int batch_size,
+                           const int *in_shape, const int *out_shape, const int *ksize,
+                           const int *stride, const int *padding, const int *dilation,
+                           int transposed, int n_out, int32_t *out_indices,
+                           int32_t *pair_fwd, int32_t *pair_bwd, uint32_t *mask_fwd,
+                           uint32_t *mask_bwd, int32_t *pair_native, int32_t *num_per_loc,
+                           void *ws, size_t ws_bytes, spx_stream_t stream);
+
+/* mask_argsort: permutation that groups rows with equal masks (stable, ascending
+ * mask value).  Replaces SpconvOps.sort_1d_by_key_allocator (all.py:935-991). */
+size_t spx_mask_argsort_ws_bytes(int n);
+int spx_mask_argsort(const uint32_t *mask, int n, int words, int32_t *argsort,
+                     void *ws, size_t ws_bytes, spx_stream_t stream);
+
+/* Layout conversions for callers that hold only one of the two rulebook forms
+ * (the reference's public ops take either the Native lists, pytorch/ops.py:811-988,
+ * or the dense tables, ops.py:1450-1896).
+ *  spx_native_to_table: table[k][dst] = src for every list entry (dst/src = out/in,
+ *     exchanged when inverse != 0); mask [n_dst, W] optional.
+ *  spx_table_to_native: Native lists from pair_fwd (subm != 0, uses the mirror
+ *     symmetry) or from pair_bwd [kv, n_in] (subm == 0); order as the CPU path. */
+int spx_native_to_table(const int32_t *pair_native, const int32_t *num_per_loc, int n_in,
+                        int n_dst, int kv, int subm, int inverse, int32_t *table,
+                        uint32_t *mask, spx_stream_t stream);
+size_t spx_table_to_native_ws_bytes(int n, int kv);
+int spx_table_to_native(const int32_t *table, int subm, int kv, int n, int32_t *pair_native,
+                        int32_t *num_per_loc, void *ws, size_t ws_bytes, spx_stream_t stream);
+
+/* -------------------------------------------------------------- convolution */
+
+/* Output-stationary implicit GEMM (atomics-free):
+ *   out[o,:] = sum_k [pair[k][o] >= 0] feat[pair[k][o],:] * W[:,k,:]^T  (+bias, act)
+ * Replaces ConvGemmOps.implicit_gemm forward (csrc/sparse/convops.py:2073-2243,
+ * pytorch/ops.py:1450-1664).
+ *   feat [n_in, C], weight KRSC [K, kv, C], out [n_out, K]: all `dtype`
+ *   pair [kv, n_out]; mask [n_out, W] or NULL; argsort [n_out] or NULL
+ *   identity_k: offset whose pair is the identity (SubM centre, kv/2) or -1
+ *   bias [K] (dtype) or NULL; act: spx_act (inference epilogue, conv.py:463-490)
+ * Every row of `out` is written (no pre-zeroing needed, cf. convops.py:2128-2134). */
+int spx_igemm_fwd(const void *feat, const void *weight, void *out, const int32_t *pair,
+                  const uint32_t *mask, const int32_t *argsort, int n_in, int n_out,
+                  int C, int K, int kv, int dtype, int identity_k, const void *bias,
+                  int act, float act_alpha, spx_stream_t stream);
+
+/* Scratch for dgrad (re-laid-out weights [kv, C, K]). */
+size_t spx_igemm_dgrad_ws_bytes(int C, int K, int kv, int dtype);
+
+/* Input gradient.  Replaces the dgrad half of ConvGemmOps.implicit_gemm_backward
+ * (convops.py:2245-2440, ops.py:1667-1896):
+ *   din[i,:] = sum_k [pair_bwd[k][i] >= 0] dout[pair_bwd[k][i],:] * W[:,k,:]
+ * For SubM pass subm=1 with the FORWARD pair/mask (mirror symmetry
+ * pair_bwd[k] == pair_fwd[kv-1-k]; the reference's reverse_mask, convops.py:2327-2345). */
+int spx_igemm_dgrad(const void *dout, const void *weight, void *din, const int32_t *pair,
+                    const uint32_t *mask, const int32_t *argsort, int n_out, int n_in,
+                    int C, int K, int kv, int dtype, int subm, void *ws, size_t ws_bytes,
+                    spx_stream_t stream);
+
+/* Scratch for wgrad (per-workgroup fp32 partials). */
+size_t spx_igemm_wgrad_ws_bytes(int n_in, int C, int K, int kv);
+
+/* Weight gradient.  Replaces the wgrad half of implicit_gemm_backward and of
+ * ConvGemmOps.indice_conv_backward (convops.py:1749-1860):
+ *   dW[:,k,:] = sum_j dout[pair_native[1][k][j],:]^T (x) feat[pair_native[0][k][j],:]
+ * over the Native lists; deterministic two-stage reduction (no atomics).
+ *   dw KRSC [K, kv, C] in `dtype`, fully overwritten.
+ *   subm=1: centre offset is the identity over all rows and offsets k > kv/2 use
+ *   num_per_loc[kv-1-k] (ops.py:962-968). */
+int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t *pair_native,
+                    const int32_t *num_per_loc, int n_in, int n_out, int C, int K, int kv,
+                    int dtype, int subm, void *ws, size_t ws_bytes, spx_stream_t stream);
+
+/* In-place epilogues for callers that keep bias/activation separate
+ * (InferenceOps.bias_add_act_inplace etc., csrc/sparse/inference.py:26-146). */
+int spx_bias_act_inplace(void *out, const void *bias, int n, int K, int dtype, int act,
+                         float act_alpha, spx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPCONV_AMD_H_ */

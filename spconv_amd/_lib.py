@@ -1,0 +1,103 @@
+"""ctypes binding of the C ABI declared in ``include/spconv_amd.h``.
+
+This is the only place the Python layer touches native code.  It mirrors the
+role of ``spconv/pytorch/cppcore.py`` in the reference (raw pointer + stream
+hand-off, ``cppcore.py:65-109``) without any tensorview / pybind types.
+
+The library is built in-tree by ``spconv_amd/csrc/build.sh`` (hipcc, gfx950).
+There is no CPU fallback: if the shared object is missing the import of any
+compute entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libspconv_amd.so")
+
+c_int_p = ctypes.POINTER(ctypes.c_int)
+vp = ctypes.c_void_p
+
+# Every exported symbol of include/spconv_amd.h with (restype, argtypes).
+SIGNATURES = {
+    "spx_last_error": (ctypes.c_char_p, []),
+    "spx_version": (ctypes.c_int, []),
+    "spx_conv_out_shape": (ctypes.c_int, [ctypes.c_int] + [c_int_p] * 6 + [ctypes.c_int, c_int_p]),
+    "spx_subm_rulebook_ws_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "spx_subm_rulebook": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_int_p,
+                                         c_int_p, c_int_p, vp, vp, vp, vp, vp, vp,
+                                         ctypes.c_size_t, vp]),
+    "spx_conv_rulebook_ws_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, c_int_p, c_int_p,
+                                                     ctypes.c_int]),
+    "spx_conv_rulebook_count": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+                                + [c_int_p] * 6 + [ctypes.c_int, vp, ctypes.c_size_t, c_int_p, vp]),
+    "spx_conv_rulebook_fill": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+                               + [c_int_p] * 6 + [ctypes.c_int, ctypes.c_int] + [vp] * 7
+                               + [vp, ctypes.c_size_t, vp]),
+    "spx_mask_argsort_ws_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "spx_mask_argsort": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_size_t, vp]),
+    "spx_native_to_table": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 5 + [vp, vp, vp]),
+    "spx_table_to_native_ws_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "spx_table_to_native": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp,
+                                           ctypes.c_size_t, vp]),
+    "spx_igemm_fwd": (ctypes.c_int, [vp] * 6 + [ctypes.c_int] * 7 + [vp, ctypes.c_int,
+                                                                     ctypes.c_float, vp]),
+    "spx_igemm_dgrad_ws_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),
+    "spx_igemm_dgrad": (ctypes.c_int, [vp] * 6 + [ctypes.c_int] * 7 + [vp, ctypes.c_size_t, vp]),
+    "spx_igemm_wgrad_ws_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),
+    "spx_igemm_wgrad": (ctypes.c_int, [vp] * 5 + [ctypes.c_int] * 7 + [vp, ctypes.c_size_t, vp]),
+    "spx_bias_act_inplace": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_float, vp]),
+}
+
+DTYPE_F32, DTYPE_F16, DTYPE_BF16, DTYPE_I8 = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_LEAKY_RELU = 0, 1, 2, 3
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP sources for gfx950 (no GPU needed)."""
+    script = os.path.join(_HERE, "csrc", "build.sh")
+    if force:
+        for f in ("rulebook.o", "igemm.o", "common.o", "libspconv_amd.so"):
+            p = os.path.join(_HERE, "lib", f)
+            if os.path.exists(p):
+                os.remove(p)
+    subprocess.check_call(["bash", script])
+    return LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """Load libspconv_amd.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"spconv_amd native library not found at {LIB_PATH}. Build it with "
+            f"`bash spconv_amd/csrc/build.sh` (hipcc --offload-arch=gfx950). "
+            f"There is no CPU fallback.")
+    # torch bundles its own libamdhip64 (same SONAME); importing it first makes
+    # our library bind to the runtime that owns torch's streams and allocations.
+    import torch  # noqa: F401
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status: int) -> None:
+    if status != 0:
+        msg = load().spx_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"spconv_amd native error ({status}): {msg}")
+
+
+def ints(values):
+    return (ctypes.c_int * len(values))(*[int(v) for v in values])

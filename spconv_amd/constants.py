@@ -1,0 +1,24 @@
+"""Flags of the path (subset of spconv/constants.py:30-121 that still has a meaning here)."""
+import os
+
+# spconv/constants.py:119-121: sort output rows by mask so that whole tiles skip offsets.
+SPCONV_DO_SORT = os.getenv("SPCONV_DO_SORT", "1") == "1"
+# spconv/constants.py:36: layout of checkpoints produced by spconv 1.x / 2.1 ("KRSC", "RSKC", "RSCK").
+SAVED_WEIGHT_LAYOUT = os.getenv("SPCONV_SAVED_WEIGHT_LAYOUT", "")
+ALL_WEIGHT_IS_KRSC = True
+FILTER_HWIO = False
+
+
+class AllocKeys:
+    """Names of the buffers the reference allocator hands out (spconv/constants.py:66-98)."""
+    PairFwd = "PairFwd"
+    PairBwd = "PairBwd"
+    PairMask = "PairMask"
+    PairMaskBwd = "PairMaskBwd"
+    MaskArgSort = "MaskArgSort"
+    MaskArgSortBwd = "MaskArgSortBwd"
+    OutIndices = "OutIndices"
+    IndiceNumPerLoc = "IndiceNumPerLoc"
+    OutFeatures = "OutFeatures"
+    DIn = "DIn"
+    DFilters = "DFilters"

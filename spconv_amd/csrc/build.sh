@@ -1,0 +1,19 @@
+#!/bin/bash
+# Builds libspconv_amd.so for gfx950 (MI355X).  Cross-compiles without a GPU.
+set -e
+cd "$(dirname "$0")"
+OUT=../lib
+mkdir -p $OUT
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+for f in rulebook igemm; do
+  if [ ! -f $OUT/$f.o ] || [ $f.hip -nt $OUT/$f.o ] || [ common.h -nt $OUT/$f.o ] || [ ../../include/spconv_amd.h -nt $OUT/$f.o ]; then
+    $HIPCC $FLAGS -c $f.hip -o $OUT/$f.o &
+  fi
+done
+if [ ! -f $OUT/common.o ] || [ common.cpp -nt $OUT/common.o ] || [ common.h -nt $OUT/common.o ]; then
+  $HIPCC $FLAGS -x hip -c common.cpp -o $OUT/common.o &
+fi
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT/libspconv_amd.so $OUT/rulebook.o $OUT/igemm.o $OUT/common.o
+echo built $OUT/libspconv_amd.so

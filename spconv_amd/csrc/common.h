@@ -1,0 +1,86 @@
+// Shared host/device helpers for the gfx950 kernels.  wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/spconv_amd.h"
+
+namespace spx {
+
+constexpr int kWave = 64;
+constexpr int kMaxNdim = SPX_MAX_NDIM;
+
+void set_error(const char *fmt, ...);
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int div_up(int a, int b) { return (a + b - 1) / b; }
+
+// Carves 256-byte aligned sub-buffers out of the caller's scratch.
+struct Carver {
+  char *base;
+  size_t off = 0;
+  explicit Carver(void *p) : base(static_cast<char *>(p)) {}
+  template <typename T> T *take(size_t count) {
+    T *r = reinterpret_cast<T *>(base + off);
+    off += align_up(count * sizeof(T), 256);
+    return r;
+  }
+};
+
+#define SPX_CHECK(cond, ...)                 \
+  do {                                       \
+    if (!(cond)) {                           \
+      ::spx::set_error(__VA_ARGS__);         \
+      return -1;                             \
+    }                                        \
+  } while (0)
+
+#define SPX_HIP(expr)                                                         \
+  do {                                                                        \
+    hipError_t e_ = (expr);                                                   \
+    if (e_ != hipSuccess) {                                                   \
+      ::spx::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                       __FILE__, __LINE__);                                   \
+      return -2;                                                              \
+    }                                                                         \
+  } while (0)
+
+#define SPX_LAUNCH_CHECK() SPX_HIP(hipGetLastError())
+
+// Canonical 4-d description of a 1..4-d problem: leading dims are padded with
+// size-1 / ksize-1 entries so one kernel serves every ndim.  Column c of an
+// index row (batch at column 0) maps to canonical spatial dim c-1+(4-ndim).
+struct Geom {
+  int ndim;           // user ndim
+  int batch;
+  int in_dims[4];
+  int out_dims[4];
+  int ksize[4], stride[4], padding[4], dilation[4];
+  int kv;
+};
+
+inline Geom make_geom(int ndim, int batch, const int *in_dims, const int *out_dims,
+                      const int *ksize, const int *stride, const int *padding,
+                      const int *dilation) {
+  Geom g;
+  g.ndim = ndim;
+  g.batch = batch;
+  const int lead = 4 - ndim;
+  g.kv = 1;
+  for (int i = 0; i < 4; ++i) {
+    const bool pad = i < lead;
+    const int j = i - lead;
+    g.in_dims[i] = pad ? 1 : in_dims[j];
+    g.out_dims[i] = pad ? 1 : out_dims[j];
+    g.ksize[i] = pad ? 1 : ksize[j];
+    g.stride[i] = pad ? 1 : (stride ? stride[j] : 1);
+    g.padding[i] = pad ? 0 : (padding ? padding[j] : 0);
+    g.dilation[i] = pad ? 1 : (dilation ? dilation[j] : 1);
+    g.kv *= g.ksize[i];
+  }
+  return g;
+}
+
+}  // namespace spx

@@ -1,0 +1,778 @@
+// Sparse convolution compute kernels for gfx950 (MI355X).
+//
+//  * gather_gemm_mfma: output-stationary implicit GEMM used for forward and
+//    dgrad.  One 256-thread workgroup owns 128 output rows (4 waves x 32 rows)
+//    -> every output row is written exactly once, no atomics.  For each kernel
+//    offset k present in the tile (OR of the rows' rulebook masks) it gathers
+//    the 128 source rows as full 128-byte lines into an XOR-swizzled LDS tile,
+//    stages the [Cout x 64] weight slice next to it and issues
+//    v_mfma_f32_16x16x32_{f16,bf16}.  Global loads of step t+1 are issued
+//    before the MFMAs of step t (register-staged software pipeline).
+//  * wgrad_mfma: per (offset, chunk-of-pairs) workgroups contract
+//    dout^T (x) feat over the Native pair lists into 64x64 fp32 partials
+//    (transposing, XOR-swizzled LDS stores), followed by a deterministic
+//    second-stage reduction (no atomics, no split-K races).
+//  * generic fp32-accumulate kernels for fp32 tensors and odd channel counts.
+//
+// Roofline note: at C=K=64 these kernels are HBM/L2-bandwidth bound (SURVEY.md
+// section 8d): ~110 MB of compulsory traffic per fwd+bwd at 100k voxels versus
+// 2.5 GFLOP, so the design spends its effort on coalesced 128-byte row
+// gathers, mask-predicated rulebook reads and single-pass outputs, not on MFMA
+// utilisation.
+#include "common.h"
+
+namespace spx {
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 256;
+constexpr int kTileM = 128;   // output rows per workgroup
+constexpr int kCK = 64;       // reduction chunk staged per step (elements)
+constexpr int kRowBytes = kCK * 2;
+
+struct GemmParams {
+  const void *A;          // [n_src, CIN] gathered operand (features / dout)
+  const void *B;          // weights; element (k, n, c) at k*strideK + n*strideN + c
+  void *out;              // [n_dst, COUT]
+  const int32_t *pair;    // [kv, n_dst]: source row for (k, dst row) or -1
+  const uint32_t *mask;   // [n_dst] or null
+  const int32_t *argsort; // [n_dst] or null
+  const void *bias;       // [COUT] or null
+  long long strideK, strideN;
+  int n_src, n_dst, CIN, COUT, kv;
+  int identity_k;         // offset whose pair is the identity, or -1
+  int b_reverse;          // use weight slice kv-1-k for offset k (SubM dgrad)
+  int act;
+  float act_alpha;
+};
+
+// ---- 16-bit <-> float helpers -------------------------------------------
+template <bool BF16> __device__ __forceinline__ float to_float(uint16_t v);
+template <> __device__ __forceinline__ float to_float<false>(uint16_t v) {
+  return static_cast<float>(__builtin_bit_cast(_Float16, v));
+}
+template <> __device__ __forceinline__ float to_float<true>(uint16_t v) {
+  return __builtin_bit_cast(float, static_cast<uint32_t>(v) << 16);
+}
+template <bool BF16> __device__ __forceinline__ uint16_t from_float(float f);
+template <> __device__ __forceinline__ uint16_t from_float<false>(float f) {
+  return __builtin_bit_cast(uint16_t, static_cast<_Float16>(f));
+}
+template <> __device__ __forceinline__ uint16_t from_float<true>(float f) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x40u);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even
+  return static_cast<uint16_t>(u >> 16);
+}
+
+__device__ __forceinline__ float apply_act(float v, int act, float alpha) {
+  if (act == SPX_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == SPX_ACT_LEAKY_RELU) return v > 0.f ? v : v * alpha;
+  if (act == SPX_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+  return v;
+}
+
+template <bool BF16>
+__device__ __forceinline__ f32x4 mfma16(const uint4 &a, const uint4 &b, f32x4 c) {
+  if constexpr (BF16) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a),
+                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+}
+
+// byte offset of 16-byte slot `slot` of row `row` in a [rows][ROWB bytes] LDS
+// tile; the XOR keeps every ds_read_b128 lane group (rows r..r+15, two
+// neighbouring slots) on 16 distinct 16-byte bank slots.
+__device__ __forceinline__ int swz_off(int row, int slot, int row_bytes, int xmask = 7) {
+  return row * row_bytes + ((slot ^ ((row >> 1) & xmask)) << 4);
+}
+
+// XCD-aware tile order: workgroup b runs on XCD b % 8 (observed), so give each
+// XCD a contiguous range of tiles -> neighbouring tiles (which gather
+// overlapping source rows) share one L2.  Bijective for any tile count.
+__device__ __forceinline__ int xcd_tile(int bid, int ntiles) {
+  const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, j = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + j;
+}
+
+// --------------------------------------------------------------------------
+// gather-GEMM, 16-bit operands, fp32 accumulate.
+//   out[d, :] = act(bias + sum_k A[pair[k][d], :] . B_k^T)
+// --------------------------------------------------------------------------
+template <int COUT, bool BF16>
+__global__ void __launch_bounds__(kThreads)
+gather_gemm_mfma_kernel(GemmParams p) {
+  constexpr int NB = COUT / 16;                       // 16-wide output-channel blocks
+  constexpr int BROWS = (COUT + 31) / 32;             // weight rows staged per thread
+  constexpr int A_BYTES = kTileM * kRowBytes;         // 16 KiB
+  constexpr int OUT_ROWB = COUT * 2;
+  constexpr int OXM = (COUT / 8 - 1) < 7 ? (COUT / 8 - 1) : 7;  // swizzle stays inside the row
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *ldsA = smem;
+  char *ldsB = smem + A_BYTES;
+  uint32_t *lds_mask = reinterpret_cast<uint32_t *>(smem + A_BYTES + COUT * kRowBytes);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntiles = (p.n_dst + kTileM - 1) / kTileM;
+  const int tile = xcd_tile(blockIdx.x, ntiles);
+  const int slot = tid & 7;        // 16-byte slot of a 128-byte row
+  const int r0 = tid >> 3;         // 0..31
+  const uint16_t *A = static_cast<const uint16_t *>(p.A);
+  const uint16_t *B = static_cast<const uint16_t *>(p.B);
+
+  // destination rows staged by this thread (4 of the tile's 128)
+  int grow[4];
+  uint32_t rmask[4];
+  uint32_t any = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int t = tile * kTileM + r0 + 32 * j;
+    int g = -1;
+    if (t < p.n_dst) g = p.argsort ? p.argsort[t] : t;
+    grow[j] = g;
+    uint32_t m = 0;
+    if (g >= 0) m = p.mask ? p.mask[g] : 0xffffffffu;
+    rmask[j] = m;
+    any |= m;
+  }
+  if (tid == 0) *lds_mask = 0;
+  __syncthreads();
+  if (any) atomicOr(lds_mask, any);
+  __syncthreads();
+  uint32_t tilemask = *lds_mask;
+  if (p.kv < 32) tilemask &= (1u << p.kv) - 1u;
+
+  f32x4 acc[NB][2];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    acc[nb][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[nb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int nchunk = (p.CIN + kCK - 1) / kCK;
+  uint4 areg[4], breg[BROWS];
+
+  // issue the global loads of step (k, c0) into registers
+  auto load_step = [&](int k, int c0) {
+    const bool cin_ok = c0 + slot * 8 < p.CIN;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int idx = -1;
+      if ((rmask[j] >> k) & 1u) {
+        idx = (k == p.identity_k) ? grow[j]
+                                  : p.pair[static_cast<size_t>(k) * p.n_dst + grow[j]];
+      }
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (idx >= 0 && cin_ok)
+        v = *reinterpret_cast<const uint4 *>(A + static_cast<size_t>(idx) * p.CIN + c0 + slot * 8);
+      areg[j] = v;
+    }
+    const int kb = p.b_reverse ? p.kv - 1 - k : k;
+    const uint16_t *Bk = B + static_cast<size_t>(kb) * p.strideK + c0 + slot * 8;
+#pragma unroll
+    for (int j = 0; j < BROWS; ++j) {
+      const int n = r0 + 32 * j;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (n < COUT && cin_ok)
+        v = *reinterpret_cast<const uint4 *>(Bk + static_cast<size_t>(n) * p.strideN);
+      breg[j] = v;
+    }
+  };
+
+  // first step
+  int k = tilemask ? __builtin_ctz(tilemask) : -1;
+  uint32_t rest = tilemask ? (tilemask & (tilemask - 1)) : 0;
+  int chunk = 0;
+  if (k >= 0) load_step(k, 0);
+
+  while (k >= 0) {
+    __syncthreads();  // previous step's fragment reads are done
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<uint4 *>(ldsA + swz_off(r0 + 32 * j, slot, kRowBytes)) = areg[j];
+#pragma unroll
+    for (int j = 0; j < BROWS; ++j) {
+      const int n = r0 + 32 * j;
+      if (n < COUT) *reinterpret_cast<uint4 *>(ldsB + swz_off(n, slot, kRowBytes)) = breg[j];
+    }
+    __syncthreads();
+
+    const int c0 = chunk * kCK;
+    const int ksteps = (min(kCK, p.CIN - c0) + 31) >> 5;  // 1 or 2
+    // advance (k, chunk) and prefetch the next step while this one computes
+    int nk = k, nchunk_i = chunk + 1;
+    if (nchunk_i == nchunk) {
+      nchunk_i = 0;
+      nk = rest ? __builtin_ctz(rest) : -1;
+      rest = rest ? (rest & (rest - 1)) : 0;
+    }
+    if (nk >= 0) load_step(nk, nchunk_i * kCK);
+
+    for (int ks = 0; ks < ksteps; ++ks) {
+      const int fslot = ks * 4 + (lane >> 4);
+      uint4 fb[2];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+        fb[mb] = *reinterpret_cast<const uint4 *>(
+            ldsA + swz_off(wave * 32 + mb * 16 + (lane & 15), fslot, kRowBytes));
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const uint4 fa = *reinterpret_cast<const uint4 *>(
+            ldsB + swz_off(nb * 16 + (lane & 15), fslot, kRowBytes));
+        acc[nb][0] = mfma16<BF16>(fa, fb[0], acc[nb][0]);
+        acc[nb][1] = mfma16<BF16>(fa, fb[1], acc[nb][1]);
+      }
+    }
+    k = nk;
+    chunk = nchunk_i;
+  }
+
+  // ---- epilogue: bias/activation, fp32 -> 16 bit, transpose through LDS so
+  // every output row leaves as full 16-byte-per-lane coalesced stores.
+  __syncthreads();
+  const uint16_t *bias = static_cast<const uint16_t *>(p.bias);
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int ch = nb * 16 + (lane >> 4) * 4;  // D row = channel, D col = voxel
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[e] = to_float<BF16>(bias[ch + e]);
+    }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const int row = wave * 32 + mb * 16 + (lane & 15);
+      uint16_t h[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        h[e] = from_float<BF16>(apply_act(acc[nb][mb][e] + bv[e], p.act, p.act_alpha));
+      uint2 pk;
+      pk.x = static_cast<uint32_t>(h[0]) | (static_cast<uint32_t>(h[1]) << 16);
+      pk.y = static_cast<uint32_t>(h[2]) | (static_cast<uint32_t>(h[3]) << 16);
+      // 8-byte piece inside 16-byte slot (ch / 8)
+      *reinterpret_cast<uint2 *>(smem + swz_off(row, ch >> 3, OUT_ROWB, OXM) + ((ch & 4) << 1)) = pk;
+    }
+  }
+  __syncthreads();
+  uint16_t *out = static_cast<uint16_t *>(p.out);
+  constexpr int OSLOTS = COUT / 8;  // 16-byte slots per output row
+  for (int s = tid; s < kTileM * OSLOTS; s += kThreads) {
+    const int row = s / OSLOTS, sl = s % OSLOTS;
+    const int t = tile * kTileM + row;
+    if (t < p.n_dst) {
+      const int g = p.argsort ? p.argsort[t] : t;
+      *reinterpret_cast<uint4 *>(out + static_cast<size_t>(g) * COUT + sl * 8) =
+          *reinterpret_cast<const uint4 *>(smem + swz_off(row, sl, OUT_ROWB, OXM));
+    }
+  }
+}
+
+template <int COUT>
+constexpr size_t gemm_smem_bytes() {
+  const size_t stage = kTileM * kRowBytes + COUT * kRowBytes + 16;
+  const size_t outb = static_cast<size_t>(kTileM) * COUT * 2;
+  return stage > outb ? stage : outb;
+}
+
+template <int COUT, bool BF16>
+int launch_gather_gemm(const GemmParams &p, hipStream_t s) {
+  const int ntiles = div_up(p.n_dst, kTileM);
+  hipLaunchKernelGGL((gather_gemm_mfma_kernel<COUT, BF16>), dim3(ntiles), dim3(kThreads),
+                     gemm_smem_bytes<COUT>(), s, p);
+  SPX_LAUNCH_CHECK();
+  return 0;
+}
+
+// --------------------------------------------------------------------------
+// generic gather-GEMM: any dtype / channel count, fp32 accumulate.
+// one thread per (dst row, out channel).
+// --------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float load_f(const T *p);
+template <> __device__ __forceinline__ float load_f<float>(const float *p) { return *p; }
+struct h16 { uint16_t v; };
+struct b16 { uint16_t v; };
+template <> __device__ __forceinline__ float load_f<h16>(const h16 *p) { return to_float<false>(p->v); }
+template <> __device__ __forceinline__ float load_f<b16>(const b16 *p) { return to_float<true>(p->v); }
+template <typename T> __device__ __forceinline__ void store_f(T *p, float f);
+template <> __device__ __forceinline__ void store_f<float>(float *p, float f) { *p = f; }
+template <> __device__ __forceinline__ void store_f<h16>(h16 *p, float f) { p->v = from_float<false>(f); }
+template <> __device__ __forceinline__ void store_f<b16>(b16 *p, float f) { p->v = from_float<true>(f); }
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+gather_gemm_generic_kernel(GemmParams p) {
+  const long long gid = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x;
+  const long long total = static_cast<long long>(p.n_dst) * p.COUT;
+  if (gid >= total) return;
+  const int d = static_cast<int>(gid / p.COUT), n = static_cast<int>(gid % p.COUT);
+  const T *A = static_cast<const T *>(p.A);
+  const T *B = static_cast<const T *>(p.B);
+  const int words = (p.kv + 31) / 32;
+  float acc = 0.f;
+  for (int k = 0; k < p.kv; ++k) {
+    if (p.mask && !((p.mask[static_cast<size_t>(d) * words + (k >> 5)] >> (k & 31)) & 1u)) continue;
+    const int idx = (k == p.identity_k) ? d : p.pair[static_cast<size_t>(k) * p.n_dst + d];
+    if (idx < 0) continue;
+    const int kb = p.b_reverse ? p.kv - 1 - k : k;
+    const T *a = A + static_cast<size_t>(idx) * p.CIN;
+    const T *b = B + static_cast<size_t>(kb) * p.strideK + static_cast<size_t>(n) * p.strideN;
+    for (int c = 0; c < p.CIN; ++c) acc = fmaf(load_f(a + c), load_f(b + c), acc);
+  }
+  if (p.bias) acc += load_f(static_cast<const T *>(p.bias) + n);
+  acc = apply_act(acc, p.act, p.act_alpha);
+  store_f(static_cast<T *>(p.out) + static_cast<size_t>(d) * p.COUT + n, acc);
+}
+
+// Wt[k][c][kk] = W[kk][k][c]  (dgrad consumes the reduction dim K contiguously)
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+weight_relayout_kernel(const T *__restrict__ W, T *__restrict__ Wt, int K, int kv, int C) {
+  const long long gid = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x;
+  const long long total = static_cast<long long>(K) * kv * C;
+  if (gid >= total) return;
+  // gid enumerates the destination [k][c][kk] so that stores are coalesced
+  const int kk = static_cast<int>(gid % K);
+  const int c = static_cast<int>((gid / K) % C);
+  const int k = static_cast<int>(gid / (static_cast<long long>(K) * C));
+  Wt[gid] = W[(static_cast<size_t>(kk) * kv + k) * C + c];
+}
+
+// --------------------------------------------------------------------------
+// wgrad, 16-bit operands: per (chunk of pairs, offset k, 64x64 dW tile) block.
+//   partial[kk][c] = sum_{j in chunk} dout[out_j][kk0+kk] * feat[in_j][c0+c]
+// LDS tiles are stored transposed ([channel][pair]) so that the MFMA
+// fragments (8 consecutive pairs of one channel) are single ds_read_b128.
+// --------------------------------------------------------------------------
+constexpr int kWJ = 128;   // pairs staged per iteration
+constexpr int kWT = 64;    // dW tile edge
+
+struct WgradParams {
+  const void *feat;        // [n_in, C]
+  const void *dout;        // [n_out, K]
+  float *partial;          // [kv][nchunks][tiles][64*64]
+  const int32_t *native;   // [2, kv, n_in]
+  const int32_t *num;      // [kv] device counts
+  int n_in, n_out, C, K, kv, subm, chunk, nchunks, tiles_c, tiles_k;
+};
+
+__device__ __forceinline__ int list_count(const WgradParams &p, int k) {
+  if (!p.subm) return p.num[k];
+  const int center = p.kv / 2;
+  if (k == center) return p.n_in;
+  return k < center ? p.num[k] : p.num[p.kv - 1 - k];  // mirror rule, ops.py:962-968
+}
+
+// element column of pair j in transposed row `ch`: XOR swizzle at 8-element
+// granularity (conflict-free fragment reads, <=2-way conflicts on the stores)
+__device__ __forceinline__ int wswz(int ch, int j) {
+  const int h = (ch & 15) ^ (((ch >> 4) & 3) << 1);
+  return j ^ ((h & 15) << 3);
+}
+
+__device__ __forceinline__ uint32_t dword_of(const uint4 &v, int i) {
+  return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
+}
+
+template <bool BF16>
+__global__ void __launch_bounds__(kThreads)
+wgrad_mfma_kernel(WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint16_t *ldsD = reinterpret_cast<uint16_t *>(smem);                    // [64 kk][128 j]
+  uint16_t *ldsF = reinterpret_cast<uint16_t *>(smem + kWT * kWJ * 2);    // [64 c ][128 j]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k = blockIdx.y;
+  const int tile = blockIdx.z;
+  const int kk0 = (tile / p.tiles_c) * kWT, c0 = (tile % p.tiles_c) * kWT;
+  const int cnt = list_count(p, k);
+  const int begin = blockIdx.x * p.chunk;
+  if (begin >= cnt) return;
+  const int end = min(cnt, begin + p.chunk);
+  const bool identity = p.subm && k == p.kv / 2;
+  const int32_t *in_list = p.native + static_cast<size_t>(k) * p.n_in;
+  const int32_t *out_list = p.native + static_cast<size_t>(p.kv + k) * p.n_in;
+  const uint16_t *F = static_cast<const uint16_t *>(p.feat);
+  const uint16_t *D = static_cast<const uint16_t *>(p.dout);
+
+  const int slot = tid & 7;       // 8-channel group
+  const int jp0 = tid >> 3;       // pair-of-rows index 0..31 (+32)
+  const int wk = wave >> 1, wc = wave & 1;  // wave quadrant: kk [32*wk,+32), c [32*wc,+32)
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int base = begin; base < end; base += kWJ) {
+    uint4 dv[2][2], fv[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int j = base + 2 * (jp0 + 32 * q) + h;
+        uint4 d = make_uint4(0, 0, 0, 0), f = make_uint4(0, 0, 0, 0);
+        if (j < end) {
+          const int oi = identity ? j : out_list[j];
+          const int ii = identity ? j : in_list[j];
+          if (kk0 + slot * 8 < p.K)
+            d = *reinterpret_cast<const uint4 *>(D + static_cast<size_t>(oi) * p.K + kk0 + slot * 8);
+          if (c0 + slot * 8 < p.C)
+            f = *reinterpret_cast<const uint4 *>(F + static_cast<size_t>(ii) * p.C + c0 + slot * 8);
+        }
+        dv[q][h] = d;
+        fv[q][h] = f;
+      }
+    __syncthreads();  // previous iteration's fragment reads are done
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int j = 2 * (jp0 + 32 * q);  // even -> a dword holds pairs (j, j+1)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ch = slot * 8 + e;
+        const int sh = (e & 1) * 16;
+        const uint32_t dd = ((dword_of(dv[q][0], e >> 1) >> sh) & 0xffffu) |
+                            (((dword_of(dv[q][1], e >> 1) >> sh) & 0xffffu) << 16);
+        const uint32_t ff = ((dword_of(fv[q][0], e >> 1) >> sh) & 0xffffu) |
+                            (((dword_of(fv[q][1], e >> 1) >> sh) & 0xffffu) << 16);
+        const int col = wswz(ch, j);
+        *reinterpret_cast<uint32_t *>(ldsD + ch * kWJ + col) = dd;
+        *reinterpret_cast<uint32_t *>(ldsF + ch * kWJ + col) = ff;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < kWJ / 32; ++ks) {
+      const int j8 = (ks * 4 + (lane >> 4)) * 8;
+      uint4 fa[2], fb[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int ch = wk * 32 + a * 16 + (lane & 15);
+        fa[a] = *reinterpret_cast<const uint4 *>(ldsD + ch * kWJ + wswz(ch, j8));
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int ch = wc * 32 + b * 16 + (lane & 15);
+        fb[b] = *reinterpret_cast<const uint4 *>(ldsF + ch * kWJ + wswz(ch, j8));
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = mfma16<BF16>(fa[a], fb[b], acc[a][b]);
+    }
+  }
+  // D[i = kk][j = c]: lane holds c = lane & 15, kk = (lane >> 4) * 4 + reg
+  float *dst = p.partial +
+               ((static_cast<size_t>(k) * p.nchunks + blockIdx.x) * (p.tiles_k * p.tiles_c) + tile) *
+                   (kWT * kWT);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int kk = wk * 32 + a * 16 + (lane >> 4) * 4 + e;
+        const int c = wc * 32 + b * 16 + (lane & 15);
+        dst[kk * kWT + c] = acc[a][b][e];
+      }
+}
+
+// generic wgrad partial: thread per (kk, c) of the 64x64 tile, 16 elems/thread
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+wgrad_generic_kernel(WgradParams p) {
+  const int k = blockIdx.y, tile = blockIdx.z;
+  const int kk0 = (tile / p.tiles_c) * kWT, c0 = (tile % p.tiles_c) * kWT;
+  const int cnt = list_count(p, k);
+  const int begin = blockIdx.x * p.chunk;
+  if (begin >= cnt) return;
+  const int end = min(cnt, begin + p.chunk);
+  const bool identity = p.subm && k == p.kv / 2;
+  const int32_t *in_list = p.native + static_cast<size_t>(k) * p.n_in;
+  const int32_t *out_list = p.native + static_cast<size_t>(p.kv + k) * p.n_in;
+  const T *F = static_cast<const T *>(p.feat);
+  const T *D = static_cast<const T *>(p.dout);
+  float *dst = p.partial +
+               ((static_cast<size_t>(k) * p.nchunks + blockIdx.x) * (p.tiles_k * p.tiles_c) + tile) *
+                   (kWT * kWT);
+  for (int e = threadIdx.x; e < kWT * kWT; e += kThreads) {
+    const int kk = kk0 + e / kWT, c = c0 + e % kWT;
+    float acc = 0.f;
+    if (kk < p.K && c < p.C) {
+      for (int j = begin; j < end; ++j) {
+        const int oi = identity ? j : out_list[j];
+        const int ii = identity ? j : in_list[j];
+        acc = fmaf(load_f(D + static_cast<size_t>(oi) * p.K + kk),
+                   load_f(F + static_cast<size_t>(ii) * p.C + c), acc);
+      }
+    }
+    dst[e] = acc;
+  }
+}
+
+// dw[kk][k][c] = sum over the chunks of list k (fixed order -> deterministic)
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+wgrad_reduce_kernel(WgradParams p, T *__restrict__ dw) {
+  constexpr int kSplit = 8;  // chunk-range groups per output element
+  __shared__ float red[kThreads];
+  const int k = blockIdx.y;
+  const int cnt = list_count(p, k);
+  const int nch = cnt > 0 ? (cnt + p.chunk - 1) / p.chunk : 0;
+  const int grp = threadIdx.x / (kThreads / kSplit);          // 0..7
+  const int el = threadIdx.x % (kThreads / kSplit);           // 0..31
+  const int ntile = p.tiles_k * p.tiles_c;
+  const int e_global = blockIdx.x * (kThreads / kSplit) + el; // element of [tiles][64*64]
+  const int tile = e_global / (kWT * kWT), e = e_global % (kWT * kWT);
+  float acc = 0.f;
+  if (tile < ntile) {
+    const float *src = p.partial + (static_cast<size_t>(k) * p.nchunks * ntile + tile) * (kWT * kWT) + e;
+    for (int ch = grp; ch < nch; ch += kSplit)
+      acc += src[static_cast<size_t>(ch) * ntile * (kWT * kWT)];
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (grp == 0 && tile < ntile) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < kSplit; ++g) s += red[g * (kThreads / kSplit) + el];
+    const int kk = (tile / p.tiles_c) * kWT + e / kWT, c = (tile % p.tiles_c) * kWT + e % kWT;
+    if (kk < p.K && c < p.C) store_f(dw + (static_cast<size_t>(kk) * p.kv + k) * p.C + c, s);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+bias_act_kernel(T *__restrict__ out, const T *__restrict__ bias, long long total, int K, int act,
+                float alpha) {
+  const long long gid = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x;
+  if (gid >= total) return;
+  float v = load_f(out + gid);
+  if (bias) v += load_f(bias + gid % K);
+  store_f(out + gid, apply_act(v, act, alpha));
+}
+
+int elem_bytes(int dtype) { return dtype == SPX_F32 ? 4 : (dtype == SPX_I8 ? 1 : 2); }
+
+bool mfma_ok(int dtype, int cin, int cout, int kv, const uint32_t *mask) {
+  if (dtype != SPX_F16 && dtype != SPX_BF16) return false;
+  if (cin % 8 != 0) return false;
+  if (kv > 32) return false;
+  (void)mask;
+  return cout == 16 || cout == 32 || cout == 64 || cout == 128 || cout == 256;
+}
+
+template <bool BF16>
+int dispatch_gather_gemm(const GemmParams &p, hipStream_t s) {
+  switch (p.COUT) {
+    case 16: return launch_gather_gemm<16, BF16>(p, s);
+    case 32: return launch_gather_gemm<32, BF16>(p, s);
+    case 64: return launch_gather_gemm<64, BF16>(p, s);
+    case 128: return launch_gather_gemm<128, BF16>(p, s);
+    case 256: return launch_gather_gemm<256, BF16>(p, s);
+  }
+  set_error("unsupported COUT %d for the MFMA path", p.COUT);
+  return -1;
+}
+
+int run_gather_gemm(const GemmParams &p, int dtype, hipStream_t s) {
+  if (p.n_dst == 0) return 0;
+  if (mfma_ok(dtype, p.CIN, p.COUT, p.kv, p.mask))
+    return dtype == SPX_BF16 ? dispatch_gather_gemm<true>(p, s) : dispatch_gather_gemm<false>(p, s);
+  const long long total = static_cast<long long>(p.n_dst) * p.COUT;
+  const dim3 grid(static_cast<unsigned>((total + kThreads - 1) / kThreads));
+  if (dtype == SPX_F32)
+    hipLaunchKernelGGL(gather_gemm_generic_kernel<float>, grid, dim3(kThreads), 0, s, p);
+  else if (dtype == SPX_F16)
+    hipLaunchKernelGGL(gather_gemm_generic_kernel<h16>, grid, dim3(kThreads), 0, s, p);
+  else if (dtype == SPX_BF16)
+    hipLaunchKernelGGL(gather_gemm_generic_kernel<b16>, grid, dim3(kThreads), 0, s, p);
+  else {
+    set_error("unsupported dtype %d", dtype);
+    return -1;
+  }
+  SPX_LAUNCH_CHECK();
+  return 0;
+}
+
+int wgrad_chunk(int n_in) {
+  // aim at >= ~512 workgroups for the dominant (centre) list, multiples of 128
+  int c = (n_in / 512 + kWJ - 1) / kWJ * kWJ;
+  if (c < kWJ) c = kWJ;
+  if (c > 1024) c = 1024;
+  return c;
+}
+
+}  // namespace
+}  // namespace spx
+
+using namespace spx;
+
+extern "C" {
+
+int spx_igemm_fwd(const void *feat, const void *weight, void *out, const int32_t *pair,
+                  const uint32_t *mask, const int32_t *argsort, int n_in, int n_out, int C,
+                  int K, int kv, int dtype, int identity_k, const void *bias, int act,
+                  float act_alpha, spx_stream_t stream) {
+  SPX_CHECK(feat && weight && out, "null tensor pointer");
+  SPX_CHECK(pair || kv == 1, "pair table required");
+  SPX_CHECK(C > 0 && K > 0 && kv > 0 && n_in >= 0 && n_out >= 0, "bad sizes");
+  GemmParams p{};
+  p.A = feat;
+  p.B = weight;
+  p.out = out;
+  p.pair = pair;
+  p.mask = mask;
+  p.argsort = argsort;
+  p.bias = bias;
+  p.strideK = C;                                  // KRSC: W[n][k][c]
+  p.strideN = static_cast<long long>(kv) * C;
+  p.n_src = n_in;
+  p.n_dst = n_out;
+  p.CIN = C;
+  p.COUT = K;
+  p.kv = kv;
+  p.identity_k = identity_k;
+  p.b_reverse = 0;
+  p.act = act;
+  p.act_alpha = act_alpha;
+  return run_gather_gemm(p, dtype, static_cast<hipStream_t>(stream));
+}
+
+size_t spx_igemm_dgrad_ws_bytes(int C, int K, int kv, int dtype) {
+  return align_up(static_cast<size_t>(C) * K * kv * elem_bytes(dtype), 256);
+}
+
+int spx_igemm_dgrad(const void *dout, const void *weight, void *din, const int32_t *pair,
+                    const uint32_t *mask, const int32_t *argsort, int n_out, int n_in, int C,
+                    int K, int kv, int dtype, int subm, void *ws, size_t ws_bytes,
+                    spx_stream_t stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  SPX_CHECK(dout && weight && din && ws, "null tensor pointer");
+  SPX_CHECK(ws_bytes >= spx_igemm_dgrad_ws_bytes(C, K, kv, dtype), "workspace too small");
+  const long long total = static_cast<long long>(C) * K * kv;
+  const dim3 grid(static_cast<unsigned>((total + kThreads - 1) / kThreads));
+  if (dtype == SPX_F32)
+    hipLaunchKernelGGL(weight_relayout_kernel<float>, grid, dim3(kThreads), 0, s,
+                       static_cast<const float *>(weight), static_cast<float *>(ws), K, kv, C);
+  else if (dtype == SPX_F16 || dtype == SPX_BF16)
+    hipLaunchKernelGGL(weight_relayout_kernel<uint16_t>, grid, dim3(kThreads), 0, s,
+                       static_cast<const uint16_t *>(weight), static_cast<uint16_t *>(ws), K, kv, C);
+  else
+    SPX_CHECK(false, "unsupported dtype %d", dtype);
+  SPX_LAUNCH_CHECK();
+  GemmParams p{};
+  p.A = dout;
+  p.B = ws;                                       // Wt[k][c][kk]
+  p.out = din;
+  p.pair = pair;
+  p.mask = mask;
+  p.argsort = argsort;
+  p.bias = nullptr;
+  p.strideK = static_cast<long long>(C) * K;
+  p.strideN = K;
+  p.n_src = n_out;
+  p.n_dst = n_in;
+  p.CIN = K;
+  p.COUT = C;
+  p.kv = kv;
+  p.identity_k = subm ? kv / 2 : -1;
+  p.b_reverse = subm ? 1 : 0;
+  p.act = SPX_ACT_NONE;
+  p.act_alpha = 0.f;
+  return run_gather_gemm(p, dtype, s);
+}
+
+size_t spx_igemm_wgrad_ws_bytes(int n_in, int C, int K, int kv) {
+  const int chunk = wgrad_chunk(n_in);
+  const size_t nchunks = div_up(n_in > 0 ? n_in : 1, chunk);
+  const size_t tiles = static_cast<size_t>(div_up(C, kWT)) * div_up(K, kWT);
+  return align_up(nchunks * kv * tiles * kWT * kWT * sizeof(float), 256);
+}
+
+int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t *pair_native,
+                    const int32_t *num_per_loc, int n_in, int n_out, int C, int K, int kv,
+                    int dtype, int subm, void *ws, size_t ws_bytes, spx_stream_t stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  SPX_CHECK(feat && dout && dw && ws, "null tensor pointer");
+  SPX_CHECK(pair_native && num_per_loc, "Native pair lists and counts are required");
+  SPX_CHECK(ws_bytes >= spx_igemm_wgrad_ws_bytes(n_in, C, K, kv), "workspace too small");
+  WgradParams p{};
+  p.feat = feat;
+  p.dout = dout;
+  p.partial = static_cast<float *>(ws);
+  p.native = pair_native;
+  p.num = num_per_loc;
+  p.n_in = n_in;
+  p.n_out = n_out;
+  p.C = C;
+  p.K = K;
+  p.kv = kv;
+  p.subm = subm;
+  p.chunk = wgrad_chunk(n_in);
+  p.nchunks = div_up(n_in > 0 ? n_in : 1, p.chunk);
+  p.tiles_c = div_up(C, kWT);
+  p.tiles_k = div_up(K, kWT);
+  const int ntile = p.tiles_c * p.tiles_k;
+  const bool mfma = (dtype == SPX_F16 || dtype == SPX_BF16) && C % 8 == 0 && K % 8 == 0;
+  if (n_in > 0) {
+    const dim3 grid(p.nchunks, kv, ntile);
+    const size_t lds = 2 * kWT * kWJ * 2;
+    if (mfma && dtype == SPX_F16)
+      hipLaunchKernelGGL(wgrad_mfma_kernel<false>, grid, dim3(kThreads), lds, s, p);
+    else if (mfma)
+      hipLaunchKernelGGL(wgrad_mfma_kernel<true>, grid, dim3(kThreads), lds, s, p);
+    else if (dtype == SPX_F32)
+      hipLaunchKernelGGL(wgrad_generic_kernel<float>, grid, dim3(kThreads), 0, s, p);
+    else if (dtype == SPX_F16)
+      hipLaunchKernelGGL(wgrad_generic_kernel<h16>, grid, dim3(kThreads), 0, s, p);
+    else if (dtype == SPX_BF16)
+      hipLaunchKernelGGL(wgrad_generic_kernel<b16>, grid, dim3(kThreads), 0, s, p);
+    else
+      SPX_CHECK(false, "unsupported dtype %d", dtype);
+    SPX_LAUNCH_CHECK();
+  }
+  // with n_in == 0 every list is empty and the reduction writes zeros
+  const dim3 rgrid(div_up(ntile * kWT * kWT, kThreads / 8), kv);
+  if (dtype == SPX_F32)
+    hipLaunchKernelGGL(wgrad_reduce_kernel<float>, rgrid, dim3(kThreads), 0, s, p,
+                       static_cast<float *>(dw));
+  else if (dtype == SPX_F16)
+    hipLaunchKernelGGL(wgrad_reduce_kernel<h16>, rgrid, dim3(kThreads), 0, s, p,
+                       static_cast<h16 *>(dw));
+  else if (dtype == SPX_BF16)
+    hipLaunchKernelGGL(wgrad_reduce_kernel<b16>, rgrid, dim3(kThreads), 0, s, p,
+                       static_cast<b16 *>(dw));
+  else
+    SPX_CHECK(false, "unsupported dtype %d", dtype);
+  SPX_LAUNCH_CHECK();
+  return 0;
+}
+
+int spx_bias_act_inplace(void *out, const void *bias, int n, int K, int dtype, int act,
+                         float act_alpha, spx_stream_t stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const long long total = static_cast<long long>(n) * K;
+  if (total == 0) return 0;
+  const dim3 grid(static_cast<unsigned>((total + kThreads - 1) / kThreads));
+  if (dtype == SPX_F32)
+    hipLaunchKernelGGL(bias_act_kernel<float>, grid, dim3(kThreads), 0, s, static_cast<float *>(out),
+                       static_cast<const float *>(bias), total, K, act, act_alpha);
+  else if (dtype == SPX_F16)
+    hipLaunchKernelGGL(bias_act_kernel<h16>, grid, dim3(kThreads), 0, s, static_cast<h16 *>(out),
+                       static_cast<const h16 *>(bias), total, K, act, act_alpha);
+  else if (dtype == SPX_BF16)
+    hipLaunchKernelGGL(bias_act_kernel<b16>, grid, dim3(kThreads), 0, s, static_cast<b16 *>(out),
+                       static_cast<const b16 *>(bias), total, K, act, act_alpha);
+  else
+    SPX_CHECK(false, "unsupported dtype %d", dtype);
+  SPX_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,856 @@
+// Rulebook ("indice pair") builder for gfx950.
+//
+// Design (MI355X-first, not a translation of the reference kernels):
+//  * one open-addressing hash table (int64 key -> int32 value) in global memory;
+//    at 2x load headroom it is ~2.4 MB per 100k voxels and stays resident in
+//    the 4 MiB XCD-local L2, so probes are L2 hits, not HBM reads;
+//  * NO order-dependent atomics anywhere: duplicate keys are resolved with
+//    atomicMin (smallest index wins == the CPU path's unordered_map::insert),
+//    the dense tables are written by the thread that owns the row (coalesced
+//    along the voxel axis), and every compaction / numbering step is a
+//    count -> scan -> scatter pipeline built on wave64 ballot + mbcnt prefix
+//    sums.  The result is therefore bit-identical to the reference CPU loops
+//    (csrc/sparse/indices.py:1639-1778), including list order and the
+//    first-seen numbering of regular-conv outputs;
+//  * kernel boundaries are the only inter-workgroup synchronisation (XCD L2s
+//    are not coherent inside a launch).
+#include "common.h"
+
+namespace spx {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kItems = 2048;  // entries per block in count/scatter passes (8 x 256)
+typedef long long hkey_t;      // EMPTY == -1
+
+struct Table {
+  hkey_t *keys;
+  int32_t *vals;
+  uint32_t mask;  // capacity - 1 (capacity is a power of two)
+};
+
+__device__ __forceinline__ uint32_t hash_key(hkey_t k) {
+  // murmur3 fmix64
+  unsigned long long x = static_cast<unsigned long long>(k);
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return static_cast<uint32_t>(x);
+}
+
+// Inserts key (if absent) and lowers its value to min(value, val). Returns the slot.
+__device__ __forceinline__ int table_insert_min(const Table &t, hkey_t key, int32_t val) {
+  uint32_t slot = hash_key(key) & t.mask;
+  for (;;) {
+    unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long *>(&t.keys[slot]),
+                                        static_cast<unsigned long long>(-1LL),
+                                        static_cast<unsigned long long>(key));
+    if (prev == static_cast<unsigned long long>(-1LL) ||
+        prev == static_cast<unsigned long long>(key)) {
+      atomicMin(&t.vals[slot], val);
+      return static_cast<int>(slot);
+    }
+    slot = (slot + 1) & t.mask;
+  }
+}
+
+__device__ __forceinline__ int table_lookup(const Table &t, hkey_t key) {
+  uint32_t slot = hash_key(key) & t.mask;
+  for (;;) {
+    hkey_t k = t.keys[slot];
+    if (k == key) return static_cast<int>(slot);
+    if (k == -1LL) return -1;
+    slot = (slot + 1) & t.mask;
+  }
+}
+
+// Reads one index row (batch, coords...) into canonical 4-d form.
+__device__ __forceinline__ void read_row(const int32_t *indices, int i, int ndim, int &b,
+                                         int (&c)[4]) {
+  if (ndim == 3) {
+    const int4 v = reinterpret_cast<const int4 *>(indices)[i];
+    b = v.x;
+    c[0] = 0;
+    c[1] = v.y;
+    c[2] = v.z;
+    c[3] = v.w;
+  } else {
+    const int32_t *row = indices + static_cast<size_t>(i) * (ndim + 1);
+    b = row[0];
+    const int lead = 4 - ndim;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) c[d] = (d < lead) ? 0 : row[1 + d - lead];
+  }
+}
+
+__device__ __forceinline__ hkey_t layout_key(int b, const int (&c)[4], const int (&dims)[4]) {
+  hkey_t v = b;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) v = v * dims[d] + c[d];
+  return v;
+}
+
+__device__ __forceinline__ void decode_offset(int k, const int (&ksize)[4], int (&r)[4]) {
+#pragma unroll
+  for (int d = 3; d >= 0; --d) {
+    r[d] = k % ksize[d];
+    k /= ksize[d];
+  }
+}
+
+__device__ __forceinline__ bool in_range(const int (&c)[4], const int (&dims)[4]) {
+  bool ok = true;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) ok = ok && c[d] >= 0 && c[d] < dims[d];
+  return ok;
+}
+
+// ---------------------------------------------------------------- SubM
+
+__global__ void __launch_bounds__(kBlock)
+subm_insert_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table t) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  int b, c[4];
+  read_row(indices, i, g.ndim, b, c);
+  // rows with a batch index outside [0, batch) ("deleted" points, docs/USAGE.md:150)
+  // never match a neighbour query in the CPU path either; do not hash them.
+  if (b < 0 || b >= g.batch || !in_range(c, g.in_dims)) return;
+  table_insert_min(t, layout_key(b, c, g.in_dims), i);
+}
+
+// One thread per voxel; loops over the kv offsets so that every store to
+// pair_fwd[k][.] / pair_bwd[k][.] is coalesced along the voxel axis and the
+// mask word is produced without atomics.
+__global__ void __launch_bounds__(kBlock)
+subm_probe_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table t,
+                  int32_t *__restrict__ pair_fwd, int32_t *__restrict__ pair_bwd,
+                  uint32_t *__restrict__ mask, int words) {
+  const int o = blockIdx.x * kBlock + threadIdx.x;
+  if (o >= n) return;
+  int b, c[4];
+  read_row(indices, o, g.ndim, b, c);
+  const bool bvalid = b >= 0 && b < g.batch;
+  const int kv = g.kv;
+  const int center = kv / 2;
+  int r[4] = {0, 0, 0, 0};
+  uint32_t mcur = 0;
+  for (int k = 0; k < kv; ++k) {
+    int v = -1;
+    if (k == center) {
+      v = o;
+    } else if (bvalid) {
+      int q[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) q[d] = c[d] - g.padding[d] + r[d] * g.dilation[d];
+      if (in_range(q, g.in_dims)) {
+        const int slot = table_lookup(t, layout_key(b, q, g.in_dims));
+        if (slot >= 0) v = t.vals[slot];
+      }
+    }
+    pair_fwd[static_cast<size_t>(k) * n + o] = v;
+    if (pair_bwd) pair_bwd[static_cast<size_t>(kv - 1 - k) * n + o] = v;
+    if (v >= 0) mcur |= 1u << (k & 31);
+    if ((k & 31) == 31 || k == kv - 1) {
+      mask[static_cast<size_t>(o) * words + (k >> 5)] = mcur;
+      mcur = 0;
+    }
+    // odometer, last dim fastest (indices.py:114-127)
+#pragma unroll
+    for (int d = 3; d >= 0; --d) {
+      if (++r[d] < g.ksize[d]) break;
+      r[d] = 0;
+    }
+  }
+}
+
+// ------------------------------------------------- block-level primitives
+
+// Exclusive rank of this thread among the threads of the block with pred set,
+// plus the block total.  wave64 ballot + mbcnt; wave totals through LDS.
+__device__ __forceinline__ int block_rank(bool pred, int &total, int *lds_wave /*[4]*/) {
+  const unsigned long long bal = __ballot(pred);
+  const int lane_rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(bal >> 32),
+                            __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(bal), 0u));
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();  // protect lds_wave reuse across calls
+  if ((threadIdx.x & 63) == 0) lds_wave[wave] = __popcll(bal);
+  __syncthreads();
+  int prefix = 0;
+  total = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) {
+    const int c = lds_wave[w];
+    if (w < wave) prefix += c;
+    total += c;
+  }
+  return prefix + lane_rank;
+}
+
+// seq-wise exclusive scan of `cnt` (length len per sequence), one block per
+// sequence; totals[seq] receives the sequence sum.
+__global__ void __launch_bounds__(kBlock)
+scan_kernel(const int32_t *__restrict__ cnt, int32_t *__restrict__ off, int len,
+            int32_t *__restrict__ totals) {
+  __shared__ int lds_wave[kBlock / 64];
+  const int seq = blockIdx.x;
+  const int32_t *c = cnt + static_cast<size_t>(seq) * len;
+  int32_t *o = off + static_cast<size_t>(seq) * len;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int carry = 0;
+  for (int base = 0; base < len; base += kBlock) {
+    const int idx = base + threadIdx.x;
+    const int v = idx < len ? c[idx] : 0;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int u = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += u;
+    }
+    __syncthreads();
+    if (lane == 63) lds_wave[wave] = incl;
+    __syncthreads();
+    int prefix = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) {
+      const int s = lds_wave[w];
+      if (w < wave) prefix += s;
+      total += s;
+    }
+    if (idx < len) o[idx] = carry + prefix + incl - v;
+    carry += total;
+  }
+  if (threadIdx.x == 0 && totals) totals[seq] = carry;
+}
+
+// ------------------------------------------- Native-list compaction (a4/a5)
+
+// mode 0 (SubM): list k in [0, kv/2) is the set {(in=e, out=row[e])} with
+//   row = pair_fwd[kv-1-k] (== pair_bwd[k]); the mirror list kv-1-k gets the
+//   roles swapped (indices.py:1692-1696).
+// mode 1 (conv): list k in [0, kv) from row = pair_bwd[k] (indices.py:1767-1768).
+__device__ __forceinline__ const int32_t *list_row(const int32_t *table, int mode, int list,
+                                                    int kv, int n) {
+  const int row = mode == 0 ? kv - 1 - list : list;
+  return table + static_cast<size_t>(row) * n;
+}
+
+__global__ void __launch_bounds__(kBlock)
+compact_count_kernel(const int32_t *__restrict__ table, int mode, int kv, int n, int nblk,
+                     int32_t *__restrict__ blockcount) {
+  __shared__ int lds_wave[kBlock / 64];
+  const int list = blockIdx.y, blk = blockIdx.x;
+  const int32_t *row = list_row(table, mode, list, kv, n);
+  const int begin = blk * kItems;
+  int cnt = 0;
+#pragma unroll
+  for (int it = 0; it < kItems / kBlock; ++it) {
+    const int e = begin + it * kBlock + threadIdx.x;
+    const bool pred = e < n && row[e] >= 0;
+    cnt += __popcll(__ballot(pred));
+  }
+  if ((threadIdx.x & 63) == 0) lds_wave[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int s = 0;
+    for (int w = 0; w < kBlock / 64; ++w) s += lds_wave[w];
+    blockcount[static_cast<size_t>(list) * nblk + blk] = s;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+compact_scatter_kernel(const int32_t *__restrict__ table, int mode, int kv, int n, int nblk,
+                       const int32_t *__restrict__ blockoff, int32_t *__restrict__ native) {
+  __shared__ int lds_wave[kBlock / 64];
+  const int list = blockIdx.y, blk = blockIdx.x;
+  const int32_t *row = list_row(table, mode, list, kv, n);
+  const int begin = blk * kItems;
+  int running = blockoff[static_cast<size_t>(list) * nblk + blk];
+  const size_t plane = static_cast<size_t>(kv) * n;  // native[1] offset
+  int32_t *in_k = native + static_cast<size_t>(list) * n;
+  int32_t *out_k = native + plane + static_cast<size_t>(list) * n;
+  int32_t *in_m = native + static_cast<size_t>(kv - 1 - list) * n;
+  int32_t *out_m = native + plane + static_cast<size_t>(kv - 1 - list) * n;
+  for (int it = 0; it < kItems / kBlock; ++it) {
+    const int e = begin + it * kBlock + threadIdx.x;
+    const int v = e < n ? row[e] : -1;
+    int total;
+    const int rank = block_rank(v >= 0, total, lds_wave);
+    if (v >= 0) {
+      const int j = running + rank;
+      in_k[j] = e;
+      out_k[j] = v;
+      if (mode == 0) {
+        in_m[j] = v;
+        out_m[j] = e;
+      }
+    }
+    running += total;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+subm_center_list_kernel(int32_t *__restrict__ native, int kv, int n) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const size_t c = static_cast<size_t>(kv / 2) * n + i;
+  native[c] = i;
+  native[static_cast<size_t>(kv) * n + c] = i;
+}
+
+// ------------------------------------------------ regular / transposed conv
+
+// Output coordinate for (input row, offset k); false if the pair does not exist.
+// Regular: query_npq (indices.py:174-203), transposed: query_nhw_out (:249-269).
+__device__ __forceinline__ bool conv_out_coord(const Geom &g, const int (&c)[4],
+                                               const int (&r)[4], int transposed,
+                                               int (&q)[4]) {
+  bool ok = true;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    if (transposed) {
+      q[d] = c[d] * g.stride[d] - g.padding[d] + r[d] * g.dilation[d];
+    } else {
+      const int h = c[d] + g.padding[d] - r[d] * g.dilation[d];
+      q[d] = h / g.stride[d];  // C++ truncation, like the reference
+      ok = ok && (h % g.stride[d]) == 0;
+    }
+    ok = ok && q[d] >= 0 && q[d] < g.out_dims[d];
+  }
+  return ok;
+}
+
+// stage 1: hash every candidate output key with value = min first-seen position
+// (k * n + i); remember the slot so later passes do not re-probe.
+__global__ void __launch_bounds__(kBlock)
+conv_stage1_kernel(const int32_t *__restrict__ indices, int n, Geom g, int transposed,
+                   Table t, int32_t *__restrict__ slot_of) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const int k = blockIdx.y;
+  if (i >= n) return;
+  int b, c[4], r[4], q[4];
+  read_row(indices, i, g.ndim, b, c);
+  decode_offset(k, g.ksize, r);
+  const size_t pos = static_cast<size_t>(k) * n + i;
+  int slot = -1;
+  if (b >= 0 && b < g.batch && conv_out_coord(g, c, r, transposed, q))
+    slot = table_insert_min(t, layout_key(b, q, g.out_dims), static_cast<int32_t>(pos));
+  slot_of[pos] = slot;
+}
+
+__device__ __forceinline__ bool is_first_seen(const int32_t *slot_of, const int32_t *vals,
+                                              size_t pos, bool inb, int &slot) {
+  slot = inb ? slot_of[pos] : -1;
+  return slot >= 0 && vals[slot] == static_cast<int32_t>(pos);
+}
+
+__global__ void __launch_bounds__(kBlock)
+conv_count_first_kernel(const int32_t *__restrict__ slot_of, const int32_t *__restrict__ vals,
+                        int n, int nblk, int32_t *__restrict__ blockcount) {
+  __shared__ int lds_wave[kBlock / 64];
+  const int k = blockIdx.y, blk = blockIdx.x;
+  const int begin = blk * kItems;
+  int cnt = 0;
+#pragma unroll
+  for (int it = 0; it < kItems / kBlock; ++it) {
+    const int e = begin + it * kBlock + threadIdx.x;
+    int slot;
+    const bool pred = is_first_seen(slot_of, vals, static_cast<size_t>(k) * n + e, e < n, slot);
+    cnt += __popcll(__ballot(pred));
+  }
+  if ((threadIdx.x & 63) == 0) lds_wave[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int s = 0;
+    for (int w = 0; w < kBlock / 64; ++w) s += lds_wave[w];
+    blockcount[static_cast<size_t>(k) * nblk + blk] = s;
+  }
+}
+
+// Numbers outputs in first-seen order and writes their coordinates.
+__global__ void __launch_bounds__(kBlock)
+conv_assign_kernel(const int32_t *__restrict__ indices, int n, Geom g, int transposed,
+                   const int32_t *__restrict__ slot_of, const int32_t *__restrict__ vals,
+                   int nblk, const int32_t *__restrict__ blockoff,
+                   int32_t *__restrict__ slot_out, int32_t *__restrict__ out_indices) {
+  __shared__ int lds_wave[kBlock / 64];
+  const int k = blockIdx.y, blk = blockIdx.x;
+  const int begin = blk * kItems;
+  int running = blockoff[static_cast<size_t>(k) * nblk + blk];
+  int r[4];
+  decode_offset(k, g.ksize, r);
+  const int lead = 4 - g.ndim;
+  for (int it = 0; it < kItems / kBlock; ++it) {
+    const int e = begin + it * kBlock + threadIdx.x;
+    int slot;
+    const bool first = is_first_seen(slot_of, vals, static_cast<size_t>(k) * n + e, e < n, slot);
+    int total;
+    const int rank = block_rank(first, total, lds_wave);
+    if (first) {
+      const int oid = running + rank;
+      slot_out[slot] = oid;
+      int b, c[4], q[4];
+      read_row(indices, e, g.ndim, b, c);
+      conv_out_coord(g, c, r, transposed, q);
+      int32_t *dst = out_indices + static_cast<size_t>(oid) * (g.ndim + 1);
+      dst[0] = b;
+      for (int d = lead; d < 4; ++d) dst[1 + d - lead] = q[d];
+    }
+    running += total;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+conv_stage2_kernel(const int32_t *__restrict__ slot_of, const int32_t *__restrict__ slot_out,
+                   int n, int n_out, int32_t *__restrict__ pair_fwd,
+                   int32_t *__restrict__ pair_bwd) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const int k = blockIdx.y;
+  if (i >= n) return;
+  const size_t pos = static_cast<size_t>(k) * n + i;
+  const int slot = slot_of[pos];
+  int oid = -1;
+  if (slot >= 0) {
+    oid = slot_out[slot];
+    pair_fwd[static_cast<size_t>(k) * n_out + oid] = i;
+  }
+  pair_bwd[pos] = oid;
+}
+
+// mask[row][w] bit k = (table[k][row] >= 0)  (indices.py:652-676)
+__global__ void __launch_bounds__(kBlock)
+mask_from_table_kernel(const int32_t *__restrict__ table, int kv, int n, int words,
+                       uint32_t *__restrict__ mask) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  uint32_t mcur = 0;
+  for (int k = 0; k < kv; ++k) {
+    if (table[static_cast<size_t>(k) * n + i] >= 0) mcur |= 1u << (k & 31);
+    if ((k & 31) == 31 || k == kv - 1) {
+      mask[static_cast<size_t>(i) * words + (k >> 5)] = mcur;
+      mcur = 0;
+    }
+  }
+}
+
+// ------------------------------------------------------- mask argsort (a9)
+// Stable LSD radix sort of (mask word, row) with 8-bit digits built from the
+// same count -> scan -> scatter primitives.  words == 1 only (kv <= 32).
+constexpr int kRadixBits = 8;
+constexpr int kRadix = 1 << kRadixBits;
+
+__global__ void __launch_bounds__(kBlock)
+radix_count_kernel(const uint32_t *__restrict__ keys, int n, int shift, int nblk,
+                   int32_t *__restrict__ hist /*[kRadix][nblk]*/) {
+  __shared__ int lds_hist[kRadix];
+  for (int d = threadIdx.x; d < kRadix; d += kBlock) lds_hist[d] = 0;
+  __syncthreads();
+  const int begin = blockIdx.x * kItems;
+  for (int it = 0; it < kItems / kBlock; ++it) {
+    const int e = begin + it * kBlock + threadIdx.x;
+    if (e < n) atomicAdd(&lds_hist[(keys[e] >> shift) & (kRadix - 1)], 1);
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < kRadix; d += kBlock)
+    hist[static_cast<size_t>(d) * nblk + blockIdx.x] = lds_hist[d];
+}
+
+// Stable scatter: processes the block's entries in order, 256 at a time; the
+// rank of an entry among equal digits inside the 256-entry tile comes from a
+// per-digit match over wave ballots.
+__global__ void __launch_bounds__(kBlock)
+radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const int32_t *__restrict__ vals_in,
+                     int n, int shift, int nblk, const int32_t *__restrict__ hist_off,
+                     uint32_t *__restrict__ keys_out, int32_t *__restrict__ vals_out) {
+  __shared__ int lds_base[kRadix];                 // running output offset per digit
+  __shared__ int lds_cnt[kBlock / 64][kRadix];     // per-wave digit counts of this tile
+  for (int d = threadIdx.x; d < kRadix; d += kBlock)
+    lds_base[d] = hist_off[static_cast<size_t>(d) * nblk + blockIdx.x];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int begin = blockIdx.x * kItems;
+  for (int it = 0; it < kItems / kBlock; ++it) {
+    for (int d = threadIdx.x; d < kRadix; d += kBlock)
+#pragma unroll
+      for (int w = 0; w < kBlock / 64; ++w) lds_cnt[w][d] = 0;
+    __syncthreads();
+    const int e = begin + it * kBlock + threadIdx.x;
+    const bool valid = e < n;
+    const uint32_t key = valid ? keys_in[e] : 0u;
+    const int val = (valid && vals_in) ? vals_in[e] : e;
+    const int digit = valid ? static_cast<int>((key >> shift) & (kRadix - 1)) : -1;
+    // lanes of this wave holding the same digit (bitwise match over 8 ballots)
+    unsigned long long same = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < kRadixBits; ++bit) {
+      const unsigned long long bal = __ballot((digit >> bit) & 1);
+      same &= ((digit >> bit) & 1) ? bal : ~bal;
+    }
+    const int rank_in_wave = __popcll(same & ((1ull << lane) - 1ull));
+    if (valid && rank_in_wave == 0) lds_cnt[wave][digit] = __popcll(same);
+    __syncthreads();
+    if (valid) {
+      int prior = 0;
+#pragma unroll
+      for (int w = 0; w < kBlock / 64; ++w)
+        if (w < wave) prior += lds_cnt[w][digit];
+      const int dst = lds_base[digit] + prior + rank_in_wave;
+      keys_out[dst] = key;
+      vals_out[dst] = val;
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < kRadix; d += kBlock) {
+      int s = 0;
+#pragma unroll
+      for (int w = 0; w < kBlock / 64; ++w) s += lds_cnt[w][d];
+      lds_base[d] += s;
+    }
+    __syncthreads();
+  }
+}
+
+// Dense table from ConvAlgo.Native lists (for callers that only hold the lists):
+// table[k][dst_j] = src_j for j < count(k).  count(): SubM mirror rule (ops.py:962-968).
+__global__ void __launch_bounds__(kBlock)
+native_to_table_kernel(const int32_t *__restrict__ native, const int32_t *__restrict__ num,
+                       int kv, int n_in, int n_dst, int subm, int inverse,
+                       int32_t *__restrict__ table) {
+  const int k = blockIdx.y;
+  const int j = blockIdx.x * kBlock + threadIdx.x;
+  int cnt;
+  if (!subm) cnt = num[k];
+  else if (k == kv / 2) cnt = n_in;
+  else cnt = k < kv / 2 ? num[k] : num[kv - 1 - k];
+  if (cnt > n_in) cnt = n_in;  // convops.py:1592 clamp
+  if (j >= cnt) return;
+  const size_t plane = static_cast<size_t>(kv) * n_in;
+  const size_t e = static_cast<size_t>(k) * n_in + j;
+  const int in_idx = native[e], out_idx = native[plane + e];
+  const int src = inverse ? out_idx : in_idx, dst = inverse ? in_idx : out_idx;
+  table[static_cast<size_t>(k) * n_dst + dst] = src;
+}
+
+uint32_t table_capacity(size_t entries) {
+  size_t cap = 256;
+  while (cap < 2 * entries) cap <<= 1;
+  return static_cast<uint32_t>(cap);
+}
+
+size_t conv_max_out(int n_in, int ndim, const int *ksize, const int *stride, int transposed) {
+  // SpconvOps.get_handcrafted_max_act_out (all.py:1557-1578): N * prod(ceil(k/s)),
+  // transposed: kv * N (ops.py:569-570).
+  size_t kv = 1, m = 1;
+  for (int i = 0; i < ndim; ++i) {
+    kv *= ksize[i];
+    m *= static_cast<size_t>((ksize[i] + stride[i] - 1) / stride[i]);
+  }
+  if (transposed || m > kv) m = kv;
+  return m * static_cast<size_t>(n_in);
+}
+
+struct ConvWs {
+  Table t;
+  int32_t *slot_out, *slot_of, *blockcount, *blockoff, *d_nout;
+  int nblk;
+  size_t bytes;
+};
+
+ConvWs carve_conv_ws(void *ws, int n_in, int ndim, const int *ksize, const int *stride,
+                     int transposed) {
+  int kv = 1;
+  for (int i = 0; i < ndim; ++i) kv *= ksize[i];
+  const uint32_t cap = table_capacity(conv_max_out(n_in, ndim, ksize, stride, transposed));
+  ConvWs w;
+  w.nblk = div_up(n_in > 0 ? n_in : 1, kItems);
+  Carver cv(ws);
+  w.t.keys = cv.take<hkey_t>(cap);
+  w.t.vals = cv.take<int32_t>(cap);
+  w.t.mask = cap - 1;
+  w.slot_out = cv.take<int32_t>(cap);
+  w.slot_of = cv.take<int32_t>(static_cast<size_t>(kv) * (n_in > 0 ? n_in : 1));
+  w.blockcount = cv.take<int32_t>(static_cast<size_t>(kv) * w.nblk);
+  w.blockoff = cv.take<int32_t>(static_cast<size_t>(kv) * w.nblk);
+  w.d_nout = cv.take<int32_t>(1);
+  w.bytes = cv.off;
+  return w;
+}
+
+int check_geom(int ndim, int n, int kv) {
+  SPX_CHECK(ndim >= 1 && ndim <= kMaxNdim, "ndim must be in [1,4], got %d", ndim);
+  SPX_CHECK(n >= 0, "negative voxel count %d", n);
+  SPX_CHECK(kv >= 1 && static_cast<long long>(kv) * n < 2147483647LL,
+            "kernel volume %d x %d voxels overflows int32 positions", kv, n);
+  return 0;
+}
+
+// Launches the count -> scan -> scatter compaction that builds the Native lists.
+int launch_native_lists(const int32_t *table, int mode, int kv, int n, int nlists, int nblk,
+                        int32_t *blockcount, int32_t *blockoff, int32_t *native,
+                        int32_t *num_per_loc, hipStream_t s) {
+  if (n == 0 || nlists == 0) return 0;
+  dim3 grid(nblk, nlists);
+  hipLaunchKernelGGL(compact_count_kernel, grid, dim3(kBlock), 0, s, table, mode, kv, n, nblk,
+                     blockcount);
+  hipLaunchKernelGGL(scan_kernel, dim3(nlists), dim3(kBlock), 0, s, blockcount, blockoff, nblk,
+                     num_per_loc);
+  hipLaunchKernelGGL(compact_scatter_kernel, grid, dim3(kBlock), 0, s, table, mode, kv, n, nblk,
+                     blockoff, native);
+  SPX_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+}  // namespace spx
+
+using namespace spx;
+
+extern "C" {
+
+size_t spx_subm_rulebook_ws_bytes(int n, int kv) {
+  const uint32_t cap = table_capacity(n > 0 ? n : 1);
+  const int nblk = div_up(n > 0 ? n : 1, kItems);
+  size_t b = 0;
+  b += align_up(cap * sizeof(hkey_t), 256) + align_up(cap * sizeof(int32_t), 256);
+  b += 2 * align_up(static_cast<size_t>(kv) * nblk * sizeof(int32_t), 256);
+  b += 256;  // scratch totals when num_per_loc is NULL
+  return b;
+}
+
+int spx_subm_rulebook(const int32_t *indices, int n, int ndim, int batch_size,
+                      const int *spatial_shape, const int *ksize, const int *dilation,
+                      int32_t *pair_fwd, int32_t *pair_bwd, uint32_t *mask,
+                      int32_t *pair_native, int32_t *num_per_loc, void *ws, size_t ws_bytes,
+                      spx_stream_t stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int padding[4], stride[4] = {1, 1, 1, 1}, kv = 1;
+  SPX_CHECK(ndim >= 1 && ndim <= kMaxNdim, "ndim must be in [1,4], got %d", ndim);
+  for (int i = 0; i < ndim; ++i) {
+    SPX_CHECK(ksize[i] % 2 == 1, "subm only support odd ksize");  // indices.py:1650
+    padding[i] = (ksize[i] / 2) * dilation[i];                    // indices.py:1652
+    kv *= ksize[i];
+  }
+  if (check_geom(ndim, n, kv)) return -1;
+  SPX_CHECK(pair_fwd && mask, "pair_fwd and mask are required");
+  SPX_CHECK(ws_bytes >= spx_subm_rulebook_ws_bytes(n, kv), "workspace too small: %zu < %zu",
+            ws_bytes, spx_subm_rulebook_ws_bytes(n, kv));
+  const Geom g = make_geom(ndim, batch_size, spatial_shape, spatial_shape, ksize, stride,
+                           padding, dilation);
+  const int words = div_up(kv, 32);
+  if (num_per_loc) SPX_HIP(hipMemsetAsync(num_per_loc, 0, sizeof(int32_t) * kv, s));
+  if (pair_native)
+    SPX_HIP(hipMemsetAsync(pair_native, 0xFF, sizeof(int32_t) * 2 * static_cast<size_t>(kv) * n, s));
+  if (n == 0) return 0;
+
+  const uint32_t cap = table_capacity(n);
+  const int nblk = div_up(n, kItems);
+  Carver cv(ws);
+  Table t;
+  t.keys = cv.take<hkey_t>(cap);
+  t.vals = cv.take<int32_t>(cap);
+  t.mask = cap - 1;
+  int32_t *blockcount = cv.take<int32_t>(static_cast<size_t>(kv) * nblk);
+  int32_t *blockoff = cv.take<int32_t>(static_cast<size_t>(kv) * nblk);
+  int32_t *scratch_totals = cv.take<int32_t>(64);
+
+  SPX_HIP(hipMemsetAsync(t.keys, 0xFF, sizeof(hkey_t) * cap, s));
+  SPX_HIP(hipMemsetAsync(t.vals, 0x7F, sizeof(int32_t) * cap, s));
+  const dim3 grid(div_up(n, kBlock));
+  hipLaunchKernelGGL(subm_insert_kernel, grid, dim3(kBlock), 0, s, indices, n, g, t);
+  hipLaunchKernelGGL(subm_probe_kernel, grid, dim3(kBlock), 0, s, indices, n, g, t, pair_fwd,
+                     pair_bwd, mask, words);
+  SPX_LAUNCH_CHECK();
+  if (pair_native) {
+    hipLaunchKernelGGL(subm_center_list_kernel, grid, dim3(kBlock), 0, s, pair_native, kv, n);
+    // num_per_loc: counts only for k < kv/2 (indices.py:1685,1692)
+    int32_t *totals = num_per_loc ? num_per_loc : scratch_totals;
+    SPX_CHECK(num_per_loc || kv / 2 <= 64, "num_per_loc required for kv > 128");
+    if (launch_native_lists(pair_fwd, 0, kv, n, kv / 2, nblk, blockcount, blockoff, pair_native,
+                            totals, s))
+      return -2;
+  } else if (num_per_loc && kv / 2 > 0) {
+    dim3 g2(nblk, kv / 2);
+    hipLaunchKernelGGL(compact_count_kernel, g2, dim3(kBlock), 0, s, pair_fwd, 0, kv, n, nblk,
+                       blockcount);
+    hipLaunchKernelGGL(scan_kernel, dim3(kv / 2), dim3(kBlock), 0, s, blockcount, blockoff, nblk,
+                       num_per_loc);
+    SPX_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+size_t spx_conv_rulebook_ws_bytes(int n_in, int ndim, const int *ksize, const int *stride,
+                                  int transposed) {
+  if (ndim < 1 || ndim > kMaxNdim) return 0;
+  return carve_conv_ws(nullptr, n_in, ndim, ksize, stride, transposed).bytes + 256;
+}
+
+int spx_conv_rulebook_count(const int32_t *indices, int n_in, int ndim, int batch_size,
+                            const int *in_shape, const int *out_shape, const int *ksize,
+                            const int *stride, const int *padding, const int *dilation,
+                            int transposed, void *ws, size_t ws_bytes, int *n_out_h,
+                            spx_stream_t stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  SPX_CHECK(ndim >= 1 && ndim <= kMaxNdim, "ndim must be in [1,4], got %d", ndim);
+  const Geom g = make_geom(ndim, batch_size, in_shape, out_shape, ksize, stride, padding, dilation);
+  if (check_geom(ndim, n_in, g.kv)) return -1;
+  for (int i = 0; i < ndim; ++i)
+    SPX_CHECK(out_shape[i] > 0 && stride[i] > 0, "bad output shape / stride at dim %d", i);
+  SPX_CHECK(ws_bytes >= spx_conv_rulebook_ws_bytes(n_in, ndim, ksize, stride, transposed),
+            "workspace too small");
+  *n_out_h = 0;
+  if (n_in == 0) return 0;
+  ConvWs w = carve_conv_ws(ws, n_in, ndim, ksize, stride, transposed);
+  const size_t cap = static_cast<size_t>(w.t.mask) + 1;
+  SPX_HIP(hipMemsetAsync(w.t.keys, 0xFF, sizeof(hkey_t) * cap, s));
+  SPX_HIP(hipMemsetAsync(w.t.vals, 0x7F, sizeof(int32_t) * cap, s));
+  const dim3 grid1(div_up(n_in, kBlock), g.kv);
+  hipLaunchKernelGGL(conv_stage1_kernel, grid1, dim3(kBlock), 0, s, indices, n_in, g, transposed,
+                     w.t, w.slot_of);
+  const dim3 grid2(w.nblk, g.kv);
+  hipLaunchKernelGGL(conv_count_first_kernel, grid2, dim3(kBlock), 0, s, w.slot_of, w.t.vals, n_in,
+                     w.nblk, w.blockcount);
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kBlock), 0, s, w.blockcount, w.blockoff,
+                     g.kv * w.nblk, w.d_nout);
+  SPX_LAUNCH_CHECK();
+  int32_t host_n = 0;
+  SPX_HIP(hipMemcpyAsync(&host_n, w.d_nout, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  SPX_HIP(hipStreamSynchronize(s));
+  *n_out_h = host_n;
+  return 0;
+}
+
+int spx_conv_rulebook_fill(const int32_t *indices, int n_in, int ndim, int batch_size,
+                           const int *in_shape, const int *out_shape, const int *ksize,
+                           const int *stride, const int *padding, const int *dilation,
+                           int transposed, int n_out, int32_t *out_indices, int32_t *pair_fwd,
+                           int32_t *pair_bwd, uint32_t *mask_fwd, uint32_t *mask_bwd,
+                           int32_t *pair_native, int32_t *num_per_loc, void *ws,
+                           size_t ws_bytes, spx_stream_t stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  SPX_CHECK(ndim >= 1 && ndim <= kMaxNdim, "ndim must be in [1,4], got %d", ndim);
+  const Geom g = make_geom(ndim, batch_size, in_shape, out_shape, ksize, stride, padding, dilation);
+  if (check_geom(ndim, n_in, g.kv)) return -1;
+  SPX_CHECK(ws_bytes >= spx_conv_rulebook_ws_bytes(n_in, ndim, ksize, stride, transposed),
+            "workspace too small");
+  SPX_CHECK(pair_fwd && pair_bwd && out_indices, "out_indices, pair_fwd and pair_bwd are required");
+  const int kv = g.kv, words = div_up(kv, 32);
+  if (num_per_loc) SPX_HIP(hipMemsetAsync(num_per_loc, 0, sizeof(int32_t) * kv, s));
+  if (pair_native && n_in > 0)
+    SPX_HIP(hipMemsetAsync(pair_native, 0xFF, sizeof(int32_t) * 2 * static_cast<size_t>(kv) * n_in, s));
+  if (n_in == 0) return 0;
+  ConvWs w = carve_conv_ws(ws, n_in, ndim, ksize, stride, transposed);
+  if (n_out > 0)
+    SPX_HIP(hipMemsetAsync(pair_fwd, 0xFF, sizeof(int32_t) * static_cast<size_t>(kv) * n_out, s));
+  const dim3 grid2(w.nblk, kv);
+  hipLaunchKernelGGL(conv_assign_kernel, grid2, dim3(kBlock), 0, s, indices, n_in, g, transposed,
+                     w.slot_of, w.t.vals, w.nblk, w.blockoff, w.slot_out, out_indices);
+  const dim3 grid1(div_up(n_in, kBlock), kv);
+  hipLaunchKernelGGL(conv_stage2_kernel, grid1, dim3(kBlock), 0, s, w.slot_of, w.slot_out, n_in,
+                     n_out, pair_fwd, pair_bwd);
+  if (mask_fwd && n_out > 0)
+    hipLaunchKernelGGL(mask_from_table_kernel, dim3(div_up(n_out, kBlock)), dim3(kBlock), 0, s,
+                       pair_fwd, kv, n_out, words, mask_fwd);
+  if (mask_bwd)
+    hipLaunchKernelGGL(mask_from_table_kernel, dim3(div_up(n_in, kBlock)), dim3(kBlock), 0, s,
+                       pair_bwd, kv, n_in, words, mask_bwd);
+  SPX_LAUNCH_CHECK();
+  if (pair_native) {
+    SPX_CHECK(num_per_loc, "num_per_loc is required with pair_native");
+    if (launch_native_lists(pair_bwd, 1, kv, n_in, kv, w.nblk, w.blockcount, w.blockoff,
+                            pair_native, num_per_loc, s))
+      return -2;
+  } else if (num_per_loc) {
+    hipLaunchKernelGGL(compact_count_kernel, grid2, dim3(kBlock), 0, s, pair_bwd, 1, kv, n_in,
+                       w.nblk, w.blockcount);
+    hipLaunchKernelGGL(scan_kernel, dim3(kv), dim3(kBlock), 0, s, w.blockcount, w.blockoff, w.nblk,
+                       num_per_loc);
+    SPX_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+size_t spx_mask_argsort_ws_bytes(int n) {
+  const int nblk = div_up(n > 0 ? n : 1, kItems);
+  size_t b = 0;
+  b += 2 * align_up(static_cast<size_t>(n > 0 ? n : 1) * sizeof(uint32_t), 256);  // key ping/pong
+  b += align_up(static_cast<size_t>(n > 0 ? n : 1) * sizeof(int32_t), 256);      // value pong
+  b += 2 * align_up(static_cast<size_t>(kRadix) * nblk * sizeof(int32_t), 256);
+  return b + 256;
+}
+
+int spx_mask_argsort(const uint32_t *mask, int n, int words, int32_t *argsort, void *ws,
+                     size_t ws_bytes, spx_stream_t stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  SPX_CHECK(words == 1, "mask_argsort supports kernel volume <= 32 (words == 1), got %d", words);
+  SPX_CHECK(ws_bytes >= spx_mask_argsort_ws_bytes(n), "workspace too small");
+  if (n == 0) return 0;
+  const int nblk = div_up(n, kItems);
+  Carver cv(ws);
+  uint32_t *kA = cv.take<uint32_t>(n);
+  uint32_t *kB = cv.take<uint32_t>(n);
+  int32_t *vB = cv.take<int32_t>(n);
+  int32_t *hist = cv.take<int32_t>(static_cast<size_t>(kRadix) * nblk);
+  int32_t *hist_off = cv.take<int32_t>(static_cast<size_t>(kRadix) * nblk);
+  // 4 passes of 8 bits.  pass 0: mask -> (kA, argsort); 1: -> (kB, vB); 2: -> (kA, argsort);
+  // 3: -> (kB, vB) ... keep it to an even number of hops ending in `argsort`.
+  const uint32_t *kin = mask;
+  const int32_t *vin = nullptr;  // identity
+  uint32_t *kout[4] = {kB, kA, kB, kA};
+  int32_t *vout[4] = {vB, argsort, vB, argsort};
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = pass * kRadixBits;
+    hipLaunchKernelGGL(radix_count_kernel, dim3(nblk), dim3(kBlock), 0, s, kin, n, shift, nblk, hist);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kBlock), 0, s, hist, hist_off, kRadix * nblk,
+                       static_cast<int32_t *>(nullptr));
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk), dim3(kBlock), 0, s, kin, vin, n, shift,
+                       nblk, hist_off, kout[pass], vout[pass]);
+    kin = kout[pass];
+    vin = vout[pass];
+  }
+  SPX_LAUNCH_CHECK();
+  return 0;
+}
+
+int spx_native_to_table(const int32_t *pair_native, const int32_t *num_per_loc, int n_in,
+                        int n_dst, int kv, int subm, int inverse, int32_t *table,
+                        uint32_t *mask, spx_stream_t stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  SPX_CHECK(pair_native && num_per_loc && table, "null pointer");
+  if (n_dst == 0) return 0;
+  SPX_HIP(hipMemsetAsync(table, 0xFF, sizeof(int32_t) * static_cast<size_t>(kv) * n_dst, s));
+  if (n_in > 0)
+    hipLaunchKernelGGL(native_to_table_kernel, dim3(div_up(n_in, kBlock), kv), dim3(kBlock), 0, s,
+                       pair_native, num_per_loc, kv, n_in, n_dst, subm, inverse, table);
+  if (mask)
+    hipLaunchKernelGGL(mask_from_table_kernel, dim3(div_up(n_dst, kBlock)), dim3(kBlock), 0, s,
+                       table, kv, n_dst, div_up(kv, 32), mask);
+  SPX_LAUNCH_CHECK();
+  return 0;
+}
+
+size_t spx_table_to_native_ws_bytes(int n, int kv) {
+  const int nblk = div_up(n > 0 ? n : 1, kItems);
+  return 2 * align_up(static_cast<size_t>(kv) * nblk * sizeof(int32_t), 256) + 256;
+}
+
+int spx_table_to_native(const int32_t *table, int subm, int kv, int n, int32_t *pair_native,
+                        int32_t *num_per_loc, void *ws, size_t ws_bytes, spx_stream_t stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  SPX_CHECK(table && pair_native && num_per_loc && ws, "null pointer");
+  SPX_CHECK(ws_bytes >= spx_table_to_native_ws_bytes(n, kv), "workspace too small");
+  SPX_HIP(hipMemsetAsync(num_per_loc, 0, sizeof(int32_t) * kv, s));
+  if (n == 0) return 0;
+  SPX_HIP(hipMemsetAsync(pair_native, 0xFF, sizeof(int32_t) * 2 * static_cast<size_t>(kv) * n, s));
+  const int nblk = div_up(n, kItems);
+  Carver cv(ws);
+  int32_t *blockcount = cv.take<int32_t>(static_cast<size_t>(kv) * nblk);
+  int32_t *blockoff = cv.take<int32_t>(static_cast<size_t>(kv) * nblk);
+  if (subm)
+    hipLaunchKernelGGL(subm_center_list_kernel, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s,
+                       pair_native, kv, n);
+  return launch_native_lists(table, subm ? 0 : 1, kv, n, subm ? kv / 2 : kv, nblk, blockcount,
+                             blockoff, pair_native, num_per_loc, s);
+}
+
+}  // extern "C"

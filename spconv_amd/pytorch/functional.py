@@ -1,0 +1,184 @@
+"""autograd glue (reference: spconv/pytorch/functional.py:59-429).
+
+``SparseConvFunction`` / ``SparseInverseConvFunction`` / ``SubMConvFunction`` /
+``SparseImplicitGemmFunction`` keep the reference's argument lists so user code
+calling ``Fsp.indice_subm_conv(...)`` etc. keeps working; all of them save
+(features, filters, rulebook tensors) and return ``(din, dW, None...)``.
+AMP: inputs are cast to fp16 under autocast like the reference
+(functional.py:44-56).
+"""
+from __future__ import annotations
+
+import sys
+from typing import List, Optional
+
+import numpy as np
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from spconv_amd.pytorch import ops
+from spconv_amd.pytorch.core import ConvAlgo
+
+import torch.amp as _amp
+
+_FWD = _amp.custom_fwd(device_type="cuda", cast_inputs=torch.float16)
+_BWD = _amp.custom_bwd(device_type="cuda")
+
+
+def _report(tag: str, **shapes) -> None:
+    msg = f"[Exception|{tag}]" + ",".join(f"{k}={v}" for k, v in shapes.items())
+    print(msg, file=sys.stderr)
+
+
+class _NativeConvBase(Function):
+    """Shared body of the three ConvAlgo.Native functions."""
+    _inverse = False
+    _subm = False
+
+    @classmethod
+    def _forward(cls, ctx, features, filters, indice_pairs, indice_pair_num, num_activate_out,
+                 algo, timer, bias, act_alpha, act_beta, act_type):
+        ctx.save_for_backward(indice_pairs, indice_pair_num, features, filters)
+        ctx.algo = algo
+        # tensors lose python attributes through save_for_backward; keep the rulebook here
+        ctx.rulebook = ops.rulebook_of(indice_pairs)
+        try:
+            return ops.indice_conv(features, filters, indice_pairs, indice_pair_num,
+                                   num_activate_out, cls._inverse, cls._subm, algo=algo,
+                                   timer=timer, bias=bias, act_alpha=act_alpha,
+                                   act_beta=act_beta, act_type=act_type)
+        except Exception:
+            _report("indice_conv", feat=features.shape, w=filters.shape, pair=indice_pairs.shape,
+                    act=num_activate_out, algo=algo)
+            raise
+
+    @classmethod
+    def _backward(cls, ctx, grad_output):
+        indice_pairs, indice_pair_num, features, filters = ctx.saved_tensors
+        if ctx.rulebook is not None:
+            ops.attach_rulebook(indice_pairs, ctx.rulebook)
+        try:
+            din, dw = ops.indice_conv_backward(features, filters, grad_output, indice_pairs,
+                                               indice_pair_num, cls._inverse, cls._subm,
+                                               algo=ctx.algo)
+        except Exception:
+            _report("indice_conv_backward", feat=features.shape, w=filters.shape,
+                    pair=indice_pairs.shape, do=grad_output.shape)
+            raise
+        return (din, dw) + (None,) * 9
+
+
+class SparseConvFunction(_NativeConvBase):
+    @staticmethod
+    @_FWD
+    def forward(ctx, features, filters, indice_pairs, indice_pair_num, num_activate_out, algo,
+                timer=None, bias: Optional[torch.Tensor] = None, act_alpha: float = 0.0,
+                act_beta: float = 0.0, act_type=ops.Activation.None_):
+        return SparseConvFunction._forward(ctx, features, filters, indice_pairs, indice_pair_num,
+                                           num_activate_out, algo, timer, bias, act_alpha,
+                                           act_beta, act_type)
+
+    @staticmethod
+    @once_differentiable
+    @_BWD
+    def backward(ctx, grad_output):
+        return SparseConvFunction._backward(ctx, grad_output)
+
+
+class SparseInverseConvFunction(_NativeConvBase):
+    _inverse = True
+
+    @staticmethod
+    @_FWD
+    def forward(ctx, features, filters, indice_pairs, indice_pair_num, num_activate_out, algo,
+                timer=None, bias: Optional[torch.Tensor] = None, act_alpha: float = 0.0,
+                act_beta: float = 0.0, act_type=ops.Activation.None_):
+        return SparseInverseConvFunction._forward(ctx, features, filters, indice_pairs,
+                                                  indice_pair_num, num_activate_out, algo, timer,
+                                                  bias, act_alpha, act_beta, act_type)
+
+    @staticmethod
+    @once_differentiable
+    @_BWD
+    def backward(ctx, grad_output):
+        return SparseInverseConvFunction._backward(ctx, grad_output)
+
+
+class SubMConvFunction(_NativeConvBase):
+    _subm = True
+
+    @staticmethod
+    @_FWD
+    def forward(ctx, features, filters, indice_pairs, indice_pair_num, num_activate_out, algo,
+                timer=None, bias: Optional[torch.Tensor] = None, act_alpha: float = 0.0,
+                act_beta: float = 0.0, act_type=ops.Activation.None_):
+        return SubMConvFunction._forward(ctx, features, filters, indice_pairs, indice_pair_num,
+                                         num_activate_out, algo, timer, bias, act_alpha, act_beta,
+                                         act_type)
+
+    @staticmethod
+    @once_differentiable
+    @_BWD
+    def backward(ctx, grad_output):
+        return SubMConvFunction._backward(ctx, grad_output)
+
+
+class SparseImplicitGemmFunction(Function):
+    @staticmethod
+    @_FWD
+    def forward(ctx, features: torch.Tensor, filters: torch.Tensor, pair_fwd: torch.Tensor,
+                pair_bwd: torch.Tensor, pair_mask_fwd_splits: List[torch.Tensor],
+                pair_mask_bwd_splits: List[torch.Tensor],
+                mask_argsort_fwd_splits: List[torch.Tensor],
+                mask_argsort_bwd_splits: List[torch.Tensor], num_activate_out: int,
+                masks: List[np.ndarray], is_train: bool, is_subm: bool, timer=None,
+                fp32_accum: Optional[bool] = None, bias: Optional[torch.Tensor] = None,
+                act_alpha: float = 0.0, act_beta: float = 0.0,
+                act_type=ops.Activation.None_):
+        try:
+            out, mask_out, mask_width = ops.implicit_gemm(
+                features, filters, pair_fwd, pair_mask_fwd_splits, mask_argsort_fwd_splits,
+                num_activate_out, masks, is_train, is_subm, timer, fp32_accum, bias, act_alpha,
+                act_beta, act_type)
+        except Exception:
+            _report("implicit_gemm", feat=features.shape, w=filters.shape, pair=pair_fwd.shape,
+                    act=num_activate_out, issubm=is_subm, istrain=is_train)
+            raise
+        ctx.save_for_backward(features, filters, pair_fwd, pair_bwd)
+        ctx.rulebook = ops.rulebook_of(pair_fwd)
+        ctx.mask_width = mask_width
+        ctx.mask_out = mask_out
+        ctx.pair_mask_fwd_splits = pair_mask_fwd_splits
+        ctx.mask_argsort_fwd_splits = mask_argsort_fwd_splits
+        ctx.pair_mask_bwd_splits = pair_mask_bwd_splits
+        ctx.mask_argsort_bwd_splits = mask_argsort_bwd_splits
+        ctx.masks = masks
+        ctx.is_subm = is_subm
+        ctx.fp32_accum = fp32_accum
+        return out
+
+    @staticmethod
+    @once_differentiable
+    @_BWD
+    def backward(ctx, grad_output):
+        features, filters, pair_fwd, pair_bwd = ctx.saved_tensors
+        if ctx.rulebook is not None:
+            ops.attach_rulebook(pair_fwd, ctx.rulebook)
+        try:
+            din, dw = ops.implicit_gemm_backward(
+                features, filters, grad_output, pair_fwd, pair_bwd, ctx.pair_mask_fwd_splits,
+                ctx.pair_mask_bwd_splits, ctx.mask_argsort_fwd_splits,
+                ctx.mask_argsort_bwd_splits, mask_output_fwd=ctx.mask_out, masks=ctx.masks,
+                mask_width=ctx.mask_width, is_subm=ctx.is_subm, fp32_accum=ctx.fp32_accum)
+        except Exception:
+            _report("implicit_gemm_backward", feat=features.shape, w=filters.shape,
+                    pair=pair_fwd.shape, issubm=ctx.is_subm, do=grad_output.shape)
+            raise
+        return (din, dw) + (None,) * 16
+
+
+indice_conv = SparseConvFunction.apply
+implicit_gemm = SparseImplicitGemmFunction.apply
+indice_inverse_conv = SparseInverseConvFunction.apply
+indice_subm_conv = SubMConvFunction.apply

@@ -1,0 +1,449 @@
+"""Op drivers: torch tensors in, C-ABI calls out.
+
+Mirrors the public functions of ``spconv/pytorch/ops.py`` (names, argument
+meaning, error behaviour) for the hot path:
+
+* ``get_conv_output_size`` / ``get_deconv_output_size``   (ops.py:73-96)
+* ``get_indice_pairs``                                     (ops.py:132-326)
+* ``get_indice_pairs_implicit_gemm``                       (ops.py:329-808)
+* ``indice_conv`` / ``indice_conv_backward``               (ops.py:811-1095,1103-1447)
+* ``implicit_gemm`` / ``implicit_gemm_backward``           (ops.py:1450-1664,1667-1896)
+
+All compute happens in the HIP library behind ``include/spconv_amd.h``; torch is
+used for allocation (the reference's TorchAllocator role, cppcore.py:112-223)
+and to read the current stream (cppcore.py:98-99).  CPU tensors are rejected:
+this implementation has no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+import functools
+import weakref
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from spconv_amd import _lib
+from spconv_amd.constants import SPCONV_DO_SORT
+from spconv_amd.pytorch.core import ConvAlgo, Rulebook
+
+INT32_MAX = 2147483647
+
+_POINT_VANISH_MSG = """Your points vanished here, this usually because you provide
+conv params that may ignore some input points. Example:
+    spatial_shape=[8, 200, 200]
+    ksize=3
+    stride=2
+    padding=[0, 1, 1]
+    dilation=1
+    Coordinates=[[0, 7, 153, 142]]
+these params will cause ALL points in z == 7 dropped because of padding_z=0.
+enlarge your spatial shape or change your conv param to make sure
+every input point has a corresponding output point.
+Your Conv Params:
+    spatial_shape={}
+    ksize={}
+    stride={}
+    padding={}
+    dilation={}"""
+
+_DTYPES = {torch.float32: _lib.DTYPE_F32, torch.float16: _lib.DTYPE_F16,
+           torch.bfloat16: _lib.DTYPE_BF16}
+
+
+class Activation:
+    """tv.gemm.Activation values used by the reference's conv modules."""
+    None_ = _lib.ACT_NONE
+    ReLU = _lib.ACT_RELU
+    Sigmoid = _lib.ACT_SIGMOID
+    LeakyReLU = _lib.ACT_LEAKY_RELU
+
+
+def get_conv_output_size(input_size, kernel_size, stride, padding, dilation):
+    output_size = []
+    for i in range(len(input_size)):
+        size = (input_size[i] + 2 * padding[i] - dilation[i] * (kernel_size[i] - 1) - 1) // stride[i] + 1
+        output_size.append(1 if kernel_size[i] == -1 else size)
+    return output_size
+
+
+def get_deconv_output_size(input_size, kernel_size, stride, padding, dilation, output_padding):
+    output_size = []
+    for i in range(len(input_size)):
+        if kernel_size[i] == -1:
+            raise ValueError("deconv don't support kernel_size < 0")
+        output_size.append((input_size[i] - 1) * stride[i] - 2 * padding[i] + kernel_size[i]
+                           + output_padding[i])
+    return output_size
+
+
+# ---------------------------------------------------------------- plumbing
+def _require_gpu(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise NotImplementedError(
+            f"spconv_amd runs on MI355X only: {what} is on {t.device}. There is no CPU path "
+            f"(move the SparseConvTensor to 'cuda').")
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=device)
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    try:
+        return _DTYPES[t.dtype]
+    except KeyError:
+        raise NotImplementedError(f"unsupported feature dtype {t.dtype}") from None
+
+
+def _kv(ksize) -> int:
+    return int(functools.reduce(lambda a, b: a * b, ksize, 1))
+
+
+# ---------------------------------------------------------------- rulebook
+def build_rulebook(indices: torch.Tensor, batch_size: int, spatial_shape: List[int],
+                   ksize: List[int], stride: List[int], padding: List[int],
+                   dilation: List[int], out_padding: List[int], subm: bool = False,
+                   transpose: bool = False, need_bwd_table: bool = False,
+                   do_sort: bool = False) -> Tuple[Rulebook, List[int]]:
+    """One call builds every artefact (dense tables, masks, Native lists)."""
+    _require_gpu(indices, "indices")
+    assert indices.dtype == torch.int32 and indices.ndim == 2
+    L = _lib.load()
+    indices = indices.contiguous()
+    dev = indices.device
+    n_in, ndim = indices.shape[0], indices.shape[1] - 1
+    kv = _kv(ksize)
+    words = (kv + 31) // 32
+    if subm:
+        out_shape = list(spatial_shape)
+    elif transpose:
+        out_shape = get_deconv_output_size(spatial_shape, ksize, stride, padding, dilation, out_padding)
+    else:
+        out_shape = get_conv_output_size(spatial_shape, ksize, stride, padding, dilation)
+    if any(x <= 0 for x in out_shape):
+        raise ValueError(f"your out spatial shape {out_shape} reach zero!!! input shape: {spatial_shape}")
+    stream = _stream(indices)
+    i32 = dict(dtype=torch.int32, device=dev)
+    if subm:
+        pair_fwd = torch.empty((kv, n_in), **i32)
+        pair_bwd = torch.empty((kv, n_in), **i32) if need_bwd_table else None
+        mask = torch.empty((n_in, words), **i32)
+        native = torch.empty((2, kv, n_in), **i32)
+        num = torch.empty((kv,), **i32)
+        ws = _ws(L.spx_subm_rulebook_ws_bytes(n_in, kv), dev)
+        _lib.check(L.spx_subm_rulebook(indices.data_ptr(), n_in, ndim, batch_size,
+                                       _lib.ints(spatial_shape), _lib.ints(ksize),
+                                       _lib.ints(dilation), pair_fwd.data_ptr(), _ptr(pair_bwd),
+                                       mask.data_ptr(), native.data_ptr(), num.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), stream))
+        rb = Rulebook(indices, pair_fwd, pair_bwd, mask, mask, native, num, n_in, n_in, kv, True)
+    else:
+        args = (_lib.ints(spatial_shape), _lib.ints(out_shape), _lib.ints(ksize), _lib.ints(stride),
+                _lib.ints(padding), _lib.ints(dilation), int(transpose))
+        ws = _ws(L.spx_conv_rulebook_ws_bytes(n_in, ndim, _lib.ints(ksize), _lib.ints(stride),
+                                              int(transpose)), dev)
+        n_out_c = ctypes.c_int(0)
+        _lib.check(L.spx_conv_rulebook_count(indices.data_ptr(), n_in, ndim, batch_size, *args,
+                                             ws.data_ptr(), ws.numel(), ctypes.byref(n_out_c),
+                                             stream))
+        n_out = int(n_out_c.value)
+        if n_out == 0:
+            raise ValueError(_POINT_VANISH_MSG.format(spatial_shape, ksize, stride, padding, dilation))
+        out_indices = torch.empty((n_out, ndim + 1), **i32)
+        pair_fwd = torch.empty((kv, n_out), **i32)
+        pair_bwd = torch.empty((kv, n_in), **i32)
+        mask_fwd = torch.empty((n_out, words), **i32)
+        mask_bwd = torch.empty((n_in, words), **i32)
+        native = torch.empty((2, kv, n_in), **i32)
+        num = torch.empty((kv,), **i32)
+        _lib.check(L.spx_conv_rulebook_fill(indices.data_ptr(), n_in, ndim, batch_size, *args,
+                                            n_out, out_indices.data_ptr(), pair_fwd.data_ptr(),
+                                            pair_bwd.data_ptr(), mask_fwd.data_ptr(),
+                                            mask_bwd.data_ptr(), native.data_ptr(), num.data_ptr(),
+                                            ws.data_ptr(), ws.numel(), stream))
+        rb = Rulebook(out_indices, pair_fwd, pair_bwd, mask_fwd, mask_bwd, native, num, n_in,
+                      n_out, kv, False)
+    if do_sort and words == 1:
+        rb.argsort_fwd = mask_argsort(rb.mask_fwd)
+        if not subm:
+            rb.argsort_bwd = mask_argsort(rb.mask_bwd)
+    return rb, out_shape
+
+
+def mask_argsort(mask: torch.Tensor) -> torch.Tensor:
+    """SpconvOps.sort_1d_by_key_allocator (all.py:935-991): argsort of the mask words."""
+    L = _lib.load()
+    n, words = mask.shape
+    out = torch.empty((n,), dtype=torch.int32, device=mask.device)
+    ws = _ws(L.spx_mask_argsort_ws_bytes(n), mask.device)
+    _lib.check(L.spx_mask_argsort(mask.data_ptr(), n, words, out.data_ptr(), ws.data_ptr(),
+                                  ws.numel(), _stream(mask)))
+    return out
+
+
+def attach_rulebook(t: torch.Tensor, rb: Rulebook) -> torch.Tensor:
+    """Side channel for the reference-shaped op signatures below: a bare pair tensor
+    remembers (weakly, to avoid a tensor<->rulebook cycle) the rulebook it belongs to."""
+    t._spx_rulebook = weakref.ref(rb)
+    return t
+
+
+def rulebook_of(t: torch.Tensor) -> Optional[Rulebook]:
+    ref = getattr(t, "_spx_rulebook", None)
+    return ref() if ref is not None else None
+
+
+_attach = attach_rulebook
+
+
+def get_indice_pairs(indices: torch.Tensor, batch_size: int, spatial_shape: List[int],
+                     algo: ConvAlgo, ksize: List[int], stride: List[int], padding: List[int],
+                     dilation: List[int], out_padding: List[int], subm: bool = False,
+                     transpose: bool = False, num_out_act_bound: int = -1):
+    """Returns (out_inds, pair [2, kv, N_in], indice_num_per_loc [kv]) -- ConvAlgo.Native layout."""
+    rb, _ = build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation,
+                           out_padding, subm, transpose)
+    return rb.out_indices, _attach(rb.pair_native, rb), rb.num_per_loc
+
+
+def get_indice_pairs_implicit_gemm(indices: torch.Tensor, batch_size: int,
+                                   spatial_shape: List[int], algo: ConvAlgo, ksize: List[int],
+                                   stride: List[int], padding: List[int], dilation: List[int],
+                                   out_padding: List[int], subm: bool = False,
+                                   transpose: bool = False, is_train: bool = True, alloc=None,
+                                   timer=None, num_out_act_bound: int = -1,
+                                   direct_table: bool = True, do_sort: bool = SPCONV_DO_SORT):
+    """Returns the reference's 9-tuple (ops.py:347-359):
+    (out_inds, num_inds_per_loc, pair_fwd, pair_bwd, pair_mask_fwd_splits, pair_mask_bwd_splits,
+     mask_argsort_fwd_splits, mask_argsort_bwd_splits, masks)."""
+    assert algo in (ConvAlgo.MaskImplicitGemm, ConvAlgo.MaskSplitImplicitGemm), "TODO"
+    kv = _kv(ksize)
+    rb, _ = build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation,
+                           out_padding, subm, transpose, need_bwd_table=subm and is_train,
+                           do_sort=do_sort and kv <= 32)
+    masks = [np.array([0xffffffff], dtype=np.uint32)]
+    arg_fwd = rb.argsort_fwd if rb.argsort_fwd is not None else torch.arange(
+        rb.n_out, dtype=torch.int32, device=indices.device)
+    pair_fwd = _attach(rb.pair_fwd, rb)
+    if subm:
+        pair_bwd = rb.pair_bwd if (is_train and rb.pair_bwd is not None) else torch.Tensor()
+        return (rb.out_indices, rb.num_per_loc, pair_fwd, pair_bwd, [rb.mask_fwd], [], [arg_fwd],
+                [], masks)
+    arg_bwd = rb.argsort_bwd if rb.argsort_bwd is not None else torch.arange(
+        rb.n_in, dtype=torch.int32, device=indices.device)
+    return (rb.out_indices, rb.num_per_loc, pair_fwd, rb.pair_bwd, [rb.mask_fwd], [rb.mask_bwd],
+            [arg_fwd], [arg_bwd], masks)
+
+
+# ------------------------------------------------------------ conv primitives
+def _check_feat(features: torch.Tensor, filters: torch.Tensor):
+    _require_gpu(features, "features")
+    if features.dtype != filters.dtype:
+        raise TypeError(f"features ({features.dtype}) and filters ({filters.dtype}) must share a dtype")
+    if features.dtype in (torch.int8, torch.qint8):
+        raise NotImplementedError("int8 inference is not implemented yet")
+
+
+def igemm_fwd(features: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
+              mask: Optional[torch.Tensor], argsort: Optional[torch.Tensor], n_out: int,
+              identity_k: int = -1, bias: Optional[torch.Tensor] = None,
+              act_type: int = Activation.None_, act_alpha: float = 0.0) -> torch.Tensor:
+    """out[o] = act(bias + sum_k feat[pair[k][o]] @ W[:, k, :].T); filters KRSC."""
+    _check_feat(features, filters)
+    L = _lib.load()
+    features = features.contiguous()
+    filters = filters.contiguous()
+    K, C = filters.shape[0], filters.shape[-1]
+    kv = filters.numel() // (K * C)
+    assert features.shape[1] == C, "channel size mismatch"
+    out = torch.empty((n_out, K), dtype=features.dtype, device=features.device)
+    if bias is not None:
+        bias = bias.to(features.dtype).contiguous()
+    _lib.check(L.spx_igemm_fwd(features.data_ptr(), filters.data_ptr(), out.data_ptr(),
+                               _ptr(pair), _ptr(mask), _ptr(argsort), features.shape[0], n_out,
+                               C, K, kv, _dtype_code(features), identity_k, _ptr(bias),
+                               int(act_type), float(act_alpha), _stream(features)))
+    return out
+
+
+def igemm_dgrad(out_bp: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
+                mask: Optional[torch.Tensor], argsort: Optional[torch.Tensor], n_in: int,
+                subm: bool) -> torch.Tensor:
+    """din[i] = sum_k dout[pair[k][i]] @ W[:, k, :] (SubM: pass the forward table, subm=True)."""
+    _check_feat(out_bp, filters)
+    L = _lib.load()
+    out_bp = out_bp.contiguous()
+    filters = filters.contiguous()
+    K, C = filters.shape[0], filters.shape[-1]
+    kv = filters.numel() // (K * C)
+    din = torch.empty((n_in, C), dtype=out_bp.dtype, device=out_bp.device)
+    code = _dtype_code(out_bp)
+    ws = _ws(L.spx_igemm_dgrad_ws_bytes(C, K, kv, code), out_bp.device)
+    _lib.check(L.spx_igemm_dgrad(out_bp.data_ptr(), filters.data_ptr(), din.data_ptr(), _ptr(pair),
+                                 _ptr(mask), _ptr(argsort), out_bp.shape[0], n_in, C, K, kv, code,
+                                 int(subm), ws.data_ptr(), ws.numel(), _stream(out_bp)))
+    return din
+
+
+def igemm_wgrad(features: torch.Tensor, out_bp: torch.Tensor, filters_shape, native: torch.Tensor,
+                num_per_loc: torch.Tensor, subm: bool) -> torch.Tensor:
+    """dW[:, k, :] = sum_j dout[native[1][k][j]].T (x) feat[native[0][k][j]]."""
+    _require_gpu(features, "features")
+    L = _lib.load()
+    features = features.contiguous()
+    out_bp = out_bp.contiguous()
+    K, C = filters_shape[0], filters_shape[-1]
+    kv = int(np.prod(filters_shape)) // (K * C)
+    n_in = native.shape[2]
+    dw = torch.empty(tuple(filters_shape), dtype=features.dtype, device=features.device)
+    ws = _ws(L.spx_igemm_wgrad_ws_bytes(n_in, C, K, kv), features.device)
+    _lib.check(L.spx_igemm_wgrad(features.data_ptr(), out_bp.data_ptr(), dw.data_ptr(),
+                                 native.data_ptr(), num_per_loc.data_ptr(), n_in, out_bp.shape[0],
+                                 C, K, kv, _dtype_code(features), int(subm), ws.data_ptr(),
+                                 ws.numel(), _stream(features)))
+    return dw
+
+
+def bias_act_inplace(out: torch.Tensor, bias: Optional[torch.Tensor], act_type: int,
+                     act_alpha: float = 0.0) -> torch.Tensor:
+    """InferenceOps.bias_add_act_inplace & friends (csrc/sparse/inference.py:26-146)."""
+    L = _lib.load()
+    if bias is not None:
+        bias = bias.to(out.dtype).contiguous()
+    _lib.check(L.spx_bias_act_inplace(out.data_ptr(), _ptr(bias), out.shape[0], out.shape[1],
+                                      _dtype_code(out), int(act_type), float(act_alpha),
+                                      _stream(out)))
+    return out
+
+
+# ----------------------------------------- layout conversion for bare tensors
+def _table_from_native(indice_pairs: torch.Tensor, indice_pair_num: torch.Tensor, n_dst: int,
+                       subm: bool, inverse: bool):
+    L = _lib.load()
+    kv, n_in = indice_pairs.shape[1], indice_pairs.shape[2]
+    table = torch.empty((kv, n_dst), dtype=torch.int32, device=indice_pairs.device)
+    mask = torch.empty((n_dst, (kv + 31) // 32), dtype=torch.int32, device=indice_pairs.device)
+    _lib.check(L.spx_native_to_table(indice_pairs.data_ptr(), indice_pair_num.data_ptr(), n_in,
+                                     n_dst, kv, int(subm), int(inverse), table.data_ptr(),
+                                     mask.data_ptr(), _stream(indice_pairs)))
+    return table, mask
+
+
+def _native_from_table(table: torch.Tensor, subm: bool):
+    L = _lib.load()
+    kv, n = table.shape
+    native = torch.empty((2, kv, n), dtype=torch.int32, device=table.device)
+    num = torch.empty((kv,), dtype=torch.int32, device=table.device)
+    ws = _ws(L.spx_table_to_native_ws_bytes(n, kv), table.device)
+    _lib.check(L.spx_table_to_native(table.data_ptr(), int(subm), kv, n, native.data_ptr(),
+                                     num.data_ptr(), ws.data_ptr(), ws.numel(), _stream(table)))
+    return native, num
+
+
+# ------------------------------------------- reference-shaped public op API
+def indice_conv(features: torch.Tensor, filters: torch.Tensor, indice_pairs: torch.Tensor,
+                indice_pair_num: torch.Tensor, num_activate_out: int, inverse: bool = False,
+                subm: bool = False, algo: ConvAlgo = ConvAlgo.Native, timer=None,
+                bias: Optional[torch.Tensor] = None, act_alpha: float = 0.0,
+                act_beta: float = 0.0, act_type: int = Activation.None_) -> torch.Tensor:
+    """ConvAlgo.Native forward (ops.py:811-1095) on the Native lists [2, kv, N_in]."""
+    _check_feat(features, filters)
+    rb: Optional[Rulebook] = rulebook_of(indice_pairs)
+    kv = indice_pairs.shape[1]
+    if rb is not None and not inverse:
+        table, mask = rb.pair_fwd, rb.mask_fwd
+    elif rb is not None and inverse and rb.pair_bwd is not None:
+        table, mask = rb.pair_bwd, rb.mask_bwd
+    else:
+        table, mask = _table_from_native(indice_pairs, indice_pair_num, num_activate_out, subm, inverse)
+    return igemm_fwd(features, filters, table, mask, None, num_activate_out,
+                     kv // 2 if subm else -1, bias, act_type, act_alpha)
+
+
+def indice_conv_backward(features: torch.Tensor, filters: torch.Tensor, out_bp: torch.Tensor,
+                         indice_pairs: torch.Tensor, indice_pair_num: torch.Tensor,
+                         inverse: bool = False, subm: bool = False,
+                         algo: ConvAlgo = ConvAlgo.Native, timer=None):
+    """ConvAlgo.Native backward (ops.py:1103-1447): returns (din, dfilters)."""
+    _check_feat(features, filters)
+    rb: Optional[Rulebook] = rulebook_of(indice_pairs)
+    n_in = features.shape[0]
+    if subm:
+        if rb is not None:
+            table, mask = rb.pair_fwd, rb.mask_fwd
+        else:
+            table, mask = _table_from_native(indice_pairs, indice_pair_num, n_in, True, False)
+        din = igemm_dgrad(out_bp, filters, table, mask, None, n_in, True)
+    else:
+        # dgrad gathers dout rows for every input row: the table indexed by the conv's input
+        if rb is not None and not inverse:
+            table, mask = rb.pair_bwd, rb.mask_bwd
+        elif rb is not None and inverse:
+            table, mask = rb.pair_fwd, rb.mask_fwd
+        else:
+            table, mask = _table_from_native(indice_pairs, indice_pair_num, n_in, False, not inverse)
+        din = igemm_dgrad(out_bp, filters, table, mask, None, n_in, False)
+    native = indice_pairs
+    if inverse:
+        native = rb.native_swapped() if rb is not None else torch.stack(
+            [indice_pairs[1], indice_pairs[0]]).contiguous()
+    dw = igemm_wgrad(features, out_bp, filters.shape, native, indice_pair_num, subm)
+    return din, dw
+
+
+def implicit_gemm(features: torch.Tensor, filters: torch.Tensor, pair_fwd: torch.Tensor,
+                  pair_mask_fwd_splits: List[torch.Tensor],
+                  mask_argsort_fwd_splits: List[torch.Tensor], num_activate_out: int,
+                  masks: List[np.ndarray], is_train: bool, is_subm: bool, timer=None,
+                  fp32_accum: Optional[bool] = None, bias: Optional[torch.Tensor] = None,
+                  act_alpha: float = 0.0, act_beta: float = 0.0,
+                  act_type: int = Activation.None_, output_scale: float = 1.0,
+                  scale: Optional[torch.Tensor] = None, output_add: Optional[torch.Tensor] = None,
+                  output_add_scale: float = 0.0, output_dtype: Optional[torch.dtype] = None):
+    """Masked implicit GEMM forward (ops.py:1450-1664).  Returns (out, mask_out, mask_width);
+    the last two exist for signature parity (this wgrad does not consume tile masks)."""
+    if scale is not None or output_add is not None:
+        raise NotImplementedError("int8 epilogue (scale / output_add) is not implemented yet")
+    mask = pair_mask_fwd_splits[0] if pair_mask_fwd_splits else None
+    rb: Optional[Rulebook] = rulebook_of(pair_fwd)
+    argsort = rb.argsort_fwd if rb is not None else None
+    kv = pair_fwd.shape[0]
+    out = igemm_fwd(features, filters, pair_fwd, mask, argsort, num_activate_out,
+                    kv // 2 if is_subm else -1, bias, act_type, act_alpha)
+    return out, None, -1
+
+
+def implicit_gemm_backward(features: torch.Tensor, filters: torch.Tensor, out_bp: torch.Tensor,
+                           pair_fwd: torch.Tensor, pair_bwd: torch.Tensor,
+                           pair_mask_fwd_splits: List[torch.Tensor],
+                           pair_mask_bwd_splits: List[torch.Tensor],
+                           mask_argsort_fwd_splits: List[torch.Tensor],
+                           mask_argsort_bwd_splits: List[torch.Tensor],
+                           mask_output_fwd: Optional[torch.Tensor], masks: List[np.ndarray],
+                           mask_width: int, is_subm: bool, timer=None,
+                           fp32_accum: Optional[bool] = None):
+    """Masked implicit GEMM backward (ops.py:1667-1896): returns (din, dfilters)."""
+    rb: Optional[Rulebook] = rulebook_of(pair_fwd)
+    n_in = features.shape[0]
+    if is_subm:
+        din = igemm_dgrad(out_bp, filters, pair_fwd, pair_mask_fwd_splits[0],
+                          rb.argsort_fwd if rb is not None else None, n_in, True)
+    else:
+        din = igemm_dgrad(out_bp, filters, pair_bwd, pair_mask_bwd_splits[0],
+                          rb.argsort_bwd if rb is not None else None, n_in, False)
+    if rb is not None and rb.pair_native is not None:
+        native, num = rb.pair_native, rb.num_per_loc
+    else:
+        native, num = _native_from_table(pair_fwd if is_subm else pair_bwd, is_subm)
+    dw = igemm_wgrad(features, out_bp, filters.shape, native, num, is_subm)
+    return din, dw

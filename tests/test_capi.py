@@ -1,0 +1,86 @@
+"""CPU: the C-ABI library loads and exports every symbol include/spconv_amd.h declares;
+host-only entry points behave (no kernel is launched in this file)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from spconv_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "spconv_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(spx_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.load()
+
+
+def test_header_and_binding_agree():
+    assert _declared() == sorted(_lib.SIGNATURES)
+
+
+def test_every_declared_symbol_is_exported(lib):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    missing = [s for s in _declared() if s not in exported]
+    assert not missing, missing
+    for s in _declared():
+        assert getattr(lib, s) is not None
+
+
+def test_no_torch_or_oracle_dependency():
+    """The boundary is a plain C ABI: the shared object links the HIP runtime only."""
+    out = subprocess.check_output(["readelf", "-d", _lib.LIB_PATH], text=True)
+    needed = re.findall(r"NEEDED.*\[(.*?)\]", out)
+    assert any("amdhip64" in n for n in needed)
+    assert not any(("torch" in n) or ("c10" in n) or ("oracle" in n) for n in needed), needed
+
+
+def test_version_and_error_channel(lib):
+    assert lib.spx_version() >= 1000
+    out = (ctypes.c_int * 3)()
+    rc = lib.spx_conv_out_shape(7, _lib.ints([1] * 3), _lib.ints([1] * 3), _lib.ints([1] * 3),
+                                _lib.ints([0] * 3), _lib.ints([1] * 3), _lib.ints([0] * 3), 0, out)
+    assert rc != 0 and b"ndim" in lib.spx_last_error()
+    with pytest.raises(RuntimeError, match="ndim"):
+        _lib.check(rc)
+
+
+def test_conv_out_shape_matches_oracle(lib):
+    import oracle
+    cases = [([41, 1600, 1408], [3] * 3, [2] * 3, [1] * 3, [1] * 3, [0] * 3, 0),
+             ([21, 800, 704], [3, 1, 1], [2, 1, 1], [0] * 3, [1] * 3, [0] * 3, 0),
+             ([19, 18, 17], [3] * 3, [1] * 3, [0] * 3, [3] * 3, [0] * 3, 0),
+             ([10, 9, 9], [3] * 3, [2] * 3, [1] * 3, [1] * 3, [1] * 3, 1),
+             ([2, 2, 2], [3] * 3, [2] * 3, [0] * 3, [1] * 3, [0] * 3, 0)]
+    for shape, k, s, p, d, op, tr in cases:
+        out = (ctypes.c_int * 3)()
+        assert lib.spx_conv_out_shape(3, _lib.ints(shape), _lib.ints(k), _lib.ints(s), _lib.ints(p),
+                                      _lib.ints(d), _lib.ints(op), tr, out) == 0
+        assert list(out) == oracle.conv_out_shape(shape, k, s, p, d, op, bool(tr))
+
+
+def test_workspace_size_queries(lib):
+    assert lib.spx_subm_rulebook_ws_bytes(100_000, 27) > 100_000 * 2 * 12
+    assert lib.spx_conv_rulebook_ws_bytes(100_000, 3, _lib.ints([3] * 3), _lib.ints([2] * 3), 0) > 0
+    assert lib.spx_igemm_dgrad_ws_bytes(64, 64, 27, _lib.DTYPE_F16) == 64 * 64 * 27 * 2
+    assert lib.spx_igemm_wgrad_ws_bytes(100_000, 64, 64, 27) % 256 == 0
+    assert lib.spx_mask_argsort_ws_bytes(100_000) > 0
+    assert lib.spx_table_to_native_ws_bytes(100_000, 27) > 0
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libspconv_amd.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()

@@ -1,0 +1,236 @@
+"""GPU parity of the convolution kernels (forward, dgrad, wgrad) against the CPU
+oracle (restating spconv/pytorch/ops.py:888-988,1164-1253) and, at module level,
+against dense torch conv3d -- the reference's own test oracle
+(test/test_conv.py:286-357).
+
+Tolerances: fp32 features 1e-3 relative (north_star); fp16 / bf16 compare against
+the fp32 oracle evaluated on the SAME rounded inputs, so the only differences are
+accumulation order and the final rounding of the 16-bit output
+(2^-11 = 4.9e-4 for fp16, 2^-8 = 3.9e-3 for bf16, relative to the value)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from util import dense_scene, gpu_rulebook, oracle_rulebook, rel_err, scene, to_np
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 1e-3, torch.float16: 2e-3, torch.bfloat16: 1.2e-2}
+
+
+def _rounded(a: np.ndarray, dtype) -> torch.Tensor:
+    """fp32 tensor holding values representable in `dtype`."""
+    return torch.from_numpy(a).to(dtype).to(torch.float32)
+
+
+def _case(shape, n, bs, C, K, ksize, stride, pad, dil, subm, dtype, seed=0, transposed=False,
+          dense=True):
+    rng = np.random.default_rng(seed)
+    idx = dense_scene(shape, n, bs, seed) if dense else scene(shape, n, bs, seed)
+    ref = oracle_rulebook(idx, bs, shape, ksize, stride, pad, dil, subm, transposed)
+    f = _rounded(rng.uniform(-1, 1, (idx.shape[0], C)).astype(np.float32), dtype)
+    w = _rounded(rng.uniform(-1, 1, (K, *ksize, C)).astype(np.float32), dtype)
+    dout = _rounded(rng.uniform(-0.2, 0.2, (ref["n_out"], K)).astype(np.float32), dtype)
+    return idx, ref, f, w, dout
+
+
+def _run_gpu(cuda, idx, bs, shape, ksize, stride, pad, dil, subm, transposed, f, w, dout, dtype,
+             use_sort=False):
+    from spconv_amd.pytorch import ops
+    rb, _ = gpu_rulebook(idx, bs, shape, ksize, stride, pad, dil, subm, transposed,
+                         do_sort=use_sort)
+    fg, wg, dg = f.to(cuda, dtype), w.to(cuda, dtype), dout.to(cuda, dtype)
+    kv = rb.kv
+    out = ops.igemm_fwd(fg, wg, rb.pair_fwd, rb.mask_fwd, rb.argsort_fwd, rb.n_out,
+                        kv // 2 if subm else -1)
+    if subm:
+        din = ops.igemm_dgrad(dg, wg, rb.pair_fwd, rb.mask_fwd, rb.argsort_fwd, rb.n_in, True)
+    else:
+        din = ops.igemm_dgrad(dg, wg, rb.pair_bwd, rb.mask_bwd, rb.argsort_bwd, rb.n_in, False)
+    dw = ops.igemm_wgrad(fg, dg, wg.shape, rb.pair_native, rb.num_per_loc, subm)
+    torch.cuda.synchronize()
+    return rb, out.float().cpu(), din.float().cpu(), dw.float().cpu()
+
+
+def _check(name, got, ref, tol):
+    e = rel_err(got.numpy(), ref.numpy())
+    assert e <= tol, f"{name}: rel err {e:.3e} > {tol:.1e}"
+
+
+CONV_CASES = [
+    # shape, n, bs, C, K, ksize, stride, pad, dil, subm
+    ([64, 64, 64], 5000, 1, 16, 16, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True),     # cfg 1
+    ([24, 24, 24], 2500, 2, 64, 64, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True),     # cfg 2 channels
+    ([24, 24, 24], 2500, 2, 32, 64, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True),
+    ([24, 24, 24], 2500, 1, 128, 32, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True),
+    ([24, 24, 24], 1500, 1, 64, 128, [3] * 3, [1] * 3, [2] * 3, [2] * 3, True),
+    ([24, 24, 24], 2500, 2, 16, 32, [3] * 3, [2] * 3, [1] * 3, [1] * 3, False),    # cfg 3 chain
+    ([24, 24, 24], 2500, 2, 32, 64, [3] * 3, [2] * 3, [1] * 3, [1] * 3, False),
+    ([24, 24, 24], 2500, 1, 64, 128, [3] * 3, [2] * 3, [1] * 3, [1] * 3, False),
+    ([24, 24, 24], 2000, 1, 64, 64, [3, 1, 1], [2, 1, 1], [0] * 3, [1] * 3, False),
+    ([24, 24, 24], 2000, 1, 64, 64, [2] * 3, [2] * 3, [0] * 3, [1] * 3, False),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape,n,bs,C,K,ksize,stride,pad,dil,subm", CONV_CASES)
+def test_conv_fwd_bwd_vs_oracle(cuda, shape, n, bs, C, K, ksize, stride, pad, dil, subm, dtype):
+    idx, ref, f, w, dout = _case(shape, n, bs, C, K, ksize, stride, pad, dil, subm, dtype)
+    out_ref = oracle.indice_conv(f, w, ref["pair"], ref["num"], ref["n_out"], subm=subm)
+    din_ref, dw_ref = oracle.indice_conv_backward(f, w, dout, ref["pair"], ref["num"], subm=subm)
+    rb, out, din, dw = _run_gpu(cuda, idx, bs, shape, ksize, stride, pad, dil, subm, False, f, w,
+                                dout, dtype)
+    tol = TOL[dtype]
+    _check("out", out, out_ref, tol)
+    _check("din", din, din_ref, tol)
+    _check("dw", dw, dw_ref, tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_odd_channels_use_generic_kernels(cuda, dtype):
+    """C=5 (raw voxel features) and K=24 are outside the MFMA tile set."""
+    shape = [20, 20, 20]
+    for C, K in ((5, 16), (16, 24), (3, 7)):
+        idx, ref, f, w, dout = _case(shape, 1200, 1, C, K, [3] * 3, [1] * 3, [1] * 3, [1] * 3,
+                                     True, dtype)
+        out_ref = oracle.indice_conv(f, w, ref["pair"], ref["num"], ref["n_out"], subm=True)
+        din_ref, dw_ref = oracle.indice_conv_backward(f, w, dout, ref["pair"], ref["num"], subm=True)
+        _, out, din, dw = _run_gpu(cuda, idx, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True,
+                                   False, f, w, dout, dtype)
+        _check("out", out, out_ref, TOL[dtype])
+        _check("din", din, din_ref, TOL[dtype])
+        _check("dw", dw, dw_ref, TOL[dtype])
+
+
+def test_large_kernel_volume_two_mask_words(cuda):
+    shape = [20, 20, 20]
+    ksize = [5, 3, 3]
+    idx, ref, f, w, dout = _case(shape, 1500, 1, 16, 16, ksize, [1] * 3, [2, 1, 1], [1] * 3, True,
+                                 torch.float32)
+    out_ref = oracle.indice_conv(f, w, ref["pair"], ref["num"], ref["n_out"], subm=True)
+    din_ref, dw_ref = oracle.indice_conv_backward(f, w, dout, ref["pair"], ref["num"], subm=True)
+    _, out, din, dw = _run_gpu(cuda, idx, 1, shape, ksize, [1] * 3, [2, 1, 1], [1] * 3, True, False,
+                               f, w, dout, torch.float32)
+    _check("out", out, out_ref, 1e-3)
+    _check("din", din, din_ref, 1e-3)
+    _check("dw", dw, dw_ref, 1e-3)
+
+
+@pytest.mark.parametrize("subm", [True, False])
+def test_mask_sorted_order_gives_same_result(cuda, subm):
+    """mask_argsort only permutes which workgroup owns a row; results must not change."""
+    shape = [24, 24, 24]
+    stride = [1] * 3 if subm else [2] * 3
+    idx, ref, f, w, dout = _case(shape, 2500, 2, 64, 64, [3] * 3, stride, [1] * 3, [1] * 3, subm,
+                                 torch.float16)
+    a = _run_gpu(cuda, idx, 2, shape, [3] * 3, stride, [1] * 3, [1] * 3, subm, False, f, w, dout,
+                 torch.float16, use_sort=False)
+    b = _run_gpu(cuda, idx, 2, shape, [3] * 3, stride, [1] * 3, [1] * 3, subm, False, f, w, dout,
+                 torch.float16, use_sort=True)
+    assert b[0].argsort_fwd is not None
+    for x, y in zip(a[1:], b[1:]):
+        torch.testing.assert_close(x, y, rtol=0, atol=0)
+
+
+def test_transposed_and_inverse_conv(cuda):
+    from spconv_amd.pytorch import ops
+    shape = [10, 9, 9]
+    ksize, stride, pad, dil = [3] * 3, [2] * 3, [1] * 3, [1] * 3
+    # transposed conv: same kernels, rulebook built with transposed coordinates
+    idx, ref, f, w, dout = _case(shape, 400, 2, 16, 32, ksize, stride, pad, dil, False,
+                                 torch.float32, transposed=True, dense=False)
+    out_ref = oracle.indice_conv(f, w, ref["pair"], ref["num"], ref["n_out"])
+    din_ref, dw_ref = oracle.indice_conv_backward(f, w, dout, ref["pair"], ref["num"])
+    _, out, din, dw = _run_gpu(cuda, idx, 2, shape, ksize, stride, pad, dil, False, True, f, w,
+                               dout, torch.float32)
+    _check("deconv out", out, out_ref, 1e-3)
+    _check("deconv din", din, din_ref, 1e-3)
+    _check("deconv dw", dw, dw_ref, 1e-3)
+    # inverse conv over a regular conv's rulebook (conv.py:348-363 role swap)
+    shape = [20, 20, 20]
+    idx, ref, f, w, _ = _case(shape, 1500, 1, 16, 32, ksize, stride, pad, dil, False, torch.float32)
+    rng = np.random.default_rng(4)
+    g = torch.from_numpy(rng.uniform(-1, 1, (ref["n_out"], 32)).astype(np.float32))    # features at conv outputs
+    wi = torch.from_numpy(rng.uniform(-1, 1, (16, 3, 3, 3, 32)).astype(np.float32))    # 32 -> 16
+    dinv = torch.from_numpy(rng.uniform(-0.2, 0.2, (ref["n_in"], 16)).astype(np.float32))
+    out_ref = oracle.indice_conv(g, wi, ref["pair"], ref["num"], ref["n_in"], inverse=True)
+    din_ref, dw_ref = oracle.indice_conv_backward(g, wi, dinv, ref["pair"], ref["num"], inverse=True)
+    rb, _ = gpu_rulebook(idx, 1, shape, ksize, stride, pad, dil, False)
+    pair = ops.attach_rulebook(rb.pair_native, rb)
+    out = ops.indice_conv(g.to(cuda), wi.to(cuda), pair, rb.num_per_loc, rb.n_in, inverse=True)
+    din, dw = ops.indice_conv_backward(g.to(cuda), wi.to(cuda), dinv.to(cuda), pair, rb.num_per_loc,
+                                       inverse=True)
+    _check("inverse out", out.cpu(), out_ref, 1e-3)
+    _check("inverse din", din.cpu(), din_ref, 1e-3)
+    _check("inverse dw", dw.cpu(), dw_ref, 1e-3)
+    # same through bare tensors (layout-conversion path, no attached rulebook)
+    bare = rb.pair_native.clone()
+    out2 = ops.indice_conv(g.to(cuda), wi.to(cuda), bare, rb.num_per_loc, rb.n_in, inverse=True)
+    din2, dw2 = ops.indice_conv_backward(g.to(cuda), wi.to(cuda), dinv.to(cuda), bare,
+                                         rb.num_per_loc, inverse=True)
+    torch.testing.assert_close(out2, out, rtol=0, atol=0)
+    torch.testing.assert_close(din2, din, rtol=0, atol=0)
+    torch.testing.assert_close(dw2, dw, rtol=0, atol=0)
+
+
+def test_fused_bias_activation(cuda):
+    from spconv_amd.pytorch import ops
+    shape = [20, 20, 20]
+    for dtype in (torch.float32, torch.float16):
+        idx, ref, f, w, _ = _case(shape, 1500, 1, 32, 64, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True, dtype)
+        bias = _rounded(np.random.default_rng(1).uniform(-1, 1, 64).astype(np.float32), dtype)
+        base = oracle.indice_conv(f, w, ref["pair"], ref["num"], ref["n_out"], subm=True) + bias
+        rb, _ = gpu_rulebook(idx, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True)
+        for act, fn in ((ops.Activation.ReLU, torch.relu),
+                        (ops.Activation.LeakyReLU, lambda x: torch.nn.functional.leaky_relu(x, 0.1)),
+                        (ops.Activation.Sigmoid, torch.sigmoid)):
+            out = ops.igemm_fwd(f.to(cuda, dtype), w.to(cuda, dtype), rb.pair_fwd, rb.mask_fwd, None,
+                                rb.n_out, 13, bias.to(cuda, dtype), act, 0.1)
+            _check(f"act{act}", out.float().cpu(), fn(base), TOL[dtype])
+            raw = ops.igemm_fwd(f.to(cuda, dtype), w.to(cuda, dtype), rb.pair_fwd, rb.mask_fwd, None,
+                                rb.n_out, 13)
+            out2 = ops.bias_act_inplace(raw, bias.to(cuda, dtype), act, 0.1)
+            _check(f"inplace act{act}", out2.float().cpu(), fn(base), 2 * TOL[dtype])
+
+
+def test_cfg2_full_size_fp16(cuda):
+    """BASELINE cfg 2 at full size (100k voxels, C=K=64, fp16) against the oracle, plus
+    linearity (a size-independent property): conv(a*f1 + f2) == a*conv(f1) + conv(f2)."""
+    from spconv_amd.pytorch import ops
+    shape = [40, 1280, 1600]
+    idx, ref, f, w, dout = _case(shape, 100_000, 1, 64, 64, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True,
+                                 torch.float16, dense=False)
+    out_ref = oracle.indice_conv(f, w, ref["pair"], ref["num"], ref["n_out"], subm=True)
+    din_ref, dw_ref = oracle.indice_conv_backward(f, w, dout, ref["pair"], ref["num"], subm=True)
+    rb, out, din, dw = _run_gpu(cuda, idx, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True, False,
+                                f, w, dout, torch.float16)
+    _check("out", out, out_ref, 2e-3)
+    _check("din", din, din_ref, 2e-3)
+    _check("dw", dw, dw_ref, 2e-3)
+    f1 = torch.randn(100_000, 64, device=cuda, dtype=torch.float32)
+    f2 = torch.randn(100_000, 64, device=cuda, dtype=torch.float32)
+    wg = w.to(cuda)
+    conv = lambda x: ops.igemm_fwd(x, wg, rb.pair_fwd, rb.mask_fwd, None, rb.n_out, 13)
+    lhs, rhs = conv(2.0 * f1 + f2), 2.0 * conv(f1) + conv(f2)
+    assert rel_err(lhs.cpu().numpy(), rhs.cpu().numpy()) < 1e-4
+
+
+def test_lidar_like_scene_fp16(cuda):
+    """Dense neighbourhoods (~5 pairs/voxel): exercises many offsets per tile."""
+    from spconv_amd.utils import synthetic
+    shape = [40, 1280, 1600]
+    idx = synthetic.lidar_like_scene(shape, 40_000, 1, seed=0)
+    ref = oracle_rulebook(idx, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True)
+    rng = np.random.default_rng(0)
+    f = _rounded(rng.uniform(-1, 1, (idx.shape[0], 64)).astype(np.float32), torch.float16)
+    w = _rounded(rng.uniform(-1, 1, (64, 3, 3, 3, 64)).astype(np.float32), torch.float16)
+    dout = _rounded(rng.uniform(-0.2, 0.2, (idx.shape[0], 64)).astype(np.float32), torch.float16)
+    out_ref = oracle.indice_conv(f, w, ref["pair"], ref["num"], ref["n_out"], subm=True)
+    din_ref, dw_ref = oracle.indice_conv_backward(f, w, dout, ref["pair"], ref["num"], subm=True)
+    for use_sort in (False, True):
+        _, out, din, dw = _run_gpu(cuda, idx, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True,
+                                   False, f, w, dout, torch.float16, use_sort=use_sort)
+        _check("out", out, out_ref, 2e-3)
+        _check("din", din, din_ref, 2e-3)
+        _check("dw", dw, dw_ref, 2e-3)

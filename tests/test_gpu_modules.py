@@ -1,0 +1,165 @@
+"""Module-level GPU tests in the style of the reference's test/test_conv.py:
+sparse modules vs dense torch conv3d on the scattered dense input
+(test_conv.py:83-109,286-357; seeds / shape from :248-274)."""
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from util import dense_scene, rel_err, scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _sparse_input(spconv, shape, n, bs, C, dev, dtype=torch.float32, seed=484, grad=False):
+    idx = scene(shape, n, bs, seed)
+    rng = np.random.default_rng(seed)
+    feat = torch.from_numpy(rng.uniform(-1, 1, (idx.shape[0], C)).astype(np.float32))
+    f = feat.to(dev, dtype).requires_grad_(grad)
+    x = spconv.SparseConvTensor(f, torch.from_numpy(idx).to(dev), shape, bs)
+    return x, f, idx, feat
+
+
+def _dense_from(feat, idx, bs, shape):
+    dense = torch.zeros((bs, feat.shape[1], *shape), dtype=feat.dtype, device=feat.device)
+    i = torch.from_numpy(idx.astype(np.int64)).to(feat.device)
+    dense[i[:, 0], :, i[:, 1], i[:, 2], i[:, 3]] = feat
+    return dense
+
+
+@pytest.mark.parametrize("k,s,p,d", [(3, 1, 1, 1), (3, 2, 1, 1), (2, 2, 0, 1), (3, 1, 0, 2),
+                                      (3, 3, 2, 1), (2, 1, 0, 1)])
+@pytest.mark.parametrize("K", [32, 48])
+def test_sparse_conv3d_matches_dense(cuda, k, s, p, d, K):
+    """reference test_spconv3d (test_conv.py:247-357): fwd dense(), din, dW at atol 1e-4."""
+    import spconv_amd.pytorch as spconv
+    torch.manual_seed(48848)
+    shape, bs, C = [19, 18, 17], 2, 32
+    x, f, idx, feat = _sparse_input(spconv, shape, 1500, bs, C, cuda, grad=True)
+    net = spconv.SparseConv3d(C, K, k, s, p, d, bias=False).to(cuda)
+    ref = nn.Conv3d(C, K, k, s, p, d, bias=False).to(cuda)
+    with torch.no_grad():   # KRSC -> KCRS
+        ref.weight.copy_(net.weight.permute(0, 4, 1, 2, 3))
+    out = net(x)
+    dense_in = _dense_from(feat.to(cuda), idx, bs, shape).requires_grad_(True)
+    out_ref = ref(dense_in)
+    got = out.dense()
+    assert got.shape == out_ref.shape
+    assert (got - out_ref).abs().max().item() < 1e-4 * max(1.0, out_ref.abs().max().item())
+    dout = torch.from_numpy(np.random.default_rng(1).uniform(-0.2, 0.2, out_ref.shape)
+                            .astype(np.float32)).to(cuda)
+    out_ref.backward(dout)
+    oi = out.indices.long()
+    out.features.backward(dout[oi[:, 0], :, oi[:, 1], oi[:, 2], oi[:, 3]])
+    ii = torch.from_numpy(idx.astype(np.int64)).to(cuda)
+    din_ref = dense_in.grad[ii[:, 0], :, ii[:, 1], ii[:, 2], ii[:, 3]]
+    assert rel_err(f.grad.cpu().numpy(), din_ref.cpu().numpy()) < 1e-4
+    dw_ref = ref.weight.grad.permute(0, 2, 3, 4, 1)
+    assert rel_err(net.weight.grad.cpu().numpy(), dw_ref.cpu().numpy()) < 1e-4
+
+
+def test_subm_conv3d_matches_dense_at_active_sites(cuda):
+    import spconv_amd.pytorch as spconv
+    torch.manual_seed(0)
+    shape, bs, C, K = [19, 18, 17], 2, 16, 32
+    x, f, idx, feat = _sparse_input(spconv, shape, 1500, bs, C, cuda, grad=True)
+    net = spconv.SubMConv3d(C, K, 3, bias=True, indice_key="subm0").to(cuda)
+    ref = nn.Conv3d(C, K, 3, 1, 1, bias=True).to(cuda)
+    with torch.no_grad():
+        ref.weight.copy_(net.weight.permute(0, 4, 1, 2, 3))
+        ref.bias.copy_(net.bias)
+    out = net(x)
+    assert out.indices.data_ptr() == x.indices.data_ptr() and "subm0" in out.indice_dict
+    dense_in = _dense_from(feat.to(cuda), idx, bs, shape).requires_grad_(True)
+    ii = torch.from_numpy(idx.astype(np.int64)).to(cuda)
+    out_ref = ref(dense_in)[ii[:, 0], :, ii[:, 1], ii[:, 2], ii[:, 3]]
+    assert rel_err(out.features.detach().cpu().numpy(), out_ref.detach().cpu().numpy()) < 1e-4
+    dout = torch.randn_like(out_ref) * 0.1
+    out_ref.backward(dout)
+    out.features.backward(dout)
+    assert rel_err(f.grad.cpu().numpy(),
+                   dense_in.grad[ii[:, 0], :, ii[:, 1], ii[:, 2], ii[:, 3]].cpu().numpy()) < 1e-4
+    assert rel_err(net.weight.grad.cpu().numpy(),
+                   ref.weight.grad.permute(0, 2, 3, 4, 1).cpu().numpy()) < 1e-4
+    assert rel_err(net.bias.grad.cpu().numpy(), ref.bias.grad.cpu().numpy()) < 1e-4
+
+
+def test_backbone_stack_trains_and_reuses_rulebooks(cuda):
+    """SECOND-style stage: SubM x2 sharing one indice_key, stride-2 SparseConv3d, inverse conv
+    back to the input coordinates; BN + ReLU applied through SparseSequential."""
+    import spconv_amd.pytorch as spconv
+    torch.manual_seed(1)
+    shape, bs = [41, 64, 64], 2
+    x, f, idx, _ = _sparse_input(spconv, shape, 6000, bs, 16, cuda)
+    net = spconv.SparseSequential(
+        spconv.SubMConv3d(16, 16, 3, bias=False, indice_key="subm1"),
+        nn.BatchNorm1d(16), nn.ReLU(),
+        spconv.SubMConv3d(16, 16, 3, bias=False, indice_key="subm1"),
+        nn.BatchNorm1d(16), nn.ReLU(),
+        spconv.SparseConv3d(16, 32, 3, 2, 1, bias=False, indice_key="down1"),
+        nn.BatchNorm1d(32), nn.ReLU(),
+        spconv.SubMConv3d(32, 32, 3, bias=False, indice_key="subm2"),
+        spconv.SparseInverseConv3d(32, 16, 3, indice_key="down1", bias=False),
+    ).to(cuda)
+    spconv.assign_name_for_sparse_modules(net)
+    out = net(x)
+    assert out.features.shape == (idx.shape[0], 16) and out.spatial_shape == shape
+    assert torch.equal(out.indices, x.indices)
+    assert set(out.indice_dict) == {"subm1", "down1", "subm2"}
+    loss = out.features.square().mean()
+    loss.backward()
+    for p in net.parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all()
+    # eval mode: fused inference path gives the same numbers as the training path
+    net.eval()
+    with torch.no_grad():
+        a = net(x).features
+    net2 = net
+    for m in net2.modules():
+        if isinstance(m, spconv.SparseConvolution):
+            m.training = True     # route through autograd functions, BN stays in eval
+    with torch.no_grad():
+        b = net2(x).features
+    assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+
+
+def test_amp_autocast_runs_fp16_kernels(cuda):
+    import spconv_amd.pytorch as spconv
+    torch.manual_seed(2)
+    shape = [24, 24, 24]
+    idx = dense_scene(shape, 2500, 2, 0)
+    feat = torch.randn(idx.shape[0], 64, device=cuda, requires_grad=True)
+    x = spconv.SparseConvTensor(feat, torch.from_numpy(idx).to(cuda), shape, 2)
+    net = spconv.SubMConv3d(64, 64, 3, bias=False).to(cuda)
+    with torch.autocast("cuda", dtype=torch.float16):
+        out = net(x)
+    assert out.features.dtype == torch.float16
+    out.features.float().sum().backward()
+    assert net.weight.grad.dtype == torch.float32 and feat.grad.dtype == torch.float32
+    with torch.no_grad():
+        ref = net(x).features
+    assert rel_err(out.features.float().detach().cpu().numpy(), ref.cpu().numpy()) < 5e-3
+
+
+def test_indice_key_checks_and_errors(cuda):
+    import spconv_amd.pytorch as spconv
+    shape = [16, 16, 16]
+    x, *_ = _sparse_input(spconv, shape, 500, 1, 16, cuda)
+    a = spconv.SubMConv3d(16, 16, 3, indice_key="k").to(cuda)
+    b = spconv.SubMConv3d(16, 16, (3, 1, 3), indice_key="k").to(cuda)
+    y = a(x)
+    with pytest.raises(ValueError, match="same kernel size"):
+        b(y)
+    c = spconv.SubMConv3d(16, 16, 3, indice_key="k", algo=spconv.ConvAlgo.Native).to(cuda)
+    with pytest.raises(AssertionError, match="same algo"):
+        c(y)
+    with pytest.raises(AssertionError, match="channel size mismatch"):
+        spconv.SubMConv3d(8, 16, 3).to(cuda)(x)
+
+
+def test_install_as_spconv_alias(cuda):
+    import spconv_amd
+    spconv_amd.install_as_spconv()
+    import spconv.pytorch as spconv
+    from spconv.pytorch import SparseConvTensor, SubMConv3d  # noqa: F401
+    assert spconv.SparseConvTensor is SparseConvTensor

@@ -1,0 +1,158 @@
+"""GPU parity: rulebook artefacts must be BIT-EXACT against the CPU oracle
+(which restates spconv/csrc/sparse/indices.py:1639-1778).  All calls go through
+the C ABI (spconv_amd/_lib.py -> libspconv_amd.so)."""
+import numpy as np
+import pytest
+import torch
+
+from util import (assert_rulebook_equal, dense_scene, gpu_rulebook, oracle_rulebook, scene, to_np)
+
+pytestmark = pytest.mark.gpu
+
+SUBM_CASES = [
+    # (shape, n, bs, ksize, dilation)
+    ([64, 64, 64], 5000, 1, [3, 3, 3], [1, 1, 1]),          # BASELINE cfg 1
+    ([19, 18, 17], 1500, 2, [3, 3, 3], [1, 1, 1]),          # reference test_conv.py:248-274 shape
+    ([19, 18, 17], 1500, 2, [3, 3, 3], [2, 2, 2]),
+    ([21, 20, 19], 2000, 1, [3, 1, 3], [1, 1, 1]),
+    ([21, 20, 19], 2000, 1, [5, 3, 3], [1, 1, 1]),          # kv = 45 > 32: two mask words
+    ([40, 50], 700, 3, [3, 3], [1, 1]),                     # 2-d
+    ([300], 120, 2, [5], [1]),                              # 1-d
+    ([9, 8, 7, 6], 900, 1, [3, 3, 3, 3], [1, 1, 1, 1]),     # 4-d, kv = 81
+    ([8, 8, 8], 3, 1, [3, 3, 3], [1, 1, 1]),                # tiny
+]
+
+
+@pytest.mark.parametrize("shape,n,bs,ksize,dil", SUBM_CASES)
+def test_subm_rulebook_bit_exact(cuda, shape, n, bs, ksize, dil):
+    idx = scene(shape, n, bs, seed=3)
+    nd = len(shape)
+    pad = [(k // 2) * d for k, d in zip(ksize, dil)]
+    ref = oracle_rulebook(idx, bs, shape, ksize, [1] * nd, pad, dil, True)
+    rb, _ = gpu_rulebook(idx, bs, shape, ksize, [1] * nd, pad, dil, True, need_bwd_table=True)
+    assert_rulebook_equal(rb, ref, True)
+
+
+def test_subm_dense_neighbourhoods(cuda):
+    shape = [24, 24, 24]
+    idx = dense_scene(shape, 3000, 2, seed=5)
+    ref = oracle_rulebook(idx, 2, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True)
+    assert ref["num"].sum() > 4 * idx.shape[0]  # really dense
+    rb, _ = gpu_rulebook(idx, 2, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True,
+                         need_bwd_table=True)
+    assert_rulebook_equal(rb, ref, True)
+
+
+def test_subm_duplicates_and_deleted_rows(cuda):
+    """Duplicate coordinates: first index wins (unordered_map::insert, indices.py:1672);
+    rows with batch index outside [0, batch) only keep the centre pair (indices.py:1678-1688)."""
+    shape = [12, 12, 12]
+    idx = dense_scene(shape, 400, 1, seed=9)
+    idx = np.concatenate([idx, idx[:50], idx[10:30]], axis=0)         # duplicates
+    idx[5, 0] = -1                                                     # "deleted" point
+    idx[77, 0] = 3                                                     # batch >= batch_size
+    idx = np.ascontiguousarray(idx)
+    ref = oracle_rulebook(idx, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True)
+    rb, _ = gpu_rulebook(idx, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True,
+                         need_bwd_table=True)
+    assert_rulebook_equal(rb, ref, True)
+
+
+def test_subm_empty(cuda):
+    idx = np.zeros((0, 4), dtype=np.int32)
+    rb, _ = gpu_rulebook(idx, 1, [8, 8, 8], [3] * 3, [1] * 3, [1] * 3, [1] * 3, True)
+    assert rb.pair_fwd.shape == (27, 0) and int(rb.num_per_loc.sum()) == 0
+
+
+CONV_CASES = [
+    # (shape, n, bs, ksize, stride, padding, dilation, transposed)
+    ([19, 18, 17], 1500, 2, [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1], False),
+    ([19, 18, 17], 1500, 2, [2, 2, 2], [2, 2, 2], [0, 0, 0], [1, 1, 1], False),
+    ([19, 18, 17], 1500, 1, [3, 3, 3], [1, 1, 1], [0, 0, 0], [2, 2, 2], False),
+    ([19, 18, 17], 1500, 1, [3, 3, 3], [3, 3, 3], [2, 2, 2], [1, 1, 1], False),
+    ([19, 18, 17], 1500, 1, [3, 3, 3], [1, 1, 1], [1, 1, 1], [1, 1, 1], False),
+    ([41, 64, 64], 6000, 2, [3, 1, 1], [2, 1, 1], [0, 0, 0], [1, 1, 1], False),  # VoxelBackBone8x tail
+    ([41, 64, 64], 6000, 2, [3, 3, 3], [2, 2, 2], [0, 1, 1], [1, 1, 1], False),
+    ([10, 9, 9], 500, 2, [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1], True),       # transposed
+    ([10, 9, 9], 500, 1, [2, 2, 2], [2, 2, 2], [0, 0, 0], [1, 1, 1], True),
+    ([60, 50], 900, 2, [3, 3], [2, 2], [1, 1], [1, 1], False),                     # 2-d
+]
+
+
+@pytest.mark.parametrize("shape,n,bs,ksize,stride,pad,dil,transposed", CONV_CASES)
+def test_conv_rulebook_bit_exact(cuda, shape, n, bs, ksize, stride, pad, dil, transposed):
+    idx = scene(shape, n, bs, seed=11)
+    ref = oracle_rulebook(idx, bs, shape, ksize, stride, pad, dil, False, transposed)
+    rb, out_shape = gpu_rulebook(idx, bs, shape, ksize, stride, pad, dil, False, transposed)
+    assert list(out_shape) == list(ref["out_shape"])
+    assert_rulebook_equal(rb, ref, False)
+
+
+def test_conv_points_vanish_raises(cuda):
+    """ops.py:260-262: zero active outputs is an error, with the reference's message."""
+    idx = np.array([[0, 7, 3, 3]], dtype=np.int32)
+    with pytest.raises(ValueError, match="points vanished"):
+        gpu_rulebook(idx, 1, [8, 8, 8], [3, 3, 3], [2, 2, 2], [0, 1, 1], [1, 1, 1], False)
+
+
+def test_subm_even_kernel_raises(cuda):
+    idx = scene([8, 8, 8], 20, 1)
+    with pytest.raises(RuntimeError, match="odd ksize"):
+        gpu_rulebook(idx, 1, [8, 8, 8], [2, 2, 2], [1] * 3, [0] * 3, [1] * 3, True)
+
+
+def test_mask_argsort_is_stable_sort(cuda):
+    from spconv_amd.pytorch import ops
+    rng = np.random.default_rng(0)
+    for n in (1, 63, 2048, 2049, 50_000):
+        m = rng.integers(0, 1 << 27, size=(n, 1), dtype=np.int64).astype(np.uint32)
+        m[rng.random(n) < 0.6] = 1 << 13                          # many equal keys
+        t = torch.from_numpy(m.view(np.int32)).to(cuda)
+        perm = to_np(ops.mask_argsort(t)).astype(np.int64)
+        expect = np.argsort(m[:, 0], kind="stable")
+        np.testing.assert_array_equal(perm, expect)
+
+
+def test_layout_conversions_round_trip(cuda):
+    """spx_native_to_table / spx_table_to_native reproduce the builder's own artefacts."""
+    from spconv_amd.pytorch import ops
+    shape = [16, 16, 16]
+    idx = dense_scene(shape, 900, 2, seed=2)
+    for subm in (True, False):
+        stride = [1] * 3 if subm else [2] * 3
+        rb, _ = gpu_rulebook(idx, 2, shape, [3] * 3, stride, [1] * 3, [1] * 3, subm,
+                             need_bwd_table=True)
+        table, mask = ops._table_from_native(rb.pair_native, rb.num_per_loc, rb.n_out, subm, False)
+        np.testing.assert_array_equal(to_np(table), to_np(rb.pair_fwd))
+        np.testing.assert_array_equal(to_np(mask), to_np(rb.mask_fwd))
+        tb, _ = ops._table_from_native(rb.pair_native, rb.num_per_loc, rb.n_in, subm, True)
+        np.testing.assert_array_equal(to_np(tb), to_np(rb.pair_bwd))
+        native, num = ops._native_from_table(rb.pair_fwd if subm else rb.pair_bwd, subm)
+        np.testing.assert_array_equal(to_np(native), to_np(rb.pair_native))
+        np.testing.assert_array_equal(to_np(num), to_np(rb.num_per_loc))
+
+
+def test_full_size_properties_cfg2(cuda):
+    """BASELINE cfg 2 (100k voxels, 40x1280x1600): size-independent rulebook properties plus
+    a full comparison (the oracle still finishes in well under a second here)."""
+    shape = [40, 1280, 1600]
+    idx = scene(shape, 100_000, 1, seed=0)
+    rb, _ = gpu_rulebook(idx, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True,
+                         need_bwd_table=True)
+    fwd, bwd = to_np(rb.pair_fwd), to_np(rb.pair_bwd)
+    kv, n = fwd.shape
+    # mirror symmetry, identity centre, involution o -> i -> o
+    np.testing.assert_array_equal(bwd, fwd[::-1])
+    np.testing.assert_array_equal(fwd[kv // 2], np.arange(n))
+    k = 5
+    valid = fwd[k] >= 0
+    np.testing.assert_array_equal(fwd[kv - 1 - k][fwd[k][valid]], np.nonzero(valid)[0])
+    # masks are the column occupancy; lists are sorted by input index
+    mask = to_np(rb.mask_fwd).view(np.uint32)[:, 0]
+    np.testing.assert_array_equal(mask, ((fwd >= 0) << np.arange(kv)[:, None]).sum(0).astype(np.uint32))
+    num, native = to_np(rb.num_per_loc), to_np(rb.pair_native)
+    for kk in range(kv // 2):
+        assert num[kk] == (fwd[kk] >= 0).sum()
+        assert np.all(np.diff(native[0, kk, :num[kk]]) > 0)
+    ref = oracle_rulebook(idx, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True)
+    assert_rulebook_equal(rb, ref, True)

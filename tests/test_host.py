@@ -1,0 +1,118 @@
+"""CPU: host-side logic of the drop-in API (no kernels run)."""
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+import spconv_amd.pytorch as spconv
+from spconv_amd.pytorch import ops
+
+
+def _x(n=6, C=4, shape=(4, 5, 6), bs=2):
+    idx = torch.tensor([[i % bs, i % shape[0], (2 * i) % shape[1], (3 * i) % shape[2]] for i in range(n)],
+                       dtype=torch.int32)
+    return spconv.SparseConvTensor(torch.arange(n * C, dtype=torch.float32).view(n, C), idx, shape, bs)
+
+
+def test_sparse_conv_tensor_container():
+    x = _x()
+    assert x.spatial_shape == [4, 5, 6] and x.batch_size == 2 and x.indice_dict == {}
+    with pytest.raises(ValueError, match="replace_feature"):
+        x.features = x.features * 2
+    y = x.replace_feature(x.features + 1)
+    assert y.indices is x.indices and y.indice_dict is x.indice_dict
+    d = x.dense()
+    assert d.shape == (2, 4, 4, 5, 6)
+    i = x.indices.long()
+    assert torch.equal(d[i[:, 0], :, i[:, 1], i[:, 2], i[:, 3]], x.features)
+    assert torch.equal(x.dense(channels_first=False).permute(0, 4, 1, 2, 3), d)
+    z = x + y
+    assert torch.equal(z.features, 2 * x.features + 1)
+    s = x.select_by_index(torch.tensor([0, 2]))
+    assert s.features.shape[0] == 2 and s.indices.shape[0] == 2
+    with pytest.raises(AssertionError, match="int32"):
+        spconv.SparseConvTensor(torch.zeros(2, 3), torch.zeros(2, 4, dtype=torch.int64), [4, 4, 4], 1)
+    r = spconv.SparseConvTensor.from_dense(d.permute(0, 2, 3, 4, 1).contiguous())
+    assert r.batch_size == 2 and list(r.spatial_shape) == [4, 5, 6]
+    assert r.find_indice_pair(None) is None and r.find_indice_pair("nope") is None
+
+
+def test_module_signatures_and_weight_layout():
+    m = spconv.SubMConv3d(16, 32, 3, indice_key="a")
+    assert list(m.weight.shape) == [32, 3, 3, 3, 16] and list(m.bias.shape) == [32]   # KRSC
+    assert m.subm and m.algo == spconv.ConvAlgo.MaskImplicitGemm and m.indice_key == "a"
+    c = spconv.SparseConv3d(16, 32, (3, 1, 1), (2, 1, 1), padding=(0, 1, 1), bias=False)
+    assert c.kernel_size == [3, 1, 1] and c.stride == [2, 1, 1] and c.padding == [0, 1, 1] and c.bias is None
+    big = spconv.SubMConv3d(4, 4, 5)
+    assert big.algo == spconv.ConvAlgo.Native                   # kv = 125 > 32 (conv.py:110-120)
+    inv = spconv.SparseInverseConv3d(32, 16, 3, "a")
+    assert inv.inverse and inv.indice_key == "a"
+    t = spconv.SparseConvTranspose3d(8, 8, 3, 2)
+    assert t.transposed
+    with pytest.raises(AssertionError, match="groups"):
+        spconv.SubMConv3d(4, 4, 3, groups=2)
+    bound = 1 / np.sqrt(16 * 27)
+    assert m.bias.abs().max() <= bound and m.weight.abs().max() <= np.sqrt(6 / ((1 + 5) * 16 * 27)) + 1e-6
+    for cls, nd in ((spconv.SubMConv1d, 1), (spconv.SparseConv2d, 2), (spconv.SparseConv4d, 4)):
+        assert cls(4, 4, 3).ndim == nd and cls.__name__.endswith(f"{nd}d")
+
+
+def test_state_dict_round_trip_and_legacy_layout(monkeypatch):
+    a, b = spconv.SparseConv3d(4, 8, 3), spconv.SparseConv3d(4, 8, 3)
+    b.load_state_dict(a.state_dict())
+    assert torch.equal(a.weight, b.weight) and torch.equal(a.bias, b.bias)
+    import spconv_amd.pytorch.conv as conv_mod
+    monkeypatch.setattr(conv_mod, "SAVED_WEIGHT_LAYOUT", "RSCK")       # spconv 1.x checkpoints
+    sd = {"weight": a.weight.detach().permute(1, 2, 3, 4, 0).contiguous(), "bias": a.bias.detach()}
+    c = spconv.SparseConv3d(4, 8, 3)
+    c.load_state_dict(sd)
+    assert torch.equal(c.weight, a.weight)
+
+
+def test_sparse_sequential_routes_dense_layers_and_conv1x1():
+    x = _x(n=10, C=4)
+    net = spconv.SparseSequential(nn.Linear(4, 8), nn.ReLU(), spconv.SubMConv3d(8, 6, 1, bias=True),
+                                  spconv.SparseBatchNorm(6), spconv.SparseReLU())
+    assert len(net) == 5 and isinstance(net[2], spconv.SubMConv3d)
+    y = net(x)                                  # kv == 1 -> torch.mm shortcut, works on CPU
+    assert isinstance(y, spconv.SparseConvTensor) and y.features.shape == (10, 6)
+    w = net[2].weight
+    mid = torch.relu(net[0](x.features))
+    expect = torch.mm(mid, w.view(8, 6)) + net[2].bias           # reference quirk conv.py:232-234
+    bn = nn.BatchNorm1d(6)
+    bn.load_state_dict(net[3].state_dict())
+    assert torch.allclose(y.features, torch.relu(bn(expect)), atol=1e-5)
+    dense = spconv.SparseSequential(spconv.SubMConv3d(4, 4, 1), spconv.ToDense())(x)
+    assert dense.shape == (2, 4, 4, 5, 6)
+    spconv.assign_name_for_sparse_modules(net)
+    assert net[2]._sparse_unique_name == "2"
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    x = _x()
+    with pytest.raises(NotImplementedError, match="no CPU path"):
+        spconv.SubMConv3d(4, 4, 3)(x)
+    with pytest.raises(NotImplementedError, match="no CPU path"):
+        ops.get_indice_pairs(x.indices, 2, x.spatial_shape, spconv.ConvAlgo.Native, [3] * 3, [1] * 3,
+                             [1] * 3, [1] * 3, [0] * 3, True)
+
+
+def test_output_size_helpers_match_reference_formula():
+    assert ops.get_conv_output_size([41, 1600, 1408], [3] * 3, [2] * 3, [1] * 3, [1] * 3) == [21, 800, 704]
+    assert ops.get_conv_output_size([8, 8], [-1, 3], [1, 1], [0, 0], [1, 1]) == [1, 6]
+    assert ops.get_deconv_output_size([5, 5], [3, 3], [2, 2], [1, 1], [1, 1], [1, 1]) == [10, 10]
+    with pytest.raises(ValueError):
+        ops.get_deconv_output_size([5], [-1], [1], [0], [1], [0])
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under spconv_amd/ may reference it."""
+    import os
+    root = os.path.dirname(os.path.abspath(spconv.__file__))
+    root = os.path.dirname(root)
+    for d, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".sh")):
+                text = open(os.path.join(d, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, os.path.join(d, f)
+                assert "liboracle" not in text, os.path.join(d, f)

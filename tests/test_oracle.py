@@ -1,0 +1,185 @@
+"""CPU: pins the oracle (test infrastructure) against
+ (a) the reference's own test oracle -- dense torch conv on the scattered dense input
+     (test/test_conv.py:83-109,286-357; shape/seeds :248-274),
+ (b) the reference's numpy per-offset formula (test/test_all_algo.py:222-288),
+ (c) the committed golden fixtures (regression pin, tests/golden/make_golden.py),
+ (d) the pair statistics SURVEY.md section 0.5 measured on the reference's LiDAR fixture."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from golden import case_names, lidar_scene, load_case
+from util import scene
+
+GRID = [  # (k, s, p, d) -- subset of the reference grid test_conv.py:255-262 (skips s>1 and d>1)
+    (2, 1, 0, 1), (3, 1, 0, 1), (3, 1, 1, 1), (3, 1, 2, 1), (3, 2, 0, 1), (3, 2, 1, 1), (3, 3, 2, 1),
+    (2, 2, 0, 1), (3, 1, 1, 2), (3, 1, 0, 3), (2, 3, 1, 1),
+]
+
+
+def _sample(dense, idx):
+    i = torch.from_numpy(idx.astype(np.int64))
+    return dense[i[:, 0], :, i[:, 1], i[:, 2], i[:, 3]]
+
+
+@pytest.mark.parametrize("k,s,p,d", GRID)
+def test_regular_conv_matches_dense_conv3d(k, s, p, d):
+    rng = np.random.default_rng(484)
+    shape, bs, C, K = [19, 18, 17], 2, 8, 12
+    idx = scene(shape, 1500, bs, seed=484)
+    f = torch.from_numpy(rng.uniform(-1, 1, (idx.shape[0], C)).astype(np.float32))
+    w = torch.from_numpy(rng.uniform(-1, 1, (K, k, k, k, C)).astype(np.float32))
+    oi, pair, num, oshape = oracle.get_indice_pairs(idx, bs, shape, [k] * 3, [s] * 3, [p] * 3, [d] * 3)
+    fd, wd = f.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    dense = oracle.dense_conv_reference(fd, idx, bs, shape, wd, [s] * 3, [p] * 3, [d] * 3)
+    assert list(dense.shape[2:]) == oshape
+    out = oracle.indice_conv(f, w, pair, num, oi.shape[0])
+    ref = _sample(dense, oi)
+    assert (out - ref).abs().max() < 1e-4
+    # every dense site that is not an active output must be exactly zero
+    m = torch.ones(dense.shape[0], *dense.shape[2:], dtype=torch.bool)
+    o = torch.from_numpy(oi.astype(np.int64))
+    m[o[:, 0], o[:, 1], o[:, 2], o[:, 3]] = False
+    rest = dense.detach().permute(0, 2, 3, 4, 1)[m]
+    assert rest.numel() == 0 or rest.abs().max() == 0
+    dout = torch.from_numpy(rng.uniform(-0.2, 0.2, ref.shape).astype(np.float32))
+    ref.backward(dout)
+    din, dw = oracle.indice_conv_backward(f, w, dout, pair, num)
+    assert (din - fd.grad).abs().max() < 1e-4
+    assert (dw - wd.grad).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize("k,d", [(3, 1), (3, 2), (5, 1)])
+def test_subm_matches_dense_conv3d_at_active_sites(k, d):
+    rng = np.random.default_rng(1)
+    shape, bs, C, K = [19, 18, 17], 2, 8, 12
+    idx = scene(shape, 1500, bs, seed=1)
+    f = torch.from_numpy(rng.uniform(-1, 1, (idx.shape[0], C)).astype(np.float32))
+    w = torch.from_numpy(rng.uniform(-1, 1, (K, k, k, k, C)).astype(np.float32))
+    pad = [(k // 2) * d] * 3
+    oi, pair, num, _ = oracle.get_indice_pairs(idx, bs, shape, [k] * 3, [1] * 3, pad, [d] * 3, subm=True)
+    fd, wd = f.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = _sample(oracle.dense_conv_reference(fd, idx, bs, shape, wd, [1] * 3, pad, [d] * 3), idx)
+    out = oracle.indice_conv(f, w, pair, num, idx.shape[0], subm=True)
+    assert (out - ref).abs().max() < 1e-4
+    dout = torch.from_numpy(rng.uniform(-0.2, 0.2, ref.shape).astype(np.float32))
+    ref.backward(dout)
+    din, dw = oracle.indice_conv_backward(f, w, dout, pair, num, subm=True)
+    assert (din - fd.grad).abs().max() < 1e-4
+    assert (dw - wd.grad).abs().max() < 1e-4
+
+
+def test_transposed_conv_matches_dense_conv_transpose3d():
+    rng = np.random.default_rng(3)
+    shape, bs, C, K = [10, 9, 9], 2, 8, 12
+    idx = scene(shape, 300, bs, seed=3)
+    f = torch.from_numpy(rng.uniform(-1, 1, (idx.shape[0], C)).astype(np.float32))
+    w = torch.from_numpy(rng.uniform(-1, 1, (K, 3, 3, 3, C)).astype(np.float32))
+    oi, pair, num, oshape = oracle.get_indice_pairs(idx, bs, shape, [3] * 3, [2] * 3, [1] * 3, [1] * 3,
+                                                    [0] * 3, False, True)
+    dense = oracle.dense_conv_reference(f, idx, bs, shape, w, [2] * 3, [1] * 3, [1] * 3, True, [0] * 3)
+    assert list(dense.shape[2:]) == oshape
+    out = oracle.indice_conv(f, w, pair, num, oi.shape[0])
+    assert (out - _sample(dense, oi)).abs().max() < 1e-4
+
+
+def test_numpy_per_offset_reference_agrees():
+    """test/test_all_algo.py:222-288 restated inline: out[o_inds] += inp[i_inds] @ W_k.T etc."""
+    rng = np.random.default_rng(50005)
+    shape, bs, C, K = [19, 18, 17], 1, 8, 12
+    idx = scene(shape, 1500, bs, seed=50005)
+    for subm in (True, False):
+        stride = [1] * 3 if subm else [2] * 3
+        oi, pair, num, _ = oracle.get_indice_pairs(idx, bs, shape, [3] * 3, stride, [1] * 3, [1] * 3,
+                                                   subm=subm)
+        f = rng.uniform(-1, 1, (idx.shape[0], C)).astype(np.float32)
+        w = rng.uniform(-1, 1, (K, 3, 3, 3, C)).astype(np.float32)
+        dout = rng.uniform(-1, 1, (oi.shape[0], K)).astype(np.float32)
+        wk = w.reshape(K, 27, C)
+        out = np.zeros((oi.shape[0], K), np.float32)
+        din = np.zeros_like(f)
+        dw = np.zeros((27, K, C), np.float32)
+        counts = oracle.native_counts(num, 27, subm, idx.shape[0])
+        for k in range(27):
+            i_, o_ = pair[0, k, :counts[k]], pair[1, k, :counts[k]]
+            out[o_] += f[i_] @ wk[:, k].T
+            din[i_] += dout[o_] @ wk[:, k]
+            dw[k] = dout[o_].T @ f[i_]
+        got = oracle.indice_conv(torch.from_numpy(f), torch.from_numpy(w), pair, num, oi.shape[0], subm=subm)
+        gdin, gdw = oracle.indice_conv_backward(torch.from_numpy(f), torch.from_numpy(w),
+                                                torch.from_numpy(dout), pair, num, subm=subm)
+        assert np.abs(got.numpy() - out).max() < 1e-4
+        assert np.abs(gdin.numpy() - din).max() < 1e-4
+        assert np.abs(gdw.numpy().reshape(K, 27, C).transpose(1, 0, 2) - dw).max() < 1e-3
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_golden_fixture(name):
+    g = load_case(name)
+    oi, pair, num, oshape = oracle.get_indice_pairs(
+        g["indices"], int(g["bs"]), list(g["shape"]), list(g["ksize"]), list(g["stride"]),
+        list(g["pad"]), list(g["dil"]), None, bool(g["subm"]), bool(g["transposed"]))
+    np.testing.assert_array_equal(oi, g["out_inds"])
+    np.testing.assert_array_equal(pair, g["pair"])
+    np.testing.assert_array_equal(num, g["num"])
+    assert oshape == list(g["out_shape"])
+    f, w, dout = (torch.from_numpy(g[k]) for k in ("features", "weight", "dout"))
+    out = oracle.indice_conv(f, w, pair, num, oi.shape[0], subm=bool(g["subm"]))
+    din, dw = oracle.indice_conv_backward(f, w, dout, pair, num, subm=bool(g["subm"]))
+    np.testing.assert_allclose(out.numpy(), g["out"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(din.numpy(), g["din"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(dw.numpy(), g["dw"], rtol=1e-5, atol=1e-4)
+
+
+def test_lidar_fixture_statistics():
+    """the reference's real-LiDAR scene has 125 562 voxels and
+    788 888 SubM pairs (6.28 per voxel); a stride-2 chain shrinks it 125k -> 137k -> 66k -> 26k."""
+    idx, shape = lidar_scene()
+    assert idx.shape == (125562, 4) and shape == [80, 1600, 1600]
+    _, pair, num, _ = oracle.get_indice_pairs(idx, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, subm=True)
+    assert sum(oracle.native_counts(num, 27, True, idx.shape[0])) == 788888
+    cur, cshape, sizes = idx, shape, []
+    for _ in range(3):
+        cur, _, _, cshape = oracle.get_indice_pairs(cur, 1, cshape, [3] * 3, [2] * 3, [1] * 3, [1] * 3)
+        sizes.append(cur.shape[0])
+    assert [round(s / 1000) for s in sizes] == [137, 66, 26]
+
+
+def test_rulebook_conventions():
+    """SubM count convention (indices.py:1685,1692): only k < kv/2 counted; centre identity;
+    -1 fill beyond the counts; mirror lists."""
+    idx = scene([12, 12, 12], 600, 1, seed=7)
+    _, pair, num, _ = oracle.get_indice_pairs(idx, 1, [12] * 3, [3] * 3, [1] * 3, [1] * 3, [1] * 3, subm=True)
+    assert np.all(num[13:] == 0) and num[:13].sum() > 0
+    np.testing.assert_array_equal(pair[0, 13], np.arange(600))
+    np.testing.assert_array_equal(pair[1, 13], np.arange(600))
+    for k in range(13):
+        c = num[k]
+        assert np.all(pair[:, k, c:] == -1) and np.all(pair[:, k, :c] >= 0)
+        np.testing.assert_array_equal(pair[0, k, :c], pair[1, 26 - k, :c])
+        np.testing.assert_array_equal(pair[1, k, :c], pair[0, 26 - k, :c])
+        assert np.all(np.diff(pair[0, k, :c]) > 0)
+
+
+def test_output_shape_formula():
+    assert oracle.conv_out_shape([41, 1600, 1408], [3] * 3, [2] * 3, [1] * 3, [1] * 3) == [21, 800, 704]
+    assert oracle.conv_out_shape([21, 800, 704], [3, 1, 1], [2, 1, 1], [0] * 3, [1] * 3) == [10, 800, 704]
+    assert oracle.conv_out_shape([5, 5], [3, 3], [2, 2], [1, 1], [1, 1], [1, 1], True) == [10, 10]
+
+
+def test_int8_formula_matches_float_path():
+    """a15: q = clip(round(relu(acc*s_k + b_k + add*s_add)), -128, 127)."""
+    rng = np.random.default_rng(0)
+    idx = scene([12, 12, 12], 500, 1, seed=0)
+    _, pair, num, _ = oracle.get_indice_pairs(idx, 1, [12] * 3, [3] * 3, [1] * 3, [1] * 3, [1] * 3, subm=True)
+    f = rng.integers(-127, 128, (500, 16)).astype(np.int8)
+    w = rng.integers(-127, 128, (8, 3, 3, 3, 16)).astype(np.int8)
+    scale = (rng.uniform(0.5, 1.5, 8) * 1e-3).astype(np.float32)
+    bias = rng.uniform(-1, 1, 8).astype(np.float32)
+    add = rng.integers(-127, 128, (500, 8)).astype(np.int8)
+    q = oracle.int8_conv_ref(f, w, pair, num, 500, True, scale, bias, add, 0.01, relu=True)
+    acc = oracle.indice_conv(torch.from_numpy(f.astype(np.float64)), torch.from_numpy(w.astype(np.float64)),
+                             pair, num, 500, subm=True).numpy()
+    r = np.maximum(acc.astype(np.float32) * scale + bias + add.astype(np.float32) * np.float32(0.01), 0)
+    assert q.dtype == np.int8 and np.array_equal(q, np.clip(np.round(r), -128, 127).astype(np.int8))

@@ -1,0 +1,63 @@
+"""Shared helpers for the parity tests: scene generation and oracle/GPU adapters."""
+import numpy as np
+import torch
+
+import oracle
+from spconv_amd.utils import synthetic
+
+
+def scene(shape, n, bs=1, seed=0):
+    return synthetic.uniform_scene(shape, n, bs, seed)
+
+
+def dense_scene(shape, n, bs=1, seed=0):
+    """Voxels concentrated in a sub-box so that neighbourhoods are well populated."""
+    sub = [max(2, s // 3) for s in shape]
+    idx = synthetic.uniform_scene(sub, min(n, int(np.prod(sub)) // 2), bs, seed)
+    return idx
+
+
+def oracle_rulebook(idx, bs, shape, ksize, stride, padding, dilation, subm, transpose=False,
+                    out_padding=None):
+    out_inds, pair, num, out_shape = oracle.get_indice_pairs(
+        idx, bs, shape, ksize, stride, padding, dilation, out_padding, subm, transpose)
+    n_in, n_out = idx.shape[0], out_inds.shape[0]
+    fwd, bwd, mfwd, mbwd = oracle.dense_tables(pair, num, n_in, n_out, subm)
+    return dict(out_inds=out_inds, pair=pair, num=num, out_shape=out_shape, fwd=fwd, bwd=bwd,
+                mfwd=mfwd, mbwd=mbwd, n_in=n_in, n_out=n_out)
+
+
+def gpu_rulebook(idx, bs, shape, ksize, stride, padding, dilation, subm, transpose=False,
+                 out_padding=None, dev="cuda:0", **kw):
+    from spconv_amd.pytorch import ops
+    ndim = len(shape)
+    t = torch.from_numpy(idx).to(dev)
+    rb, out_shape = ops.build_rulebook(t, bs, list(shape), list(ksize), list(stride),
+                                       list(padding), list(dilation),
+                                       list(out_padding or [0] * ndim), subm, transpose, **kw)
+    torch.cuda.synchronize()
+    return rb, out_shape
+
+
+def to_np(t):
+    return None if t is None else t.detach().cpu().numpy()
+
+
+def assert_rulebook_equal(rb, ref, subm, check_bwd=True):
+    """Bit-exact comparison of every artefact against the oracle."""
+    assert rb.n_out == ref["n_out"], (rb.n_out, ref["n_out"])
+    np.testing.assert_array_equal(to_np(rb.out_indices), ref["out_inds"])
+    np.testing.assert_array_equal(to_np(rb.num_per_loc), ref["num"])
+    np.testing.assert_array_equal(to_np(rb.pair_native), ref["pair"])
+    np.testing.assert_array_equal(to_np(rb.pair_fwd), ref["fwd"])
+    np.testing.assert_array_equal(to_np(rb.mask_fwd).view(np.uint32), ref["mfwd"])
+    if check_bwd and rb.pair_bwd is not None:
+        np.testing.assert_array_equal(to_np(rb.pair_bwd), ref["bwd"])
+    if not subm:
+        np.testing.assert_array_equal(to_np(rb.mask_bwd).view(np.uint32), ref["mbwd"])
+
+
+def rel_err(a, ref):
+    a = np.asarray(a, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    return float(np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-12))
