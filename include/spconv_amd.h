@@ -159,8 +159,16 @@ int spx_igemm_dgrad(const void *dout, const void *weight, void *din, const int32
                     int C, int K, int kv, int dtype, int subm, void *ws, size_t ws_bytes,
                     spx_stream_t stream);
 
-/* Scratch for wgrad (per-workgroup fp32 partials). */
+/* Scratch for wgrad (per-workgroup fp32 partials + room for a work plan). */
 size_t spx_igemm_wgrad_ws_bytes(int n_in, int C, int K, int kv);
+
+/* Work plan of wgrad: the list of (offset, chunk-of-pairs) items that exist for a
+ * rulebook, so the wgrad grid holds no empty workgroups.  It depends only on
+ * num_per_loc, so callers build it once per rulebook and pass it to every
+ * spx_igemm_wgrad call (plan == NULL makes wgrad rebuild it in `ws`). */
+size_t spx_wgrad_plan_bytes(int n_in, int kv);
+int spx_wgrad_plan(const int32_t *num_per_loc, int n_in, int kv, int subm, int32_t *plan,
+                   spx_stream_t stream);
 
 /* Weight gradient.  Replaces the wgrad half of implicit_gemm_backward and of
  * ConvGemmOps.indice_conv_backward (convops.py:1749-1860):
@@ -170,8 +178,9 @@ size_t spx_igemm_wgrad_ws_bytes(int n_in, int C, int K, int kv);
  *   subm=1: centre offset is the identity over all rows and offsets k > kv/2 use
  *   num_per_loc[kv-1-k] (ops.py:962-968). */
 int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t *pair_native,
-                    const int32_t *num_per_loc, int n_in, int n_out, int C, int K, int kv,
-                    int dtype, int subm, void *ws, size_t ws_bytes, spx_stream_t stream);
+                    const int32_t *num_per_loc, const int32_t *plan, int n_in, int n_out, int C,
+                    int K, int kv, int dtype, int subm, void *ws, size_t ws_bytes,
+                    spx_stream_t stream);
 
 /* In-place epilogues for callers that keep bias/activation separate
  * (InferenceOps.bias_add_act_inplace etc., csrc/sparse/inference.py:26-146). */

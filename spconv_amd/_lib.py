@@ -48,7 +48,9 @@ SIGNATURES = {
     "spx_igemm_dgrad_ws_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),
     "spx_igemm_dgrad": (ctypes.c_int, [vp] * 6 + [ctypes.c_int] * 7 + [vp, ctypes.c_size_t, vp]),
     "spx_igemm_wgrad_ws_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),
-    "spx_igemm_wgrad": (ctypes.c_int, [vp] * 5 + [ctypes.c_int] * 7 + [vp, ctypes.c_size_t, vp]),
+    "spx_wgrad_plan_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "spx_wgrad_plan": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "spx_igemm_wgrad": (ctypes.c_int, [vp] * 6 + [ctypes.c_int] * 7 + [vp, ctypes.c_size_t, vp]),
     "spx_bias_act_inplace": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_float, vp]),
 }

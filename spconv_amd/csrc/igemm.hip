@@ -21,6 +21,9 @@
 // utilisation.
 #include "common.h"
 
+#include <stdlib.h>
+#include <type_traits>
+
 namespace spx {
 namespace {
 
@@ -106,9 +109,38 @@ __device__ __forceinline__ int xcd_tile(int bid, int ntiles) {
 // gather-GEMM, 16-bit operands, fp32 accumulate.
 //   out[d, :] = act(bias + sum_k A[pair[k][d], :] . B_k^T)
 // --------------------------------------------------------------------------
-template <int COUT, bool BF16>
+// Step iterator over (offset k, reduction chunk): k runs over the set bits of the
+// tile mask, chunk over ceil(CIN / 64).
+struct StepIt {
+  int k;           // -1 = end
+  int chunk;
+  uint32_t rest;   // offsets still to visit after k
+};
+
+__device__ __forceinline__ StepIt step_begin(uint32_t bits) {
+  StepIt it;
+  it.chunk = 0;
+  it.k = bits ? __builtin_ctz(bits) : -1;
+  it.rest = bits ? (bits & (bits - 1)) : 0u;
+  return it;
+}
+
+__device__ __forceinline__ StepIt step_next(StepIt it, int nchunk) {
+  if (it.k < 0) return it;
+  if (it.chunk + 1 < nchunk) {
+    ++it.chunk;
+    return it;
+  }
+  it.chunk = 0;
+  it.k = it.rest ? __builtin_ctz(it.rest) : -1;
+  it.rest = it.rest ? (it.rest & (it.rest - 1)) : 0u;
+  return it;
+}
+
+template <int COUT, bool BF16, int DEPTH>
 __global__ void __launch_bounds__(kThreads)
 gather_gemm_mfma_kernel(GemmParams p) {
+  static_assert(DEPTH == 1 || DEPTH == 2, "prefetch depth");
   constexpr int NB = COUT / 16;                       // 16-wide output-channel blocks
   constexpr int BROWS = (COUT + 31) / 32;             // weight rows staged per thread
   constexpr int A_BYTES = kTileM * kRowBytes;         // 16 KiB
@@ -117,6 +149,7 @@ gather_gemm_mfma_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char *ldsA = smem;
   char *ldsB = smem + A_BYTES;
+  // [0] = tile mask, [1..4] = per-wave masks of the 32 rows each wave multiplies
   uint32_t *lds_mask = reinterpret_cast<uint32_t *>(smem + A_BYTES + COUT * kRowBytes);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -126,41 +159,27 @@ gather_gemm_mfma_kernel(GemmParams p) {
   const int r0 = tid >> 3;         // 0..31
   const uint16_t *A = static_cast<const uint16_t *>(p.A);
   const uint16_t *B = static_cast<const uint16_t *>(p.B);
+  const int nchunk = (p.CIN + kCK - 1) / kCK;
 
-  // destination rows staged by this thread (4 of the tile's 128)
+  // destination rows staged by this thread: tile rows r0 + 32 j (row block j is
+  // multiplied by wave j)
   int grow[4];
   uint32_t rmask[4];
-  uint32_t any = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int t = tile * kTileM + r0 + 32 * j;
     int g = -1;
     if (t < p.n_dst) g = p.argsort ? p.argsort[t] : t;
     grow[j] = g;
-    uint32_t m = 0;
-    if (g >= 0) m = p.mask ? p.mask[g] : 0xffffffffu;
-    rmask[j] = m;
-    any |= m;
-  }
-  if (tid == 0) *lds_mask = 0;
-  __syncthreads();
-  if (any) atomicOr(lds_mask, any);
-  __syncthreads();
-  uint32_t tilemask = *lds_mask;
-  if (p.kv < 32) tilemask &= (1u << p.kv) - 1u;
-
-  f32x4 acc[NB][2];
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    acc[nb][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    acc[nb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    rmask[j] = g >= 0 ? 0xffffffffu : 0u;   // refined below once the mask words arrive
   }
 
-  const int nchunk = (p.CIN + kCK - 1) / kCK;
-  uint4 areg[4], breg[BROWS];
+  uint4 areg[DEPTH][4], breg[DEPTH][BROWS];
 
-  // issue the global loads of step (k, c0) into registers
-  auto load_step = [&](int k, int c0) {
+  // issue the global loads of step `it` into register set SET
+  auto load_step = [&](auto SET, const StepIt &it) {
+    constexpr int S = decltype(SET)::value;
+    const int k = it.k, c0 = it.chunk * kCK;
     const bool cin_ok = c0 + slot * 8 < p.CIN;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -172,7 +191,7 @@ gather_gemm_mfma_kernel(GemmParams p) {
       uint4 v = make_uint4(0, 0, 0, 0);
       if (idx >= 0 && cin_ok)
         v = *reinterpret_cast<const uint4 *>(A + static_cast<size_t>(idx) * p.CIN + c0 + slot * 8);
-      areg[j] = v;
+      areg[S][j] = v;
     }
     const int kb = p.b_reverse ? p.kv - 1 - k : k;
     const uint16_t *Bk = B + static_cast<size_t>(kb) * p.strideK + c0 + slot * 8;
@@ -182,56 +201,115 @@ gather_gemm_mfma_kernel(GemmParams p) {
       uint4 v = make_uint4(0, 0, 0, 0);
       if (n < COUT && cin_ok)
         v = *reinterpret_cast<const uint4 *>(Bk + static_cast<size_t>(n) * p.strideN);
-      breg[j] = v;
+      breg[S][j] = v;
     }
   };
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, DEPTH - 1>;
 
-  // first step
-  int k = tilemask ? __builtin_ctz(tilemask) : -1;
-  uint32_t rest = tilemask ? (tilemask & (tilemask - 1)) : 0;
-  int chunk = 0;
-  if (k >= 0) load_step(k, 0);
+  // SubM: the identity offset is present for every valid row, so its loads do not
+  // need the mask words -> issue them before the (dependent) mask loads return.
+  const bool spec = p.identity_k >= 0;
+  StepIt it0;
+  if (spec) {
+    it0.k = p.identity_k;
+    it0.chunk = 0;
+    it0.rest = 0;
+    load_step(Set0{}, it0);
+  }
+  uint32_t any = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t m = 0;
+    if (grow[j] >= 0) m = p.mask ? p.mask[grow[j]] : 0xffffffffu;
+    rmask[j] = m;
+    any |= m;
+  }
+  if (tid < 5) lds_mask[tid] = 0;
+  __syncthreads();
+  if (any) {
+    atomicOr(&lds_mask[0], any);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (rmask[j]) atomicOr(&lds_mask[1 + j], rmask[j]);
+  }
+  __syncthreads();
+  uint32_t tilemask = lds_mask[0];
+  const uint32_t wavemask = lds_mask[1 + wave];
+  if (p.kv < 32) tilemask &= (1u << p.kv) - 1u;
+  if (spec) {
+    it0.rest = tilemask & ~(1u << p.identity_k);
+    // a tile without valid rows has an empty mask: nothing to do for the speculated step
+    if (!((tilemask >> p.identity_k) & 1u)) it0 = step_begin(it0.rest);
+  } else {
+    it0 = step_begin(tilemask);
+    if (it0.k >= 0) load_step(Set0{}, it0);
+  }
+  StepIt it1 = step_next(it0, nchunk);
+  if (DEPTH == 2 && it1.k >= 0) load_step(Set1{}, it1);
 
-  while (k >= 0) {
+  f32x4 acc[NB][2];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    acc[nb][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[nb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // one pipeline step: registers of set SET -> LDS, prefetch, MFMA
+  auto do_step = [&](auto SET, const StepIt &cur, const StepIt &pre) {
+    constexpr int S = decltype(SET)::value;
     __syncthreads();  // previous step's fragment reads are done
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      *reinterpret_cast<uint4 *>(ldsA + swz_off(r0 + 32 * j, slot, kRowBytes)) = areg[j];
+      *reinterpret_cast<uint4 *>(ldsA + swz_off(r0 + 32 * j, slot, kRowBytes)) = areg[S][j];
 #pragma unroll
     for (int j = 0; j < BROWS; ++j) {
       const int n = r0 + 32 * j;
-      if (n < COUT) *reinterpret_cast<uint4 *>(ldsB + swz_off(n, slot, kRowBytes)) = breg[j];
+      if (n < COUT) *reinterpret_cast<uint4 *>(ldsB + swz_off(n, slot, kRowBytes)) = breg[S][j];
     }
     __syncthreads();
-
-    const int c0 = chunk * kCK;
-    const int ksteps = (min(kCK, p.CIN - c0) + 31) >> 5;  // 1 or 2
-    // advance (k, chunk) and prefetch the next step while this one computes
-    int nk = k, nchunk_i = chunk + 1;
-    if (nchunk_i == nchunk) {
-      nchunk_i = 0;
-      nk = rest ? __builtin_ctz(rest) : -1;
-      rest = rest ? (rest & (rest - 1)) : 0;
-    }
-    if (nk >= 0) load_step(nk, nchunk_i * kCK);
-
-    for (int ks = 0; ks < ksteps; ++ks) {
-      const int fslot = ks * 4 + (lane >> 4);
-      uint4 fb[2];
+    if (pre.k >= 0) load_step(SET, pre);   // this set is free again: refill DEPTH steps ahead
+    if ((wavemask >> cur.k) & 1u) {        // none of this wave's 32 rows uses offset k: skip
+      const int c0 = cur.chunk * kCK;
+      const int ksteps = (min(kCK, p.CIN - c0) + 31) >> 5;  // 1 or 2
+      for (int ks = 0; ks < ksteps; ++ks) {
+        const int fslot = ks * 4 + (lane >> 4);
+        uint4 fb[2];
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
-        fb[mb] = *reinterpret_cast<const uint4 *>(
-            ldsA + swz_off(wave * 32 + mb * 16 + (lane & 15), fslot, kRowBytes));
+        for (int mb = 0; mb < 2; ++mb)
+          fb[mb] = *reinterpret_cast<const uint4 *>(
+              ldsA + swz_off(wave * 32 + mb * 16 + (lane & 15), fslot, kRowBytes));
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const uint4 fa = *reinterpret_cast<const uint4 *>(
-            ldsB + swz_off(nb * 16 + (lane & 15), fslot, kRowBytes));
-        acc[nb][0] = mfma16<BF16>(fa, fb[0], acc[nb][0]);
-        acc[nb][1] = mfma16<BF16>(fa, fb[1], acc[nb][1]);
+        for (int nb = 0; nb < NB; ++nb) {
+          const uint4 fa = *reinterpret_cast<const uint4 *>(
+              ldsB + swz_off(nb * 16 + (lane & 15), fslot, kRowBytes));
+          acc[nb][0] = mfma16<BF16>(fa, fb[0], acc[nb][0]);
+          acc[nb][1] = mfma16<BF16>(fa, fb[1], acc[nb][1]);
+        }
       }
     }
-    k = nk;
-    chunk = nchunk_i;
+  };
+
+  if constexpr (DEPTH == 1) {
+    StepIt cur = it0, nxt = it1;
+    while (cur.k >= 0) {
+      do_step(Set0{}, cur, nxt);
+      cur = nxt;
+      nxt = step_next(nxt, nchunk);
+    }
+  } else {
+    StepIt cur = it0, nxt = it1, pre = step_next(it1, nchunk);
+    while (cur.k >= 0) {
+      do_step(Set0{}, cur, pre);           // set 0 holds `cur`, refilled with `pre`
+      cur = nxt;                            // now in set 1
+      nxt = pre;                            // now in set 0
+      pre = step_next(pre, nchunk);
+      if (cur.k < 0) break;
+      do_step(Set1{}, cur, pre);
+      cur = nxt;
+      nxt = pre;
+      pre = step_next(pre, nchunk);
+    }
   }
 
   // ---- epilogue: bias/activation, fp32 -> 16 bit, transpose through LDS so
@@ -276,16 +354,26 @@ gather_gemm_mfma_kernel(GemmParams p) {
 
 template <int COUT>
 constexpr size_t gemm_smem_bytes() {
-  const size_t stage = kTileM * kRowBytes + COUT * kRowBytes + 16;
+  const size_t stage = kTileM * kRowBytes + COUT * kRowBytes + 32;
   const size_t outb = static_cast<size_t>(kTileM) * COUT * 2;
   return stage > outb ? stage : outb;
+}
+
+int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v ? atoi(v) : dflt;
 }
 
 template <int COUT, bool BF16>
 int launch_gather_gemm(const GemmParams &p, hipStream_t s) {
   const int ntiles = div_up(p.n_dst, kTileM);
-  hipLaunchKernelGGL((gather_gemm_mfma_kernel<COUT, BF16>), dim3(ntiles), dim3(kThreads),
-                     gemm_smem_bytes<COUT>(), s, p);
+  static const int depth = env_int("SPX_GEMM_DEPTH", 1);   // tuning knob (1 or 2 steps ahead)
+  if (depth == 2 && COUT <= 128)
+    hipLaunchKernelGGL((gather_gemm_mfma_kernel<COUT, BF16, 2>), dim3(ntiles), dim3(kThreads),
+                       gemm_smem_bytes<COUT>(), s, p);
+  else
+    hipLaunchKernelGGL((gather_gemm_mfma_kernel<COUT, BF16, 1>), dim3(ntiles), dim3(kThreads),
+                       gemm_smem_bytes<COUT>(), s, p);
   SPX_LAUNCH_CHECK();
   return 0;
 }
@@ -330,18 +418,23 @@ gather_gemm_generic_kernel(GemmParams p) {
   store_f(static_cast<T *>(p.out) + static_cast<size_t>(d) * p.COUT + n, acc);
 }
 
-// Wt[k][c][kk] = W[kk][k][c]  (dgrad consumes the reduction dim K contiguously)
+// Wt[k][c][kk] = W[kk][k][c]  (dgrad consumes the reduction dim K contiguously).
+// One 64x64 tile per block, transposed through LDS so both sides are coalesced.
 template <typename T>
 __global__ void __launch_bounds__(kThreads)
 weight_relayout_kernel(const T *__restrict__ W, T *__restrict__ Wt, int K, int kv, int C) {
-  const long long gid = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x;
-  const long long total = static_cast<long long>(K) * kv * C;
-  if (gid >= total) return;
-  // gid enumerates the destination [k][c][kk] so that stores are coalesced
-  const int kk = static_cast<int>(gid % K);
-  const int c = static_cast<int>((gid / K) % C);
-  const int k = static_cast<int>(gid / (static_cast<long long>(K) * C));
-  Wt[gid] = W[(static_cast<size_t>(kk) * kv + k) * C + c];
+  __shared__ T tile[64][65];
+  const int k = blockIdx.x, kk0 = blockIdx.y * 64, c0 = blockIdx.z * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+  for (int r = ty; r < 64; r += 4) {
+    const int kk = kk0 + r, c = c0 + tx;
+    if (kk < K && c < C) tile[r][tx] = W[(static_cast<size_t>(kk) * kv + k) * C + c];
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int c = c0 + r, kk = kk0 + tx;
+    if (kk < K && c < C) Wt[(static_cast<size_t>(k) * C + c) * K + kk] = tile[tx][r];
+  }
 }
 
 // --------------------------------------------------------------------------
@@ -356,17 +449,55 @@ constexpr int kWT = 64;    // dW tile edge
 struct WgradParams {
   const void *feat;        // [n_in, C]
   const void *dout;        // [n_out, K]
-  float *partial;          // [kv][nchunks][tiles][64*64]
+  float *partial;          // [item][tiles][64*64]
   const int32_t *native;   // [2, kv, n_in]
   const int32_t *num;      // [kv] device counts
+  const int32_t *plan;     // see wgrad_plan_kernel
   int n_in, n_out, C, K, kv, subm, chunk, nchunks, tiles_c, tiles_k;
 };
 
-__device__ __forceinline__ int list_count(const WgradParams &p, int k) {
-  if (!p.subm) return p.num[k];
-  const int center = p.kv / 2;
-  if (k == center) return p.n_in;
-  return k < center ? p.num[k] : p.num[p.kv - 1 - k];  // mirror rule, ops.py:962-968
+__device__ __forceinline__ int list_count(const int32_t *num, int kv, int subm, int n_in, int k) {
+  int c;
+  if (!subm) c = num[k];
+  else if (k == kv / 2) c = n_in;
+  else c = k < kv / 2 ? num[k] : num[kv - 1 - k];  // mirror rule, ops.py:962-968
+  return c < n_in ? c : n_in;                         // convops.py:1592 clamp
+}
+
+// Work plan: the (offset, chunk) items that actually exist, so that the wgrad grid
+// holds no empty workgroups.  Layout (int32):
+//   [0] total items   [1 .. 1+kv) first item of offset k   [1+kv .. 1+2kv) chunks of offset k
+//   [1+2kv + 2 i] = offset of item i,  [2+2kv + 2 i] = first pair of item i
+__global__ void __launch_bounds__(kThreads)
+wgrad_plan_kernel(const int32_t *__restrict__ num, int n_in, int kv, int subm, int chunk,
+                  int32_t *__restrict__ plan) {
+  __shared__ int first[129], nch[128];
+  const int tid = threadIdx.x;
+  if (tid < kv) {
+    const int c = list_count(num, kv, subm, n_in, tid);
+    nch[tid] = (c + chunk - 1) / chunk;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int k = 0; k < kv; ++k) {
+      first[k] = run;
+      run += nch[k];
+    }
+    first[kv] = run;
+    plan[0] = run;
+  }
+  __syncthreads();
+  if (tid < kv) {
+    plan[1 + tid] = first[tid];
+    plan[1 + kv + tid] = nch[tid];
+  }
+  int32_t *items = plan + 1 + 2 * kv;
+  for (int k = 0; k < kv; ++k)
+    for (int c = tid; c < nch[k]; c += kThreads) {
+      items[2 * (first[k] + c)] = k;
+      items[2 * (first[k] + c) + 1] = c * chunk;
+    }
 }
 
 // element column of pair j in transposed row `ch`: XOR swizzle at 8-element
@@ -387,160 +518,178 @@ wgrad_mfma_kernel(WgradParams p) {
   uint16_t *ldsD = reinterpret_cast<uint16_t *>(smem);                    // [64 kk][128 j]
   uint16_t *ldsF = reinterpret_cast<uint16_t *>(smem + kWT * kWJ * 2);    // [64 c ][128 j]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int k = blockIdx.y;
-  const int tile = blockIdx.z;
-  const int kk0 = (tile / p.tiles_c) * kWT, c0 = (tile % p.tiles_c) * kWT;
-  const int cnt = list_count(p, k);
-  const int begin = blockIdx.x * p.chunk;
-  if (begin >= cnt) return;
-  const int end = min(cnt, begin + p.chunk);
-  const bool identity = p.subm && k == p.kv / 2;
-  const int32_t *in_list = p.native + static_cast<size_t>(k) * p.n_in;
-  const int32_t *out_list = p.native + static_cast<size_t>(p.kv + k) * p.n_in;
+  const int ntile = p.tiles_k * p.tiles_c;
+  const int total = p.plan[0] * ntile;
+  const int32_t *items = p.plan + 1 + 2 * p.kv;
   const uint16_t *F = static_cast<const uint16_t *>(p.feat);
   const uint16_t *D = static_cast<const uint16_t *>(p.dout);
-
   const int slot = tid & 7;       // 8-channel group
   const int jp0 = tid >> 3;       // pair-of-rows index 0..31 (+32)
   const int wk = wave >> 1, wc = wave & 1;  // wave quadrant: kk [32*wk,+32), c [32*wc,+32)
-  f32x4 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int base = begin; base < end; base += kWJ) {
+  for (int work = blockIdx.x; work < total; work += gridDim.x) {
+    const int item = work / ntile, tile = work - item * ntile;
+    const int k = items[2 * item], begin = items[2 * item + 1];
+    const int kk0 = (tile / p.tiles_c) * kWT, c0 = (tile % p.tiles_c) * kWT;
+    const int cnt = list_count(p.num, p.kv, p.subm, p.n_in, k);
+    const int end = min(cnt, begin + p.chunk);
+    const bool identity = p.subm && k == p.kv / 2;
+    const int32_t *in_list = p.native + static_cast<size_t>(k) * p.n_in;
+    const int32_t *out_list = p.native + static_cast<size_t>(p.kv + k) * p.n_in;
+    const bool d_ok = kk0 + slot * 8 < p.K, f_ok = c0 + slot * 8 < p.C;
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
     uint4 dv[2][2], fv[2][2];
+    auto load_rows = [&](int base) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+      for (int q = 0; q < 2; ++q)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int j = base + 2 * (jp0 + 32 * q) + h;
-        uint4 d = make_uint4(0, 0, 0, 0), f = make_uint4(0, 0, 0, 0);
-        if (j < end) {
-          const int oi = identity ? j : out_list[j];
-          const int ii = identity ? j : in_list[j];
-          if (kk0 + slot * 8 < p.K)
-            d = *reinterpret_cast<const uint4 *>(D + static_cast<size_t>(oi) * p.K + kk0 + slot * 8);
-          if (c0 + slot * 8 < p.C)
-            f = *reinterpret_cast<const uint4 *>(F + static_cast<size_t>(ii) * p.C + c0 + slot * 8);
+        for (int h = 0; h < 2; ++h) {
+          const int j = base + 2 * (jp0 + 32 * q) + h;
+          uint4 d = make_uint4(0, 0, 0, 0), f = make_uint4(0, 0, 0, 0);
+          if (j < end) {
+            const int oi = identity ? j : out_list[j];
+            const int ii = identity ? j : in_list[j];
+            if (d_ok) d = *reinterpret_cast<const uint4 *>(D + static_cast<size_t>(oi) * p.K + kk0 + slot * 8);
+            if (f_ok) f = *reinterpret_cast<const uint4 *>(F + static_cast<size_t>(ii) * p.C + c0 + slot * 8);
+          }
+          dv[q][h] = d;
+          fv[q][h] = f;
         }
-        dv[q][h] = d;
-        fv[q][h] = f;
+    };
+    load_rows(begin);
+    for (int base = begin; base < end; base += kWJ) {
+      __syncthreads();  // previous iteration's fragment reads are done
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int j = 2 * (jp0 + 32 * q);  // even -> a dword holds pairs (j, j+1)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int ch = slot * 8 + e;
+          const int sh = (e & 1) * 16;
+          const uint32_t dd = ((dword_of(dv[q][0], e >> 1) >> sh) & 0xffffu) |
+                              (((dword_of(dv[q][1], e >> 1) >> sh) & 0xffffu) << 16);
+          const uint32_t ff = ((dword_of(fv[q][0], e >> 1) >> sh) & 0xffffu) |
+                              (((dword_of(fv[q][1], e >> 1) >> sh) & 0xffffu) << 16);
+          const int col = wswz(ch, j);
+          *reinterpret_cast<uint32_t *>(ldsD + ch * kWJ + col) = dd;
+          *reinterpret_cast<uint32_t *>(ldsF + ch * kWJ + col) = ff;
+        }
       }
-    __syncthreads();  // previous iteration's fragment reads are done
+      __syncthreads();
+      if (base + kWJ < end) load_rows(base + kWJ);   // in flight during the MFMAs
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int j = 2 * (jp0 + 32 * q);  // even -> a dword holds pairs (j, j+1)
+      for (int ks = 0; ks < kWJ / 32; ++ks) {
+        const int j8 = (ks * 4 + (lane >> 4)) * 8;
+        uint4 fa[2], fb[2];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int ch = slot * 8 + e;
-        const int sh = (e & 1) * 16;
-        const uint32_t dd = ((dword_of(dv[q][0], e >> 1) >> sh) & 0xffffu) |
-                            (((dword_of(dv[q][1], e >> 1) >> sh) & 0xffffu) << 16);
-        const uint32_t ff = ((dword_of(fv[q][0], e >> 1) >> sh) & 0xffffu) |
-                            (((dword_of(fv[q][1], e >> 1) >> sh) & 0xffffu) << 16);
-        const int col = wswz(ch, j);
-        *reinterpret_cast<uint32_t *>(ldsD + ch * kWJ + col) = dd;
-        *reinterpret_cast<uint32_t *>(ldsF + ch * kWJ + col) = ff;
+        for (int a = 0; a < 2; ++a) {
+          const int ch = wk * 32 + a * 16 + (lane & 15);
+          fa[a] = *reinterpret_cast<const uint4 *>(ldsD + ch * kWJ + wswz(ch, j8));
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int ch = wc * 32 + b * 16 + (lane & 15);
+          fb[b] = *reinterpret_cast<const uint4 *>(ldsF + ch * kWJ + wswz(ch, j8));
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[a][b] = mfma16<BF16>(fa[a], fb[b], acc[a][b]);
       }
     }
-    __syncthreads();
+    // D[i = kk][j = c]: lane holds c = lane & 15, kk = (lane >> 4) * 4 + reg
+    float *dst = p.partial + static_cast<size_t>(work) * (kWT * kWT);
 #pragma unroll
-    for (int ks = 0; ks < kWJ / 32; ++ks) {
-      const int j8 = (ks * 4 + (lane >> 4)) * 8;
-      uint4 fa[2], fb[2];
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const int ch = wk * 32 + a * 16 + (lane & 15);
-        fa[a] = *reinterpret_cast<const uint4 *>(ldsD + ch * kWJ + wswz(ch, j8));
-      }
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int ch = wc * 32 + b * 16 + (lane & 15);
-        fb[b] = *reinterpret_cast<const uint4 *>(ldsF + ch * kWJ + wswz(ch, j8));
-      }
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = mfma16<BF16>(fa[a], fb[b], acc[a][b]);
-    }
+        for (int e = 0; e < 4; ++e) {
+          const int kk = wk * 32 + a * 16 + (lane >> 4) * 4 + e;
+          const int c = wc * 32 + b * 16 + (lane & 15);
+          dst[kk * kWT + c] = acc[a][b][e];
+        }
+    __syncthreads();  // LDS is rewritten by the next work item
   }
-  // D[i = kk][j = c]: lane holds c = lane & 15, kk = (lane >> 4) * 4 + reg
-  float *dst = p.partial +
-               ((static_cast<size_t>(k) * p.nchunks + blockIdx.x) * (p.tiles_k * p.tiles_c) + tile) *
-                   (kWT * kWT);
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int kk = wk * 32 + a * 16 + (lane >> 4) * 4 + e;
-        const int c = wc * 32 + b * 16 + (lane & 15);
-        dst[kk * kWT + c] = acc[a][b][e];
-      }
 }
 
 // generic wgrad partial: thread per (kk, c) of the 64x64 tile, 16 elems/thread
 template <typename T>
 __global__ void __launch_bounds__(kThreads)
 wgrad_generic_kernel(WgradParams p) {
-  const int k = blockIdx.y, tile = blockIdx.z;
-  const int kk0 = (tile / p.tiles_c) * kWT, c0 = (tile % p.tiles_c) * kWT;
-  const int cnt = list_count(p, k);
-  const int begin = blockIdx.x * p.chunk;
-  if (begin >= cnt) return;
-  const int end = min(cnt, begin + p.chunk);
-  const bool identity = p.subm && k == p.kv / 2;
-  const int32_t *in_list = p.native + static_cast<size_t>(k) * p.n_in;
-  const int32_t *out_list = p.native + static_cast<size_t>(p.kv + k) * p.n_in;
+  const int ntile = p.tiles_k * p.tiles_c;
+  const int total = p.plan[0] * ntile;
+  const int32_t *items = p.plan + 1 + 2 * p.kv;
   const T *F = static_cast<const T *>(p.feat);
   const T *D = static_cast<const T *>(p.dout);
-  float *dst = p.partial +
-               ((static_cast<size_t>(k) * p.nchunks + blockIdx.x) * (p.tiles_k * p.tiles_c) + tile) *
-                   (kWT * kWT);
-  for (int e = threadIdx.x; e < kWT * kWT; e += kThreads) {
-    const int kk = kk0 + e / kWT, c = c0 + e % kWT;
-    float acc = 0.f;
-    if (kk < p.K && c < p.C) {
-      for (int j = begin; j < end; ++j) {
-        const int oi = identity ? j : out_list[j];
-        const int ii = identity ? j : in_list[j];
-        acc = fmaf(load_f(D + static_cast<size_t>(oi) * p.K + kk),
-                   load_f(F + static_cast<size_t>(ii) * p.C + c), acc);
+  for (int work = blockIdx.x; work < total; work += gridDim.x) {
+    const int item = work / ntile, tile = work - item * ntile;
+    const int k = items[2 * item], begin = items[2 * item + 1];
+    const int kk0 = (tile / p.tiles_c) * kWT, c0 = (tile % p.tiles_c) * kWT;
+    const int cnt = list_count(p.num, p.kv, p.subm, p.n_in, k);
+    const int end = min(cnt, begin + p.chunk);
+    const bool identity = p.subm && k == p.kv / 2;
+    const int32_t *in_list = p.native + static_cast<size_t>(k) * p.n_in;
+    const int32_t *out_list = p.native + static_cast<size_t>(p.kv + k) * p.n_in;
+    float *dst = p.partial + static_cast<size_t>(work) * (kWT * kWT);
+    for (int e = threadIdx.x; e < kWT * kWT; e += kThreads) {
+      const int kk = kk0 + e / kWT, c = c0 + e % kWT;
+      float acc = 0.f;
+      if (kk < p.K && c < p.C) {
+        for (int j = begin; j < end; ++j) {
+          const int oi = identity ? j : out_list[j];
+          const int ii = identity ? j : in_list[j];
+          acc = fmaf(load_f(D + static_cast<size_t>(oi) * p.K + kk),
+                     load_f(F + static_cast<size_t>(ii) * p.C + c), acc);
+        }
       }
+      dst[e] = acc;
     }
-    dst[e] = acc;
   }
 }
 
-// dw[kk][k][c] = sum over the chunks of list k (fixed order -> deterministic)
+// dw[kk][k][c] = sum over the items of offset k (fixed order -> deterministic).
+// 512 threads = 32 consecutive elements x 16 item groups; every thread keeps 8 loads in flight.
+constexpr int kRedThreads = 512;
+constexpr int kRedSplit = 16;
+constexpr int kRedElems = kRedThreads / kRedSplit;  // 32
+
 template <typename T>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kRedThreads)
 wgrad_reduce_kernel(WgradParams p, T *__restrict__ dw) {
-  constexpr int kSplit = 8;  // chunk-range groups per output element
-  __shared__ float red[kThreads];
+  __shared__ float red[kRedThreads];
   const int k = blockIdx.y;
-  const int cnt = list_count(p, k);
-  const int nch = cnt > 0 ? (cnt + p.chunk - 1) / p.chunk : 0;
-  const int grp = threadIdx.x / (kThreads / kSplit);          // 0..7
-  const int el = threadIdx.x % (kThreads / kSplit);           // 0..31
+  const int first = p.plan[1 + k], nch = p.plan[1 + p.kv + k];
+  const int grp = threadIdx.x / kRedElems, el = threadIdx.x % kRedElems;
   const int ntile = p.tiles_k * p.tiles_c;
-  const int e_global = blockIdx.x * (kThreads / kSplit) + el; // element of [tiles][64*64]
+  const int e_global = blockIdx.x * kRedElems + el;  // element of [tiles][64*64]
   const int tile = e_global / (kWT * kWT), e = e_global % (kWT * kWT);
+  const size_t stride = static_cast<size_t>(ntile) * (kWT * kWT);
   float acc = 0.f;
   if (tile < ntile) {
-    const float *src = p.partial + (static_cast<size_t>(k) * p.nchunks * ntile + tile) * (kWT * kWT) + e;
-    for (int ch = grp; ch < nch; ch += kSplit)
-      acc += src[static_cast<size_t>(ch) * ntile * (kWT * kWT)];
+    const float *src = p.partial + (static_cast<size_t>(first) * ntile + tile) * (kWT * kWT) + e;
+    int ch = grp;
+    for (; ch + 7 * kRedSplit < nch; ch += 8 * kRedSplit) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[static_cast<size_t>(ch + u * kRedSplit) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; ch < nch; ch += kRedSplit) acc += src[static_cast<size_t>(ch) * stride];
   }
   red[threadIdx.x] = acc;
   __syncthreads();
   if (grp == 0 && tile < ntile) {
     float s = 0.f;
 #pragma unroll
-    for (int g = 0; g < kSplit; ++g) s += red[g * (kThreads / kSplit) + el];
+    for (int g = 0; g < kRedSplit; ++g) s += red[g * kRedElems + el];
     const int kk = (tile / p.tiles_c) * kWT + e / kWT, c = (tile % p.tiles_c) * kWT + e % kWT;
     if (kk < p.K && c < p.C) store_f(dw + (static_cast<size_t>(kk) * p.kv + k) * p.C + c, s);
   }
@@ -601,11 +750,18 @@ int run_gather_gemm(const GemmParams &p, int dtype, hipStream_t s) {
 }
 
 int wgrad_chunk(int n_in) {
+  static const int forced = env_int("SPX_WGRAD_CHUNK", 0);  // tuning knob
+  if (forced > 0) return (forced + kWJ - 1) / kWJ * kWJ;
   // aim at >= ~512 workgroups for the dominant (centre) list, multiples of 128
   int c = (n_in / 512 + kWJ - 1) / kWJ * kWJ;
   if (c < kWJ) c = kWJ;
   if (c > 1024) c = 1024;
   return c;
+}
+
+size_t wgrad_plan_ints(int n_in, int kv) {
+  const size_t nchunks = div_up(n_in > 0 ? n_in : 1, wgrad_chunk(n_in));
+  return 1 + 2 * static_cast<size_t>(kv) + 2 * nchunks * kv;
 }
 
 }  // namespace
@@ -655,8 +811,7 @@ int spx_igemm_dgrad(const void *dout, const void *weight, void *din, const int32
   hipStream_t s = static_cast<hipStream_t>(stream);
   SPX_CHECK(dout && weight && din && ws, "null tensor pointer");
   SPX_CHECK(ws_bytes >= spx_igemm_dgrad_ws_bytes(C, K, kv, dtype), "workspace too small");
-  const long long total = static_cast<long long>(C) * K * kv;
-  const dim3 grid(static_cast<unsigned>((total + kThreads - 1) / kThreads));
+  const dim3 grid(kv, div_up(K, 64), div_up(C, 64));
   if (dtype == SPX_F32)
     hipLaunchKernelGGL(weight_relayout_kernel<float>, grid, dim3(kThreads), 0, s,
                        static_cast<const float *>(weight), static_cast<float *>(ws), K, kv, C);
@@ -688,19 +843,36 @@ int spx_igemm_dgrad(const void *dout, const void *weight, void *din, const int32
   return run_gather_gemm(p, dtype, s);
 }
 
+size_t spx_wgrad_plan_bytes(int n_in, int kv) {
+  return align_up(wgrad_plan_ints(n_in, kv) * sizeof(int32_t), 256);
+}
+
+int spx_wgrad_plan(const int32_t *num_per_loc, int n_in, int kv, int subm, int32_t *plan,
+                   spx_stream_t stream) {
+  SPX_CHECK(num_per_loc && plan, "null pointer");
+  SPX_CHECK(kv >= 1 && kv <= 128, "kernel volume %d not supported by wgrad (max 128)", kv);
+  hipLaunchKernelGGL(wgrad_plan_kernel, dim3(1), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+                     num_per_loc, n_in, kv, subm, wgrad_chunk(n_in), plan);
+  SPX_LAUNCH_CHECK();
+  return 0;
+}
+
 size_t spx_igemm_wgrad_ws_bytes(int n_in, int C, int K, int kv) {
   const int chunk = wgrad_chunk(n_in);
   const size_t nchunks = div_up(n_in > 0 ? n_in : 1, chunk);
   const size_t tiles = static_cast<size_t>(div_up(C, kWT)) * div_up(K, kWT);
-  return align_up(nchunks * kv * tiles * kWT * kWT * sizeof(float), 256);
+  return align_up(nchunks * kv * tiles * kWT * kWT * sizeof(float), 256) +
+         spx_wgrad_plan_bytes(n_in, kv);
 }
 
 int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t *pair_native,
-                    const int32_t *num_per_loc, int n_in, int n_out, int C, int K, int kv,
-                    int dtype, int subm, void *ws, size_t ws_bytes, spx_stream_t stream) {
+                    const int32_t *num_per_loc, const int32_t *plan, int n_in, int n_out, int C,
+                    int K, int kv, int dtype, int subm, void *ws, size_t ws_bytes,
+                    spx_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   SPX_CHECK(feat && dout && dw && ws, "null tensor pointer");
   SPX_CHECK(pair_native && num_per_loc, "Native pair lists and counts are required");
+  SPX_CHECK(kv >= 1 && kv <= 128, "kernel volume %d not supported by wgrad (max 128)", kv);
   SPX_CHECK(ws_bytes >= spx_igemm_wgrad_ws_bytes(n_in, C, K, kv), "workspace too small");
   WgradParams p{};
   p.feat = feat;
@@ -719,9 +891,19 @@ int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t 
   p.tiles_c = div_up(C, kWT);
   p.tiles_k = div_up(K, kWT);
   const int ntile = p.tiles_c * p.tiles_k;
+  if (!plan) {  // caller did not cache a plan: build it behind the partials
+    int32_t *own = reinterpret_cast<int32_t *>(static_cast<char *>(ws) + ws_bytes -
+                                               spx_wgrad_plan_bytes(n_in, kv));
+    if (spx_wgrad_plan(num_per_loc, n_in, kv, subm, own, stream)) return -2;
+    plan = own;
+  }
+  p.plan = plan;
   const bool mfma = (dtype == SPX_F16 || dtype == SPX_BF16) && C % 8 == 0 && K % 8 == 0;
-  if (n_in > 0) {
-    const dim3 grid(p.nchunks, kv, ntile);
+  {
+    // upper bound of work items is nchunks * kv * ntile; the kernels loop over the real count
+    const long long bound = static_cast<long long>(p.nchunks) * kv * ntile;
+    static const int max_grid = env_int("SPX_WGRAD_GRID", 1024);
+    const dim3 grid(static_cast<unsigned>(bound < max_grid ? bound : max_grid));
     const size_t lds = 2 * kWT * kWJ * 2;
     if (mfma && dtype == SPX_F16)
       hipLaunchKernelGGL(wgrad_mfma_kernel<false>, grid, dim3(kThreads), lds, s, p);
@@ -737,16 +919,15 @@ int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t 
       SPX_CHECK(false, "unsupported dtype %d", dtype);
     SPX_LAUNCH_CHECK();
   }
-  // with n_in == 0 every list is empty and the reduction writes zeros
-  const dim3 rgrid(div_up(ntile * kWT * kWT, kThreads / 8), kv);
+  const dim3 rgrid(div_up(ntile * kWT * kWT, kRedElems), kv);
   if (dtype == SPX_F32)
-    hipLaunchKernelGGL(wgrad_reduce_kernel<float>, rgrid, dim3(kThreads), 0, s, p,
+    hipLaunchKernelGGL(wgrad_reduce_kernel<float>, rgrid, dim3(kRedThreads), 0, s, p,
                        static_cast<float *>(dw));
   else if (dtype == SPX_F16)
-    hipLaunchKernelGGL(wgrad_reduce_kernel<h16>, rgrid, dim3(kThreads), 0, s, p,
+    hipLaunchKernelGGL(wgrad_reduce_kernel<h16>, rgrid, dim3(kRedThreads), 0, s, p,
                        static_cast<h16 *>(dw));
   else if (dtype == SPX_BF16)
-    hipLaunchKernelGGL(wgrad_reduce_kernel<b16>, rgrid, dim3(kThreads), 0, s, p,
+    hipLaunchKernelGGL(wgrad_reduce_kernel<b16>, rgrid, dim3(kRedThreads), 0, s, p,
                        static_cast<b16 *>(dw));
   else
     SPX_CHECK(false, "unsupported dtype %d", dtype);

@@ -43,7 +43,7 @@ __device__ __forceinline__ uint32_t hash_key(hkey_t k) {
 // Inserts key (if absent) and lowers its value to min(value, val). Returns the slot.
 __device__ __forceinline__ int table_insert_min(const Table &t, hkey_t key, int32_t val) {
   uint32_t slot = hash_key(key) & t.mask;
-  for (;;) {
+  for (uint32_t probe = 0; probe <= t.mask; ++probe) {  // bounded: the table is never full
     unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long *>(&t.keys[slot]),
                                         static_cast<unsigned long long>(-1LL),
                                         static_cast<unsigned long long>(key));
@@ -54,16 +54,18 @@ __device__ __forceinline__ int table_insert_min(const Table &t, hkey_t key, int3
     }
     slot = (slot + 1) & t.mask;
   }
+  return -1;
 }
 
 __device__ __forceinline__ int table_lookup(const Table &t, hkey_t key) {
   uint32_t slot = hash_key(key) & t.mask;
-  for (;;) {
+  for (uint32_t probe = 0; probe <= t.mask; ++probe) {
     hkey_t k = t.keys[slot];
     if (k == key) return static_cast<int>(slot);
     if (k == -1LL) return -1;
     slot = (slot + 1) & t.mask;
   }
+  return -1;
 }
 
 // Reads one index row (batch, coords...) into canonical 4-d form.
@@ -135,13 +137,22 @@ subm_probe_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table t,
   const bool bvalid = b >= 0 && b < g.batch;
   const int kv = g.kv;
   const int center = kv / 2;
+  // Duplicate coordinates: the CPU path only ever *finds* the first index of a
+  // coordinate (unordered_map::insert keeps it, indices.py:1672), so a later
+  // duplicate never appears as the found side.  In the dense table that side is
+  // the output for k < centre -> such rows keep only the k > centre half.
+  bool first_of_coord = false;
+  if (bvalid && in_range(c, g.in_dims)) {
+    const int self = table_lookup(t, layout_key(b, c, g.in_dims));
+    first_of_coord = self >= 0 && t.vals[self] == o;
+  }
   int r[4] = {0, 0, 0, 0};
   uint32_t mcur = 0;
   for (int k = 0; k < kv; ++k) {
     int v = -1;
     if (k == center) {
       v = o;
-    } else if (bvalid) {
+    } else if (bvalid && (k > center || first_of_coord)) {
       int q[4];
 #pragma unroll
       for (int d = 0; d < 4; ++d) q[d] = c[d] - g.padding[d] + r[d] * g.dilation[d];
@@ -631,6 +642,10 @@ int spx_subm_rulebook(const int32_t *indices, int n, int ndim, int batch_size,
     kv *= ksize[i];
   }
   if (check_geom(ndim, n, kv)) return -1;
+  if (n == 0) {
+    if (num_per_loc) SPX_HIP(hipMemsetAsync(num_per_loc, 0, sizeof(int32_t) * kv, s));
+    return 0;
+  }
   SPX_CHECK(pair_fwd && mask, "pair_fwd and mask are required");
   SPX_CHECK(ws_bytes >= spx_subm_rulebook_ws_bytes(n, kv), "workspace too small: %zu < %zu",
             ws_bytes, spx_subm_rulebook_ws_bytes(n, kv));

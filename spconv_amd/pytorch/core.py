@@ -50,6 +50,7 @@ class Rulebook:
         self.subm = subm
         self.argsort_fwd = argsort_fwd
         self.argsort_bwd = argsort_bwd
+        self.wgrad_plan = None          # built lazily by ops._plan_of
         self._native_swapped = None
 
     def native_swapped(self) -> torch.Tensor:

@@ -295,8 +295,19 @@ def igemm_dgrad(out_bp: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
     return din
 
 
+def wgrad_plan(num_per_loc: torch.Tensor, n_in: int, kv: int, subm: bool) -> torch.Tensor:
+    """Work plan of wgrad for one rulebook (built once, reused by every backward)."""
+    L = _lib.load()
+    plan = torch.empty((L.spx_wgrad_plan_bytes(n_in, kv) // 4,), dtype=torch.int32,
+                       device=num_per_loc.device)
+    _lib.check(L.spx_wgrad_plan(num_per_loc.data_ptr(), n_in, kv, int(subm), plan.data_ptr(),
+                                _stream(num_per_loc)))
+    return plan
+
+
 def igemm_wgrad(features: torch.Tensor, out_bp: torch.Tensor, filters_shape, native: torch.Tensor,
-                num_per_loc: torch.Tensor, subm: bool) -> torch.Tensor:
+                num_per_loc: torch.Tensor, subm: bool,
+                plan: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dW[:, k, :] = sum_j dout[native[1][k][j]].T (x) feat[native[0][k][j]]."""
     _require_gpu(features, "features")
     L = _lib.load()
@@ -308,10 +319,18 @@ def igemm_wgrad(features: torch.Tensor, out_bp: torch.Tensor, filters_shape, nat
     dw = torch.empty(tuple(filters_shape), dtype=features.dtype, device=features.device)
     ws = _ws(L.spx_igemm_wgrad_ws_bytes(n_in, C, K, kv), features.device)
     _lib.check(L.spx_igemm_wgrad(features.data_ptr(), out_bp.data_ptr(), dw.data_ptr(),
-                                 native.data_ptr(), num_per_loc.data_ptr(), n_in, out_bp.shape[0],
-                                 C, K, kv, _dtype_code(features), int(subm), ws.data_ptr(),
-                                 ws.numel(), _stream(features)))
+                                 native.data_ptr(), num_per_loc.data_ptr(), _ptr(plan), n_in,
+                                 out_bp.shape[0], C, K, kv, _dtype_code(features), int(subm),
+                                 ws.data_ptr(), ws.numel(), _stream(features)))
     return dw
+
+
+def _plan_of(rb: Optional[Rulebook]) -> Optional[torch.Tensor]:
+    if rb is None or rb.pair_native is None:
+        return None
+    if rb.wgrad_plan is None:
+        rb.wgrad_plan = wgrad_plan(rb.num_per_loc, rb.n_in, rb.kv, rb.subm)
+    return rb.wgrad_plan
 
 
 def bias_act_inplace(out: torch.Tensor, bias: Optional[torch.Tensor], act_type: int,
@@ -397,7 +416,7 @@ def indice_conv_backward(features: torch.Tensor, filters: torch.Tensor, out_bp: 
     if inverse:
         native = rb.native_swapped() if rb is not None else torch.stack(
             [indice_pairs[1], indice_pairs[0]]).contiguous()
-    dw = igemm_wgrad(features, out_bp, filters.shape, native, indice_pair_num, subm)
+    dw = igemm_wgrad(features, out_bp, filters.shape, native, indice_pair_num, subm, _plan_of(rb))
     return din, dw
 
 
@@ -445,5 +464,5 @@ def implicit_gemm_backward(features: torch.Tensor, filters: torch.Tensor, out_bp
         native, num = rb.pair_native, rb.num_per_loc
     else:
         native, num = _native_from_table(pair_fwd if is_subm else pair_bwd, is_subm)
-    dw = igemm_wgrad(features, out_bp, filters.shape, native, num, is_subm)
+    dw = igemm_wgrad(features, out_bp, filters.shape, native, num, is_subm, _plan_of(rb))
     return din, dw

@@ -36,7 +36,7 @@ def _case(shape, n, bs, C, K, ksize, stride, pad, dil, subm, dtype, seed=0, tran
 
 
 def _run_gpu(cuda, idx, bs, shape, ksize, stride, pad, dil, subm, transposed, f, w, dout, dtype,
-             use_sort=False):
+             use_sort=False, use_plan=True):
     from spconv_amd.pytorch import ops
     rb, _ = gpu_rulebook(idx, bs, shape, ksize, stride, pad, dil, subm, transposed,
                          do_sort=use_sort)
@@ -48,7 +48,8 @@ def _run_gpu(cuda, idx, bs, shape, ksize, stride, pad, dil, subm, transposed, f,
         din = ops.igemm_dgrad(dg, wg, rb.pair_fwd, rb.mask_fwd, rb.argsort_fwd, rb.n_in, True)
     else:
         din = ops.igemm_dgrad(dg, wg, rb.pair_bwd, rb.mask_bwd, rb.argsort_bwd, rb.n_in, False)
-    dw = ops.igemm_wgrad(fg, dg, wg.shape, rb.pair_native, rb.num_per_loc, subm)
+    plan = ops._plan_of(rb) if use_plan else None
+    dw = ops.igemm_wgrad(fg, dg, wg.shape, rb.pair_native, rb.num_per_loc, subm, plan)
     torch.cuda.synchronize()
     return rb, out.float().cpu(), din.float().cpu(), dw.float().cpu()
 

@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""Per-kernel device times (HIP events) for the hot path over a small scene/sort matrix.
+Used for A/B tuning runs on the GPU box: `SPX_GEMM_DEPTH=2 python tools/kbench.py`."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import SHAPE, event_time_ms  # noqa: E402
+from spconv_amd.pytorch import ops  # noqa: E402
+from spconv_amd.utils import synthetic  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda:0")
+    C = K = int(os.environ.get("KB_CHANNELS", "64"))
+    n = int(os.environ.get("KB_VOXELS", "100000"))
+    tag = {k: v for k, v in os.environ.items() if k.startswith("SPX_")}
+    rows = []
+    for scene in ("uniform", "lidar"):
+        gen = synthetic.uniform_scene if scene == "uniform" else synthetic.lidar_like_scene
+        idx = torch.from_numpy(gen(SHAPE, n, 1, seed=0)).to(dev)
+        nn = idx.shape[0]
+        f = (torch.rand(nn, C, device=dev) * 2 - 1).half()
+        d = ((torch.rand(nn, K, device=dev) * 2 - 1) * 0.2).half()
+        w = (torch.rand(K, 3, 3, 3, C, device=dev) * 2 - 1).half()
+        for sort in (False, True):
+            rb, _ = ops.build_rulebook(idx, 1, SHAPE, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True,
+                                       do_sort=sort)
+            plan = ops._plan_of(rb)
+            t_f = event_time_ms(lambda: ops.igemm_fwd(f, w, rb.pair_fwd, rb.mask_fwd, rb.argsort_fwd, nn, 13))
+            t_d = event_time_ms(lambda: ops.igemm_dgrad(d, w, rb.pair_fwd, rb.mask_fwd, rb.argsort_fwd, nn, True))
+            t_w = event_time_ms(lambda: ops.igemm_wgrad(f, d, w.shape, rb.pair_native, rb.num_per_loc, True, plan))
+            t_r = event_time_ms(lambda: ops.build_rulebook(idx, 1, SHAPE, [3] * 3, [1] * 3, [1] * 3, [1] * 3,
+                                                           [0] * 3, True, do_sort=sort), iters=5, warm=2)
+            rows.append(dict(scene=scene, sort=sort, fwd_us=round(t_f * 1e3, 2), dgrad_us=round(t_d * 1e3, 2),
+                             wgrad_us=round(t_w * 1e3, 2), rulebook_us=round(t_r * 1e3, 1)))
+    print(json.dumps({"env": tag, "C": C, "n": n, "rows": rows}))
+
+
+if __name__ == "__main__":
+    main()
