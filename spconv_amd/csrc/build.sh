@@ -6,14 +6,19 @@ OUT=../lib
 mkdir -p $OUT
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+pids=()
 for f in rulebook igemm; do
   if [ ! -f $OUT/$f.o ] || [ $f.hip -nt $OUT/$f.o ] || [ common.h -nt $OUT/$f.o ] || [ ../../include/spconv_amd.h -nt $OUT/$f.o ]; then
+    rm -f $OUT/$f.o
     $HIPCC $FLAGS -c $f.hip -o $OUT/$f.o &
+    pids+=($!)
   fi
 done
 if [ ! -f $OUT/common.o ] || [ common.cpp -nt $OUT/common.o ] || [ common.h -nt $OUT/common.o ]; then
+  rm -f $OUT/common.o
   $HIPCC $FLAGS -x hip -c common.cpp -o $OUT/common.o &
+  pids+=($!)
 fi
-wait
+for p in "${pids[@]}"; do wait $p; done   # a failed compile aborts the build (set -e)
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT/libspconv_amd.so $OUT/rulebook.o $OUT/igemm.o $OUT/common.o
 echo built $OUT/libspconv_amd.so

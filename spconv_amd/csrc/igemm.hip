@@ -44,7 +44,7 @@ struct GemmParams {
   const uint32_t *mask;   // [n_dst] or null
   const int32_t *argsort; // [n_dst] or null
   const void *bias;       // [COUT] or null
-  long long strideK, strideN;
+  long long strideK, strideN, strideD;   // strideD: stride of the reduction index (1 = contiguous)
   int n_src, n_dst, CIN, COUT, kv;
   int identity_k;         // offset whose pair is the identity, or -1
   int b_reverse;          // use weight slice kv-1-k for offset k (SubM dgrad)
@@ -87,6 +87,15 @@ __device__ __forceinline__ f32x4 mfma16(const uint4 &a, const uint4 &b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a),
                                                   __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   }
+}
+
+__device__ __forceinline__ uint32_t dword_of4(const uint4 &v, int i) {
+  return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
+}
+
+// value-wise select (a ?: on the uint4 objects themselves would force them into memory)
+__device__ __forceinline__ uint4 sel4(bool ok, const uint4 &v) {
+  return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
 }
 
 // byte offset of 16-byte slot `slot` of row `row` in a [rows][ROWB bytes] LDS
@@ -137,116 +146,143 @@ __device__ __forceinline__ StepIt step_next(StepIt it, int nchunk) {
   return it;
 }
 
-template <int COUT, bool BF16, int DEPTH>
+// BT = false: weight slice rows are [n][reduction] contiguous (forward, KRSC).
+// BT = true : the slice is stored [reduction][n] (dgrad reads KRSC directly: reduction = K,
+//             n = C); it is transposed on its way into LDS, so no re-laid-out copy of
+//             the weights is ever written to memory.
+template <int COUT, bool BF16, bool BT>
 __global__ void __launch_bounds__(kThreads)
 gather_gemm_mfma_kernel(GemmParams p) {
-  static_assert(DEPTH == 1 || DEPTH == 2, "prefetch depth");
   constexpr int NB = COUT / 16;                       // 16-wide output-channel blocks
-  constexpr int BROWS = (COUT + 31) / 32;             // weight rows staged per thread
+  // 16-byte weight vectors staged per thread
+  constexpr int BROWS = BT ? 2 * ((COUT + 63) / 64) : (COUT + 31) / 32;
   constexpr int A_BYTES = kTileM * kRowBytes;         // 16 KiB
   constexpr int OUT_ROWB = COUT * 2;
   constexpr int OXM = (COUT / 8 - 1) < 7 ? (COUT / 8 - 1) : 7;  // swizzle stays inside the row
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char *ldsA = smem;
   char *ldsB = smem + A_BYTES;
-  // [0] = tile mask, [1..4] = per-wave masks of the 32 rows each wave multiplies
-  uint32_t *lds_mask = reinterpret_cast<uint32_t *>(smem + A_BYTES + COUT * kRowBytes);
+  uint32_t *lds_mask = reinterpret_cast<uint32_t *>(smem + A_BYTES + COUT * kRowBytes);  // [4]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntiles = (p.n_dst + kTileM - 1) / kTileM;
   const int tile = xcd_tile(blockIdx.x, ntiles);
   const int slot = tid & 7;        // 16-byte slot of a 128-byte row
-  const int r0 = tid >> 3;         // 0..31
+  const int r0 = tid >> 3;         // 0..31 (weight staging)
+  const int rw = lane >> 3;        // 0..7  (row inside the wave's 32-row block)
   const uint16_t *A = static_cast<const uint16_t *>(p.A);
   const uint16_t *B = static_cast<const uint16_t *>(p.B);
   const int nchunk = (p.CIN + kCK - 1) / kCK;
 
-  // destination rows staged by this thread: tile rows r0 + 32 j (row block j is
-  // multiplied by wave j)
+  // Each wave stages the 32 rows it multiplies: tile rows 32*wave + rw + 8*j.
   int grow[4];
-  uint32_t rmask[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int t = tile * kTileM + r0 + 32 * j;
+    const int t = tile * kTileM + wave * 32 + rw + 8 * j;
     int g = -1;
     if (t < p.n_dst) g = p.argsort ? p.argsort[t] : t;
     grow[j] = g;
-    rmask[j] = g >= 0 ? 0xffffffffu : 0u;   // refined below once the mask words arrive
   }
 
-  uint4 areg[DEPTH][4], breg[DEPTH][BROWS];
+  uint32_t rmask[4];
+  int idxraw[4];                 // raw pair-table words of the step whose data is fetched next
+  uint32_t aok = 0;              // bit j: row j of the data in flight is a real row
+  uint4 areg[4], breg[BROWS];    // raw loaded vectors; invalid ones are zeroed at the LDS write
 
-  // issue the global loads of step `it` into register set SET
-  auto load_step = [&](auto SET, const StepIt &it) {
-    constexpr int S = decltype(SET)::value;
-    const int k = it.k, c0 = it.chunk * kCK;
-    const bool cin_ok = c0 + slot * 8 < p.CIN;
+  // NOTE on structure: nothing below consumes a loaded value right after its load -- the
+  // compiler puts s_waitcnt at the first use, so selects on fresh data would serialise
+  // the prefetch.  Validity is applied one step later (aok / rmask), at the LDS write.
+
+  // (1) index fetch for step `it`: straight-line, unconditional loads (an invalid row reads
+  // entry 0) so that all four are in flight together.
+  auto load_idx = [&](const StepIt &it) __attribute__((always_inline)) {
+    if (it.k == p.identity_k) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int idx = -1;
-      if ((rmask[j] >> k) & 1u) {
-        idx = (k == p.identity_k) ? grow[j]
-                                  : p.pair[static_cast<size_t>(k) * p.n_dst + grow[j]];
-      }
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (idx >= 0 && cin_ok)
-        v = *reinterpret_cast<const uint4 *>(A + static_cast<size_t>(idx) * p.CIN + c0 + slot * 8);
-      areg[S][j] = v;
-    }
-    const int kb = p.b_reverse ? p.kv - 1 - k : k;
-    const uint16_t *Bk = B + static_cast<size_t>(kb) * p.strideK + c0 + slot * 8;
+      for (int j = 0; j < 4; ++j) idxraw[j] = grow[j];
+    } else {
+      const int32_t *row = p.pair + static_cast<size_t>(it.k) * p.n_dst;
 #pragma unroll
-    for (int j = 0; j < BROWS; ++j) {
-      const int n = r0 + 32 * j;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (n < COUT && cin_ok)
-        v = *reinterpret_cast<const uint4 *>(Bk + static_cast<size_t>(n) * p.strideN);
-      breg[S][j] = v;
+      for (int j = 0; j < 4; ++j) idxraw[j] = row[grow[j] < 0 ? 0 : grow[j]];
     }
   };
-  using Set0 = std::integral_constant<int, 0>;
-  using Set1 = std::integral_constant<int, DEPTH - 1>;
 
-  // SubM: the identity offset is present for every valid row, so its loads do not
-  // need the mask words -> issue them before the (dependent) mask loads return.
+  // (2) data fetch for step `it` from the rows in idxraw + the weight slice.
+  auto load_data = [&](const StepIt &it) __attribute__((always_inline)) {
+    const int c0 = it.chunk * kCK;
+    const bool cin_ok = c0 + slot * 8 < p.CIN;
+    const int coff = cin_ok ? c0 + slot * 8 : 0;
+    aok = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = ((rmask[j] >> it.k) & 1u) ? idxraw[j] : -1;
+      aok |= (idx >= 0 ? 1u : 0u) << j;
+      areg[j] = *reinterpret_cast<const uint4 *>(
+          A + static_cast<size_t>(idx < 0 ? 0 : idx) * p.CIN + coff);
+    }
+    const int kb = p.b_reverse ? p.kv - 1 - it.k : it.k;
+    const uint16_t *Bk = B + static_cast<size_t>(kb) * p.strideK;
+    if constexpr (!BT) {
+#pragma unroll
+      for (int j = 0; j < BROWS; ++j) {
+        const int n = r0 + 32 * j;
+        breg[j] = *reinterpret_cast<const uint4 *>(
+            Bk + static_cast<size_t>(n < COUT ? n : 0) * p.strideN + coff);
+      }
+    } else {
+      // vector j: reduction row d = c0 + 2*r0 + (j & 1), n-block (j >> 1)*64 + slot*8 .. +8
+#pragma unroll
+      for (int j = 0; j < BROWS; ++j) {
+        const int d = c0 + 2 * r0 + (j & 1);
+        const int n = (j >> 1) * 64 + slot * 8;
+        const bool ok = d < p.CIN && n < COUT;
+        breg[j] = *reinterpret_cast<const uint4 *>(
+            Bk + static_cast<size_t>(ok ? d : 0) * p.strideD + (ok ? n : 0));
+      }
+    }
+  };
+
+  // SubM: the identity offset exists for every valid row, so its data does not depend on the
+  // mask words -> start it before the mask loads return.
   const bool spec = p.identity_k >= 0;
   StepIt it0;
+  it0.k = p.identity_k;
+  it0.chunk = 0;
+  it0.rest = 0;
   if (spec) {
-    it0.k = p.identity_k;
-    it0.chunk = 0;
-    it0.rest = 0;
-    load_step(Set0{}, it0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      rmask[j] = grow[j] >= 0 ? 0xffffffffu : 0u;
+      idxraw[j] = grow[j];
+    }
+    load_data(it0);
   }
-  uint32_t any = 0;
+  uint32_t wm = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    uint32_t m = 0;
-    if (grow[j] >= 0) m = p.mask ? p.mask[grow[j]] : 0xffffffffu;
-    rmask[j] = m;
-    any |= m;
+    const uint32_t m = p.mask ? p.mask[grow[j] < 0 ? 0 : grow[j]] : 0xffffffffu;
+    rmask[j] = grow[j] >= 0 ? m : 0u;
+    wm |= rmask[j];
   }
-  if (tid < 5) lds_mask[tid] = 0;
+  // OR over the wave's rows: lanes with equal (lane >> 3) hold the same rows
+  wm |= __shfl_xor(wm, 8, 64);
+  wm |= __shfl_xor(wm, 16, 64);
+  wm |= __shfl_xor(wm, 32, 64);
+  const uint32_t wavemask = wm;
+  if (lane == 0) lds_mask[wave] = wm;
   __syncthreads();
-  if (any) {
-    atomicOr(&lds_mask[0], any);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (rmask[j]) atomicOr(&lds_mask[1 + j], rmask[j]);
-  }
-  __syncthreads();
-  uint32_t tilemask = lds_mask[0];
-  const uint32_t wavemask = lds_mask[1 + wave];
+  uint32_t tilemask = lds_mask[0] | lds_mask[1] | lds_mask[2] | lds_mask[3];
   if (p.kv < 32) tilemask &= (1u << p.kv) - 1u;
-  if (spec) {
+  if (spec && ((tilemask >> p.identity_k) & 1u)) {
     it0.rest = tilemask & ~(1u << p.identity_k);
-    // a tile without valid rows has an empty mask: nothing to do for the speculated step
-    if (!((tilemask >> p.identity_k) & 1u)) it0 = step_begin(it0.rest);
   } else {
     it0 = step_begin(tilemask);
-    if (it0.k >= 0) load_step(Set0{}, it0);
+    if (it0.k >= 0) {
+      load_idx(it0);
+      load_data(it0);
+    }
   }
   StepIt it1 = step_next(it0, nchunk);
-  if (DEPTH == 2 && it1.k >= 0) load_step(Set1{}, it1);
+  if (it1.k >= 0) load_idx(it1);
 
   f32x4 acc[NB][2];
 #pragma unroll
@@ -255,20 +291,44 @@ gather_gemm_mfma_kernel(GemmParams p) {
     acc[nb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  // one pipeline step: registers of set SET -> LDS, prefetch, MFMA
-  auto do_step = [&](auto SET, const StepIt &cur, const StepIt &pre) {
-    constexpr int S = decltype(SET)::value;
+  StepIt cur = it0, nxt = it1;
+  while (cur.k >= 0) {
     __syncthreads();  // previous step's fragment reads are done
+    const bool cur_cin_ok = cur.chunk * kCK + slot * 8 < p.CIN;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      *reinterpret_cast<uint4 *>(ldsA + swz_off(r0 + 32 * j, slot, kRowBytes)) = areg[S][j];
+      *reinterpret_cast<uint4 *>(ldsA + swz_off(wave * 32 + rw + 8 * j, slot, kRowBytes)) =
+          sel4(((aok >> j) & 1u) && cur_cin_ok, areg[j]);
+    if constexpr (!BT) {
 #pragma unroll
-    for (int j = 0; j < BROWS; ++j) {
-      const int n = r0 + 32 * j;
-      if (n < COUT) *reinterpret_cast<uint4 *>(ldsB + swz_off(n, slot, kRowBytes)) = breg[S][j];
+      for (int j = 0; j < BROWS; ++j) {
+        const int n = r0 + 32 * j;
+        if (n < COUT)
+          *reinterpret_cast<uint4 *>(ldsB + swz_off(n, slot, kRowBytes)) = sel4(cur_cin_ok, breg[j]);
+      }
+    } else {
+      // transpose: dword (d even, d odd) of channel n lands in row n, reduction column 2*r0
+      const bool d_ok = cur.chunk * kCK + 2 * r0 < p.CIN;
+#pragma unroll
+      for (int jj = 0; jj < BROWS / 2; ++jj) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int n = jj * 64 + slot * 8 + e;
+          const int sh = (e & 1) * 16;
+          const uint32_t lo = (dword_of4(breg[2 * jj], e >> 1) >> sh) & 0xffffu;
+          const uint32_t hi = (dword_of4(breg[2 * jj + 1], e >> 1) >> sh) & 0xffffu;
+          if (n < COUT)
+            *reinterpret_cast<uint32_t *>(ldsB + swz_off(n, r0 >> 2, kRowBytes) + (r0 & 3) * 4) =
+                d_ok ? (lo | (hi << 16)) : 0u;
+        }
+      }
     }
     __syncthreads();
-    if (pre.k >= 0) load_step(SET, pre);   // this set is free again: refill DEPTH steps ahead
+    // prefetch: data of the next step (its indices arrived during the previous step), then
+    // the indices of the step after it
+    const StepIt nn = step_next(nxt, nchunk);
+    if (nxt.k >= 0) load_data(nxt);
+    if (nn.k >= 0) load_idx(nn);
     if ((wavemask >> cur.k) & 1u) {        // none of this wave's 32 rows uses offset k: skip
       const int c0 = cur.chunk * kCK;
       const int ksteps = (min(kCK, p.CIN - c0) + 31) >> 5;  // 1 or 2
@@ -288,34 +348,15 @@ gather_gemm_mfma_kernel(GemmParams p) {
         }
       }
     }
-  };
-
-  if constexpr (DEPTH == 1) {
-    StepIt cur = it0, nxt = it1;
-    while (cur.k >= 0) {
-      do_step(Set0{}, cur, nxt);
-      cur = nxt;
-      nxt = step_next(nxt, nchunk);
-    }
-  } else {
-    StepIt cur = it0, nxt = it1, pre = step_next(it1, nchunk);
-    while (cur.k >= 0) {
-      do_step(Set0{}, cur, pre);           // set 0 holds `cur`, refilled with `pre`
-      cur = nxt;                            // now in set 1
-      nxt = pre;                            // now in set 0
-      pre = step_next(pre, nchunk);
-      if (cur.k < 0) break;
-      do_step(Set1{}, cur, pre);
-      cur = nxt;
-      nxt = pre;
-      pre = step_next(pre, nchunk);
-    }
+    cur = nxt;
+    nxt = nn;
   }
 
   // ---- epilogue: bias/activation, fp32 -> 16 bit, transpose through LDS so
   // every output row leaves as full 16-byte-per-lane coalesced stores.
   __syncthreads();
   const uint16_t *bias = static_cast<const uint16_t *>(p.bias);
+  const bool plain = bias == nullptr && p.act == SPX_ACT_NONE;   // uniform: training path
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int ch = nb * 16 + (lane >> 4) * 4;  // D row = channel, D col = voxel
@@ -328,9 +369,14 @@ gather_gemm_mfma_kernel(GemmParams p) {
     for (int mb = 0; mb < 2; ++mb) {
       const int row = wave * 32 + mb * 16 + (lane & 15);
       uint16_t h[4];
+      if (plain) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        h[e] = from_float<BF16>(apply_act(acc[nb][mb][e] + bv[e], p.act, p.act_alpha));
+        for (int e = 0; e < 4; ++e) h[e] = from_float<BF16>(acc[nb][mb][e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          h[e] = from_float<BF16>(apply_act(acc[nb][mb][e] + bv[e], p.act, p.act_alpha));
+      }
       uint2 pk;
       pk.x = static_cast<uint32_t>(h[0]) | (static_cast<uint32_t>(h[1]) << 16);
       pk.y = static_cast<uint32_t>(h[2]) | (static_cast<uint32_t>(h[3]) << 16);
@@ -367,16 +413,16 @@ int env_int(const char *name, int dflt) {
 template <int COUT, bool BF16>
 int launch_gather_gemm(const GemmParams &p, hipStream_t s) {
   const int ntiles = div_up(p.n_dst, kTileM);
-  static const int depth = env_int("SPX_GEMM_DEPTH", 1);   // tuning knob (1 or 2 steps ahead)
-  if (depth == 2 && COUT <= 128)
-    hipLaunchKernelGGL((gather_gemm_mfma_kernel<COUT, BF16, 2>), dim3(ntiles), dim3(kThreads),
+  if (p.strideD == 1)
+    hipLaunchKernelGGL((gather_gemm_mfma_kernel<COUT, BF16, false>), dim3(ntiles), dim3(kThreads),
                        gemm_smem_bytes<COUT>(), s, p);
   else
-    hipLaunchKernelGGL((gather_gemm_mfma_kernel<COUT, BF16, 1>), dim3(ntiles), dim3(kThreads),
+    hipLaunchKernelGGL((gather_gemm_mfma_kernel<COUT, BF16, true>), dim3(ntiles), dim3(kThreads),
                        gemm_smem_bytes<COUT>(), s, p);
   SPX_LAUNCH_CHECK();
   return 0;
 }
+
 
 // --------------------------------------------------------------------------
 // generic gather-GEMM: any dtype / channel count, fp32 accumulate.
@@ -411,30 +457,11 @@ gather_gemm_generic_kernel(GemmParams p) {
     const int kb = p.b_reverse ? p.kv - 1 - k : k;
     const T *a = A + static_cast<size_t>(idx) * p.CIN;
     const T *b = B + static_cast<size_t>(kb) * p.strideK + static_cast<size_t>(n) * p.strideN;
-    for (int c = 0; c < p.CIN; ++c) acc = fmaf(load_f(a + c), load_f(b + c), acc);
+    for (int c = 0; c < p.CIN; ++c) acc = fmaf(load_f(a + c), load_f(b + c * p.strideD), acc);
   }
   if (p.bias) acc += load_f(static_cast<const T *>(p.bias) + n);
   acc = apply_act(acc, p.act, p.act_alpha);
   store_f(static_cast<T *>(p.out) + static_cast<size_t>(d) * p.COUT + n, acc);
-}
-
-// Wt[k][c][kk] = W[kk][k][c]  (dgrad consumes the reduction dim K contiguously).
-// One 64x64 tile per block, transposed through LDS so both sides are coalesced.
-template <typename T>
-__global__ void __launch_bounds__(kThreads)
-weight_relayout_kernel(const T *__restrict__ W, T *__restrict__ Wt, int K, int kv, int C) {
-  __shared__ T tile[64][65];
-  const int k = blockIdx.x, kk0 = blockIdx.y * 64, c0 = blockIdx.z * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
-  for (int r = ty; r < 64; r += 4) {
-    const int kk = kk0 + r, c = c0 + tx;
-    if (kk < K && c < C) tile[r][tx] = W[(static_cast<size_t>(kk) * kv + k) * C + c];
-  }
-  __syncthreads();
-  for (int r = ty; r < 64; r += 4) {
-    const int c = c0 + r, kk = kk0 + tx;
-    if (kk < K && c < C) Wt[(static_cast<size_t>(k) * C + c) * K + kk] = tile[tx][r];
-  }
 }
 
 // --------------------------------------------------------------------------
@@ -545,7 +572,7 @@ wgrad_mfma_kernel(WgradParams p) {
       for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     uint4 dv[2][2], fv[2][2];
-    auto load_rows = [&](int base) {
+    auto load_rows = [&](int base) __attribute__((always_inline)) {
 #pragma unroll
       for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -788,6 +815,7 @@ int spx_igemm_fwd(const void *feat, const void *weight, void *out, const int32_t
   p.bias = bias;
   p.strideK = C;                                  // KRSC: W[n][k][c]
   p.strideN = static_cast<long long>(kv) * C;
+  p.strideD = 1;
   p.n_src = n_in;
   p.n_dst = n_out;
   p.CIN = C;
@@ -801,36 +829,28 @@ int spx_igemm_fwd(const void *feat, const void *weight, void *out, const int32_t
 }
 
 size_t spx_igemm_dgrad_ws_bytes(int C, int K, int kv, int dtype) {
-  return align_up(static_cast<size_t>(C) * K * kv * elem_bytes(dtype), 256);
+  (void)C; (void)K; (void)kv; (void)dtype;
+  return 0;  // the weight transpose happens inside the kernel (LDS staging)
 }
 
 int spx_igemm_dgrad(const void *dout, const void *weight, void *din, const int32_t *pair,
                     const uint32_t *mask, const int32_t *argsort, int n_out, int n_in, int C,
                     int K, int kv, int dtype, int subm, void *ws, size_t ws_bytes,
                     spx_stream_t stream) {
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  SPX_CHECK(dout && weight && din && ws, "null tensor pointer");
-  SPX_CHECK(ws_bytes >= spx_igemm_dgrad_ws_bytes(C, K, kv, dtype), "workspace too small");
-  const dim3 grid(kv, div_up(K, 64), div_up(C, 64));
-  if (dtype == SPX_F32)
-    hipLaunchKernelGGL(weight_relayout_kernel<float>, grid, dim3(kThreads), 0, s,
-                       static_cast<const float *>(weight), static_cast<float *>(ws), K, kv, C);
-  else if (dtype == SPX_F16 || dtype == SPX_BF16)
-    hipLaunchKernelGGL(weight_relayout_kernel<uint16_t>, grid, dim3(kThreads), 0, s,
-                       static_cast<const uint16_t *>(weight), static_cast<uint16_t *>(ws), K, kv, C);
-  else
-    SPX_CHECK(false, "unsupported dtype %d", dtype);
-  SPX_LAUNCH_CHECK();
+  (void)ws; (void)ws_bytes;
+  SPX_CHECK(dout && weight && din, "null tensor pointer");
+  SPX_CHECK(pair || kv == 1, "pair table required");
   GemmParams p{};
   p.A = dout;
-  p.B = ws;                                       // Wt[k][c][kk]
+  p.B = weight;                                   // KRSC read in place: (k, n=c, d=kk)
   p.out = din;
   p.pair = pair;
   p.mask = mask;
   p.argsort = argsort;
   p.bias = nullptr;
-  p.strideK = static_cast<long long>(C) * K;
-  p.strideN = K;
+  p.strideK = C;
+  p.strideN = 1;
+  p.strideD = static_cast<long long>(kv) * C;
   p.n_src = n_out;
   p.n_dst = n_in;
   p.CIN = K;
@@ -840,7 +860,7 @@ int spx_igemm_dgrad(const void *dout, const void *weight, void *din, const int32
   p.b_reverse = subm ? 1 : 0;
   p.act = SPX_ACT_NONE;
   p.act_alpha = 0.f;
-  return run_gather_gemm(p, dtype, s);
+  return run_gather_gemm(p, dtype, static_cast<hipStream_t>(stream));
 }
 
 size_t spx_wgrad_plan_bytes(int n_in, int kv) {
