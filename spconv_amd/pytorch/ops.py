@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from spconv_amd import _lib
-from spconv_amd.constants import SPCONV_DO_SORT
+from spconv_amd.constants import BWD_OVERLAP, SPCONV_DO_SORT
 from spconv_amd.pytorch.core import ConvAlgo, Rulebook
 
 INT32_MAX = 2147483647
@@ -389,6 +389,33 @@ def indice_conv(features: torch.Tensor, filters: torch.Tensor, indice_pairs: tor
                      kv // 2 if subm else -1, bias, act_type, act_alpha)
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    key = torch.device(device).index
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
+def _backward_pair(dgrad_fn, wgrad_fn, ref: torch.Tensor):
+    """dgrad and wgrad only share read-only inputs: run wgrad on a side HIP stream so the two
+    (individually latency-bound) kernels overlap.  Works under hipGraph capture (fork/join
+    through events becomes two parallel graph branches)."""
+    if not BWD_OVERLAP:
+        return dgrad_fn(), wgrad_fn()
+    main = torch.cuda.current_stream(ref.device)
+    side = _side_stream(ref.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        dw = wgrad_fn()
+    din = dgrad_fn()
+    main.wait_stream(side)
+    dw.record_stream(main)
+    return din, dw
+
+
 def indice_conv_backward(features: torch.Tensor, filters: torch.Tensor, out_bp: torch.Tensor,
                          indice_pairs: torch.Tensor, indice_pair_num: torch.Tensor,
                          inverse: bool = False, subm: bool = False,
@@ -402,22 +429,25 @@ def indice_conv_backward(features: torch.Tensor, filters: torch.Tensor, out_bp: 
             table, mask = rb.pair_fwd, rb.mask_fwd
         else:
             table, mask = _table_from_native(indice_pairs, indice_pair_num, n_in, True, False)
-        din = igemm_dgrad(out_bp, filters, table, mask, None, n_in, True)
+        argsort = rb.argsort_fwd if rb is not None else None
     else:
         # dgrad gathers dout rows for every input row: the table indexed by the conv's input
         if rb is not None and not inverse:
-            table, mask = rb.pair_bwd, rb.mask_bwd
+            table, mask, argsort = rb.pair_bwd, rb.mask_bwd, rb.argsort_bwd
         elif rb is not None and inverse:
-            table, mask = rb.pair_fwd, rb.mask_fwd
+            table, mask, argsort = rb.pair_fwd, rb.mask_fwd, rb.argsort_fwd
         else:
             table, mask = _table_from_native(indice_pairs, indice_pair_num, n_in, False, not inverse)
-        din = igemm_dgrad(out_bp, filters, table, mask, None, n_in, False)
+            argsort = None
     native = indice_pairs
     if inverse:
         native = rb.native_swapped() if rb is not None else torch.stack(
             [indice_pairs[1], indice_pairs[0]]).contiguous()
-    dw = igemm_wgrad(features, out_bp, filters.shape, native, indice_pair_num, subm, _plan_of(rb))
-    return din, dw
+    plan = _plan_of(rb)
+    return _backward_pair(
+        lambda: igemm_dgrad(out_bp, filters, table, mask, argsort, n_in, subm),
+        lambda: igemm_wgrad(features, out_bp, filters.shape, native, indice_pair_num, subm, plan),
+        features)
 
 
 def implicit_gemm(features: torch.Tensor, filters: torch.Tensor, pair_fwd: torch.Tensor,
@@ -454,15 +484,18 @@ def implicit_gemm_backward(features: torch.Tensor, filters: torch.Tensor, out_bp
     """Masked implicit GEMM backward (ops.py:1667-1896): returns (din, dfilters)."""
     rb: Optional[Rulebook] = rulebook_of(pair_fwd)
     n_in = features.shape[0]
-    if is_subm:
-        din = igemm_dgrad(out_bp, filters, pair_fwd, pair_mask_fwd_splits[0],
-                          rb.argsort_fwd if rb is not None else None, n_in, True)
-    else:
-        din = igemm_dgrad(out_bp, filters, pair_bwd, pair_mask_bwd_splits[0],
-                          rb.argsort_bwd if rb is not None else None, n_in, False)
     if rb is not None and rb.pair_native is not None:
         native, num = rb.pair_native, rb.num_per_loc
     else:
         native, num = _native_from_table(pair_fwd if is_subm else pair_bwd, is_subm)
-    dw = igemm_wgrad(features, out_bp, filters.shape, native, num, is_subm, _plan_of(rb))
-    return din, dw
+    plan = _plan_of(rb)
+    if is_subm:
+        table, mask = pair_fwd, pair_mask_fwd_splits[0]
+        argsort = rb.argsort_fwd if rb is not None else None
+    else:
+        table, mask = pair_bwd, pair_mask_bwd_splits[0]
+        argsort = rb.argsort_bwd if rb is not None else None
+    return _backward_pair(
+        lambda: igemm_dgrad(out_bp, filters, table, mask, argsort, n_in, is_subm),
+        lambda: igemm_wgrad(features, out_bp, filters.shape, native, num, is_subm, plan),
+        features)
