@@ -16,7 +16,8 @@ import subprocess
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libspconv_amd.so")
+# SPX_LIB selects another build of the same ABI (the -DSPX_TIMELINE debug build of tools/timeline.py)
+LIB_PATH = os.environ.get("SPX_LIB") or os.path.join(_HERE, "lib", "libspconv_amd.so")
 
 c_int_p = ctypes.POINTER(ctypes.c_int)
 vp = ctypes.c_void_p

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Debug build with the in-kernel timeline stamps (tools/timeline.py): lib/libspconv_amd_dbg.so
+set -e
+cd "$(dirname "$0")"
+OUT=../lib
+mkdir -p $OUT/dbg
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DSPX_TIMELINE"
+$HIPCC $FLAGS -c rulebook.hip -o $OUT/dbg/rulebook.o &
+$HIPCC $FLAGS -c igemm.hip -o $OUT/dbg/igemm.o &
+$HIPCC $FLAGS -x hip -c common.cpp -o $OUT/dbg/common.o &
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT/libspconv_amd_dbg.so $OUT/dbg/rulebook.o $OUT/dbg/igemm.o $OUT/dbg/common.o
+echo built $OUT/libspconv_amd_dbg.so

@@ -23,6 +23,7 @@
 
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 
 namespace spx {
 namespace {
@@ -69,6 +70,18 @@ template <> __device__ __forceinline__ uint16_t from_float<true>(float f) {
   if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x40u);  // NaN
   u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even
   return static_cast<uint16_t>(u >> 16);
+}
+
+// two floats -> packed 16-bit pair, round to nearest even (v_cvt_pk_{f16,bf16}_f32 on gfx950)
+template <bool BF16> __device__ __forceinline__ uint32_t pack2(float a, float b) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  if constexpr (BF16) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
+  } else {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, f16x2));
+  }
 }
 
 __device__ __forceinline__ float apply_act(float v, int act, float alpha) {
@@ -425,6 +438,391 @@ int launch_gather_gemm(const GemmParams &p, hipStream_t s) {
 
 
 // --------------------------------------------------------------------------
+// gather-GEMM v4 ("direct fragments"): same contract as gather_gemm_mfma_kernel.
+//  * the gathered operand never touches LDS: every lane loads the 16 bytes it
+//    feeds to the MFMA (row = lane & 15 of an m-block, 8 reduction elements
+//    selected by lane >> 4) with raw buffer loads; a missing pair (-1) turns into
+//    an out-of-range offset, which the buffer unit answers with zeros -- no
+//    selects, no wasted traffic;
+//  * pair-table words and weight slices are fetched through buffer resources
+//    with scalar (SGPR) offsets per step, so the per-step VALU address math is
+//    one multiply-add and one min per row;
+//  * weight slices go global -> registers -> LDS into a two-stage ring: one
+//    __syncthreads() per step;
+//  * register pipeline of depth two for the gathered rows (two named register
+//    sets, statically indexed), depth three for the pair-table words.
+// Limits (checked on the host, v3 handles the rest): n_src * CIN * 2 < 2^31 and
+// n_dst * 4 < 2^31 (32-bit buffer offsets, bit 31 reserved for "out of range").
+// --------------------------------------------------------------------------
+// Optional per-workgroup timeline (debug builds only: -DSPX_TIMELINE, see tools/timeline.py):
+// wave 0 of every workgroup stamps s_memtime at fixed points of igemm_v4_kernel into a global
+// table, read back through spx_debug_timeline().
+#ifdef SPX_TIMELINE
+constexpr int kTlSlots = 8, kTlMaxWg = 8192;
+__device__ unsigned long long g_timeline[kTlMaxWg * kTlSlots];
+#define SPX_STAMP(i)                                                                     \
+  do {                                                                                   \
+    if (threadIdx.x == 0 && blockIdx.x < kTlMaxWg)                                       \
+      g_timeline[blockIdx.x * kTlSlots + (i)] = __builtin_amdgcn_s_memtime();            \
+  } while (0)
+#else
+#define SPX_STAMP(i) do {} while (0)
+#endif
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t kOob = 0x80000000u;      // any offset >= this is out of range for our buffers
+constexpr int kRsrcFlags = 0x00020000;      // raw buffer, 32-bit data format
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, static_cast<int>(bytes),
+                                           kRsrcFlags);
+}
+
+template <int COUT, int MB, bool BF16, bool BT>
+__global__ void __launch_bounds__(kThreads)
+igemm_v4_kernel(GemmParams p) {
+  constexpr int NB = COUT / 16;
+  constexpr int TM = 64 * MB;                           // rows per workgroup: 4 waves x MB x 16
+  constexpr int BROWS = BT ? 2 * ((COUT + 63) / 64) : (COUT + 31) / 32;
+  // one-element arrays captured by the lambdas below defeat SROA in hipcc 7.2 (the whole
+  // parameter block then lives in scratch): keep every register array at >= 2 elements
+  constexpr int BA = BROWS < 2 ? 2 : BROWS;
+  constexpr int B_BYTES = COUT * kRowBytes;             // one staged weight slice [COUT][64]
+  constexpr int CPL = NB * 4;                           // consecutive output channels per lane
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t *lds_mask = reinterpret_cast<uint32_t *>(smem + 2 * B_BYTES);  // [4]
+
+  SPX_STAMP(0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntiles = (p.n_dst + TM - 1) / TM;
+  const int tile = xcd_tile(blockIdx.x, ntiles);
+  const int lrow = lane & 15, lgrp = lane >> 4;
+  const int slot = tid & 7, r0 = tid >> 3;
+  // Output-channel permutation: MFMA row (g = i >> 2, e = i & 3) of channel block nb carries
+  // channel g * CPL + nb * 4 + e, so a lane ends up with CPL CONSECUTIVE channels of its voxel
+  // row and stores them straight from registers (no LDS transpose in the epilogue).  The
+  // weight stage in LDS is [channel][64 reduction elements], 16-byte slots XOR-swizzled with
+  // (bit 1 of the channel, g): the 16 lanes of every ds_read_b128 group hit 16 distinct slots.
+  auto swzB = [](int row, int sl) __attribute__((always_inline)) {
+    const int x = ((row >> 1) & 1) | (((row / CPL) & 3) << 1);
+    return row * kRowBytes + ((sl ^ x) << 4);
+  };
+  const int nchunk = (p.CIN + kCK - 1) / kCK;
+  const uint32_t rowB = static_cast<uint32_t>(p.CIN) * 2u;
+  const bool cfull = (p.CIN & (kCK - 1)) == 0;
+
+  const uint32_t a_bytes = static_cast<uint32_t>(p.n_src) * rowB;
+  const uint32_t w_bytes = static_cast<uint32_t>(p.COUT) * p.kv * p.CIN * 2u;
+  const uint32_t pair_bytes = static_cast<uint32_t>(p.n_dst) * 4u;
+
+  // rows of this lane: tile rows wave*16*MB + mb*16 + lrow
+  int grow[MB];
+  uint32_t goff[MB];      // byte offset of the row's entry inside one pair-table row
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int t = tile * TM + (wave * MB + mb) * 16 + lrow;
+    int g = -1;
+    if (t < p.n_dst) g = p.argsort ? p.argsort[t] : t;
+    grow[mb] = g;
+    goff[mb] = g < 0 ? kOob : static_cast<uint32_t>(g) * 4u;
+  }
+
+  // per-thread constant offsets.  *_tail is the out-of-range bit to OR in for the last
+  // reduction chunk when CIN is not a multiple of 64 (reduction elements >= CIN must read as
+  // zero on BOTH operands).  Bitwise on purpose: a ?: between two arrays becomes a pointer
+  // select that pins them (and the parameter block) in scratch.
+  const int ctail = p.CIN - (nchunk - 1) * kCK;          // elements in the last chunk (1..64)
+  uint32_t aoff[2], aoff_tail[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int c = ks * 32 + lgrp * 8;
+    aoff[ks] = static_cast<uint32_t>(c) * 2u;
+    aoff_tail[ks] = c < ctail ? 0u : kOob;
+  }
+  uint32_t boff[BA], boff_tail[BA];
+  if constexpr (!BT) {
+#pragma unroll
+    for (int j = 0; j < BROWS; ++j) {
+      const int n = r0 + 32 * j;
+      const uint32_t o = static_cast<uint32_t>(n) * static_cast<uint32_t>(p.strideN) * 2u + slot * 16u;
+      boff[j] = n < COUT ? o : kOob;
+      boff_tail[j] = slot * 8 < ctail ? 0u : kOob;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < BROWS; ++j) {
+      const int d = 2 * r0 + (j & 1);                   // reduction row inside the chunk
+      const int n = (j >> 1) * 64 + slot * 8;
+      const uint32_t o = static_cast<uint32_t>(d) * static_cast<uint32_t>(p.strideD) * 2u + n * 2u;
+      boff[j] = n < COUT ? o : kOob;
+      boff_tail[j] = d < ctail ? 0u : kOob;
+    }
+  }
+
+  int idxr[2][MB];
+  uint32_t identr[2] = {0u, 0u};   // wave-uniform: idxr[S] stands for the identity offset
+  u32x4 areg[2][MB][2];
+  u32x4 breg[BA];
+
+  // Straight-line on purpose (no branch around a load): the compiler's s_waitcnt counts stay
+  // exact only when every path issues the same loads.  A step that does not exist (k < 0)
+  // reads through a zero-sized resource: every lane is out of range, nothing is fetched.
+  auto load_idx = [&](const StepIt &it, auto SET) __attribute__((always_inline)) {
+    constexpr int S = decltype(SET)::value;
+    const int k = it.k < 0 ? 0 : it.k;
+    const __amdgpu_buffer_rsrc_t rP = make_rsrc(p.pair + static_cast<size_t>(k) * p.n_dst,
+                                                (p.pair && it.k >= 0) ? pair_bytes : 0u);
+    // the identity select happens where the words are consumed (load_a): selecting here would
+    // make the loop-carried value depend on the load and park the wave on it at the loop end
+    identr[S] = it.k == p.identity_k ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+      idxr[S][mb] = static_cast<int>(__builtin_amdgcn_raw_buffer_load_b32(rP, goff[mb], 0, 0));
+  };
+  auto load_a = [&](const StepIt &it, auto SET) __attribute__((always_inline)) {
+    constexpr int S = decltype(SET)::value;
+    const uint32_t tail = (!cfull && it.chunk == nchunk - 1) ? 0xffffffffu : 0u;
+    const uint32_t so = static_cast<uint32_t>(it.chunk) * (kCK * 2);
+    const __amdgpu_buffer_rsrc_t r = make_rsrc(p.A, it.k >= 0 ? a_bytes : 0u);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const uint32_t idx = (static_cast<uint32_t>(grow[mb]) & identr[S]) |
+                           (static_cast<uint32_t>(idxr[S][mb]) & ~identr[S]);
+      const uint32_t rbase = idx * rowB;                                   // -1 -> >= kOob
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const uint32_t lo = aoff[ks] | (aoff_tail[ks] & tail);
+        const uint32_t vo = min(rbase + lo, kOob) | (lo & kOob);
+        areg[S][mb][ks] = __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0);
+      }
+    }
+  };
+  auto load_b = [&](const StepIt &it) __attribute__((always_inline)) {
+    const uint32_t tail = (!cfull && it.chunk == nchunk - 1) ? 0xffffffffu : 0u;
+    const int k = it.k < 0 ? 0 : it.k;
+    const int kb = p.b_reverse ? p.kv - 1 - k : k;
+    uint32_t so = static_cast<uint32_t>(kb) * static_cast<uint32_t>(p.strideK) * 2u;
+    if constexpr (!BT) so += static_cast<uint32_t>(it.chunk) * (kCK * 2);
+    else so += static_cast<uint32_t>(it.chunk) * kCK * static_cast<uint32_t>(p.strideD) * 2u;
+    const __amdgpu_buffer_rsrc_t r = make_rsrc(p.B, it.k >= 0 ? w_bytes : 0u);
+#pragma unroll
+    for (int j = 0; j < BROWS; ++j)
+      breg[j] = __builtin_amdgcn_raw_buffer_load_b128(r, boff[j] | (boff_tail[j] & tail), so, 0);
+  };
+  auto store_b = [&](char *ldsB) __attribute__((always_inline)) {
+    if constexpr (!BT) {
+#pragma unroll
+      for (int j = 0; j < BROWS; ++j) {
+        const int n = r0 + 32 * j;
+        if (COUT >= 32 * (j + 1) || n < COUT)    // compile-time true except for COUT == 16
+          *reinterpret_cast<u32x4 *>(ldsB + swzB(n, slot)) = breg[j];
+      }
+    } else {
+      // transpose: the (d even, d odd) halves of channel n land in row n, reduction column 2*r0
+#pragma unroll
+      for (int jj = 0; jj < BROWS / 2; ++jj) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int n = jj * 64 + slot * 8 + e;
+          const uint32_t ev = breg[2 * jj][e >> 1], od = breg[2 * jj + 1][e >> 1];
+          const uint32_t v = (e & 1) ? __builtin_amdgcn_perm(od, ev, 0x07060302u)
+                                     : __builtin_amdgcn_perm(od, ev, 0x05040100u);
+          if (COUT >= 64 * (jj + 1) || n < COUT)
+            *reinterpret_cast<uint32_t *>(ldsB + swzB(n, r0 >> 2) + (r0 & 3) * 4) = v;
+        }
+      }
+    }
+  };
+
+  // ---- prologue ---------------------------------------------------------------------
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
+  const bool spec = p.identity_k >= 0;    // SubM: the identity offset exists for every row
+  StepIt it0;
+  it0.k = p.identity_k;
+  it0.chunk = 0;
+  it0.rest = 0;
+  // the mask words head the longest dependency chain of the tile (mask -> pair words -> rows):
+  // request them first, so they are not queued behind the 24 KB of identity-step loads
+  const __amdgpu_buffer_rsrc_t rM = make_rsrc(p.mask, p.mask ? pair_bytes : 0u);
+  uint32_t mraw[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+    mraw[mb] = __builtin_amdgcn_raw_buffer_load_b32(rM, goff[mb], 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  // identity step: start its loads before the mask words arrive.  Unconditional (a regular
+  // conv has it0.k == -1 here and reads zero-sized resources) so that the wait for the mask
+  // words below stays a counted one.
+  load_b(it0);
+  identr[0] = 0xffffffffu;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) idxr[0][mb] = 0;
+  load_a(it0, Set0{});
+  __builtin_amdgcn_sched_barrier(0);
+  SPX_STAMP(1);   // identity-step loads issued
+  uint32_t wm = 0;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) wm |= mraw[mb];         // rows past the end read 0
+  if (!p.mask) wm = 0xffffffffu;
+  wm |= __shfl_xor(wm, 1, 64);
+  wm |= __shfl_xor(wm, 2, 64);
+  wm |= __shfl_xor(wm, 4, 64);
+  wm |= __shfl_xor(wm, 8, 64);
+  const uint32_t wavemask =
+      __builtin_amdgcn_readfirstlane(wm) | (spec ? (1u << p.identity_k) : 0u);
+  if (lane == 0) lds_mask[wave] = wm;
+  __syncthreads();
+  SPX_STAMP(2);   // mask words arrived, tile mask exchanged
+  uint32_t tilemask = lds_mask[0] | lds_mask[1] | lds_mask[2] | lds_mask[3];
+  tilemask = __builtin_amdgcn_readfirstlane(tilemask);
+  if (p.kv < 32) tilemask &= (1u << p.kv) - 1u;
+  if (spec) {
+    it0.rest = tilemask & ~(1u << p.identity_k);
+  } else {
+    it0 = step_begin(tilemask);
+    load_b(it0);
+    load_idx(it0, Set0{});
+    load_a(it0, Set0{});
+  }
+  StepIt it1 = step_next(it0, nchunk);
+  StepIt it2 = step_next(it1, nchunk);
+  // same issue order as a loop step (weights, pair words, rows), so that the wait counts the
+  // compiler derives at the loop header are the steady-state ones
+  load_idx(it1, Set1{});
+  store_b(smem);                // B(0) -> stage 0
+  __builtin_amdgcn_sched_barrier(0);   // pin the issue order: the scheduler must not sink load_b
+  load_b(it1);
+  __builtin_amdgcn_sched_barrier(0);
+  load_idx(it2, Set0{});        // idxr[0] has been consumed by load_a(it0): reuse it for step 2
+  __builtin_amdgcn_sched_barrier(0);
+  load_a(it1, Set1{});
+
+  f32x4 acc[NB][MB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- main loop: one step = one (offset, 64-wide reduction chunk), two steps per trip ---
+  // at step t (register set S = t & 1): areg[S] = gathered rows of step t, stage S of the
+  // ring = weights of step t, breg = weights of step t+1, idxr[S] = pair words of step t+2.
+  // Loads are unconditional (steps past the end read zero-sized resources).
+  auto step = [&](auto SET) __attribute__((always_inline)) {
+    constexpr int S = decltype(SET)::value;
+    __syncthreads();   // stage 1-S is free (read at step t-1), stage S is complete
+    store_b(smem + (1 - S) * B_BYTES);
+    // none of this wave's rows uses offset k (or the step does not exist): skip the MFMAs
+    if (it0.k >= 0 && ((wavemask >> it0.k) & 1u)) {
+      const char *cur = smem + S * B_BYTES;
+      const int c0 = it0.chunk * kCK;
+      const int ksteps = (min(kCK, p.CIN - c0) + 31) >> 5;  // 1 or 2
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if (ks < ksteps) {
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const uint4 fa = *reinterpret_cast<const uint4 *>(
+                cur + swzB((lrow >> 2) * CPL + nb * 4 + (lrow & 3), ks * 4 + lgrp));
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+              acc[nb][mb] = mfma16<BF16>(fa, __builtin_bit_cast(uint4, areg[S][mb][ks]), acc[nb][mb]);
+          }
+        }
+      }
+    }
+    const StepIt it3 = step_next(it2, nchunk);
+    load_b(it2);
+    __builtin_amdgcn_sched_barrier(0);   // weights first: they are the first thing step t+1 waits for
+    load_idx(it3, std::integral_constant<int, 1 - S>{});
+    __builtin_amdgcn_sched_barrier(0);
+    load_a(it2, SET);
+    it0 = it1;
+    it1 = it2;
+    it2 = it3;
+  };
+  SPX_STAMP(3);   // prologue done
+  while (it0.k >= 0) {
+    step(Set0{});
+    step(Set1{});   // may be a step past the end (no MFMAs, zero-sized loads): an early exit
+                    // here would cost the exact wait counts of the whole loop
+  }
+  SPX_STAMP(4);   // main loop done
+
+  // ---- epilogue: bias/activation, fp32 -> 16 bit (packed converts), CPL consecutive channels
+  // per lane stored straight from registers; rows past the end have an out-of-range offset
+  // and are dropped by the buffer unit.
+  const uint16_t *bias = static_cast<const uint16_t *>(p.bias);
+  const bool plain = bias == nullptr && p.act == SPX_ACT_NONE;   // uniform: training path
+  const __amdgpu_buffer_rsrc_t rO = make_rsrc(p.out, static_cast<uint32_t>(p.n_dst) * (COUT * 2u));
+  float bv[CPL];
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) bv[q] = 0.f;
+  if (bias) {
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) bv[q] = to_float<BF16>(bias[lgrp * CPL + q]);
+  }
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    uint32_t d[CPL / 2];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float v0 = acc[nb][mb][2 * h], v1 = acc[nb][mb][2 * h + 1];
+        if (!plain) {
+          v0 = apply_act(v0 + bv[nb * 4 + 2 * h], p.act, p.act_alpha);
+          v1 = apply_act(v1 + bv[nb * 4 + 2 * h + 1], p.act, p.act_alpha);
+        }
+        d[nb * 2 + h] = pack2<BF16>(v0, v1);
+      }
+    }
+    const uint32_t vo = grow[mb] < 0 ? kOob
+                                     : static_cast<uint32_t>(grow[mb]) * (COUT * 2u) + lgrp * (CPL * 2u);
+    if constexpr (CPL == 4) {
+      typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2{d[0], d[1]}, rO, vo, 0, 0);
+    } else {
+#pragma unroll
+      for (int q = 0; q < CPL / 8; ++q)
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]},
+                                               rO, vo + q * 16, 0, 0);
+    }
+  }
+  SPX_STAMP(6);   // stores issued
+#ifdef SPX_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  SPX_STAMP(7);   // stores retired
+#endif
+}
+
+template <int COUT, int MB>
+constexpr size_t v4_smem_bytes() {
+  return 2 * static_cast<size_t>(COUT) * kRowBytes + 64;   // two weight stages + 4 mask words
+}
+
+bool v4_ok(const GemmParams &p) {
+  const unsigned long long abytes = static_cast<unsigned long long>(p.n_src) * p.CIN * 2ull;
+  const unsigned long long pbytes = static_cast<unsigned long long>(p.n_dst) * 4ull;
+  const unsigned long long wbytes = static_cast<unsigned long long>(p.COUT) * p.kv * p.CIN * 2ull;
+  const unsigned long long obytes = static_cast<unsigned long long>(p.n_dst) * p.COUT * 2ull;
+  return abytes < 0x7fff0000ull && pbytes < 0x7fff0000ull && wbytes < 0x7fff0000ull &&
+         obytes < 0x7fff0000ull;
+}
+
+template <int COUT, int MB, bool BF16>
+int launch_v4(const GemmParams &p, hipStream_t s) {
+  const int ntiles = div_up(p.n_dst, 64 * MB);
+  if (p.strideD == 1)
+    hipLaunchKernelGGL((igemm_v4_kernel<COUT, MB, BF16, false>), dim3(ntiles), dim3(kThreads),
+                       (v4_smem_bytes<COUT, MB>()), s, p);
+  else
+    hipLaunchKernelGGL((igemm_v4_kernel<COUT, MB, BF16, true>), dim3(ntiles), dim3(kThreads),
+                       (v4_smem_bytes<COUT, MB>()), s, p);
+  SPX_LAUNCH_CHECK();
+  return 0;
+}
+
+// --------------------------------------------------------------------------
 // generic gather-GEMM: any dtype / channel count, fp32 accumulate.
 // one thread per (dst row, out channel).
 // --------------------------------------------------------------------------
@@ -745,6 +1143,19 @@ bool mfma_ok(int dtype, int cin, int cout, int kv, const uint32_t *mask) {
 
 template <bool BF16>
 int dispatch_gather_gemm(const GemmParams &p, hipStream_t s) {
+  static const int version = env_int("SPX_GEMM_V", 4);     // tuning knobs (A/B runs)
+  static const int mb_forced = env_int("SPX_GEMM_MB", 0);
+  if (version >= 4 && v4_ok(p)) {
+    // 64-row tiles while the grid would otherwise leave CUs idle, 128-row tiles beyond
+    const int mb = mb_forced ? mb_forced : (p.n_dst <= 64 * 1024 ? 1 : 2);
+    switch (p.COUT) {
+      case 16: return mb == 1 ? launch_v4<16, 1, BF16>(p, s) : launch_v4<16, 2, BF16>(p, s);
+      case 32: return mb == 1 ? launch_v4<32, 1, BF16>(p, s) : launch_v4<32, 2, BF16>(p, s);
+      case 64: return mb == 1 ? launch_v4<64, 1, BF16>(p, s) : launch_v4<64, 2, BF16>(p, s);
+      case 128: return mb == 1 ? launch_v4<128, 1, BF16>(p, s) : launch_v4<128, 2, BF16>(p, s);
+      case 256: return launch_v4<256, 1, BF16>(p, s);
+    }
+  }
   switch (p.COUT) {
     case 16: return launch_gather_gemm<16, BF16>(p, s);
     case 32: return launch_gather_gemm<32, BF16>(p, s);
@@ -975,5 +1386,14 @@ int spx_bias_act_inplace(void *out, const void *bias, int n, int K, int dtype, i
   SPX_LAUNCH_CHECK();
   return 0;
 }
+
+#ifdef SPX_TIMELINE
+// debug builds only: copies the timeline table (8192 workgroups x 8 stamps, uint64) to host memory
+int spx_debug_timeline(unsigned long long *dst_h) {
+  SPX_HIP(hipDeviceSynchronize());
+  SPX_HIP(hipMemcpyFromSymbol(dst_h, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * kTlMaxWg * kTlSlots));
+  return 0;
+}
+#endif
 
 }  // extern "C"

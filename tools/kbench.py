@@ -20,6 +20,13 @@ def main():
     n = int(os.environ.get("KB_VOXELS", "100000"))
     tag = {k: v for k, v in os.environ.items() if k.startswith("SPX_")}
     rows = []
+    # reference floors on this box: a plain 12.8 MB -> 12.8 MB copy and the dense centre GEMM
+    ff = (torch.rand(n, C, device=dev) * 2 - 1).half()
+    oo = torch.empty_like(ff)
+    ww = (torch.rand(C, K, device=dev) * 2 - 1).half()
+    floors = dict(copy_us=round(event_time_ms(lambda: oo.copy_(ff)) * 1e3, 2),
+                  mm_us=round(event_time_ms(lambda: torch.mm(ff, ww, out=oo)) * 1e3, 2),
+                  empty_launch_us=round(event_time_ms(lambda: oo[:64].zero_()) * 1e3, 2))
     for scene in ("uniform", "lidar"):
         gen = synthetic.uniform_scene if scene == "uniform" else synthetic.lidar_like_scene
         idx = torch.from_numpy(gen(SHAPE, n, 1, seed=0)).to(dev)
@@ -34,11 +41,18 @@ def main():
             t_f = event_time_ms(lambda: ops.igemm_fwd(f, w, rb.pair_fwd, rb.mask_fwd, rb.argsort_fwd, nn, 13))
             t_d = event_time_ms(lambda: ops.igemm_dgrad(d, w, rb.pair_fwd, rb.mask_fwd, rb.argsort_fwd, nn, True))
             t_w = event_time_ms(lambda: ops.igemm_wgrad(f, d, w.shape, rb.pair_native, rb.num_per_loc, True, plan))
+            if not sort:
+                # centre-only mask: cost of the kernels without any non-identity step
+                m1 = torch.full_like(rb.mask_fwd, 1 << 13)
+                rowx = dict(fwd_centre_only_us=round(event_time_ms(
+                    lambda: ops.igemm_fwd(f, w, rb.pair_fwd, m1, None, nn, 13)) * 1e3, 2))
+            else:
+                rowx = {}
             t_r = event_time_ms(lambda: ops.build_rulebook(idx, 1, SHAPE, [3] * 3, [1] * 3, [1] * 3, [1] * 3,
                                                            [0] * 3, True, do_sort=sort), iters=5, warm=2)
             rows.append(dict(scene=scene, sort=sort, fwd_us=round(t_f * 1e3, 2), dgrad_us=round(t_d * 1e3, 2),
-                             wgrad_us=round(t_w * 1e3, 2), rulebook_us=round(t_r * 1e3, 1)))
-    print(json.dumps({"env": tag, "C": C, "n": n, "rows": rows}))
+                             wgrad_us=round(t_w * 1e3, 2), rulebook_us=round(t_r * 1e3, 1), **rowx))
+    print(json.dumps({"env": tag, "C": C, "n": n, "floors": floors, "rows": rows}))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,75 @@
+#!/usr/bin/env python
+"""Per-workgroup timeline of igemm_v4_kernel (debug build, spconv_amd/csrc/build_debug.sh).
+
+    SPX_LIB=spconv_amd/lib/libspconv_amd_dbg.so python tools/timeline.py [uniform|lidar] [centre]
+
+Every workgroup stamps s_memtime (100 MHz constant clock on gfx950: 10 ns ticks) at
+0 entry, 1 identity loads issued, 2 tile mask known, 3 prologue done, 4 main loop done,
+5 accumulators staged, 6 stores issued, 7 stores retired.  Prints percentiles of each stamp
+relative to the first workgroup's entry, and of the phase durations."""
+import ctypes
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import SHAPE  # noqa: E402
+from spconv_amd import _lib  # noqa: E402
+from spconv_amd.pytorch import ops  # noqa: E402
+from spconv_amd.utils import synthetic  # noqa: E402
+
+
+def main():
+    scene = sys.argv[1] if len(sys.argv) > 1 else "uniform"
+    centre = len(sys.argv) > 2 and sys.argv[2] == "centre"
+    dev = torch.device("cuda:0")
+    n, C = 100000, 64
+    gen = synthetic.uniform_scene if scene == "uniform" else synthetic.lidar_like_scene
+    idx = torch.from_numpy(gen(SHAPE, n, 1, seed=0)).to(dev)
+    f = (torch.rand(n, C, device=dev) * 2 - 1).half()
+    w = (torch.rand(C, 3, 3, 3, C, device=dev) * 2 - 1).half()
+    rb, _ = ops.build_rulebook(idx, 1, SHAPE, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True)
+    mask = torch.full_like(rb.mask_fwd, 1 << 13) if centre else rb.mask_fwd
+    L = _lib.load()
+    L.spx_debug_timeline.restype = ctypes.c_int
+    L.spx_debug_timeline.argtypes = [ctypes.c_void_p]
+    for _ in range(20):
+        ops.igemm_fwd(f, w, rb.pair_fwd, mask, None, n, 13)
+    torch.cuda.synchronize()
+    ops.igemm_fwd(f, w, rb.pair_fwd, mask, None, n, 13)
+    buf = np.zeros((8192, 8), dtype=np.uint64)
+    _lib.check(L.spx_debug_timeline(buf.ctypes.data))
+    mb = int(os.environ.get("SPX_GEMM_MB", "2"))
+    ntiles = (n + 64 * mb - 1) // (64 * mb)
+    t = buf[:ntiles].astype(np.int64)
+    t0 = t[:, 0].min()
+    rel = (t - t0) / float(os.environ.get("SPX_TICK_MHZ", "100"))
+    names = ["entry", "ident_issued", "mask_known", "prologue_done", "loop_done", "staged",
+             "stores_issued", "stores_retired"]
+    out = {"scene": scene, "centre_only": centre, "tiles": int(ntiles), "stamps_us": {}, "phases_us": {}}
+    for i, nm in enumerate(names):
+        q = np.percentile(rel[:, i], [0, 10, 50, 90, 100])
+        out["stamps_us"][nm] = [round(float(v), 2) for v in q]
+    for i in range(1, 8):
+        d = rel[:, i] - rel[:, i - 1]
+        q = np.percentile(d, [10, 50, 90, 100])
+        out["phases_us"][f"{names[i - 1]}->{names[i]}"] = [round(float(v), 2) for v in q]
+    # s_memtime is per XCD (not synchronised across dies): spans are taken inside each XCD
+    # (workgroup b runs on XCD b % 8) and the stamps above are only meaningful as differences
+    tick = 1.0 / float(os.environ.get("SPX_TICK_MHZ", "100"))
+    spans, ramps = [], []
+    for x in range(8):
+        g = t[x::8]
+        spans.append((g[:, 7].max() - g[:, 0].min()) * tick)
+        ramps.append((g[:, 0].max() - g[:, 0].min()) * tick)
+    out["xcd_span_us"] = [round(float(v), 2) for v in spans]
+    out["xcd_entry_ramp_us"] = [round(float(v), 2) for v in ramps]
+    out["wg_lifetime_us"] = [round(float(v), 2) for v in np.percentile((t[:, 7] - t[:, 0]) * tick, [10, 50, 90, 100])]
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
