@@ -258,9 +258,9 @@ def main():
                        "mask_sort": bool(args.sort), "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": {"fwd": "gather_gemm_mfma_kernel (forward)",
-                                    "dgrad": "gather_gemm_mfma_kernel (dgrad)",
-                                    "wgrad": "wgrad_mfma_kernel + wgrad_reduce_kernel"}[dom],
+                         "kernel": {"fwd": "igemm_v4_kernel<64,2,f16,fwd>",
+                                    "dgrad": "igemm_v4_kernel<64,2,f16,dgrad>",
+                                    "wgrad": "wgrad_tr_kernel + wgrad_reduce2_kernel"}[dom],
                          "algorithmic_bytes": ab[dom], "ms": round(groups[dom], 5)},
             "kernels": kernels,
             "step_GBps_algorithmic": round(total_bytes / (ms_per_step * 1e-3) / 1e9, 1),

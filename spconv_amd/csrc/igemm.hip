@@ -1120,6 +1120,338 @@ wgrad_reduce_kernel(WgradParams p, T *__restrict__ dw) {
   }
 }
 
+// --------------------------------------------------------------------------
+// wgrad v2 ("balanced segments + transpose reads"), 16-bit operands.
+//  * work split: the concatenation of all pair lists is cut into G equal ranges, one per
+//    workgroup; a range that crosses a list boundary becomes several segments.  Every
+//    workgroup streams the same number of rows, so all CUs finish together (per-CU HBM
+//    bandwidth is ~24 GB/s: an idle CU is lost bandwidth).
+//  * rows go global -> registers -> LDS exactly as they lie in memory ([pair][channel],
+//    ds_write_b128, 32-byte granules XOR-swizzled); the MFMA operands, which need 8
+//    consecutive PAIRS of one channel per lane, come out of LDS through the hardware
+//    transpose read ds_read_b64_tr_b16 (two per fragment) -- no shuffling VALU work.
+//  * two LDS stages: one __syncthreads() per 128-pair chunk; the next chunk's rows are in
+//    flight during the MFMAs, the pair-list words one chunk further ahead.
+//  * per-segment fp32 partials + the deterministic second stage below (no atomics).
+// --------------------------------------------------------------------------
+constexpr int kW2MaxG = 1024;
+constexpr int kW2J = 128;        // pairs per chunk
+constexpr int kW2Rec = 8;        // ints per workgroup record in the plan
+
+struct Wgrad2Params {
+  const void *feat;        // [n_in, C]
+  const void *dout;        // [n_out, K]
+  float *partial;          // [segment][tile][64*64]
+  const int32_t *native;   // [2, kv, n_in]
+  const int32_t *num;      // [kv]
+  const int32_t *plan2;    // see wgrad_plan2_kernel
+  int n_in, n_out, C, K, kv, subm, tiles_c, tiles_k, G;
+};
+
+// plan2 layout (int32):
+//   [0] number of segments   [1] pairs per workgroup
+//   [8 + 8 w ..]             workgroup w: first segment, number of segments, then its first
+//                            segment inline (offset k, first pair, end pair)      (G records)
+//   [8 + 8 G ..]             first segment of offset k                           (kv + 1)
+//   then 3 ints per segment: offset k, first pair, end pair (positions inside list k)
+__host__ __device__ inline int plan2_wg(int w) { return 8 + kW2Rec * w; }
+__host__ __device__ inline int plan2_kf(int G) { return 8 + kW2Rec * G; }
+__host__ __device__ inline int plan2_seg(int G, int kv) { return 8 + kW2Rec * G + kv + 1; }
+// work list of the second stage: [0] items, then 2 ints per item: offset k | mode << 8, first
+// element inside a 64x64 tile.  At most kv * 128 items.
+__host__ __device__ inline int plan2_red(int G, int kv) { return plan2_seg(G, kv) + 3 * (G + kv); }
+
+__global__ void __launch_bounds__(kW2MaxG)
+wgrad_plan2_kernel(const int32_t *__restrict__ num, int n_in, int kv, int subm, int G,
+                   int32_t *__restrict__ plan) {
+  __shared__ int start[130], cnt[129], nseg_of[kW2MaxG + 1], per_s, total_s;
+  const int tid = threadIdx.x;
+  if (tid < kv) cnt[tid] = list_count(num, kv, subm, n_in, tid);
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int k = 0; k < kv; ++k) {
+      start[k] = run;
+      run += cnt[k];
+    }
+    start[kv] = run;
+    total_s = run;
+    per_s = run > 0 ? (run + G - 1) / G : 1;
+  }
+  __syncthreads();
+  const int per = per_s, total = total_s;
+  int lo = 0, hi = 0, mine = 0;
+  if (tid < G) {
+    lo = min(total, tid * per);
+    hi = min(total, lo + per);
+    for (int k = 0; k < kv; ++k) mine += (min(hi, start[k + 1]) > max(lo, start[k])) ? 1 : 0;
+    nseg_of[tid] = mine;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int w = 0; w < G; ++w) {
+      const int c = nseg_of[w];
+      nseg_of[w] = run;
+      run += c;
+    }
+    nseg_of[G] = run;
+    plan[0] = run;
+    plan[1] = per;
+  }
+  __syncthreads();
+  int32_t *seg = plan + plan2_seg(G, kv);
+  if (tid < G) {
+    int s = nseg_of[tid];
+    int32_t *rec = plan + plan2_wg(tid);
+    rec[0] = s;
+    rec[1] = mine;
+    rec[2] = 0;
+    rec[3] = 0;
+    rec[4] = 0;
+    bool first = true;
+    for (int k = 0; k < kv; ++k) {
+      const int a = max(lo, start[k]), b = min(hi, start[k + 1]);
+      if (b > a) {
+        seg[3 * s] = k;
+        seg[3 * s + 1] = a - start[k];
+        seg[3 * s + 2] = b - start[k];
+        if (first) {
+          rec[2] = k;
+          rec[3] = a - start[k];
+          rec[4] = b - start[k];
+          first = false;
+        }
+        ++s;
+      }
+    }
+  }
+  // first segment of offset k = number of segments of offsets < k (segments are ordered by k)
+  if (tid <= kv) {
+    int c = 0;
+    for (int w = 0; w < G; ++w) {
+      const int l = min(total, w * per), h = min(total, l + per);
+      for (int k = 0; k < tid && k < kv; ++k) c += (min(h, start[k + 1]) > max(l, start[k])) ? 1 : 0;
+    }
+    plan[plan2_kf(G) + tid] = c;
+  }
+  __syncthreads();
+  if (tid == 0) {   // second-stage work list (short: <= kv * ntile * 128 items)
+    int32_t *rl = plan + plan2_red(G, kv);
+    const int32_t *kf = plan + plan2_kf(G);
+    int n = 0;
+    const int elems = kWT * kWT;          // per 64x64 tile; tiles are the grid's y dimension
+    for (int k = 0; k < kv; ++k) {
+      const int ns = kf[k + 1] - kf[k];
+      const int mode = ns >= 48 ? 0 : (ns >= 6 ? 1 : 2);
+      const int E = 32 << (2 * mode);
+      for (int e0 = 0; e0 < elems; e0 += E) {
+        rl[1 + 2 * n] = k | (mode << 8);
+        rl[2 + 2 * n] = e0;
+        ++n;
+      }
+    }
+    rl[0] = n;
+  }
+}
+
+// byte offset of 16-byte slot `sl` of pair row `row` in a [128 pairs][64 channels] stage; the
+// 32-byte granule index is XORed with (bit 1, bit 3) of the row: the 32 lanes of one
+// ds_read_b64_tr_b16 half (rows r..r+3 and r+8..r+11, one granule each) cover all 64 banks.
+__device__ __forceinline__ int wtr_x(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
+__device__ __forceinline__ int wtr_slot(int row, int sl) {
+  return row * 128 + ((((sl >> 1) ^ wtr_x(row)) << 5) | ((sl & 1) << 4));
+}
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// 8 consecutive pairs (row0 .. row0+7 as seen by this lane group) of channel granule*16 + lrow
+__device__ __forceinline__ uint4 wtr_frag(const char *stage, int row0, int lrow, int gran) {
+  const int r = row0 + (lrow >> 2);
+  const char *a0 = stage + r * 128 + ((gran ^ wtr_x(r)) << 5) + ((lrow & 3) << 3);
+  const int r1 = r + 4;
+  const char *a1 = stage + r1 * 128 + ((gran ^ wtr_x(r1)) << 5) + ((lrow & 3) << 3);
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (lds_s16x4 *)(__attribute__((address_space(3))) char *)a0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (lds_s16x4 *)(__attribute__((address_space(3))) char *)a1);
+  const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+  return make_uint4(l2.x, l2.y, h2.x, h2.y);
+}
+
+template <bool BF16>
+__global__ void __launch_bounds__(kThreads)
+wgrad_tr_kernel(Wgrad2Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TILE_B = kW2J * 128;                // one operand tile: 128 pairs x 128 bytes
+  constexpr int RQ = kW2J / 32;                     // rows per thread and operand (4)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 15, lgrp = lane >> 4;
+  const int wk = wave >> 1, wc = wave & 1;          // wave quadrant: kk [32*wk,+32), c [32*wc,+32)
+  const int ntile = p.tiles_k * p.tiles_c;
+  const int w = blockIdx.x / ntile, tile = blockIdx.x - w * ntile;
+  const int kk0 = (tile / p.tiles_c) * kWT, c0 = (tile % p.tiles_c) * kWT;
+  const int32_t *__restrict__ rec = p.plan2 + plan2_wg(w);     // uniform address: scalar loads
+  const int32_t *__restrict__ segs = p.plan2 + plan2_seg(p.G, p.kv);
+  const int seg_lo = rec[0], nseg = rec[1];
+
+  const uint32_t rowD = static_cast<uint32_t>(p.K) * 2u, rowF = static_cast<uint32_t>(p.C) * 2u;
+  const __amdgpu_buffer_rsrc_t rD = make_rsrc(p.dout, static_cast<uint32_t>(p.n_out) * rowD);
+  const __amdgpu_buffer_rsrc_t rF = make_rsrc(p.feat, static_cast<uint32_t>(p.n_in) * rowF);
+  const uint32_t list_bytes = static_cast<uint32_t>(p.n_in) * 4u;
+
+  // load role: 16-byte slot `slot` of rows r0 + 32 q (q = 0..3) of both operand tiles
+  const int slot = tid & 7, r0 = tid >> 3;
+  const uint32_t dcol = kk0 + slot * 8 < p.K ? static_cast<uint32_t>(kk0 + slot * 8) * 2u : kOob;
+  const uint32_t fcol = c0 + slot * 8 < p.C ? static_cast<uint32_t>(c0 + slot * 8) * 2u : kOob;
+  int lds_w[RQ];
+#pragma unroll
+  for (int q = 0; q < RQ; ++q) lds_w[q] = wtr_slot(r0 + 32 * q, slot);
+
+  for (int si = 0; si < nseg; ++si) {
+    int k, begin, end;
+    if (si == 0) {
+      k = rec[2];
+      begin = rec[3];
+      end = rec[4];
+    } else {
+      k = segs[3 * (seg_lo + si)];
+      begin = segs[3 * (seg_lo + si) + 1];
+      end = segs[3 * (seg_lo + si) + 2];
+    }
+    const bool identity = p.subm && k == p.kv / 2;
+    const __amdgpu_buffer_rsrc_t rIn =
+        make_rsrc(p.native + static_cast<size_t>(k) * p.n_in, list_bytes);
+    const __amdgpu_buffer_rsrc_t rOut =
+        make_rsrc(p.native + static_cast<size_t>(p.kv + k) * p.n_in, list_bytes);
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint32_t ii[RQ], oi[RQ];     // pair-list words of the chunk whose rows are fetched next
+    u32x4 dv[RQ], fv[RQ];        // rows in flight
+    auto load_words = [&](int base) __attribute__((always_inline)) {
+#pragma unroll
+      for (int q = 0; q < RQ; ++q) {
+        const int j = base + r0 + 32 * q;
+        if (identity) {
+          ii[q] = static_cast<uint32_t>(j);
+          oi[q] = static_cast<uint32_t>(j);
+        } else {
+          const uint32_t vo = j < end ? static_cast<uint32_t>(j) * 4u : kOob;
+          ii[q] = __builtin_amdgcn_raw_buffer_load_b32(rIn, vo, 0, 0);
+          oi[q] = __builtin_amdgcn_raw_buffer_load_b32(rOut, vo, 0, 0);
+        }
+      }
+    };
+    auto load_rows = [&](int base) __attribute__((always_inline)) {
+#pragma unroll
+      for (int q = 0; q < RQ; ++q) {
+        const bool ok = base + r0 + 32 * q < end;      // rows past the segment read as zero
+        dv[q] = __builtin_amdgcn_raw_buffer_load_b128(rD, ok ? (oi[q] * rowD + dcol) | (dcol & kOob) : kOob, 0, 0);
+        fv[q] = __builtin_amdgcn_raw_buffer_load_b128(rF, ok ? (ii[q] * rowF + fcol) | (fcol & kOob) : kOob, 0, 0);
+      }
+    };
+    load_words(begin);
+    load_rows(begin);
+    load_words(begin + kW2J);
+    int stage = 0;
+    for (int base = begin; base < end; base += kW2J, stage ^= 1) {
+      char *sD = smem + stage * (2 * TILE_B);
+      char *sF = sD + TILE_B;
+#pragma unroll
+      for (int q = 0; q < RQ; ++q) {
+        *reinterpret_cast<u32x4 *>(sD + lds_w[q]) = dv[q];
+        *reinterpret_cast<u32x4 *>(sF + lds_w[q]) = fv[q];
+      }
+      __syncthreads();   // stage complete; the other stage was last read one iteration ago
+      load_rows(base + kW2J);         // in flight during the MFMAs (out of range past the end)
+      load_words(base + 2 * kW2J);
+#pragma unroll
+      for (int ks = 0; ks < kW2J / 32; ++ks) {
+        const int row0 = ks * 32 + lgrp * 8;
+        uint4 fa[2], fb[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) fa[a] = wtr_frag(sD, row0, lrow, wk * 2 + a);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) fb[b] = wtr_frag(sF, row0, lrow, wc * 2 + b);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[a][b] = mfma16<BF16>(fa[a], fb[b], acc[a][b]);
+      }
+    }
+    // D[i = kk][j = c]: lane holds c = lane & 15, kk = (lane >> 4) * 4 + reg
+    float *dst = p.partial + (static_cast<size_t>(seg_lo + si) * ntile + tile) * (kWT * kWT);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int kk = wk * 32 + a * 16 + lgrp * 4 + e;
+          const int c = wc * 32 + b * 16 + lrow;
+          dst[kk * kWT + c] = acc[a][b][e];
+        }
+    __syncthreads();  // both stages are rewritten by the next segment
+  }
+}
+
+// dw[kk][k][c] = sum over the segments of offset k (deterministic: fixed assignment of
+// segments to threads, fixed summation order).  The work list (built with the plan) gives
+// every offset a block shape that fits its segment count -- 32 elements x 16 segment groups
+// for long lists, 128 x 4 or 512 x 1 for short ones -- so a SubM rulebook with one long and
+// 26 short lists runs ~340 blocks instead of 27 x 128.
+template <typename T>
+__global__ void __launch_bounds__(kRedThreads)
+wgrad_reduce2_kernel(Wgrad2Params p, T *__restrict__ dw) {
+  __shared__ float red[kRedThreads];
+  const int32_t *__restrict__ kf = p.plan2 + plan2_kf(p.G);
+  const int32_t *__restrict__ rl = p.plan2 + plan2_red(p.G, p.kv);
+  const int nitems = rl[0];
+  const int ntile = p.tiles_k * p.tiles_c;
+  const size_t stride = static_cast<size_t>(ntile) * (kWT * kWT);
+  const int tile = blockIdx.y;
+  for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+    const int k = rl[1 + 2 * it] & 0xff, mode = rl[1 + 2 * it] >> 8, e0 = rl[2 + 2 * it];
+    const int E = 32 << (2 * mode), S = kRedThreads / E;
+    const int first = kf[k], nseg = kf[k + 1] - kf[k];
+    const int grp = threadIdx.x / E, el = threadIdx.x % E;
+    const int e = tile * (kWT * kWT) + e0 + el;  // element of [tiles][64*64]
+    float acc = 0.f;
+    {
+      const float *src = p.partial + static_cast<size_t>(first) * stride + e;
+      int ch = grp;
+      for (; ch + 7 * S < nseg; ch += 8 * S) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[static_cast<size_t>(ch + u * S) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+      }
+      for (; ch < nseg; ch += S) acc += src[static_cast<size_t>(ch) * stride];
+    }
+    if (S > 1) {
+      red[threadIdx.x] = acc;
+      __syncthreads();
+      if (grp == 0) {
+        acc = 0.f;
+        for (int g = 0; g < S; ++g) acc += red[g * E + el];
+      }
+    }
+    if (grp == 0) {
+      const int ee = e0 + el;
+      const int kk = (tile / p.tiles_c) * kWT + ee / kWT, c = (tile % p.tiles_c) * kWT + ee % kWT;
+      if (kk < p.K && c < p.C) store_f(dw + (static_cast<size_t>(kk) * p.kv + k) * p.C + c, acc);
+    }
+    if (S > 1) __syncthreads();   // red[] is reused by the next item
+  }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(kThreads)
 bias_act_kernel(T *__restrict__ out, const T *__restrict__ bias, long long total, int K, int act,
@@ -1202,6 +1534,23 @@ size_t wgrad_plan_ints(int n_in, int kv) {
   return 1 + 2 * static_cast<size_t>(kv) + 2 * nchunks * kv;
 }
 
+// workgroups of the balanced wgrad: 1.5 per CU once there is enough work (more workgroups
+// mean more partials for the second stage: 384 measured best at 100k voxels), never more
+// ranges than twice the 128-pair chunks of the identity list
+int wgrad_groups(int n_in) {
+  static const int forced = env_int("SPX_WGRAD_G", 0);   // tuning knob
+  int g = forced > 0 ? forced : 384;
+  const int chunks = div_up(n_in > 0 ? n_in : 1, 128);
+  if (g > 2 * chunks) g = 2 * chunks;
+  if (g > kW2MaxG - 1) g = kW2MaxG - 1;   // the plan kernel needs thread G for the end marker
+  return g < 1 ? 1 : g;
+}
+
+size_t wgrad_plan2_ints(int n_in, int kv) {
+  const size_t G = wgrad_groups(n_in);
+  return 8 + kW2Rec * G + kv + 1 + 3 * (G + kv) + 1 + 2 * static_cast<size_t>(kv) * 128 + 8;
+}
+
 }  // namespace
 }  // namespace spx
 
@@ -1274,8 +1623,14 @@ int spx_igemm_dgrad(const void *dout, const void *weight, void *din, const int32
   return run_gather_gemm(p, dtype, static_cast<hipStream_t>(stream));
 }
 
-size_t spx_wgrad_plan_bytes(int n_in, int kv) {
+// the plan blob holds both forms: the item list of the generic kernels and, behind it, the
+// balanced segment plan of the MFMA kernel
+static size_t plan1_bytes(int n_in, int kv) {
   return align_up(wgrad_plan_ints(n_in, kv) * sizeof(int32_t), 256);
+}
+
+size_t spx_wgrad_plan_bytes(int n_in, int kv) {
+  return plan1_bytes(n_in, kv) + align_up(wgrad_plan2_ints(n_in, kv) * sizeof(int32_t), 256);
 }
 
 int spx_wgrad_plan(const int32_t *num_per_loc, int n_in, int kv, int subm, int32_t *plan,
@@ -1284,6 +1639,9 @@ int spx_wgrad_plan(const int32_t *num_per_loc, int n_in, int kv, int subm, int32
   SPX_CHECK(kv >= 1 && kv <= 128, "kernel volume %d not supported by wgrad (max 128)", kv);
   hipLaunchKernelGGL(wgrad_plan_kernel, dim3(1), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
                      num_per_loc, n_in, kv, subm, wgrad_chunk(n_in), plan);
+  int32_t *plan2 = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(plan) + plan1_bytes(n_in, kv));
+  hipLaunchKernelGGL(wgrad_plan2_kernel, dim3(1), dim3(kW2MaxG), 0, static_cast<hipStream_t>(stream),
+                     num_per_loc, n_in, kv, subm, wgrad_groups(n_in), plan2);
   SPX_LAUNCH_CHECK();
   return 0;
 }
@@ -1292,8 +1650,10 @@ size_t spx_igemm_wgrad_ws_bytes(int n_in, int C, int K, int kv) {
   const int chunk = wgrad_chunk(n_in);
   const size_t nchunks = div_up(n_in > 0 ? n_in : 1, chunk);
   const size_t tiles = static_cast<size_t>(div_up(C, kWT)) * div_up(K, kWT);
-  return align_up(nchunks * kv * tiles * kWT * kWT * sizeof(float), 256) +
-         spx_wgrad_plan_bytes(n_in, kv);
+  size_t parts = nchunks * kv;                                   // item list (generic kernels)
+  const size_t segs = static_cast<size_t>(wgrad_groups(n_in)) + kv;   // balanced segments
+  if (segs > parts) parts = segs;
+  return align_up(parts * tiles * kWT * kWT * sizeof(float), 256) + spx_wgrad_plan_bytes(n_in, kv);
 }
 
 int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t *pair_native,
@@ -1330,6 +1690,43 @@ int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t 
   }
   p.plan = plan;
   const bool mfma = (dtype == SPX_F16 || dtype == SPX_BF16) && C % 8 == 0 && K % 8 == 0;
+  static const int wgrad_version = env_int("SPX_WGRAD_V", 2);    // tuning knob (A/B runs)
+  const bool small_offsets = static_cast<unsigned long long>(n_out) * K * 2ull < 0x7fff0000ull &&
+                             static_cast<unsigned long long>(n_in) * C * 2ull < 0x7fff0000ull &&
+                             static_cast<unsigned long long>(n_in) * 4ull < 0x7fff0000ull;
+  if (mfma && wgrad_version >= 2 && small_offsets) {
+    Wgrad2Params q{};
+    q.feat = feat;
+    q.dout = dout;
+    q.partial = static_cast<float *>(ws);
+    q.native = pair_native;
+    q.num = num_per_loc;
+    q.plan2 = reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(plan) + plan1_bytes(n_in, kv));
+    q.n_in = n_in;
+    q.n_out = n_out;
+    q.C = C;
+    q.K = K;
+    q.kv = kv;
+    q.subm = subm;
+    q.tiles_c = p.tiles_c;
+    q.tiles_k = p.tiles_k;
+    q.G = wgrad_groups(n_in);
+    const dim3 grid(static_cast<unsigned>(q.G) * ntile);
+    const size_t lds = 2 * 2 * kW2J * 128;    // two stages x two operand tiles
+    if (dtype == SPX_F16)
+      hipLaunchKernelGGL(wgrad_tr_kernel<false>, grid, dim3(kThreads), lds, s, q);
+    else
+      hipLaunchKernelGGL(wgrad_tr_kernel<true>, grid, dim3(kThreads), lds, s, q);
+    const dim3 rgrid2(kv * 128 < 512 ? kv * 128 : 512, ntile);   // block-stride over the work list
+    if (dtype == SPX_F16)
+      hipLaunchKernelGGL(wgrad_reduce2_kernel<h16>, rgrid2, dim3(kRedThreads), 0, s, q,
+                         static_cast<h16 *>(dw));
+    else
+      hipLaunchKernelGGL(wgrad_reduce2_kernel<b16>, rgrid2, dim3(kRedThreads), 0, s, q,
+                         static_cast<b16 *>(dw));
+    SPX_LAUNCH_CHECK();
+    return 0;
+  }
   {
     // upper bound of work items is nchunks * kv * ntile; the kernels loop over the real count
     const long long bound = static_cast<long long>(p.nchunks) * kv * ntile;
