@@ -146,7 +146,23 @@ int spx_igemm_fwd(const void *feat, const void *weight, void *out, const int32_t
                   int C, int K, int kv, int dtype, int identity_k, const void *bias,
                   int act, float act_alpha, spx_stream_t stream);
 
-/* Scratch for dgrad (re-laid-out weights [kv, C, K]). */
+/* int8 inference forward.  Replaces the int8 branch of ConvGemmOps.implicit_gemm
+ * (pytorch/ops.py:1540-1553,1631-1662, csrc/sparse/convops.py:2176-2205) as driven by the
+ * quantised module (pytorch/quantization/quantized/conv.py:368-378).  Numerics pinned by the
+ * reference's numpy formula (test/test_all_algo.py:272-287):
+ *   v = acc_i32 * scale[k] + bias[k] + add[o][k] * add_scale;  v = act(v)
+ *   out_dtype SPX_I8: clip(round_half_even(v), -128, 127);  SPX_F16 / SPX_BF16 / SPX_F32: v
+ *   feat int8 [n_in, C], weight int8 KRSC [K, kv, C], scale / bias fp32 [K] (or NULL = 1 / 0),
+ *   add int8 [n_out, K] or NULL (the module passes add_scale = add_q_scale / output_scale).
+ * C must be a multiple of 16, K one of 16/32/64/128/256, kv <= 32 (the reference's int8 kernels
+ * need C, K % 16 == 0 as well, test/test_all_algo.py:376-377). */
+int spx_igemm_fwd_int8(const void *feat, const void *weight, void *out, const int32_t *pair,
+                       const uint32_t *mask, const int32_t *argsort, int n_in, int n_out, int C,
+                       int K, int kv, int identity_k, const float *scale, const float *bias,
+                       const void *add, float add_scale, int out_dtype, int act, float act_alpha,
+                       spx_stream_t stream);
+
+/* Scratch for dgrad (always 0: the weight transpose happens inside the kernel). */
 size_t spx_igemm_dgrad_ws_bytes(int C, int K, int kv, int dtype);
 
 /* Input gradient.  Replaces the dgrad half of ConvGemmOps.implicit_gemm_backward

@@ -331,3 +331,42 @@ def dense_conv_reference(features: torch.Tensor, indices: np.ndarray, batch_size
         return convt(dense, wt, None, stride, padding,
                      out_padding if out_padding is not None else 0, 1, dilation)
     return conv(dense, w, None, stride, padding, dilation)
+
+
+# --------------------------------------------------------------------------
+# int8 inference reference (test/test_all_algo.py:222-288, numpy; the module semantics are
+# spconv/pytorch/quantization/quantized/conv.py:368-378)
+def int8_conv_ref(features_i8: np.ndarray, weight_i8: np.ndarray, pair: np.ndarray,
+                  num_per_loc: np.ndarray, n_out: int, subm: bool, scale: np.ndarray,
+                  bias: np.ndarray, add_i8: Optional[np.ndarray] = None, add_scale: float = 0.0,
+                  relu: bool = False, out_dtype=np.int8) -> np.ndarray:
+    """acc_i32 over the Native lists, then ``clip(round(act(acc*scale + bias + add*add_scale)))``.
+    The integer accumulation is done in float64 BLAS (exact below 2**53) to stay fast."""
+    K, C = weight_i8.shape[0], weight_i8.shape[-1]
+    kv = pair.shape[1]
+    w = weight_i8.reshape(K, kv, C).astype(np.float64)
+    f = features_i8.astype(np.float64)
+    acc = np.zeros((n_out, K), dtype=np.float64)
+    for k in range(kv):
+        if subm and k == kv // 2:
+            acc += f @ w[:, k, :].T
+            continue
+        if subm and k > kv // 2:
+            nhot = int(num_per_loc[kv - 1 - k])
+        else:
+            nhot = int(num_per_loc[k])
+        if nhot == 0:
+            continue
+        i_inds, o_inds = pair[0][k][:nhot], pair[1][k][:nhot]
+        np.add.at(acc, o_inds, f[i_inds] @ w[:, k, :].T)
+    acc_i32 = acc.astype(np.int64).astype(np.int32)
+    rescaled = acc_i32.astype(np.float32) * scale.astype(np.float32)
+    rescaled = rescaled + bias.astype(np.float32)
+    if add_i8 is not None:
+        rescaled = rescaled + add_i8.astype(np.float32) * np.float32(add_scale)
+    if relu:
+        rescaled = np.maximum(rescaled, 0)
+    if out_dtype == np.int8:
+        return np.clip(np.round(rescaled), -128, 127).astype(np.int8)
+    return rescaled.astype(out_dtype)
+

@@ -46,6 +46,9 @@ SIGNATURES = {
                                            ctypes.c_size_t, vp]),
     "spx_igemm_fwd": (ctypes.c_int, [vp] * 6 + [ctypes.c_int] * 7 + [vp, ctypes.c_int,
                                                                      ctypes.c_float, vp]),
+    "spx_igemm_fwd_int8": (ctypes.c_int, [vp] * 6 + [ctypes.c_int] * 6 + [vp, vp, vp, ctypes.c_float,
+                                                                       ctypes.c_int, ctypes.c_int,
+                                                                       ctypes.c_float, vp]),
     "spx_igemm_dgrad_ws_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),
     "spx_igemm_dgrad": (ctypes.c_int, [vp] * 6 + [ctypes.c_int] * 7 + [vp, ctypes.c_size_t, vp]),
     "spx_igemm_wgrad_ws_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),

@@ -51,6 +51,11 @@ struct GemmParams {
   int b_reverse;          // use weight slice kv-1-k for offset k (SubM dgrad)
   int act;
   float act_alpha;
+  // int8 inference epilogue (igemm_v4_kernel<.., DT = 2, ..>): bias is fp32 here
+  const float *scale;     // [COUT] per-channel multiplier of the i32 accumulator, or null
+  const void *add;        // int8 [n_dst, COUT] residual input, or null
+  float add_scale;
+  int out_dtype;          // SPX_I8 / SPX_F16 / SPX_BF16 / SPX_F32
 };
 
 // ---- 16-bit <-> float helpers -------------------------------------------
@@ -478,9 +483,65 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, ui
                                            kRsrcFlags);
 }
 
-template <int COUT, int MB, bool BF16, bool BT>
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// one MFMA of a step: 16 bytes per lane and operand -- v_mfma_f32_16x16x32_{f16,bf16} (8
+// elements) or v_mfma_i32_16x16x64_i8 (16 elements)
+template <int DT, typename ACC>
+__device__ __forceinline__ ACC mfma_step(const uint4 &a, const uint4 &b, ACC c) {
+  if constexpr (DT == 2) {
+    return __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a),
+                                                 __builtin_bit_cast(i32x4, b), c, 0, 0, 0);
+  } else {
+    return mfma16<DT == 1>(a, b, c);
+  }
+}
+
+// N consecutive dwords of one lane to / from a raw buffer, in the widest pieces
+template <int N>
+__device__ __forceinline__ void store_dwords(const uint32_t (&d)[N], __amdgpu_buffer_rsrc_t r,
+                                             uint32_t vo) {
+  if constexpr (N == 1) {
+    __builtin_amdgcn_raw_buffer_store_b32(d[0], r, vo, 0, 0);
+  } else if constexpr (N == 2) {
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{d[0], d[1]}, r, vo, 0, 0);
+  } else {
+#pragma unroll
+    for (int q = 0; q < N / 4; ++q)
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]},
+                                             r, vo + q * 16, 0, 0);
+  }
+}
+template <int N>
+__device__ __forceinline__ void load_dwords(uint32_t (&d)[N], __amdgpu_buffer_rsrc_t r, uint32_t vo) {
+  if constexpr (N == 1) {
+    d[0] = __builtin_amdgcn_raw_buffer_load_b32(r, vo, 0, 0);
+  } else if constexpr (N == 2) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, vo, 0, 0);
+    d[0] = v[0];
+    d[1] = v[1];
+  } else {
+#pragma unroll
+    for (int q = 0; q < N / 4; ++q) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, vo + q * 16, 0, 0);
+      d[4 * q] = v[0];
+      d[4 * q + 1] = v[1];
+      d[4 * q + 2] = v[2];
+      d[4 * q + 3] = v[3];
+    }
+  }
+}
+
+// DT: 0 = f16, 1 = bf16, 2 = int8 (i32 accumulate, quantised epilogue; forward only).  All
+// addressing is in BYTES: a step contracts one 128-byte piece of the rows (64 16-bit or 128
+// 8-bit reduction elements), a lane feeds 16 bytes per MFMA to either instruction family.
+template <int COUT, int MB, int DT, bool BT>
 __global__ void __launch_bounds__(kThreads)
 igemm_v4_kernel(GemmParams p) {
+  constexpr bool BF16 = DT == 1, I8 = DT == 2;
+  constexpr int ES = I8 ? 1 : 2;                        // bytes per element
+  static_assert(!(I8 && BT), "int8 is forward only");
   constexpr int NB = COUT / 16;
   constexpr int TM = 64 * MB;                           // rows per workgroup: 4 waves x MB x 16
   constexpr int BROWS = BT ? 2 * ((COUT + 63) / 64) : (COUT + 31) / 32;
@@ -507,12 +568,12 @@ igemm_v4_kernel(GemmParams p) {
     const int x = ((row >> 1) & 1) | (((row / CPL) & 3) << 1);
     return row * kRowBytes + ((sl ^ x) << 4);
   };
-  const int nchunk = (p.CIN + kCK - 1) / kCK;
-  const uint32_t rowB = static_cast<uint32_t>(p.CIN) * 2u;
-  const bool cfull = (p.CIN & (kCK - 1)) == 0;
+  const uint32_t rowB = static_cast<uint32_t>(p.CIN) * ES;
+  const int nchunk = (static_cast<int>(rowB) + kRowBytes - 1) / kRowBytes;
+  const bool cfull = (rowB & (kRowBytes - 1)) == 0;
 
   const uint32_t a_bytes = static_cast<uint32_t>(p.n_src) * rowB;
-  const uint32_t w_bytes = static_cast<uint32_t>(p.COUT) * p.kv * p.CIN * 2u;
+  const uint32_t w_bytes = static_cast<uint32_t>(p.COUT) * p.kv * rowB;
   const uint32_t pair_bytes = static_cast<uint32_t>(p.n_dst) * 4u;
 
   // rows of this lane: tile rows wave*16*MB + mb*16 + lrow
@@ -531,12 +592,12 @@ igemm_v4_kernel(GemmParams p) {
   // reduction chunk when CIN is not a multiple of 64 (reduction elements >= CIN must read as
   // zero on BOTH operands).  Bitwise on purpose: a ?: between two arrays becomes a pointer
   // select that pins them (and the parameter block) in scratch.
-  const int ctail = p.CIN - (nchunk - 1) * kCK;          // elements in the last chunk (1..64)
+  const int ctail = static_cast<int>(rowB) - (nchunk - 1) * kRowBytes;   // bytes in the last chunk
   uint32_t aoff[2], aoff_tail[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    const int c = ks * 32 + lgrp * 8;
-    aoff[ks] = static_cast<uint32_t>(c) * 2u;
+    const int c = ks * 64 + lgrp * 16;                  // byte inside the 128-byte piece
+    aoff[ks] = static_cast<uint32_t>(c);
     aoff_tail[ks] = c < ctail ? 0u : kOob;
   }
   uint32_t boff[BA], boff_tail[BA];
@@ -544,9 +605,9 @@ igemm_v4_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < BROWS; ++j) {
       const int n = r0 + 32 * j;
-      const uint32_t o = static_cast<uint32_t>(n) * static_cast<uint32_t>(p.strideN) * 2u + slot * 16u;
+      const uint32_t o = static_cast<uint32_t>(n) * static_cast<uint32_t>(p.strideN) * ES + slot * 16u;
       boff[j] = n < COUT ? o : kOob;
-      boff_tail[j] = slot * 8 < ctail ? 0u : kOob;
+      boff_tail[j] = slot * 16 < ctail ? 0u : kOob;
     }
   } else {
 #pragma unroll
@@ -555,7 +616,7 @@ igemm_v4_kernel(GemmParams p) {
       const int n = (j >> 1) * 64 + slot * 8;
       const uint32_t o = static_cast<uint32_t>(d) * static_cast<uint32_t>(p.strideD) * 2u + n * 2u;
       boff[j] = n < COUT ? o : kOob;
-      boff_tail[j] = d < ctail ? 0u : kOob;
+      boff_tail[j] = d * 2 < ctail ? 0u : kOob;
     }
   }
 
@@ -582,7 +643,7 @@ igemm_v4_kernel(GemmParams p) {
   auto load_a = [&](const StepIt &it, auto SET) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
     const uint32_t tail = (!cfull && it.chunk == nchunk - 1) ? 0xffffffffu : 0u;
-    const uint32_t so = static_cast<uint32_t>(it.chunk) * (kCK * 2);
+    const uint32_t so = static_cast<uint32_t>(it.chunk) * kRowBytes;
     const __amdgpu_buffer_rsrc_t r = make_rsrc(p.A, it.k >= 0 ? a_bytes : 0u);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
@@ -601,8 +662,8 @@ igemm_v4_kernel(GemmParams p) {
     const uint32_t tail = (!cfull && it.chunk == nchunk - 1) ? 0xffffffffu : 0u;
     const int k = it.k < 0 ? 0 : it.k;
     const int kb = p.b_reverse ? p.kv - 1 - k : k;
-    uint32_t so = static_cast<uint32_t>(kb) * static_cast<uint32_t>(p.strideK) * 2u;
-    if constexpr (!BT) so += static_cast<uint32_t>(it.chunk) * (kCK * 2);
+    uint32_t so = static_cast<uint32_t>(kb) * static_cast<uint32_t>(p.strideK) * ES;
+    if constexpr (!BT) so += static_cast<uint32_t>(it.chunk) * kRowBytes;
     else so += static_cast<uint32_t>(it.chunk) * kCK * static_cast<uint32_t>(p.strideD) * 2u;
     const __amdgpu_buffer_rsrc_t r = make_rsrc(p.B, it.k >= 0 ? w_bytes : 0u);
 #pragma unroll
@@ -697,11 +758,12 @@ igemm_v4_kernel(GemmParams p) {
   __builtin_amdgcn_sched_barrier(0);
   load_a(it1, Set1{});
 
-  f32x4 acc[NB][MB];
+  using acc_t = typename std::conditional<I8, i32x4, f32x4>::type;
+  acc_t acc[NB][MB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = acc_t{0, 0, 0, 0};
 
   // ---- main loop: one step = one (offset, 64-wide reduction chunk), two steps per trip ---
   // at step t (register set S = t & 1): areg[S] = gathered rows of step t, stage S of the
@@ -714,8 +776,7 @@ igemm_v4_kernel(GemmParams p) {
     // none of this wave's rows uses offset k (or the step does not exist): skip the MFMAs
     if (it0.k >= 0 && ((wavemask >> it0.k) & 1u)) {
       const char *cur = smem + S * B_BYTES;
-      const int c0 = it0.chunk * kCK;
-      const int ksteps = (min(kCK, p.CIN - c0) + 31) >> 5;  // 1 or 2
+      const int ksteps = (min(kRowBytes, static_cast<int>(rowB) - it0.chunk * kRowBytes) + 63) >> 6;  // 1 or 2
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         if (ks < ksteps) {
@@ -725,7 +786,7 @@ igemm_v4_kernel(GemmParams p) {
                 cur + swzB((lrow >> 2) * CPL + nb * 4 + (lrow & 3), ks * 4 + lgrp));
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
-              acc[nb][mb] = mfma16<BF16>(fa, __builtin_bit_cast(uint4, areg[S][mb][ks]), acc[nb][mb]);
+              acc[nb][mb] = mfma_step<DT>(fa, __builtin_bit_cast(uint4, areg[S][mb][ks]), acc[nb][mb]);
           }
         }
       }
@@ -748,44 +809,101 @@ igemm_v4_kernel(GemmParams p) {
   }
   SPX_STAMP(4);   // main loop done
 
-  // ---- epilogue: bias/activation, fp32 -> 16 bit (packed converts), CPL consecutive channels
-  // per lane stored straight from registers; rows past the end have an out-of-range offset
-  // and are dropped by the buffer unit.
-  const uint16_t *bias = static_cast<const uint16_t *>(p.bias);
-  const bool plain = bias == nullptr && p.act == SPX_ACT_NONE;   // uniform: training path
-  const __amdgpu_buffer_rsrc_t rO = make_rsrc(p.out, static_cast<uint32_t>(p.n_dst) * (COUT * 2u));
-  float bv[CPL];
+  // ---- epilogue: CPL consecutive channels per lane, stored straight from registers; rows past
+  // the end have an out-of-range offset and are dropped by the buffer unit.
+  if constexpr (!I8) {
+    // bias/activation, fp32 -> 16 bit (packed converts)
+    const uint16_t *bias = static_cast<const uint16_t *>(p.bias);
+    const bool plain = bias == nullptr && p.act == SPX_ACT_NONE;   // uniform: training path
+    const __amdgpu_buffer_rsrc_t rO = make_rsrc(p.out, static_cast<uint32_t>(p.n_dst) * (COUT * 2u));
+    float bv[CPL];
 #pragma unroll
-  for (int q = 0; q < CPL; ++q) bv[q] = 0.f;
-  if (bias) {
+    for (int q = 0; q < CPL; ++q) bv[q] = 0.f;
+    if (bias) {
 #pragma unroll
-    for (int q = 0; q < CPL; ++q) bv[q] = to_float<BF16>(bias[lgrp * CPL + q]);
-  }
+      for (int q = 0; q < CPL; ++q) bv[q] = to_float<BF16>(bias[lgrp * CPL + q]);
+    }
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-    uint32_t d[CPL / 2];
+    for (int mb = 0; mb < MB; ++mb) {
+      uint32_t d[CPL / 2];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float v0 = acc[nb][mb][2 * h], v1 = acc[nb][mb][2 * h + 1];
+          if (!plain) {
+            v0 = apply_act(v0 + bv[nb * 4 + 2 * h], p.act, p.act_alpha);
+            v1 = apply_act(v1 + bv[nb * 4 + 2 * h + 1], p.act, p.act_alpha);
+          }
+          d[nb * 2 + h] = pack2<BF16>(v0, v1);
+        }
+      }
+      const uint32_t vo = grow[mb] < 0 ? kOob
+                                       : static_cast<uint32_t>(grow[mb]) * (COUT * 2u) + lgrp * (CPL * 2u);
+      store_dwords<CPL / 2>(d, rO, vo);
+    }
+  } else {
+    // int8 inference epilogue (reference numerics: test/test_all_algo.py:272-287):
+    //   v = acc_i32 * scale[k] + bias[k] + add[o][k] * add_scale;  v = act(v)
+    //   int8 out: clip(round_half_even(v), -128, 127);  f16 / f32 out: v
+    const int oes = p.out_dtype == SPX_I8 ? 1 : (p.out_dtype == SPX_F32 ? 4 : 2);
+    const __amdgpu_buffer_rsrc_t rO =
+        make_rsrc(p.out, static_cast<uint32_t>(p.n_dst) * static_cast<uint32_t>(COUT * oes));
+    const __amdgpu_buffer_rsrc_t rAdd =
+        make_rsrc(p.add, p.add ? static_cast<uint32_t>(p.n_dst) * COUT : 0u);
+    const float *bias = static_cast<const float *>(p.bias);
+    uint32_t rowoff[MB];
+    uint32_t addw[MB][CPL / 4];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      rowoff[mb] = grow[mb] < 0 ? kOob : static_cast<uint32_t>(grow[mb]) * COUT + lgrp * CPL;
+      load_dwords<CPL / 4>(addw[mb], rAdd, rowoff[mb]);   // zeros when there is no residual input
+    }
+    // four channels (one output dword of an int8 row) at a time keeps the live set small
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
+      float sc[4], bv[4];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        float v0 = acc[nb][mb][2 * h], v1 = acc[nb][mb][2 * h + 1];
-        if (!plain) {
-          v0 = apply_act(v0 + bv[nb * 4 + 2 * h], p.act, p.act_alpha);
-          v1 = apply_act(v1 + bv[nb * 4 + 2 * h + 1], p.act, p.act_alpha);
+      for (int e = 0; e < 4; ++e) {
+        sc[e] = p.scale ? p.scale[lgrp * CPL + nb * 4 + e] : 1.f;
+        bv[e] = bias ? bias[lgrp * CPL + nb * 4 + e] : 0.f;
+      }
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int a8 = static_cast<int>(static_cast<int8_t>((addw[mb][nb] >> (e * 8)) & 0xff));
+          float t = static_cast<float>(acc[nb][mb][e]) * sc[e] + bv[e];
+          t += static_cast<float>(a8) * p.add_scale;
+          v[e] = apply_act(t, p.act, p.act_alpha);
         }
-        d[nb * 2 + h] = pack2<BF16>(v0, v1);
+        if (p.out_dtype == SPX_I8) {
+          uint32_t word = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float r = fminf(fmaxf(__builtin_rintf(v[e]), -128.f), 127.f);
+            word |= (static_cast<uint32_t>(static_cast<int>(r)) & 0xffu) << (8 * e);
+          }
+          addw[mb][nb] = word;                            // reuse: the residual word is consumed
+        } else if (p.out_dtype == SPX_F32) {
+          uint32_t d[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) d[e] = __builtin_bit_cast(uint32_t, v[e]);
+          store_dwords<4>(d, rO, rowoff[mb] == kOob ? kOob : (rowoff[mb] + nb * 4) * 4u);
+        } else {
+          uint32_t d[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            d[q] = p.out_dtype == SPX_BF16 ? pack2<true>(v[2 * q], v[2 * q + 1])
+                                           : pack2<false>(v[2 * q], v[2 * q + 1]);
+          store_dwords<2>(d, rO, rowoff[mb] == kOob ? kOob : (rowoff[mb] + nb * 4) * 2u);
+        }
       }
     }
-    const uint32_t vo = grow[mb] < 0 ? kOob
-                                     : static_cast<uint32_t>(grow[mb]) * (COUT * 2u) + lgrp * (CPL * 2u);
-    if constexpr (CPL == 4) {
-      typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-      __builtin_amdgcn_raw_buffer_store_b64(u32x2{d[0], d[1]}, rO, vo, 0, 0);
-    } else {
+    if (p.out_dtype == SPX_I8) {
 #pragma unroll
-      for (int q = 0; q < CPL / 8; ++q)
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]},
-                                               rO, vo + q * 16, 0, 0);
+      for (int mb = 0; mb < MB; ++mb) store_dwords<CPL / 4>(addw[mb], rO, rowoff[mb]);
     }
   }
   SPX_STAMP(6);   // stores issued
@@ -800,24 +918,29 @@ constexpr size_t v4_smem_bytes() {
   return 2 * static_cast<size_t>(COUT) * kRowBytes + 64;   // two weight stages + 4 mask words
 }
 
-bool v4_ok(const GemmParams &p) {
-  const unsigned long long abytes = static_cast<unsigned long long>(p.n_src) * p.CIN * 2ull;
+bool v4_ok(const GemmParams &p, int es = 2, int out_es = 2) {
+  const unsigned long long abytes = static_cast<unsigned long long>(p.n_src) * p.CIN * es;
   const unsigned long long pbytes = static_cast<unsigned long long>(p.n_dst) * 4ull;
-  const unsigned long long wbytes = static_cast<unsigned long long>(p.COUT) * p.kv * p.CIN * 2ull;
-  const unsigned long long obytes = static_cast<unsigned long long>(p.n_dst) * p.COUT * 2ull;
+  const unsigned long long wbytes = static_cast<unsigned long long>(p.COUT) * p.kv * p.CIN * es;
+  const unsigned long long obytes = static_cast<unsigned long long>(p.n_dst) * p.COUT * out_es;
   return abytes < 0x7fff0000ull && pbytes < 0x7fff0000ull && wbytes < 0x7fff0000ull &&
          obytes < 0x7fff0000ull;
 }
 
-template <int COUT, int MB, bool BF16>
+template <int COUT, int MB, int DT>
 int launch_v4(const GemmParams &p, hipStream_t s) {
   const int ntiles = div_up(p.n_dst, 64 * MB);
-  if (p.strideD == 1)
-    hipLaunchKernelGGL((igemm_v4_kernel<COUT, MB, BF16, false>), dim3(ntiles), dim3(kThreads),
+  if constexpr (DT == 2) {
+    hipLaunchKernelGGL((igemm_v4_kernel<COUT, MB, DT, false>), dim3(ntiles), dim3(kThreads),
                        (v4_smem_bytes<COUT, MB>()), s, p);
-  else
-    hipLaunchKernelGGL((igemm_v4_kernel<COUT, MB, BF16, true>), dim3(ntiles), dim3(kThreads),
-                       (v4_smem_bytes<COUT, MB>()), s, p);
+  } else {
+    if (p.strideD == 1)
+      hipLaunchKernelGGL((igemm_v4_kernel<COUT, MB, DT, false>), dim3(ntiles), dim3(kThreads),
+                         (v4_smem_bytes<COUT, MB>()), s, p);
+    else
+      hipLaunchKernelGGL((igemm_v4_kernel<COUT, MB, DT, true>), dim3(ntiles), dim3(kThreads),
+                         (v4_smem_bytes<COUT, MB>()), s, p);
+  }
   SPX_LAUNCH_CHECK();
   return 0;
 }
@@ -1481,11 +1604,11 @@ int dispatch_gather_gemm(const GemmParams &p, hipStream_t s) {
     // 64-row tiles while the grid would otherwise leave CUs idle, 128-row tiles beyond
     const int mb = mb_forced ? mb_forced : (p.n_dst <= 64 * 1024 ? 1 : 2);
     switch (p.COUT) {
-      case 16: return mb == 1 ? launch_v4<16, 1, BF16>(p, s) : launch_v4<16, 2, BF16>(p, s);
-      case 32: return mb == 1 ? launch_v4<32, 1, BF16>(p, s) : launch_v4<32, 2, BF16>(p, s);
-      case 64: return mb == 1 ? launch_v4<64, 1, BF16>(p, s) : launch_v4<64, 2, BF16>(p, s);
-      case 128: return mb == 1 ? launch_v4<128, 1, BF16>(p, s) : launch_v4<128, 2, BF16>(p, s);
-      case 256: return launch_v4<256, 1, BF16>(p, s);
+      case 16: return mb == 1 ? launch_v4<16, 1, BF16 ? 1 : 0>(p, s) : launch_v4<16, 2, BF16 ? 1 : 0>(p, s);
+      case 32: return mb == 1 ? launch_v4<32, 1, BF16 ? 1 : 0>(p, s) : launch_v4<32, 2, BF16 ? 1 : 0>(p, s);
+      case 64: return mb == 1 ? launch_v4<64, 1, BF16 ? 1 : 0>(p, s) : launch_v4<64, 2, BF16 ? 1 : 0>(p, s);
+      case 128: return mb == 1 ? launch_v4<128, 1, BF16 ? 1 : 0>(p, s) : launch_v4<128, 2, BF16 ? 1 : 0>(p, s);
+      case 256: return launch_v4<256, 1, BF16 ? 1 : 0>(p, s);
     }
   }
   switch (p.COUT) {
@@ -1586,6 +1709,59 @@ int spx_igemm_fwd(const void *feat, const void *weight, void *out, const int32_t
   p.act = act;
   p.act_alpha = act_alpha;
   return run_gather_gemm(p, dtype, static_cast<hipStream_t>(stream));
+}
+
+int spx_igemm_fwd_int8(const void *feat, const void *weight, void *out, const int32_t *pair,
+                       const uint32_t *mask, const int32_t *argsort, int n_in, int n_out, int C,
+                       int K, int kv, int identity_k, const float *scale, const float *bias,
+                       const void *add, float add_scale, int out_dtype, int act, float act_alpha,
+                       spx_stream_t stream) {
+  SPX_CHECK(feat && weight && out, "null tensor pointer");
+  SPX_CHECK(pair || kv == 1, "pair table required");
+  SPX_CHECK(C > 0 && K > 0 && kv > 0 && n_in >= 0 && n_out >= 0, "bad sizes");
+  // the reference has the same restriction (test/test_all_algo.py:376-377)
+  SPX_CHECK(C % 16 == 0, "int8 needs in_channels %% 16 == 0, got %d", C);
+  SPX_CHECK(K == 16 || K == 32 || K == 64 || K == 128 || K == 256,
+            "int8 supports out_channels 16/32/64/128/256, got %d", K);
+  SPX_CHECK(kv <= 32, "int8 supports kernel volumes up to 32, got %d", kv);
+  SPX_CHECK(out_dtype == SPX_I8 || out_dtype == SPX_F16 || out_dtype == SPX_BF16 || out_dtype == SPX_F32,
+            "bad output dtype %d", out_dtype);
+  GemmParams p{};
+  p.A = feat;
+  p.B = weight;
+  p.out = out;
+  p.pair = pair;
+  p.mask = mask;
+  p.argsort = argsort;
+  p.bias = bias;
+  p.strideK = C;
+  p.strideN = static_cast<long long>(kv) * C;
+  p.strideD = 1;
+  p.n_src = n_in;
+  p.n_dst = n_out;
+  p.CIN = C;
+  p.COUT = K;
+  p.kv = kv;
+  p.identity_k = identity_k;
+  p.b_reverse = 0;
+  p.act = act;
+  p.act_alpha = act_alpha;
+  p.scale = scale;
+  p.add = add;
+  p.add_scale = add_scale;
+  p.out_dtype = out_dtype;
+  if (n_out == 0) return 0;
+  const int oes = out_dtype == SPX_I8 ? 1 : (out_dtype == SPX_F32 ? 4 : 2);
+  SPX_CHECK(v4_ok(p, 1, oes), "tensor too large for 32-bit buffer offsets");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (K) {
+    case 16: return launch_v4<16, 2, 2>(p, s);
+    case 32: return launch_v4<32, 2, 2>(p, s);
+    case 64: return launch_v4<64, 2, 2>(p, s);
+    case 128: return launch_v4<128, 2, 2>(p, s);
+    case 256: return launch_v4<256, 1, 2>(p, s);
+  }
+  return -1;
 }
 
 size_t spx_igemm_dgrad_ws_bytes(int C, int K, int kv, int dtype) {

@@ -105,9 +105,14 @@ class SparseConvolution(SparseModule):
         if record_voxel_count and not self.subm and not self.inverse:
             self.register_buffer(_MAX_NUM_VOXELS_DURING_TRAINING,
                                  torch.zeros(1, dtype=torch.int32, device=device))
+        self._init_parameters(bias, factory_kwargs)
+
+    def _init_parameters(self, bias: bool, factory_kwargs) -> None:
+        """Float weight / bias Parameters (the quantised module overrides this, like the
+        reference's SparseConvolutionBase / SparseConvolution split, conv.py:63-147,563-764)."""
         self.weight = Parameter(torch.zeros(*self.weight_shape, **factory_kwargs))
         if bias:
-            self.bias = Parameter(torch.zeros(out_channels, **factory_kwargs))
+            self.bias = Parameter(torch.zeros(self.out_channels, **factory_kwargs))
         else:
             self.register_parameter("bias", None)
         self.reset_parameters()
@@ -236,8 +241,13 @@ class SparseConvolution(SparseModule):
                       sparse_unique_name: str = "", act_type=Activation.None_,
                       act_alpha: float = 0, act_beta: float = 0):
         assert isinstance(input, SparseConvTensor)
-        if input.is_quantized or channel_scale is not None or output_scale is not None:
-            raise NotImplementedError("int8 inference is not implemented yet")
+        is_int8 = input.is_quantized and weight.is_quantized
+        if is_int8:
+            assert output_scale is not None and channel_scale is not None, \
+                "int8 must be called in static quantized module"
+            assert bias is not None, "currently you must specify a bias"
+            assert not training, "int8 is inference only"
+            assert not self.conv1x1 and not self.inverse, "int8 supports regular and subm convolutions"
         assert input.features.shape[1] == self.in_channels, "channel size mismatch"
         features = input.features
         indices = input.indices
@@ -335,6 +345,15 @@ class SparseConvolution(SparseModule):
             fn = (Fsp.indice_subm_conv if self.subm
                   else Fsp.indice_inverse_conv if self.inverse else Fsp.indice_conv)
             out_features = fn(features, weight, pair_native, rb.num_per_loc, num_out, algo)
+        elif is_int8:
+            # quantised inference (conv.py:463-490): add + activation are fused in the kernel
+            out_features, _, _ = ops.implicit_gemm(
+                features, weight, ops.attach_rulebook(rb.pair_fwd, rb), [rb.mask_fwd],
+                [rb.argsort_fwd] if rb.argsort_fwd is not None else [], num_out, [], False,
+                self.subm, None, self.fp32_accum, bias_for_infer, act_alpha, act_beta, act_type,
+                output_scale, channel_scale,
+                output_add=add_input.features if add_input is not None else None,
+                output_add_scale=add_input.q_scale() if add_input is not None else 0.0)
         else:
             w = weight if weight.dtype == features.dtype else weight.to(features.dtype)
             if self.inverse:
@@ -359,7 +378,7 @@ class SparseConvolution(SparseModule):
         out_tensor.indices = outids
         out_tensor.indice_dict = indice_dict
         out_tensor.spatial_shape = out_spatial_shape
-        if add_input is not None:
+        if add_input is not None and not is_int8:   # in int8 add + act happen in the kernel
             out_tensor = out_tensor.replace_feature(
                 _apply_act(out_tensor.features + add_input.features, self.act_type,
                            self.act_alpha, self.act_beta))

@@ -251,7 +251,48 @@ def _check_feat(features: torch.Tensor, filters: torch.Tensor):
     if features.dtype != filters.dtype:
         raise TypeError(f"features ({features.dtype}) and filters ({filters.dtype}) must share a dtype")
     if features.dtype in (torch.int8, torch.qint8):
-        raise NotImplementedError("int8 inference is not implemented yet")
+        raise NotImplementedError("int8 tensors go through implicit_gemm / igemm_fwd_int8 "
+                                  "(inference only, like the reference)")
+
+
+_OUT_CODES = {torch.int8: _lib.DTYPE_I8, torch.float16: _lib.DTYPE_F16,
+              torch.bfloat16: _lib.DTYPE_BF16, torch.float32: _lib.DTYPE_F32}
+
+
+def _int_repr(t: torch.Tensor) -> torch.Tensor:
+    return t.int_repr() if t.is_quantized else t
+
+
+def igemm_fwd_int8(features: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
+                   mask: Optional[torch.Tensor], argsort: Optional[torch.Tensor], n_out: int,
+                   identity_k: int = -1, scale: Optional[torch.Tensor] = None,
+                   bias: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None,
+                   add_scale: float = 0.0, out_dtype: torch.dtype = torch.int8,
+                   act_type: int = Activation.None_, act_alpha: float = 0.0) -> torch.Tensor:
+    """int8 inference forward (i32 accumulate on v_mfma_i32_16x16x64_i8):
+    ``v = acc * scale[k] + bias[k] + add * add_scale; v = act(v)``; int8 output =
+    ``clip(round_half_even(v), -128, 127)`` (reference numerics test/test_all_algo.py:272-287)."""
+    _require_gpu(features, "features")
+    L = _lib.load()
+    features = _int_repr(features).contiguous()
+    filters = _int_repr(filters).contiguous()
+    if features.dtype != torch.int8 or filters.dtype != torch.int8:
+        raise TypeError("igemm_fwd_int8 needs int8 features and filters")
+    K, C = filters.shape[0], filters.shape[-1]
+    kv = filters.numel() // (K * C)
+    assert features.shape[1] == C, "channel size mismatch"
+    out = torch.empty((n_out, K), dtype=out_dtype, device=features.device)
+    f32 = lambda t: None if t is None else t.to(device=features.device, dtype=torch.float32).contiguous()
+    scale, bias = f32(scale), f32(bias)
+    if add is not None:
+        add = _int_repr(add).contiguous()
+        assert add.dtype == torch.int8 and tuple(add.shape) == (n_out, K)
+    _lib.check(L.spx_igemm_fwd_int8(features.data_ptr(), filters.data_ptr(), out.data_ptr(), _ptr(pair),
+                                    _ptr(mask), _ptr(argsort), features.shape[0], n_out, C, K, kv,
+                                    identity_k, _ptr(scale), _ptr(bias), _ptr(add), float(add_scale),
+                                    _OUT_CODES[out_dtype], int(act_type), float(act_alpha),
+                                    _stream(features)))
+    return out
 
 
 def igemm_fwd(features: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
@@ -461,12 +502,24 @@ def implicit_gemm(features: torch.Tensor, filters: torch.Tensor, pair_fwd: torch
                   output_add_scale: float = 0.0, output_dtype: Optional[torch.dtype] = None):
     """Masked implicit GEMM forward (ops.py:1450-1664).  Returns (out, mask_out, mask_width);
     the last two exist for signature parity (this wgrad does not consume tile masks)."""
-    if scale is not None or output_add is not None:
-        raise NotImplementedError("int8 epilogue (scale / output_add) is not implemented yet")
     mask = pair_mask_fwd_splits[0] if pair_mask_fwd_splits else None
     rb: Optional[Rulebook] = rulebook_of(pair_fwd)
     argsort = rb.argsort_fwd if rb is not None else None
     kv = pair_fwd.shape[0]
+    if features.dtype in (torch.int8, torch.qint8):
+        # int8 inference (ops.py:1540-1553,1631-1662): scale = per-channel multiplier, bias is
+        # fp32 in output-quantised units, the residual input is scaled by add_scale / out_scale
+        assert not is_train, "int8 is inference only"
+        out_dt = torch.int8 if output_dtype in (None, torch.int8, torch.qint8) else output_dtype
+        beta = output_add_scale / output_scale if output_add is not None else 0.0
+        out = igemm_fwd_int8(features, filters, pair_fwd, mask, argsort, num_activate_out,
+                             kv // 2 if is_subm else -1, scale, bias, output_add, beta, out_dt,
+                             act_type, act_alpha)
+        if out_dt == torch.int8 and features.is_quantized:
+            out = torch._make_per_tensor_quantized_tensor(out, float(output_scale), 0)
+        return out, None, -1
+    if scale is not None or output_add is not None:
+        raise NotImplementedError("scale / output_add belong to the int8 path")
     out = igemm_fwd(features, filters, pair_fwd, mask, argsort, num_activate_out,
                     kv // 2 if is_subm else -1, bias, act_type, act_alpha)
     return out, None, -1

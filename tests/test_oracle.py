@@ -183,3 +183,30 @@ def test_int8_formula_matches_float_path():
                              pair, num, 500, subm=True).numpy()
     r = np.maximum(acc.astype(np.float32) * scale + bias + add.astype(np.float32) * np.float32(0.01), 0)
     assert q.dtype == np.int8 and np.array_equal(q, np.clip(np.round(r), -128, 127).astype(np.int8))
+
+
+def test_int8_reference_formula_small():
+    """oracle.int8_conv_ref (float64 BLAS accumulation) against plain integer loops following
+    test/test_all_algo.py:222-288 literally."""
+    rng = np.random.default_rng(1)
+    shape, n, C, K = [8, 8, 8], 120, 16, 16
+    idx = scene(shape, n, 1, 1)
+    out_inds, pair, num, _ = oracle.get_indice_pairs(idx, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3,
+                                                     None, True, False)
+    f = rng.integers(-127, 128, (n, C), dtype=np.int8)
+    w = rng.integers(-127, 128, (K, 3, 3, 3, C), dtype=np.int8)
+    scale = rng.uniform(0.5, 1.5, K).astype(np.float32) * 1e-3
+    bias = rng.uniform(-5, 5, K).astype(np.float32)
+    add = rng.integers(-127, 128, (n, K), dtype=np.int8)
+    got = oracle.int8_conv_ref(f, w, pair, num, n, True, scale, bias, add, 0.3, True)
+    wr = w.reshape(K, 27, C)
+    acc = np.zeros((n, K), dtype=np.int32)
+    for k in range(27):
+        nhot = n if k == 13 else int(num[k] if k < 13 else num[26 - k])
+        for j in range(nhot):
+            i, o = (j, j) if k == 13 else (pair[0][k][j], pair[1][k][j])
+            acc[o] += wr[:, k, :].astype(np.int32) @ f[i].astype(np.int32)
+    r = acc.astype(np.float32) * scale + bias + add.astype(np.float32) * np.float32(0.3)
+    want = np.clip(np.round(np.maximum(r, 0)), -128, 127).astype(np.int8)
+    np.testing.assert_array_equal(got, want)
+
