@@ -5,7 +5,7 @@ cd "$(dirname "$0")"
 OUT=../lib
 mkdir -p $OUT/dbg
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DSPX_TIMELINE"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -mllvm -amdgpu-kernarg-preload-count=16 -DSPX_TIMELINE"
 $HIPCC $FLAGS -c rulebook.hip -o $OUT/dbg/rulebook.o &
 $HIPCC $FLAGS -c igemm.hip -o $OUT/dbg/igemm.o &
 $HIPCC $FLAGS -x hip -c common.cpp -o $OUT/dbg/common.o &

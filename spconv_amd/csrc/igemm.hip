@@ -536,9 +536,51 @@ __device__ __forceinline__ void load_dwords(uint32_t (&d)[N], __amdgpu_buffer_rs
 // DT: 0 = f16, 1 = bf16, 2 = int8 (i32 accumulate, quantised epilogue; forward only).  All
 // addressing is in BYTES: a step contracts one 128-byte piece of the rows (64 16-bit or 128
 // 8-bit reduction elements), a lane feeds 16 bytes per MFMA to either instruction family.
+// Kernel arguments: the 16 dwords every wave needs before its first load are separate scalar
+// arguments, which -amdgpu-kernarg-preload-count=16 (csrc/build.sh) turns into SGPRs
+// preloaded at wave launch -- the two dependent kernarg fetches (~0.5 us each under load) at
+// the head of every workgroup's critical path disappear.  The rest travels as a struct.
+struct GemmRest {
+  void *out;
+  const void *bias;
+  long long strideK, strideN, strideD;
+  int COUT, act;
+  float act_alpha;
+  const float *scale;
+  const void *add;
+  float add_scale;
+  int out_dtype;
+};
+
 template <int COUT, int MB, int DT, bool BT>
 __global__ void __launch_bounds__(kThreads)
-igemm_v4_kernel(GemmParams p) {
+igemm_v4_kernel(const void *argA, const void *argB, const uint32_t *arg_mask,
+                const int32_t *arg_argsort, const int32_t *arg_pair, int n_dst, int n_src, int CIN,
+                int kv, int identity_k, int b_reverse, GemmRest rest) {
+  GemmParams p;
+  p.A = argA;
+  p.B = argB;
+  p.mask = arg_mask;
+  p.argsort = arg_argsort;
+  p.pair = arg_pair;
+  p.n_dst = n_dst;
+  p.n_src = n_src;
+  p.CIN = CIN;
+  p.kv = kv;
+  p.identity_k = identity_k;
+  p.b_reverse = b_reverse;
+  p.out = rest.out;
+  p.bias = rest.bias;
+  p.strideK = rest.strideK;
+  p.strideN = rest.strideN;
+  p.strideD = rest.strideD;
+  p.COUT = rest.COUT;
+  p.act = rest.act;
+  p.act_alpha = rest.act_alpha;
+  p.scale = rest.scale;
+  p.add = rest.add;
+  p.add_scale = rest.add_scale;
+  p.out_dtype = rest.out_dtype;
   constexpr bool BF16 = DT == 1, I8 = DT == 2;
   constexpr int ES = I8 ? 1 : 2;                        // bytes per element
   static_assert(!(I8 && BT), "int8 is forward only");
@@ -930,17 +972,27 @@ bool v4_ok(const GemmParams &p, int es = 2, int out_es = 2) {
 template <int COUT, int MB, int DT>
 int launch_v4(const GemmParams &p, hipStream_t s) {
   const int ntiles = div_up(p.n_dst, 64 * MB);
-  if constexpr (DT == 2) {
+  GemmRest r{};
+  r.out = p.out;
+  r.bias = p.bias;
+  r.strideK = p.strideK;
+  r.strideN = p.strideN;
+  r.strideD = p.strideD;
+  r.COUT = p.COUT;
+  r.act = p.act;
+  r.act_alpha = p.act_alpha;
+  r.scale = p.scale;
+  r.add = p.add;
+  r.add_scale = p.add_scale;
+  r.out_dtype = p.out_dtype;
+  if (DT == 2 || p.strideD == 1)
     hipLaunchKernelGGL((igemm_v4_kernel<COUT, MB, DT, false>), dim3(ntiles), dim3(kThreads),
-                       (v4_smem_bytes<COUT, MB>()), s, p);
-  } else {
-    if (p.strideD == 1)
-      hipLaunchKernelGGL((igemm_v4_kernel<COUT, MB, DT, false>), dim3(ntiles), dim3(kThreads),
-                         (v4_smem_bytes<COUT, MB>()), s, p);
-    else
-      hipLaunchKernelGGL((igemm_v4_kernel<COUT, MB, DT, true>), dim3(ntiles), dim3(kThreads),
-                         (v4_smem_bytes<COUT, MB>()), s, p);
-  }
+                       (v4_smem_bytes<COUT, MB>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,
+                       p.n_src, p.CIN, p.kv, p.identity_k, p.b_reverse, r);
+  else if constexpr (DT != 2)
+    hipLaunchKernelGGL((igemm_v4_kernel<COUT, MB, DT, true>), dim3(ntiles), dim3(kThreads),
+                       (v4_smem_bytes<COUT, MB>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,
+                       p.n_src, p.CIN, p.kv, p.identity_k, p.b_reverse, r);
   SPX_LAUNCH_CHECK();
   return 0;
 }

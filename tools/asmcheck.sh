@@ -3,7 +3,7 @@
 #   tools/asmcheck.sh <mangled-name-regex> [lines]
 cd /root/repo/spconv_amd/csrc || exit 1
 mkdir -p /tmp/t
-[ -n "$NOCOMPILE" ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Rpass-analysis=kernel-resource-usage -save-temps=obj -c ${SRC:-igemm.hip} -o /tmp/t/asmcheck.o 2> /tmp/t/asmcheck.log
+[ -n "$NOCOMPILE" ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -mllvm -amdgpu-kernarg-preload-count=16 -Rpass-analysis=kernel-resource-usage -save-temps=obj -c ${SRC:-igemm.hip} -o /tmp/t/asmcheck.o 2> /tmp/t/asmcheck.log
 grep -v "remark:" /tmp/t/asmcheck.log | head -20
 S=/tmp/t/$(basename ${SRC:-igemm.hip} .hip)-hip-amdgcn-amd-amdhsa-gfx950.s
 name=$(grep -o "^_Z[A-Za-z0-9_]*" $S | grep -E "$1" | head -1)

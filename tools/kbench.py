@@ -52,7 +52,25 @@ def main():
                                                            [0] * 3, True, do_sort=sort), iters=5, warm=2)
             rows.append(dict(scene=scene, sort=sort, fwd_us=round(t_f * 1e3, 2), dgrad_us=round(t_d * 1e3, 2),
                              wgrad_us=round(t_w * 1e3, 2), rulebook_us=round(t_r * 1e3, 1), **rowx))
-    print(json.dumps({"env": tag, "C": C, "n": n, "floors": floors, "rows": rows}))
+    # BASELINE config 5: int8 SubMConv3d C = K = 128, 200k voxels, per-channel scale + ReLU, int8 out
+    cfg5 = {}
+    if os.environ.get("KB_INT8", "1") == "1":
+        n5, C5 = 200_000, 128
+        idx = torch.from_numpy(synthetic.uniform_scene(SHAPE, n5, 1, seed=0)).to(dev)
+        rb, _ = ops.build_rulebook(idx, 1, SHAPE, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True)
+        f8 = torch.randint(-127, 128, (n5, C5), dtype=torch.int8, device=dev)
+        w8 = torch.randint(-127, 128, (C5, 3, 3, 3, C5), dtype=torch.int8, device=dev)
+        sc = torch.rand(C5, device=dev) * 1e-3 + 5e-4
+        bs = torch.rand(C5, device=dev) * 10 - 5
+        t_i8 = event_time_ms(lambda: ops.igemm_fwd_int8(f8, w8, rb.pair_fwd, rb.mask_fwd, None, n5, 13, sc, bs,
+                                                        None, 0.0, torch.int8, ops.Activation.ReLU))
+        fh = (torch.rand(n5, C5, device=dev) * 2 - 1).half()
+        wh = (torch.rand(C5, 3, 3, 3, C5, device=dev) * 2 - 1).half()
+        t_h = event_time_ms(lambda: ops.igemm_fwd(fh, wh, rb.pair_fwd, rb.mask_fwd, None, n5, 13))
+        alg = n5 * (C5 + C5) + 4 * 27 * n5 + 27 * C5 * C5       # algorithmic bytes
+        cfg5 = dict(n=n5, C=C5, int8_fwd_us=round(t_i8 * 1e3, 2), f16_fwd_us=round(t_h * 1e3, 2),
+                    int8_Gvox_s=round(n5 / t_i8 / 1e6, 3), int8_alg_GBps=round(alg / t_i8 / 1e6, 1))
+    print(json.dumps({"env": tag, "C": C, "n": n, "floors": floors, "rows": rows, "cfg5_int8": cfg5}))
 
 
 if __name__ == "__main__":
