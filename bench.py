@@ -72,6 +72,21 @@ def event_time_ms(fn, iters=30, warm=10):
     return a.elapsed_time(b) / iters
 
 
+def pmc_traffic(group, args):
+    """HBM bytes per launch of the dominant kernel group from the committed rocprofv3 PMC passes
+    (FETCH_SIZE x 2 [gfx950 wide-read correction, MI355X_MICROARCH.md] + WRITE_SIZE, separate
+    --pmc runs of THIS command; tools/pmc_traffic.py wrote profiles/traffic.json).  None when
+    no measurement of the current configuration is on file."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        key = f"{args.scene}-{args.dtype}-c{args.channels}-n{args.voxels}"
+        return t[key][group]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(idx, C, K, seed):
     """The oracle (port of the reference CPU path) on this host: rulebook once, then fwd+bwd."""
     import oracle
@@ -237,15 +252,21 @@ def main():
                                                         rb.argsort_fwd, n, True))
         t_wgrad = event_time_ms(lambda: ops.igemm_wgrad(fd, dout, w.shape, rb.pair_native,
                                                         rb.num_per_loc, True, ops._plan_of(rb)))
+        # the backward of a layer is ONE launch (igemm_bwd_kernel: dgrad tiles and wgrad ranges side
+        # by side) plus the wgrad second stage; dgrad / wgrad alone are reported for reference
+        t_bwd = event_time_ms(lambda: ops.igemm_bwd(fd, dout, w, rb.pair_fwd, rb.mask_fwd, rb.argsort_fwd,
+                                                    rb.pair_native, rb.num_per_loc, True, ops._plan_of(rb)))
         t_eager = event_time_ms(compute, iters=20, warm=5)
         s = feats.element_size()
         ab = algorithmic_bytes(n, P, C, K, 27, s)
-        groups = {"fwd": t_fwd, "dgrad": t_dgrad, "wgrad": t_wgrad}
+        ab["bwd"] = ab["dgrad"] + ab["wgrad"]
+        groups = {"fwd": t_fwd, "bwd": t_bwd}
+        alone = {"dgrad": t_dgrad, "wgrad": t_wgrad}
         kernels = {k: {"ms": round(v, 5), "algorithmic_MB": round(ab[k] / 1e6, 3),
-                       "GBps": round(ab[k] / (v * 1e-3) / 1e9, 1)} for k, v in groups.items()}
+                       "GBps": round(ab[k] / (v * 1e-3) / 1e9, 1)} for k, v in {**groups, **alone}.items()}
         dom = max(groups, key=groups.get)
         achieved = ab[dom] / (groups[dom] * 1e-3) / 1e9
-        total_bytes = sum(ab.values())
+        total_bytes = ab["fwd"] + ab["bwd"]
         result = {
             "metric": "active-voxels/sec fwd+bwd, 3x3x3 SubMConv3d C=64, ~100k voxels/scene",
             "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
@@ -257,10 +278,10 @@ def main():
                        "voxels_per_gpu": n, "pairs_per_voxel": round(P / n, 4), "launch": launch,
                        "mask_sort": bool(args.sort), "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": pmc_traffic(dom, args),
                          "kernel": {"fwd": "igemm_v4_kernel<64,2,f16,fwd>",
-                                    "dgrad": "igemm_v4_kernel<64,2,f16,dgrad>",
-                                    "wgrad": "wgrad_tr_kernel + wgrad_reduce2_kernel"}[dom],
+                                    "bwd": "igemm_bwd_kernel<64,2,f16> + wgrad_reduce2_kernel"}[dom],
                          "algorithmic_bytes": ab[dom], "ms": round(groups[dom], 5)},
             "kernels": kernels,
             "step_GBps_algorithmic": round(total_bytes / (ms_per_step * 1e-3) / 1e9, 1),

@@ -198,6 +198,18 @@ int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t 
                     int K, int kv, int dtype, int subm, void *ws, size_t ws_bytes,
                     spx_stream_t stream);
 
+/* Backward of one layer: din (as spx_igemm_dgrad) and dw (as spx_igemm_wgrad) from ONE kernel
+ * launch plus the wgrad second stage.  Replaces ConvGemmOps.implicit_gemm_backward /
+ * indice_conv_backward as a whole (pytorch/ops.py:1667-1896,1103-1447), which also return both
+ * gradients from one call.  pair / mask / argsort are the dgrad table (the FORWARD table for
+ * SubM), pair_native / num_per_loc / plan as for spx_igemm_wgrad, ws as spx_igemm_wgrad_ws_bytes.
+ * Shapes the fused kernel does not cover fall back to the two separate calls internally. */
+int spx_igemm_bwd(const void *feat, const void *dout, const void *weight, void *din, void *dw,
+                  const int32_t *pair, const uint32_t *mask, const int32_t *argsort,
+                  const int32_t *pair_native, const int32_t *num_per_loc, const int32_t *plan,
+                  int n_in, int n_out, int C, int K, int kv, int dtype, int subm, void *ws,
+                  size_t ws_bytes, spx_stream_t stream);
+
 /* In-place epilogues for callers that keep bias/activation separate
  * (InferenceOps.bias_add_act_inplace etc., csrc/sparse/inference.py:26-146). */
 int spx_bias_act_inplace(void *out, const void *bias, int n, int K, int dtype, int act,

@@ -55,6 +55,7 @@ SIGNATURES = {
     "spx_wgrad_plan_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "spx_wgrad_plan": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "spx_igemm_wgrad": (ctypes.c_int, [vp] * 6 + [ctypes.c_int] * 7 + [vp, ctypes.c_size_t, vp]),
+    "spx_igemm_bwd": (ctypes.c_int, [vp] * 11 + [ctypes.c_int] * 7 + [vp, ctypes.c_size_t, vp]),
     "spx_bias_act_inplace": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_float, vp]),
 }

@@ -553,11 +553,29 @@ struct GemmRest {
 };
 
 template <int COUT, int MB, int DT, bool BT>
+__device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block);
+__device__ __forceinline__ void unpack_gemm_args(GemmParams &p, const void *argA, const void *argB,
+                                                 const uint32_t *arg_mask, const int32_t *arg_argsort,
+                                                 const int32_t *arg_pair, int n_dst, int n_src, int CIN,
+                                                 int kv, int identity_k, int b_reverse,
+                                                 const GemmRest &rest);
+
+template <int COUT, int MB, int DT, bool BT>
 __global__ void __launch_bounds__(kThreads)
 igemm_v4_kernel(const void *argA, const void *argB, const uint32_t *arg_mask,
                 const int32_t *arg_argsort, const int32_t *arg_pair, int n_dst, int n_src, int CIN,
                 int kv, int identity_k, int b_reverse, GemmRest rest) {
   GemmParams p;
+  unpack_gemm_args(p, argA, argB, arg_mask, arg_argsort, arg_pair, n_dst, n_src, CIN, kv, identity_k,
+                   b_reverse, rest);
+  igemm_v4_body<COUT, MB, DT, BT>(p, blockIdx.x);
+}
+
+__device__ __forceinline__ void unpack_gemm_args(GemmParams &p, const void *argA, const void *argB,
+                                                 const uint32_t *arg_mask, const int32_t *arg_argsort,
+                                                 const int32_t *arg_pair, int n_dst, int n_src, int CIN,
+                                                 int kv, int identity_k, int b_reverse,
+                                                 const GemmRest &rest) {
   p.A = argA;
   p.B = argB;
   p.mask = arg_mask;
@@ -581,6 +599,10 @@ igemm_v4_kernel(const void *argA, const void *argB, const uint32_t *arg_mask,
   p.add = rest.add;
   p.add_scale = rest.add_scale;
   p.out_dtype = rest.out_dtype;
+}
+
+template <int COUT, int MB, int DT, bool BT>
+__device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   constexpr bool BF16 = DT == 1, I8 = DT == 2;
   constexpr int ES = I8 ? 1 : 2;                        // bytes per element
   static_assert(!(I8 && BT), "int8 is forward only");
@@ -598,7 +620,7 @@ igemm_v4_kernel(const void *argA, const void *argB, const uint32_t *arg_mask,
   SPX_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntiles = (p.n_dst + TM - 1) / TM;
-  const int tile = xcd_tile(blockIdx.x, ntiles);
+  const int tile = xcd_tile(block, ntiles);
   const int lrow = lane & 15, lgrp = lane >> 4;
   const int slot = tid & 7, r0 = tid >> 3;
   // Output-channel permutation: MFMA row (g = i >> 2, e = i & 3) of channel block nb carries
@@ -970,21 +992,13 @@ bool v4_ok(const GemmParams &p, int es = 2, int out_es = 2) {
 }
 
 template <int COUT, int MB, int DT>
+int launch_v4(const GemmParams &p, hipStream_t s);
+GemmRest rest_of(const GemmParams &p);
+
+template <int COUT, int MB, int DT>
 int launch_v4(const GemmParams &p, hipStream_t s) {
   const int ntiles = div_up(p.n_dst, 64 * MB);
-  GemmRest r{};
-  r.out = p.out;
-  r.bias = p.bias;
-  r.strideK = p.strideK;
-  r.strideN = p.strideN;
-  r.strideD = p.strideD;
-  r.COUT = p.COUT;
-  r.act = p.act;
-  r.act_alpha = p.act_alpha;
-  r.scale = p.scale;
-  r.add = p.add;
-  r.add_scale = p.add_scale;
-  r.out_dtype = p.out_dtype;
+  const GemmRest r = rest_of(p);
   if (DT == 2 || p.strideD == 1)
     hipLaunchKernelGGL((igemm_v4_kernel<COUT, MB, DT, false>), dim3(ntiles), dim3(kThreads),
                        (v4_smem_bytes<COUT, MB>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,
@@ -1401,32 +1415,40 @@ wgrad_plan2_kernel(const int32_t *__restrict__ num, int n_in, int kv, int subm, 
       }
     }
   }
-  // first segment of offset k = number of segments of offsets < k (segments are ordered by k)
-  if (tid <= kv) {
-    int c = 0;
-    for (int w = 0; w < G; ++w) {
-      const int l = min(total, w * per), h = min(total, l + per);
-      for (int k = 0; k < tid && k < kv; ++k) c += (min(h, start[k + 1]) > max(l, start[k])) ? 1 : 0;
-    }
-    plan[plan2_kf(G) + tid] = c;
+  // first segment of offset k = number of segments of offsets < k (segments are ordered by k):
+  // count the segments per offset (LDS atomics), then a kv-long prefix sum
+  __shared__ int kcount[130], kfirst[130], ritems[130];
+  if (tid <= kv) kcount[tid] = 0;
+  __syncthreads();
+  if (tid < G) {
+    for (int k = 0; k < kv; ++k)
+      if (min(hi, start[k + 1]) > max(lo, start[k])) atomicAdd(&kcount[k], 1);
   }
   __syncthreads();
-  if (tid == 0) {   // second-stage work list (short: <= kv * ntile * 128 items)
-    int32_t *rl = plan + plan2_red(G, kv);
-    const int32_t *kf = plan + plan2_kf(G);
-    int n = 0;
-    const int elems = kWT * kWT;          // per 64x64 tile; tiles are the grid's y dimension
+  if (tid == 0) {
+    int run = 0, items = 0;
     for (int k = 0; k < kv; ++k) {
-      const int ns = kf[k + 1] - kf[k];
-      const int mode = ns >= 48 ? 0 : (ns >= 6 ? 1 : 2);
-      const int E = 32 << (2 * mode);
-      for (int e0 = 0; e0 < elems; e0 += E) {
-        rl[1 + 2 * n] = k | (mode << 8);
-        rl[2 + 2 * n] = e0;
-        ++n;
-      }
+      kfirst[k] = run;
+      run += kcount[k];
+      // second-stage work list: block shape by segment count (see wgrad_reduce2_kernel)
+      const int mode = kcount[k] >= 48 ? 0 : (kcount[k] >= 6 ? 1 : 2);
+      ritems[k] = items;
+      items += (kWT * kWT) / (32 << (2 * mode));
     }
-    rl[0] = n;
+    kfirst[kv] = run;
+    ritems[kv] = items;
+    plan[plan2_red(G, kv)] = items;
+  }
+  __syncthreads();
+  if (tid <= kv) plan[plan2_kf(G) + tid] = kfirst[tid];
+  int32_t *rl = plan + plan2_red(G, kv);
+  for (int k = 0; k < kv; ++k) {
+    const int mode = kcount[k] >= 48 ? 0 : (kcount[k] >= 6 ? 1 : 2);
+    const int E = 32 << (2 * mode), cnt_items = (kWT * kWT) / E;
+    for (int q = tid; q < cnt_items; q += kW2MaxG) {
+      rl[1 + 2 * (ritems[k] + q)] = k | (mode << 8);
+      rl[2 + 2 * (ritems[k] + q)] = q * E;
+    }
   }
 }
 
@@ -1455,9 +1477,10 @@ __device__ __forceinline__ uint4 wtr_frag(const char *stage, int row0, int lrow,
   return make_uint4(l2.x, l2.y, h2.x, h2.y);
 }
 
-template <bool BF16>
-__global__ void __launch_bounds__(kThreads)
-wgrad_tr_kernel(Wgrad2Params p) {
+// STAGES = 2: one barrier per chunk (64 KB of LDS); STAGES = 1: two barriers per chunk, 32 KB
+// (used when the kernel shares a launch with dgrad, see igemm_bwd_kernel)
+template <bool BF16, int STAGES>
+__device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, int block) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TILE_B = kW2J * 128;                // one operand tile: 128 pairs x 128 bytes
   constexpr int RQ = kW2J / 32;                     // rows per thread and operand (4)
@@ -1465,7 +1488,7 @@ wgrad_tr_kernel(Wgrad2Params p) {
   const int lrow = lane & 15, lgrp = lane >> 4;
   const int wk = wave >> 1, wc = wave & 1;          // wave quadrant: kk [32*wk,+32), c [32*wc,+32)
   const int ntile = p.tiles_k * p.tiles_c;
-  const int w = blockIdx.x / ntile, tile = blockIdx.x - w * ntile;
+  const int w = block / ntile, tile = block - w * ntile;
   const int kk0 = (tile / p.tiles_c) * kWT, c0 = (tile % p.tiles_c) * kWT;
   const int32_t *__restrict__ rec = p.plan2 + plan2_wg(w);     // uniform address: scalar loads
   const int32_t *__restrict__ segs = p.plan2 + plan2_seg(p.G, p.kv);
@@ -1535,9 +1558,10 @@ wgrad_tr_kernel(Wgrad2Params p) {
     load_rows(begin);
     load_words(begin + kW2J);
     int stage = 0;
-    for (int base = begin; base < end; base += kW2J, stage ^= 1) {
+    for (int base = begin; base < end; base += kW2J, stage ^= (STAGES - 1)) {
       char *sD = smem + stage * (2 * TILE_B);
       char *sF = sD + TILE_B;
+      if (STAGES == 1) __syncthreads();   // the previous chunk's fragment reads are done
 #pragma unroll
       for (int q = 0; q < RQ; ++q) {
         *reinterpret_cast<u32x4 *>(sD + lds_w[q]) = dv[q];
@@ -1573,6 +1597,32 @@ wgrad_tr_kernel(Wgrad2Params p) {
           dst[kk * kWT + c] = acc[a][b][e];
         }
     __syncthreads();  // both stages are rewritten by the next segment
+  }
+}
+
+template <bool BF16>
+__global__ void __launch_bounds__(kThreads)
+wgrad_tr_kernel(Wgrad2Params p) {
+  wgrad_tr_body<BF16, 2>(p, blockIdx.x);
+}
+
+// Backward of one layer in ONE launch: workgroups [0, n_dgrad) run the dgrad tiles, the rest
+// the wgrad ranges.  The two halves only share read-only inputs; at ~100k voxels each of them
+// is latency-bound with idle issue slots and idle HBM bandwidth, so running them side by side
+// on the same CUs costs little more than the slower one -- and one kernel boundary (~1.7 us)
+// disappears.  (Two HIP streams were tried first: the fork/join costs more than it buys.)
+template <int COUT, int MB, int DT>
+__global__ void __launch_bounds__(kThreads, COUT <= 64 ? 4 : 2)   // 4 waves/SIMD: 1024 resident workgroups
+igemm_bwd_kernel(const void *argA, const void *argB, const uint32_t *arg_mask,
+                 const int32_t *arg_argsort, const int32_t *arg_pair, int n_dst, int n_src, int CIN,
+                 int kv, int identity_k, int b_reverse, GemmRest rest, int n_dgrad, Wgrad2Params wp) {
+  if (static_cast<int>(blockIdx.x) < n_dgrad) {
+    GemmParams p;
+    unpack_gemm_args(p, argA, argB, arg_mask, arg_argsort, arg_pair, n_dst, n_src, CIN, kv,
+                     identity_k, b_reverse, rest);
+    igemm_v4_body<COUT, MB, DT, true>(p, blockIdx.x);
+  } else {
+    wgrad_tr_body<DT == 1, 1>(wp, static_cast<int>(blockIdx.x) - n_dgrad);
   }
 }
 
@@ -1726,6 +1776,77 @@ size_t wgrad_plan2_ints(int n_in, int kv) {
   return 8 + kW2Rec * G + kv + 1 + 3 * (G + kv) + 1 + 2 * static_cast<size_t>(kv) * 128 + 8;
 }
 
+GemmParams dgrad_params(const void *dout, const void *weight, void *din, const int32_t *pair,
+                        const uint32_t *mask, const int32_t *argsort, int n_out, int n_in, int C,
+                        int K, int kv, int subm) {
+  GemmParams p{};
+  p.A = dout;
+  p.B = weight;                                   // KRSC read in place: (k, n=c, d=kk)
+  p.out = din;
+  p.pair = pair;
+  p.mask = mask;
+  p.argsort = argsort;
+  p.bias = nullptr;
+  p.strideK = C;
+  p.strideN = 1;
+  p.strideD = static_cast<long long>(kv) * C;
+  p.n_src = n_out;
+  p.n_dst = n_in;
+  p.CIN = K;
+  p.COUT = C;
+  p.kv = kv;
+  p.identity_k = subm ? kv / 2 : -1;
+  p.b_reverse = subm ? 1 : 0;
+  p.act = SPX_ACT_NONE;
+  p.act_alpha = 0.f;
+  return p;
+}
+
+GemmRest rest_of(const GemmParams &p) {
+  GemmRest r{};
+  r.out = p.out;
+  r.bias = p.bias;
+  r.strideK = p.strideK;
+  r.strideN = p.strideN;
+  r.strideD = p.strideD;
+  r.COUT = p.COUT;
+  r.act = p.act;
+  r.act_alpha = p.act_alpha;
+  r.scale = p.scale;
+  r.add = p.add;
+  r.add_scale = p.add_scale;
+  r.out_dtype = p.out_dtype;
+  return r;
+}
+
+// LDS of the fused backward launch: the dgrad weight ring or one wgrad stage pair
+template <int COUT, int MB>
+constexpr size_t bwd_smem_bytes() {
+  const size_t a = v4_smem_bytes<COUT, MB>(), b = 2 * static_cast<size_t>(kW2J) * 128;
+  return a > b ? a : b;
+}
+
+template <int COUT, int MB, int DT>
+int launch_bwd(const GemmParams &p, const Wgrad2Params &q, int n_wgrad_blocks, hipStream_t s) {
+  const int n_dgrad = div_up(p.n_dst, 64 * MB);
+  hipLaunchKernelGGL((igemm_bwd_kernel<COUT, MB, DT>), dim3(n_dgrad + n_wgrad_blocks), dim3(kThreads),
+                     (bwd_smem_bytes<COUT, MB>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,
+                     p.n_src, p.CIN, p.kv, p.identity_k, p.b_reverse, rest_of(p), n_dgrad, q);
+  SPX_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int DT>
+int dispatch_bwd(const GemmParams &p, const Wgrad2Params &q, int nwb, hipStream_t s) {
+  switch (p.COUT) {
+    case 16: return launch_bwd<16, 2, DT>(p, q, nwb, s);
+    case 32: return launch_bwd<32, 2, DT>(p, q, nwb, s);
+    case 64: return launch_bwd<64, 2, DT>(p, q, nwb, s);
+    case 128: return launch_bwd<128, 2, DT>(p, q, nwb, s);
+  }
+  return -1;
+}
+
 }  // namespace
 }  // namespace spx
 
@@ -1828,26 +1949,7 @@ int spx_igemm_dgrad(const void *dout, const void *weight, void *din, const int32
   (void)ws; (void)ws_bytes;
   SPX_CHECK(dout && weight && din, "null tensor pointer");
   SPX_CHECK(pair || kv == 1, "pair table required");
-  GemmParams p{};
-  p.A = dout;
-  p.B = weight;                                   // KRSC read in place: (k, n=c, d=kk)
-  p.out = din;
-  p.pair = pair;
-  p.mask = mask;
-  p.argsort = argsort;
-  p.bias = nullptr;
-  p.strideK = C;
-  p.strideN = 1;
-  p.strideD = static_cast<long long>(kv) * C;
-  p.n_src = n_out;
-  p.n_dst = n_in;
-  p.CIN = K;
-  p.COUT = C;
-  p.kv = kv;
-  p.identity_k = subm ? kv / 2 : -1;
-  p.b_reverse = subm ? 1 : 0;
-  p.act = SPX_ACT_NONE;
-  p.act_alpha = 0.f;
+  const GemmParams p = dgrad_params(dout, weight, din, pair, mask, argsort, n_out, n_in, C, K, kv, subm);
   return run_gather_gemm(p, dtype, static_cast<hipStream_t>(stream));
 }
 
@@ -1987,6 +2089,65 @@ int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t 
                        static_cast<b16 *>(dw));
   else
     SPX_CHECK(false, "unsupported dtype %d", dtype);
+  SPX_LAUNCH_CHECK();
+  return 0;
+}
+
+int spx_igemm_bwd(const void *feat, const void *dout, const void *weight, void *din, void *dw,
+                  const int32_t *pair, const uint32_t *mask, const int32_t *argsort,
+                  const int32_t *pair_native, const int32_t *num_per_loc, const int32_t *plan,
+                  int n_in, int n_out, int C, int K, int kv, int dtype, int subm, void *ws,
+                  size_t ws_bytes, spx_stream_t stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  SPX_CHECK(feat && dout && weight && din && dw && ws, "null tensor pointer");
+  SPX_CHECK(pair_native && num_per_loc, "Native pair lists and counts are required");
+  SPX_CHECK(pair || kv == 1, "pair table required");
+  SPX_CHECK(ws_bytes >= spx_igemm_wgrad_ws_bytes(n_in, C, K, kv), "workspace too small");
+  static const int fuse = env_int("SPX_BWD_FUSE", 1);             // tuning knob (A/B runs)
+  const GemmParams p = dgrad_params(dout, weight, din, pair, mask, argsort, n_out, n_in, C, K, kv, subm);
+  const bool small_offsets = static_cast<unsigned long long>(n_out) * K * 2ull < 0x7fff0000ull &&
+                             static_cast<unsigned long long>(n_in) * C * 2ull < 0x7fff0000ull &&
+                             static_cast<unsigned long long>(n_in) * 4ull < 0x7fff0000ull;
+  const bool fusable = fuse && (dtype == SPX_F16 || dtype == SPX_BF16) && C % 8 == 0 && K % 8 == 0 &&
+                       mfma_ok(dtype, p.CIN, p.COUT, kv, mask) && p.COUT <= 128 && v4_ok(p) &&
+                       small_offsets && kv <= 128 && n_in > 0 && n_out > 0;
+  if (!fusable) {
+    if (spx_igemm_dgrad(dout, weight, din, pair, mask, argsort, n_out, n_in, C, K, kv, dtype, subm,
+                        nullptr, 0, stream))
+      return -2;
+    return spx_igemm_wgrad(feat, dout, dw, pair_native, num_per_loc, plan, n_in, n_out, C, K, kv, dtype,
+                           subm, ws, ws_bytes, stream);
+  }
+  if (!plan) {  // caller did not cache a plan: build it behind the partials
+    int32_t *own = reinterpret_cast<int32_t *>(static_cast<char *>(ws) + ws_bytes -
+                                               spx_wgrad_plan_bytes(n_in, kv));
+    if (spx_wgrad_plan(num_per_loc, n_in, kv, subm, own, stream)) return -2;
+    plan = own;
+  }
+  Wgrad2Params q{};
+  q.feat = feat;
+  q.dout = dout;
+  q.partial = static_cast<float *>(ws);
+  q.native = pair_native;
+  q.num = num_per_loc;
+  q.plan2 = reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(plan) + plan1_bytes(n_in, kv));
+  q.n_in = n_in;
+  q.n_out = n_out;
+  q.C = C;
+  q.K = K;
+  q.kv = kv;
+  q.subm = subm;
+  q.tiles_c = div_up(C, kWT);
+  q.tiles_k = div_up(K, kWT);
+  q.G = wgrad_groups(n_in);
+  const int ntile = q.tiles_c * q.tiles_k;
+  const int rc = dtype == SPX_BF16 ? dispatch_bwd<1>(p, q, q.G * ntile, s) : dispatch_bwd<0>(p, q, q.G * ntile, s);
+  if (rc) return rc;
+  const dim3 rgrid2(kv * 128 < 512 ? kv * 128 : 512, ntile);   // block-stride over the work list
+  if (dtype == SPX_F16)
+    hipLaunchKernelGGL(wgrad_reduce2_kernel<h16>, rgrid2, dim3(kRedThreads), 0, s, q, static_cast<h16 *>(dw));
+  else
+    hipLaunchKernelGGL(wgrad_reduce2_kernel<b16>, rgrid2, dim3(kRedThreads), 0, s, q, static_cast<b16 *>(dw));
   SPX_LAUNCH_CHECK();
   return 0;
 }

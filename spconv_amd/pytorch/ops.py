@@ -366,6 +366,30 @@ def igemm_wgrad(features: torch.Tensor, out_bp: torch.Tensor, filters_shape, nat
     return dw
 
 
+def igemm_bwd(features: torch.Tensor, out_bp: torch.Tensor, filters: torch.Tensor,
+              table: torch.Tensor, mask: Optional[torch.Tensor], argsort: Optional[torch.Tensor],
+              native: torch.Tensor, num_per_loc: torch.Tensor, subm: bool,
+              plan: Optional[torch.Tensor] = None):
+    """(din, dW) of one layer from one launch (+ the wgrad second stage)."""
+    _check_feat(out_bp, filters)
+    L = _lib.load()
+    features = features.contiguous()
+    out_bp = out_bp.contiguous()
+    filters = filters.contiguous()
+    K, C = filters.shape[0], filters.shape[-1]
+    kv = filters.numel() // (K * C)
+    n_in = features.shape[0]
+    din = torch.empty((n_in, C), dtype=out_bp.dtype, device=out_bp.device)
+    dw = torch.empty_like(filters)
+    ws = _ws(L.spx_igemm_wgrad_ws_bytes(native.shape[2], C, K, kv), features.device)
+    _lib.check(L.spx_igemm_bwd(features.data_ptr(), out_bp.data_ptr(), filters.data_ptr(),
+                               din.data_ptr(), dw.data_ptr(), _ptr(table), _ptr(mask), _ptr(argsort),
+                               native.data_ptr(), num_per_loc.data_ptr(), _ptr(plan), n_in,
+                               out_bp.shape[0], C, K, kv, _dtype_code(out_bp), int(subm),
+                               ws.data_ptr(), ws.numel(), _stream(out_bp)))
+    return din, dw
+
+
 def _plan_of(rb: Optional[Rulebook]) -> Optional[torch.Tensor]:
     if rb is None or rb.pair_native is None:
         return None
@@ -485,6 +509,9 @@ def indice_conv_backward(features: torch.Tensor, filters: torch.Tensor, out_bp: 
         native = rb.native_swapped() if rb is not None else torch.stack(
             [indice_pairs[1], indice_pairs[0]]).contiguous()
     plan = _plan_of(rb)
+    if native.shape[2] == n_in and not BWD_OVERLAP:
+        return igemm_bwd(features, out_bp, filters, table, mask, argsort, native, indice_pair_num,
+                         subm, plan)
     return _backward_pair(
         lambda: igemm_dgrad(out_bp, filters, table, mask, argsort, n_in, subm),
         lambda: igemm_wgrad(features, out_bp, filters.shape, native, indice_pair_num, subm, plan),
@@ -548,6 +575,8 @@ def implicit_gemm_backward(features: torch.Tensor, filters: torch.Tensor, out_bp
     else:
         table, mask = pair_bwd, pair_mask_bwd_splits[0]
         argsort = rb.argsort_bwd if rb is not None else None
+    if native.shape[2] == n_in and not BWD_OVERLAP:
+        return igemm_bwd(features, out_bp, filters, table, mask, argsort, native, num, is_subm, plan)
     return _backward_pair(
         lambda: igemm_dgrad(out_bp, filters, table, mask, argsort, n_in, is_subm),
         lambda: igemm_wgrad(features, out_bp, filters.shape, native, num, is_subm, plan),
