@@ -163,3 +163,71 @@ def test_install_as_spconv_alias(cuda):
     import spconv.pytorch as spconv
     from spconv.pytorch import SparseConvTensor, SubMConv3d  # noqa: F401
     assert spconv.SparseConvTensor is SparseConvTensor
+
+
+def test_cfg3_downsample_chain_on_reference_lidar_fixture(cuda):
+    """BASELINE config 3: SparseConv3d k3 s2 p1 chain 16 -> 32 -> 64 -> 128 (fp16) on the voxel
+    coordinates of the reference's real-LiDAR fixture (test/data/test_spconv.pkl, 125 562 voxels
+    in [80,1600,1600]; SURVEY.md 8d measured 125k -> 137k -> 66k -> 26k outputs).  Every layer's
+    output coordinates must equal the CPU oracle's (bit-exact, first-seen order) and its features
+    must match the oracle's fp32 forward on the same fp16-rounded data."""
+    import oracle
+    import spconv_amd.pytorch as spconv
+    from golden import lidar_scene
+    idx, shape = lidar_scene()
+    assert idx.shape[0] == 125562
+    rng = np.random.default_rng(3)
+    chans = [16, 32, 64, 128]
+    f32 = torch.from_numpy(rng.uniform(-1, 1, (idx.shape[0], chans[0])).astype(np.float32)).half().float()
+    x = spconv.SparseConvTensor(f32.to(cuda).half(), torch.from_numpy(idx).to(cuda), shape, 1)
+    cur_idx, cur_shape, cur_f = idx, shape, f32
+    counts = [idx.shape[0]]
+    for li, (ci, co) in enumerate(zip(chans[:-1], chans[1:])):
+        conv = spconv.SparseConv3d(ci, co, 3, 2, 1, bias=False).to(cuda).half().eval()
+        with torch.no_grad():
+            x = conv(x)
+        w32 = conv.weight.detach().float().cpu()
+        out_inds, pair, num, out_shape = oracle.get_indice_pairs(
+            cur_idx, 1, cur_shape, [3] * 3, [2] * 3, [1] * 3, [1] * 3, None, False, False)
+        np.testing.assert_array_equal(x.indices.cpu().numpy(), out_inds)
+        assert x.spatial_shape == list(out_shape)
+        ref = oracle.indice_conv(cur_f, w32, pair, num, out_inds.shape[0], subm=False)
+        got = x.features.float().cpu()
+        assert rel_err(got.numpy(), ref.numpy()) < 3e-3, f"layer {li}"
+        # continue from the GPU's fp16 output so that errors do not compound in the comparison
+        cur_idx, cur_shape, cur_f = out_inds, list(out_shape), got
+        counts.append(out_inds.shape[0])
+    assert counts[0] > counts[2] > counts[3], counts   # 125k -> 137k -> 66k -> 26k in SURVEY 8d
+
+
+def test_cfg4_second_style_backbone_batch_vs_oracle(cuda):
+    """BASELINE config 4 shape in miniature: SubM(C->16) / SubM16 / SparseConv s2 16->32 / SubM32
+    over a BATCH of scenes; the per-scene results of the batched run must equal the results of
+    running every scene alone (scenes never interact: the batch index is part of the hash key),
+    which is what lets the batch shard across GPUs without any exchange inside the op."""
+    import spconv_amd.pytorch as spconv
+    from spconv_amd.dist import shard_scenes
+    from spconv_amd.utils import synthetic
+    torch.manual_seed(4)
+    shape, bs, n = [24, 96, 96], 4, 3000
+    idx = synthetic.lidar_like_scene(shape, n, bs, seed=4)
+    f = torch.randn(idx.shape[0], 8)
+    net = spconv.SparseSequential(
+        spconv.SubMConv3d(8, 16, 3, bias=False, indice_key="s1"), nn.ReLU(),
+        spconv.SubMConv3d(16, 16, 3, bias=False, indice_key="s1"), nn.ReLU(),
+        spconv.SparseConv3d(16, 32, 3, 2, 1, bias=False, indice_key="d1"), nn.ReLU(),
+        spconv.SubMConv3d(32, 32, 3, bias=False, indice_key="s2"),
+    ).to(cuda).half().eval()
+    ind_t = torch.from_numpy(idx)
+    with torch.no_grad():
+        full = net(spconv.SparseConvTensor(f.to(cuda).half(), ind_t.to(cuda), shape, bs))
+        fi, ff = full.indices.cpu(), full.features.float().cpu()
+        for rank in range(bs):
+            si, sf, lb = shard_scenes(ind_t, f, bs, rank, bs)
+            assert lb == 1
+            one = net(spconv.SparseConvTensor(sf.to(cuda).half(), si.to(cuda), shape, 1))
+            sel = fi[:, 0] == rank
+            a_idx, a_f = fi[sel].clone(), ff[sel]
+            a_idx[:, 0] = 0
+            assert torch.equal(a_idx, one.indices.cpu())
+            assert rel_err(one.features.float().cpu().numpy(), a_f.numpy()) < 2e-3
