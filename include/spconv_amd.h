@@ -215,6 +215,32 @@ int spx_igemm_bwd(const void *feat, const void *dout, const void *weight, void *
 int spx_bias_act_inplace(void *out, const void *bias, int n, int K, int dtype, int act,
                          float act_alpha, spx_stream_t stream);
 
+/* ------------------------------------------------------------------ pooling */
+
+/* Sparse max / average pooling over the same rulebook tables.
+ * Replace IndiceMaxPool::forward_implicit_gemm / backward_implicit_gemm /
+ * forward_avgpool_implicit_gemm / backward_avgpool_implicit_gemm
+ * (csrc/sparse/maxpool.py:96-300,397-588; pytorch/ops.py:1899-2084).
+ *   pair_fwd [kv, n_out] / pair_bwd [kv, n_in] with -1 = absent; mask (one uint32 word per 32
+ *   offsets and row) is optional and only used to skip absent offsets.
+ *   max forward: out[o] = max over the valid pairs; init_zero != 0 starts from 0 instead of the
+ *   lowest value (the reference's ConvAlgo.Native pooling does, pytorch/ops.py:1910).
+ *   max backward: din[i] = sum of dout[o] over the outputs o with out[o] == feat[i].
+ *   avg forward: mean over the valid pairs, count_out [n_out] (or NULL) receives their number.
+ *   avg backward: din[i] = sum_o dout[o] / count[o].
+ * dtypes: f32 / f16 / bf16, plus int8 for the max forward. */
+int spx_maxpool_fwd(const void *feat, void *out, const int32_t *pair_fwd, const uint32_t *mask,
+                    int n_out, int C, int kv, int dtype, int init_zero, spx_stream_t stream);
+int spx_maxpool_bwd(const void *feat, const void *out, const void *dout, void *din,
+                    const int32_t *pair_bwd, const uint32_t *mask_bwd, int n_in, int C, int kv,
+                    int dtype, spx_stream_t stream);
+int spx_avgpool_fwd(const void *feat, void *out, int32_t *count_out, const int32_t *pair_fwd,
+                    const uint32_t *mask, int n_out, int C, int kv, int dtype,
+                    spx_stream_t stream);
+int spx_avgpool_bwd(const void *dout, void *din, const int32_t *count, const int32_t *pair_bwd,
+                    const uint32_t *mask_bwd, int n_in, int C, int kv, int dtype,
+                    spx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

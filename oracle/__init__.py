@@ -370,3 +370,64 @@ def int8_conv_ref(features_i8: np.ndarray, weight_i8: np.ndarray, pair: np.ndarr
         return np.clip(np.round(rescaled), -128, 127).astype(np.int8)
     return rescaled.astype(out_dtype)
 
+
+# --------------------------------------------------------------------------
+# pooling over the Native lists (spconv/csrc/sparse/maxpool.py:96-300 GPU kernels,
+# :620-700 CPU loops; drivers spconv/pytorch/ops.py:1899-2084)
+def _pool_lists(pair: np.ndarray, num_per_loc: np.ndarray, subm: bool, n_in: int):
+    kv = pair.shape[1]
+    for k in range(kv):
+        if subm and k == kv // 2:
+            ar = np.arange(n_in, dtype=np.int64)
+            yield ar, ar
+            continue
+        nhot = int(num_per_loc[kv - 1 - k] if (subm and k > kv // 2) else num_per_loc[k])
+        if nhot:
+            yield pair[0][k][:nhot].astype(np.int64), pair[1][k][:nhot].astype(np.int64)
+
+
+def maxpool_ref(features: np.ndarray, pair: np.ndarray, num_per_loc: np.ndarray, n_out: int,
+                subm: bool = False, init_zero: bool = False) -> np.ndarray:
+    """out[o] = max over its pairs (maxpool.py:96-140); init_zero = the Native path's zero-filled
+    output (ops.py:1910)."""
+    f = features.astype(np.float64)
+    lowest = 0.0 if init_zero else -np.inf
+    out = np.full((n_out, f.shape[1]), lowest, dtype=np.float64)
+    for i_inds, o_inds in _pool_lists(pair, num_per_loc, subm, f.shape[0]):
+        np.maximum.at(out, o_inds, f[i_inds])
+    return out.astype(features.dtype)
+
+
+def maxpool_bwd_ref(features: np.ndarray, out: np.ndarray, dout: np.ndarray, pair: np.ndarray,
+                    num_per_loc: np.ndarray, subm: bool = False) -> np.ndarray:
+    """din[i] += dout[o] where in[i] == out[o] (maxpool.py:142-209)."""
+    din = np.zeros(features.shape, dtype=np.float64)
+    for i_inds, o_inds in _pool_lists(pair, num_per_loc, subm, features.shape[0]):
+        hit = features[i_inds] == out[o_inds]
+        np.add.at(din, i_inds, dout[o_inds].astype(np.float64) * hit)
+    return din.astype(features.dtype)
+
+
+def avgpool_ref(features: np.ndarray, pair: np.ndarray, num_per_loc: np.ndarray, n_out: int,
+                subm: bool = False):
+    """(mean over the pairs, count) -- maxpool.py:211-260."""
+    f = features.astype(np.float64)
+    acc = np.zeros((n_out, f.shape[1]), dtype=np.float64)
+    cnt = np.zeros((n_out,), dtype=np.int32)
+    for i_inds, o_inds in _pool_lists(pair, num_per_loc, subm, f.shape[0]):
+        np.add.at(acc, o_inds, f[i_inds])
+        np.add.at(cnt, o_inds, 1)
+    out = np.where(cnt[:, None] > 0, acc / np.maximum(cnt, 1)[:, None], 0.0)
+    return out.astype(features.dtype), cnt
+
+
+def avgpool_bwd_ref(dout: np.ndarray, count: np.ndarray, pair: np.ndarray, num_per_loc: np.ndarray,
+                    n_in: int, subm: bool = False) -> np.ndarray:
+    """Gradient of the mean: din[i] += dout[o] / count[o].  (The reference kernel multiplies by
+    count, maxpool.py:262-300 -- not the derivative of its forward; see DESIGN.md.)"""
+    din = np.zeros((n_in, dout.shape[1]), dtype=np.float64)
+    inv = np.where(count > 0, 1.0 / np.maximum(count, 1), 0.0)
+    for i_inds, o_inds in _pool_lists(pair, num_per_loc, subm, n_in):
+        np.add.at(din, i_inds, dout[o_inds].astype(np.float64) * inv[o_inds][:, None])
+    return din.astype(dout.dtype)
+

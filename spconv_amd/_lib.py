@@ -56,6 +56,10 @@ SIGNATURES = {
     "spx_wgrad_plan": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "spx_igemm_wgrad": (ctypes.c_int, [vp] * 6 + [ctypes.c_int] * 7 + [vp, ctypes.c_size_t, vp]),
     "spx_igemm_bwd": (ctypes.c_int, [vp] * 11 + [ctypes.c_int] * 7 + [vp, ctypes.c_size_t, vp]),
+    "spx_maxpool_fwd": (ctypes.c_int, [vp] * 4 + [ctypes.c_int] * 5 + [vp]),
+    "spx_maxpool_bwd": (ctypes.c_int, [vp] * 6 + [ctypes.c_int] * 4 + [vp]),
+    "spx_avgpool_fwd": (ctypes.c_int, [vp] * 5 + [ctypes.c_int] * 4 + [vp]),
+    "spx_avgpool_bwd": (ctypes.c_int, [vp] * 5 + [ctypes.c_int] * 4 + [vp]),
     "spx_bias_act_inplace": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_float, vp]),
 }
@@ -70,7 +74,7 @@ def build(force: bool = False) -> str:
     """Compile the HIP sources for gfx950 (no GPU needed)."""
     script = os.path.join(_HERE, "csrc", "build.sh")
     if force:
-        for f in ("rulebook.o", "igemm.o", "common.o", "libspconv_amd.so"):
+        for f in ("rulebook.o", "igemm.o", "pool.o", "common.o", "libspconv_amd.so"):
             p = os.path.join(_HERE, "lib", f)
             if os.path.exists(p):
                 os.remove(p)

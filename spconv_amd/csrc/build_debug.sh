@@ -8,7 +8,8 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -mllvm -amdgpu-kernarg-preload-count=16 -DSPX_TIMELINE"
 $HIPCC $FLAGS -c rulebook.hip -o $OUT/dbg/rulebook.o &
 $HIPCC $FLAGS -c igemm.hip -o $OUT/dbg/igemm.o &
+$HIPCC $FLAGS -c pool.hip -o $OUT/dbg/pool.o &
 $HIPCC $FLAGS -x hip -c common.cpp -o $OUT/dbg/common.o &
 wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT/libspconv_amd_dbg.so $OUT/dbg/rulebook.o $OUT/dbg/igemm.o $OUT/dbg/common.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT/libspconv_amd_dbg.so $OUT/dbg/rulebook.o $OUT/dbg/igemm.o $OUT/dbg/pool.o $OUT/dbg/common.o
 echo built $OUT/libspconv_amd_dbg.so

@@ -178,7 +178,76 @@ class SparseImplicitGemmFunction(Function):
         return (din, dw) + (None,) * 16
 
 
+class SparseMaxPoolFunction(Function):
+    """ConvAlgo.Native max pool (reference functional.py:360-377)."""
+    @staticmethod
+    @_FWD
+    def forward(ctx, features, indice_pairs, indice_pair_num, num_activate_out):
+        out = ops.indice_maxpool(features, indice_pairs, indice_pair_num, num_activate_out)
+        ctx.save_for_backward(indice_pairs, indice_pair_num, features, out)
+        ctx.rulebook = ops.rulebook_of(indice_pairs)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    @_BWD
+    def backward(ctx, grad_output):
+        indice_pairs, indice_pair_num, features, out = ctx.saved_tensors
+        if ctx.rulebook is not None:
+            ops.attach_rulebook(indice_pairs, ctx.rulebook)
+        input_bp = ops.indice_maxpool_backward(features, out, grad_output, indice_pairs, indice_pair_num)
+        return input_bp, None, None, None
+
+
+class SparseMaxPoolImplicitGemmFunction(Function):
+    """reference functional.py:380-397"""
+    @staticmethod
+    @_FWD
+    def forward(ctx, features: torch.Tensor, indice_pairs_fwd: torch.Tensor,
+                indice_pairs_bwd: torch.Tensor, num_activate_out: int):
+        out = ops.indice_maxpool_implicit_gemm(features, indice_pairs_fwd, num_activate_out)
+        ctx.save_for_backward(indice_pairs_bwd, features, out)
+        ctx.rulebook = ops.rulebook_of(indice_pairs_fwd)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    @_BWD
+    def backward(ctx, grad_output):
+        indice_pairs_bwd, features, out = ctx.saved_tensors
+        if ctx.rulebook is not None:
+            ops.attach_rulebook(indice_pairs_bwd, ctx.rulebook)
+        input_bp = ops.indice_maxpool_implicit_gemm_backward(features, out, grad_output, indice_pairs_bwd)
+        return input_bp, None, None, None
+
+
+class SparseAvgPoolImplicitGemmFunction(Function):
+    """reference functional.py:400-420"""
+    @staticmethod
+    @_FWD
+    def forward(ctx, features: torch.Tensor, indice_pairs_fwd: torch.Tensor,
+                indice_pairs_bwd: torch.Tensor, num_activate_out: int, calc_count):
+        out, count = ops.indice_avgpool_implicit_gemm(features, indice_pairs_fwd, num_activate_out,
+                                                      calc_count)
+        ctx.save_for_backward(indice_pairs_bwd, features, out, count)
+        ctx.rulebook = ops.rulebook_of(indice_pairs_fwd)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    @_BWD
+    def backward(ctx, grad_output):
+        indice_pairs_bwd, features, out, count = ctx.saved_tensors
+        if ctx.rulebook is not None:
+            ops.attach_rulebook(indice_pairs_bwd, ctx.rulebook)
+        input_bp = ops.indice_avgpool_implicit_gemm_backward(grad_output, indice_pairs_bwd, count)
+        return input_bp, None, None, None, None
+
+
 indice_conv = SparseConvFunction.apply
 implicit_gemm = SparseImplicitGemmFunction.apply
 indice_inverse_conv = SparseInverseConvFunction.apply
 indice_subm_conv = SubMConvFunction.apply
+indice_maxpool = SparseMaxPoolFunction.apply
+indice_maxpool_implicit_gemm = SparseMaxPoolImplicitGemmFunction.apply
+indice_avgpool_implicit_gemm = SparseAvgPoolImplicitGemmFunction.apply

@@ -581,3 +581,122 @@ def implicit_gemm_backward(features: torch.Tensor, filters: torch.Tensor, out_bp
         lambda: igemm_dgrad(out_bp, filters, table, mask, argsort, n_in, is_subm),
         lambda: igemm_wgrad(features, out_bp, filters.shape, native, num, is_subm, plan),
         features)
+
+
+# ------------------------------------------------------------------ pooling
+_POOL_CODES = dict(_DTYPES)
+_POOL_CODES[torch.int8] = _lib.DTYPE_I8
+
+
+def _pool_code(t: torch.Tensor) -> int:
+    try:
+        return _POOL_CODES[t.dtype]
+    except KeyError:
+        raise NotImplementedError(f"unsupported pooling dtype {t.dtype}") from None
+
+
+def _mask_of(pair: torch.Tensor, fwd: bool) -> Optional[torch.Tensor]:
+    rb = rulebook_of(pair)
+    if rb is None:
+        return None
+    if fwd:
+        return rb.mask_fwd
+    # a SubM rulebook keeps ONE mask (bits of pair_fwd); its pair_bwd is the mirrored table, whose
+    # bit positions differ -> walk every offset instead
+    return None if rb.subm else rb.mask_bwd
+
+
+def indice_maxpool_implicit_gemm(features: torch.Tensor, indice_pairs: torch.Tensor,
+                                 num_activate_out: int, init_zero: bool = False) -> torch.Tensor:
+    """out[o] = max over the valid pairs of column o of pair_fwd [kv, n_out] (ops.py:1976-1997)."""
+    _require_gpu(features, "features")
+    L = _lib.load()
+    q = features.is_quantized
+    feats = _int_repr(features).contiguous()
+    out = torch.empty((num_activate_out, feats.shape[1]), dtype=feats.dtype, device=feats.device)
+    _lib.check(L.spx_maxpool_fwd(feats.data_ptr(), out.data_ptr(), indice_pairs.data_ptr(),
+                                 _ptr(_mask_of(indice_pairs, True)), num_activate_out, feats.shape[1],
+                                 indice_pairs.shape[0], _pool_code(feats), int(init_zero), _stream(feats)))
+    if q:
+        out = torch._make_per_tensor_quantized_tensor(out, features.q_scale(), features.q_zero_point())
+    return out
+
+
+def indice_maxpool_implicit_gemm_backward(features: torch.Tensor, out_features: torch.Tensor,
+                                          out_bp: torch.Tensor, indice_pairs: torch.Tensor) -> torch.Tensor:
+    """din from pair_bwd [kv, n_in] (ops.py:2000-2023)."""
+    L = _lib.load()
+    features, out_features, out_bp = features.contiguous(), out_features.contiguous(), out_bp.contiguous()
+    din = torch.empty_like(features)
+    _lib.check(L.spx_maxpool_bwd(features.data_ptr(), out_features.data_ptr(), out_bp.data_ptr(),
+                                 din.data_ptr(), indice_pairs.data_ptr(),
+                                 _ptr(_mask_of(indice_pairs, False)), features.shape[0],
+                                 features.shape[1], indice_pairs.shape[0], _pool_code(features),
+                                 _stream(features)))
+    return din
+
+
+def indice_avgpool_implicit_gemm(features: torch.Tensor, indice_pairs: torch.Tensor,
+                                 num_activate_out: int, calc_count: bool):
+    """(mean over the valid pairs, count [n_out] or empty) -- ops.py:2026-2056."""
+    _require_gpu(features, "features")
+    L = _lib.load()
+    features = features.contiguous()
+    out = torch.empty((num_activate_out, features.shape[1]), dtype=features.dtype, device=features.device)
+    count = (torch.empty((num_activate_out,), dtype=torch.int32, device=features.device)
+             if calc_count else None)
+    _lib.check(L.spx_avgpool_fwd(features.data_ptr(), out.data_ptr(), _ptr(count), indice_pairs.data_ptr(),
+                                 _ptr(_mask_of(indice_pairs, True)), num_activate_out, features.shape[1],
+                                 indice_pairs.shape[0], _pool_code(features), _stream(features)))
+    return out, (count if count is not None else torch.Tensor())
+
+
+def indice_avgpool_implicit_gemm_backward(out_bp: torch.Tensor, indice_pairs: torch.Tensor,
+                                          count_out: torch.Tensor) -> torch.Tensor:
+    """din[i] = sum_o dout[o] / count[o] over pair_bwd [kv, n_in] (cf. ops.py:2059-2084)."""
+    L = _lib.load()
+    out_bp = out_bp.contiguous()
+    n_in = indice_pairs.shape[1]
+    din = torch.empty((n_in, out_bp.shape[1]), dtype=out_bp.dtype, device=out_bp.device)
+    _lib.check(L.spx_avgpool_bwd(out_bp.data_ptr(), din.data_ptr(), count_out.data_ptr(),
+                                 indice_pairs.data_ptr(), _ptr(_mask_of(indice_pairs, False)), n_in,
+                                 out_bp.shape[1], indice_pairs.shape[0], _pool_code(out_bp),
+                                 _stream(out_bp)))
+    return din
+
+
+def indice_maxpool(features: torch.Tensor, indice_pairs: torch.Tensor, indice_pair_num: torch.Tensor,
+                   num_activate_out: int) -> torch.Tensor:
+    """ConvAlgo.Native max pool on the lists [2, kv, N_in] (ops.py:1899-1935).  Its output starts
+    as zeros in the reference, so the result is max(0, max over the pairs); kept."""
+    rb = rulebook_of(indice_pairs)
+    table = rb.pair_fwd if rb is not None else _table_from_native(
+        indice_pairs, indice_pair_num, num_activate_out, False, False)[0]
+    if rb is not None:
+        attach_rulebook(table, rb)
+    return indice_maxpool_implicit_gemm(features, table, num_activate_out, init_zero=True)
+
+
+def indice_maxpool_backward(features, out_features, out_bp, indice_pairs, indice_pair_num):
+    """ConvAlgo.Native max pool backward (ops.py:1938-1973)."""
+    rb = rulebook_of(indice_pairs)
+    n_in = features.shape[0]
+    table = rb.pair_bwd if rb is not None and rb.pair_bwd is not None else _table_from_native(
+        indice_pairs, indice_pair_num, n_in, False, True)[0]
+    if rb is not None:
+        attach_rulebook(table, rb)
+    return indice_maxpool_implicit_gemm_backward(features, out_features, out_bp, table)
+
+
+def global_pool_rearrange(indices: torch.Tensor, batch_size: int):
+    """Row ids of every batch item, padded to [batch, N], and the counts (ops.py:2087-2100)."""
+    b = indices[:, 0].long()
+    n = indices.shape[0]
+    out = torch.zeros((batch_size, n), dtype=torch.int32, device=indices.device)
+    counts = torch.zeros((batch_size,), dtype=torch.int32, device=indices.device)
+    for i in range(batch_size):
+        rows = torch.nonzero(b == i, as_tuple=False).flatten().int()
+        out[i, :rows.numel()] = rows
+        counts[i] = rows.numel()
+    return out, counts
+

@@ -210,3 +210,28 @@ def test_int8_reference_formula_small():
     want = np.clip(np.round(np.maximum(r, 0)), -128, 127).astype(np.int8)
     np.testing.assert_array_equal(got, want)
 
+
+def test_pool_oracle_matches_dense_torch_pooling():
+    """oracle.maxpool_ref / avgpool_ref over the CPU rulebook vs dense torch pooling: with
+    non-negative features an empty site (0 in the dense tensor) never wins a max, and a 2x2x2
+    stride-2 average over the ACTIVE voxels is sum / count of the dense window."""
+    rng = np.random.default_rng(5)
+    shape, n, C = [8, 8, 8], 150, 4
+    idx = scene(shape, n, 1, 5)
+    out_inds, pair, num, out_shape = oracle.get_indice_pairs(idx, 1, shape, [2] * 3, [2] * 3, [0] * 3,
+                                                             [1] * 3, None, False, False)
+    f = (rng.uniform(0.1, 1.0, (n, C))).astype(np.float32)
+    dense = np.zeros((1, C, *shape), dtype=np.float32)
+    occ = np.zeros((1, 1, *shape), dtype=np.float32)
+    dense[0, :, idx[:, 1], idx[:, 2], idx[:, 3]] = f
+    occ[0, 0, idx[:, 1], idx[:, 2], idx[:, 3]] = 1
+    got = oracle.maxpool_ref(f, pair, num, out_inds.shape[0])
+    want = torch.nn.functional.max_pool3d(torch.from_numpy(dense), 2, 2).numpy()
+    np.testing.assert_array_equal(got, want[0][:, out_inds[:, 1], out_inds[:, 2], out_inds[:, 3]].T)
+    avg, cnt = oracle.avgpool_ref(f, pair, num, out_inds.shape[0])
+    s = torch.nn.functional.avg_pool3d(torch.from_numpy(dense), 2, 2).numpy() * 8
+    c = torch.nn.functional.avg_pool3d(torch.from_numpy(occ), 2, 2).numpy() * 8
+    sel = (slice(None), out_inds[:, 1], out_inds[:, 2], out_inds[:, 3])
+    np.testing.assert_array_equal(cnt, np.rint(c[0][sel][0]).astype(np.int32))
+    np.testing.assert_allclose(avg, (s[0][sel] / c[0][sel]).T, rtol=1e-6)
+
