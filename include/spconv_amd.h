@@ -241,6 +241,26 @@ int spx_avgpool_bwd(const void *dout, void *din, const int32_t *count, const int
                     const uint32_t *mask_bwd, int n_in, int C, int kv, int dtype,
                     spx_stream_t stream);
 
+/* ------------------------------------------------------------ point -> voxel */
+
+/* Voxeliser.  Replaces SpconvOps.point2voxel_cuda / point2voxel_cpu
+ * (csrc/sparse/all.py:1389-1500, csrc/sparse/pointops.py; driver pytorch/utils.py:23-160).
+ * Result identical to the reference's CPU loop: voxels numbered in first-seen point order, the
+ * first max_points points of a voxel kept in point order, voxels beyond max_voxels dropped.
+ *   points [n, nfeat] fp32, the first ndim columns are x, y, z(, t)
+ *   vsize [ndim], coors_range [2 ndim] (lows, then highs), grid_size [ndim]: all in ZYX order as
+ *   returned by calc_point2voxel_meta_data (all.py:1349-1386)
+ *   voxels [max_voxels, max_points, nfeat] fp32, indices [max_voxels, ndim] (zyx),
+ *   num_per_voxel [max_voxels], pc_voxel_id [n] int64 (-1 = dropped point)
+ *   empty_mean: unused slots of a voxel receive the mean of its points; clear_voxels: zero
+ *   `voxels` first.  *n_voxels_h receives the number of voxels (one D->H read). */
+size_t spx_point2voxel_ws_bytes(int n_points, int max_voxels);
+int spx_point2voxel(const float *points, int n, int nfeat, int ndim, const float *vsize,
+                    const float *coors_range, const int *grid_size, int max_voxels, int max_points,
+                    int empty_mean, int clear_voxels, float *voxels, int32_t *indices,
+                    int32_t *num_per_voxel, long long *pc_voxel_id, int *n_voxels_h, void *ws,
+                    size_t ws_bytes, spx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

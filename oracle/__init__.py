@@ -431,3 +431,26 @@ def avgpool_bwd_ref(dout: np.ndarray, count: np.ndarray, pair: np.ndarray, num_p
         np.add.at(din, i_inds, dout[o_inds].astype(np.float64) * inv[o_inds][:, None])
     return din.astype(dout.dtype)
 
+
+# --------------------------------------------------------------------------
+# voxeliser (spconv/pytorch/utils.py:23-160 over csrc/sparse/pointops.py Point2VoxelCPU)
+def point2voxel(points: np.ndarray, vsize_zyx, coors_range_zyx, grid_size_zyx, max_voxels: int,
+                max_points: int, empty_mean: bool = False):
+    """-> (voxels [V, max_points, F], indices [V, ndim] zyx, num_per_voxel [V], pc_voxel_id [N])."""
+    L = lib()
+    L.orc_point2voxel.restype = ctypes.c_int
+    pts = np.ascontiguousarray(points, dtype=np.float32)
+    n, nfeat = pts.shape
+    ndim = len(vsize_zyx)
+    voxels = np.zeros((max_voxels, max_points, nfeat), dtype=np.float32)
+    indices = np.zeros((max_voxels, ndim), dtype=np.int32)
+    num = np.zeros((max_voxels,), dtype=np.int32)
+    pid = np.zeros((n,), dtype=np.int64)
+    fl = lambda v: (ctypes.c_float * len(v))(*[float(x) for x in v])
+    nv = L.orc_point2voxel(pts.ctypes.data_as(ctypes.c_void_p), n, nfeat, ndim, fl(vsize_zyx),
+                           fl(coors_range_zyx), _ints(grid_size_zyx), int(max_voxels), int(max_points),
+                           int(empty_mean), voxels.ctypes.data_as(ctypes.c_void_p),
+                           indices.ctypes.data_as(ctypes.c_void_p), num.ctypes.data_as(ctypes.c_void_p),
+                           pid.ctypes.data_as(ctypes.c_void_p))
+    return voxels[:nv], indices[:nv], num[:nv], pid
+

@@ -17,6 +17,7 @@
 //
 // Build: see oracle/Makefile (g++ -O3 -shared -fPIC).
 
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <limits>
@@ -302,3 +303,67 @@ void orc_scatter_add_f32_omp(float *out, const float *in, const int32_t *inds,
 }
 
 }  // extern "C"
+
+// Point2VoxelCPU::point_to_voxel (spconv/csrc/sparse/pointops.py, lines 97-196 of the class;
+// zyx = true): sequential, first-seen voxel numbering, first max_points points per voxel.
+// mean fill: the arithmetic mean of the voxel's points (the reference's accumulator is not
+// reset between voxels -- `mean_value.clear()` keeps the old contents -- which is not restated).
+extern "C" int orc_point2voxel(const float *points, int n, int nfeat, int ndim, const float *vsize,
+                               const float *coors_range, const int *grid_size, int max_voxels,
+                               int max_points, int empty_mean, float *voxels, int32_t *indices,
+                               int32_t *num_per_voxel, int64_t *pc_voxel_id) {
+  std::unordered_map<int64_t, int> coor_to_voxelidx;   // stands in for the dense grid table
+  int voxel_num = 0;
+  for (int i = 0; i < n; ++i) {
+    int coor[4];
+    bool failed = false;
+    for (int j = 0; j < ndim; ++j) {
+      const float v = std::floor((points[static_cast<size_t>(i) * nfeat + (ndim - 1 - j)] - coors_range[j]) / vsize[j]);
+      if (v < 0 || v >= static_cast<float>(grid_size[j])) {
+        failed = true;
+        break;
+      }
+      coor[j] = static_cast<int>(v);
+    }
+    if (failed) {
+      pc_voxel_id[i] = -1;
+      continue;
+    }
+    int64_t key = 0;
+    for (int j = 0; j < ndim; ++j) key = key * grid_size[j] + coor[j];
+    auto it = coor_to_voxelidx.find(key);
+    int voxelidx;
+    if (it == coor_to_voxelidx.end()) {
+      voxelidx = voxel_num;
+      if (voxel_num >= max_voxels) {
+        pc_voxel_id[i] = -1;
+        continue;
+      }
+      voxel_num += 1;
+      coor_to_voxelidx.emplace(key, voxelidx);
+      for (int k = 0; k < ndim; ++k) indices[static_cast<size_t>(voxelidx) * ndim + k] = coor[k];
+    } else {
+      voxelidx = it->second;
+    }
+    pc_voxel_id[i] = voxelidx;
+    const int num = num_per_voxel[voxelidx];
+    if (num < max_points) {
+      for (int k = 0; k < nfeat; ++k)
+        voxels[(static_cast<size_t>(voxelidx) * max_points + num) * nfeat + k] = points[static_cast<size_t>(i) * nfeat + k];
+      num_per_voxel[voxelidx] += 1;
+    }
+  }
+  if (empty_mean) {
+    for (int v = 0; v < voxel_num; ++v) {
+      const int num = num_per_voxel[v];
+      if (num <= 0) continue;
+      for (int k = 0; k < nfeat; ++k) {
+        float sum = 0.f;
+        for (int j = 0; j < num; ++j) sum += voxels[(static_cast<size_t>(v) * max_points + j) * nfeat + k];
+        const float mean = sum / static_cast<float>(num);
+        for (int j = num; j < max_points; ++j) voxels[(static_cast<size_t>(v) * max_points + j) * nfeat + k] = mean;
+      }
+    }
+  }
+  return voxel_num;
+}

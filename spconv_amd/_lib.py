@@ -60,6 +60,11 @@ SIGNATURES = {
     "spx_maxpool_bwd": (ctypes.c_int, [vp] * 6 + [ctypes.c_int] * 4 + [vp]),
     "spx_avgpool_fwd": (ctypes.c_int, [vp] * 5 + [ctypes.c_int] * 4 + [vp]),
     "spx_avgpool_bwd": (ctypes.c_int, [vp] * 5 + [ctypes.c_int] * 4 + [vp]),
+    "spx_point2voxel_ws_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "spx_point2voxel": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
+                                       c_int_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       vp, vp, vp, vp, c_int_p, vp, ctypes.c_size_t, vp]),
     "spx_bias_act_inplace": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_float, vp]),
 }

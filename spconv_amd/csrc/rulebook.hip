@@ -611,6 +611,194 @@ int launch_native_lists(const int32_t *table, int mode, int kv, int n, int nlist
   return 0;
 }
 
+// ------------------------------------------------------------- point -> voxel
+// Voxeliser.  Deterministic and identical to the reference's CPU loop
+// (csrc/sparse/pointops.py Point2VoxelCPU::point_to_voxel, lines 135-172 of the class): voxels
+// are numbered in first-seen point order, a voxel keeps its first max_points points in point
+// order, voxels past max_voxels are dropped.  Same building blocks as the rulebook: hash with
+// atomicMin (first point of a voxel), count -> scan -> assign (numbering), stable radix sort by
+// voxel id (slot of a point inside its voxel), no order-dependent atomics.
+struct P2VGeom {
+  int ndim;
+  float vsize[4], lo[4];
+  int grid[4];
+};
+
+__device__ __forceinline__ bool p2v_coor(const float *__restrict__ pt, const P2VGeom &g, int (&c)[4]) {
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (j < g.ndim) {
+      // zyx order: coordinate j comes from point column ndim-1-j (pointops.py:107,138)
+      const float v = floorf((pt[g.ndim - 1 - j] - g.lo[j]) / g.vsize[j]);
+      const int ci = static_cast<int>(v);
+      ok = ok && !(v < 0.f) && v < static_cast<float>(g.grid[j]);
+      c[j] = ci;
+    } else {
+      c[j] = 0;
+    }
+  }
+  return ok;
+}
+
+__global__ void __launch_bounds__(kBlock)
+p2v_insert_kernel(const float *__restrict__ pts, int n, int nfeat, P2VGeom g, Table t,
+                  int32_t *__restrict__ slot_of) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  int c[4];
+  int slot = -1;
+  if (p2v_coor(pts + static_cast<size_t>(i) * nfeat, g, c)) {
+    hkey_t key = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < g.ndim) key = key * g.grid[j] + c[j];
+    slot = table_insert_min(t, key, i);
+  }
+  slot_of[i] = slot;
+}
+
+__global__ void __launch_bounds__(kBlock)
+p2v_count_first_kernel(const int32_t *__restrict__ slot_of, const int32_t *__restrict__ vals, int n,
+                       int32_t *__restrict__ blockcount) {
+  __shared__ int lds_wave[kBlock / 64];
+  const int begin = blockIdx.x * kItems;
+  int cnt = 0;
+#pragma unroll
+  for (int it = 0; it < kItems / kBlock; ++it) {
+    const int e = begin + it * kBlock + threadIdx.x;
+    const int slot = e < n ? slot_of[e] : -1;
+    cnt += __popcll(__ballot(slot >= 0 && vals[slot] == e));
+  }
+  if ((threadIdx.x & 63) == 0) lds_wave[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int sum = 0;
+    for (int w = 0; w < kBlock / 64; ++w) sum += lds_wave[w];
+    blockcount[blockIdx.x] = sum;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+p2v_assign_kernel(const float *__restrict__ pts, int n, int nfeat, P2VGeom g,
+                  const int32_t *__restrict__ slot_of, const int32_t *__restrict__ vals,
+                  const int32_t *__restrict__ blockoff, int max_voxels,
+                  int32_t *__restrict__ slot_vid, int32_t *__restrict__ indices) {
+  __shared__ int lds_wave[kBlock / 64];
+  const int begin = blockIdx.x * kItems;
+  int running = blockoff[blockIdx.x];
+  for (int it = 0; it < kItems / kBlock; ++it) {
+    const int e = begin + it * kBlock + threadIdx.x;
+    const int slot = e < n ? slot_of[e] : -1;
+    const bool first = slot >= 0 && vals[slot] == e;
+    int total;
+    const int rank = block_rank(first, total, lds_wave);
+    if (first) {
+      const int vid = running + rank;
+      if (vid < max_voxels) {
+        slot_vid[slot] = vid;
+        int c[4];
+        p2v_coor(pts + static_cast<size_t>(e) * nfeat, g, c);
+        for (int j = 0; j < g.ndim; ++j) indices[static_cast<size_t>(vid) * g.ndim + j] = c[j];
+      }
+    }
+    running += total;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+p2v_point_vid_kernel(const int32_t *__restrict__ slot_of, const int32_t *__restrict__ slot_vid, int n,
+                     long long *__restrict__ pc_voxel_id, uint32_t *__restrict__ key32) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int slot = slot_of[i];
+  const int vid = slot >= 0 ? slot_vid[slot] : -1;
+  pc_voxel_id[i] = vid;
+  key32[i] = vid < 0 ? 0xffffffffu : static_cast<uint32_t>(vid);
+}
+
+// sorted (voxel id, point) pairs -> slot of the point inside its voxel
+__global__ void __launch_bounds__(kBlock)
+p2v_segment_kernel(const uint32_t *__restrict__ keys, int n, int32_t *__restrict__ seg_start) {
+  const int q = blockIdx.x * kBlock + threadIdx.x;
+  if (q >= n) return;
+  const uint32_t v = keys[q];
+  if (v != 0xffffffffu && (q == 0 || keys[q - 1] != v)) seg_start[v] = q;
+}
+
+__global__ void __launch_bounds__(kBlock)
+p2v_scatter_kernel(const float *__restrict__ pts, int nfeat, const uint32_t *__restrict__ keys,
+                   const int32_t *__restrict__ order, int n, const int32_t *__restrict__ seg_start,
+                   int max_points, float *__restrict__ voxels, int32_t *__restrict__ num_per_voxel) {
+  const int q = blockIdx.x * kBlock + threadIdx.x;
+  if (q >= n) return;
+  const uint32_t v = keys[q];
+  if (v == 0xffffffffu) return;
+  const int rank = q - seg_start[v];
+  if (rank < max_points) {
+    const float *src = pts + static_cast<size_t>(order[q]) * nfeat;
+    float *dst = voxels + (static_cast<size_t>(v) * max_points + rank) * nfeat;
+    for (int k = 0; k < nfeat; ++k) dst[k] = src[k];
+  }
+  if (q == n - 1 || keys[q + 1] != v) num_per_voxel[v] = min(rank + 1, max_points);
+}
+
+// empty_mean: slots num..max_points-1 of a voxel receive the mean of its points
+__global__ void __launch_bounds__(kBlock)
+p2v_mean_kernel(float *__restrict__ voxels, const int32_t *__restrict__ num_per_voxel,
+                const int32_t *__restrict__ n_voxels, int max_points, int nfeat) {
+  const long long gid = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x;
+  const int v = static_cast<int>(gid / nfeat), k = static_cast<int>(gid % nfeat);
+  if (v >= *n_voxels) return;
+  const int num = num_per_voxel[v];
+  if (num <= 0 || num >= max_points) return;
+  float *base = voxels + static_cast<size_t>(v) * max_points * nfeat + k;
+  float sum = 0.f;
+  for (int j = 0; j < num; ++j) sum += base[static_cast<size_t>(j) * nfeat];
+  const float mean = sum / static_cast<float>(num);
+  for (int j = num; j < max_points; ++j) base[static_cast<size_t>(j) * nfeat] = mean;
+}
+
+__global__ void p2v_clamp_count_kernel(const int32_t *total, int max_voxels, int32_t *n_voxels) {
+  *n_voxels = *total < max_voxels ? *total : max_voxels;
+}
+
+struct P2VWs {
+  Table t;
+  int32_t *slot_of, *slot_vid, *blockcount, *blockoff, *total, *n_voxels, *seg_start, *order, *hist, *hist_off;
+  uint32_t *key32, *kA, *kB;
+  int32_t *vB;
+  int nblk;
+  size_t bytes;
+};
+
+P2VWs carve_p2v_ws(void *ws, int n, int max_voxels) {
+  const uint32_t cap = table_capacity(n > 0 ? n : 1);
+  const size_t np = n > 0 ? n : 1;
+  P2VWs w;
+  w.nblk = div_up(static_cast<int>(np), kItems);
+  Carver cv(ws);
+  w.t.keys = cv.take<hkey_t>(cap);
+  w.t.vals = cv.take<int32_t>(cap);
+  w.t.mask = cap - 1;
+  w.slot_vid = cv.take<int32_t>(cap);
+  w.slot_of = cv.take<int32_t>(np);
+  w.blockcount = cv.take<int32_t>(w.nblk);
+  w.blockoff = cv.take<int32_t>(w.nblk);
+  w.total = cv.take<int32_t>(1);
+  w.n_voxels = cv.take<int32_t>(1);
+  w.seg_start = cv.take<int32_t>(max_voxels > 0 ? max_voxels : 1);
+  w.order = cv.take<int32_t>(np);
+  w.key32 = cv.take<uint32_t>(np);
+  w.kA = cv.take<uint32_t>(np);
+  w.kB = cv.take<uint32_t>(np);
+  w.vB = cv.take<int32_t>(np);
+  w.hist = cv.take<int32_t>(static_cast<size_t>(kRadix) * w.nblk);
+  w.hist_off = cv.take<int32_t>(static_cast<size_t>(kRadix) * w.nblk);
+  w.bytes = cv.off;
+  return w;
+}
+
 }  // namespace
 }  // namespace spx
 
@@ -866,6 +1054,80 @@ int spx_table_to_native(const int32_t *table, int subm, int kv, int n, int32_t *
                        pair_native, kv, n);
   return launch_native_lists(table, subm ? 0 : 1, kv, n, subm ? kv / 2 : kv, nblk, blockcount,
                              blockoff, pair_native, num_per_loc, s);
+}
+
+size_t spx_point2voxel_ws_bytes(int n_points, int max_voxels) {
+  return carve_p2v_ws(nullptr, n_points, max_voxels).bytes + 256;
+}
+
+int spx_point2voxel(const float *points, int n, int nfeat, int ndim, const float *vsize,
+                    const float *coors_range, const int *grid_size, int max_voxels, int max_points,
+                    int empty_mean, int clear_voxels, float *voxels, int32_t *indices,
+                    int32_t *num_per_voxel, long long *pc_voxel_id, int *n_voxels_h, void *ws,
+                    size_t ws_bytes, spx_stream_t stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  SPX_CHECK(ndim >= 1 && ndim <= kMaxNdim, "ndim must be in [1,4], got %d", ndim);
+  SPX_CHECK(nfeat >= ndim, "points need at least %d columns, got %d", ndim, nfeat);
+  SPX_CHECK(max_voxels > 0 && max_points > 0 && n >= 0, "bad sizes");
+  SPX_CHECK(voxels && indices && num_per_voxel && (pc_voxel_id || n == 0) && n_voxels_h, "null pointer");
+  SPX_CHECK(ws_bytes >= spx_point2voxel_ws_bytes(n, max_voxels), "workspace too small");
+  *n_voxels_h = 0;
+  SPX_HIP(hipMemsetAsync(num_per_voxel, 0, sizeof(int32_t) * max_voxels, s));
+  if (clear_voxels)
+    SPX_HIP(hipMemsetAsync(voxels, 0, sizeof(float) * static_cast<size_t>(max_voxels) * max_points * nfeat, s));
+  if (n == 0) return 0;
+  SPX_CHECK(points, "null pointer");
+  P2VGeom g;
+  g.ndim = ndim;
+  for (int j = 0; j < 4; ++j) {
+    g.vsize[j] = j < ndim ? vsize[j] : 1.f;
+    g.lo[j] = j < ndim ? coors_range[j] : 0.f;
+    g.grid[j] = j < ndim ? grid_size[j] : 1;
+  }
+  P2VWs w = carve_p2v_ws(ws, n, max_voxels);
+  const size_t cap = static_cast<size_t>(w.t.mask) + 1;
+  SPX_HIP(hipMemsetAsync(w.t.keys, 0xFF, sizeof(hkey_t) * cap, s));
+  SPX_HIP(hipMemsetAsync(w.t.vals, 0x7F, sizeof(int32_t) * cap, s));
+  SPX_HIP(hipMemsetAsync(w.slot_vid, 0xFF, sizeof(int32_t) * cap, s));
+  const dim3 gp(div_up(n, kBlock));
+  hipLaunchKernelGGL(p2v_insert_kernel, gp, dim3(kBlock), 0, s, points, n, nfeat, g, w.t, w.slot_of);
+  hipLaunchKernelGGL(p2v_count_first_kernel, dim3(w.nblk), dim3(kBlock), 0, s, w.slot_of, w.t.vals, n,
+                     w.blockcount);
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kBlock), 0, s, w.blockcount, w.blockoff, w.nblk, w.total);
+  hipLaunchKernelGGL(p2v_clamp_count_kernel, dim3(1), dim3(1), 0, s, w.total, max_voxels, w.n_voxels);
+  hipLaunchKernelGGL(p2v_assign_kernel, dim3(w.nblk), dim3(kBlock), 0, s, points, n, nfeat, g, w.slot_of,
+                     w.t.vals, w.blockoff, max_voxels, w.slot_vid, indices);
+  hipLaunchKernelGGL(p2v_point_vid_kernel, gp, dim3(kBlock), 0, s, w.slot_of, w.slot_vid, n, pc_voxel_id,
+                     w.key32);
+  // stable sort of the points by voxel id (4 x 8-bit LSD passes, as mask_argsort)
+  const uint32_t *kin = w.key32;
+  const int32_t *vin = nullptr;
+  uint32_t *kout[4] = {w.kB, w.kA, w.kB, w.kA};
+  int32_t *vout[4] = {w.vB, w.order, w.vB, w.order};
+  for (int pass = 0; pass < 4; ++pass) {
+    hipLaunchKernelGGL(radix_count_kernel, dim3(w.nblk), dim3(kBlock), 0, s, kin, n, pass * kRadixBits,
+                       w.nblk, w.hist);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kBlock), 0, s, w.hist, w.hist_off, kRadix * w.nblk,
+                       static_cast<int32_t *>(nullptr));
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(w.nblk), dim3(kBlock), 0, s, kin, vin, n,
+                       pass * kRadixBits, w.nblk, w.hist_off, kout[pass], vout[pass]);
+    kin = kout[pass];
+    vin = vout[pass];
+  }
+  hipLaunchKernelGGL(p2v_segment_kernel, gp, dim3(kBlock), 0, s, w.kA, n, w.seg_start);
+  hipLaunchKernelGGL(p2v_scatter_kernel, gp, dim3(kBlock), 0, s, points, nfeat, w.kA, w.order, n,
+                     w.seg_start, max_points, voxels, num_per_voxel);
+  if (empty_mean) {
+    const long long total = static_cast<long long>(max_voxels) * nfeat;
+    hipLaunchKernelGGL(p2v_mean_kernel, dim3(static_cast<unsigned>((total + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, s, voxels, num_per_voxel, w.n_voxels, max_points, nfeat);
+  }
+  SPX_LAUNCH_CHECK();
+  int32_t host_n = 0;
+  SPX_HIP(hipMemcpyAsync(&host_n, w.n_voxels, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  SPX_HIP(hipStreamSynchronize(s));
+  *n_voxels_h = host_n;
+  return 0;
 }
 
 }  // extern "C"

@@ -1,0 +1,56 @@
+"""GPU voxeliser against the sequential CPU restatement of the
+reference's Point2VoxelCPU (oracle.point2voxel): bit-exact voxels, indices (zyx), counts and
+per-point voxel ids, including the max_voxels / max_points caps and points outside the range."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _cloud(n, seed, lo=(-1.0, -5.0, -3.0), hi=(9.0, 5.0, 3.0), nfeat=4):
+    rng = np.random.default_rng(seed)
+    pts = rng.uniform(lo + (0.0,) * (nfeat - 3), hi + (1.0,) * (nfeat - 3), (n, nfeat)).astype(np.float32)
+    # clusters -> several points per voxel
+    pts[: n // 2, :3] = pts[: n // 2, :3] * 0.05 + np.array([4.0, 0.0, 0.0], dtype=np.float32)
+    return pts
+
+
+@pytest.mark.parametrize("n,max_voxels,max_points,empty_mean",
+                         [(20000, 40000, 5, False), (20000, 40000, 5, True), (20000, 300, 3, True),
+                          (50, 100, 1, False), (0, 10, 2, False)])
+def test_point2voxel_bit_exact(cuda, n, max_voxels, max_points, empty_mean):
+    from spconv_amd.pytorch.utils import PointToVoxel
+    vsize, rng_xyz = [0.1, 0.1, 0.2], [0, -4, -2, 8, 4, 2]
+    gen = PointToVoxel(vsize, rng_xyz, 4, max_voxels, max_points, device=cuda)
+    pts = _cloud(n, 1)
+    v, i, c, pid = gen.generate_voxel_with_id(torch.from_numpy(pts).to(cuda), True, empty_mean)
+    rv, ri, rc, rpid = oracle.point2voxel(pts, gen.vsize, gen.coors_range, gen.grid_size, max_voxels,
+                                          max_points, empty_mean)
+    assert v.shape[0] == rv.shape[0]
+    np.testing.assert_array_equal(i.cpu().numpy(), ri)
+    np.testing.assert_array_equal(c.cpu().numpy(), rc)
+    np.testing.assert_array_equal(pid.cpu().numpy(), rpid)
+    np.testing.assert_array_equal(v.cpu().numpy(), rv)
+    if n:
+        assert (rpid == -1).any() and rc.max() == max_points      # caps and range checks are exercised
+
+
+def test_point2voxel_feeds_a_sparse_conv(cuda):
+    """points -> voxels -> mean features -> SparseConvTensor -> SubMConv3d: the pipeline of
+    docs/USAGE.md (indices ZYX, batch column prepended)."""
+    import spconv_amd.pytorch as spconv
+    from spconv_amd.pytorch.utils import PointToVoxel, gather_features_by_pc_voxel_id
+    gen = PointToVoxel([0.2, 0.2, 0.4], [0, -4, -2, 8, 4, 2], 4, 20000, 4, device=cuda)
+    pts = torch.from_numpy(_cloud(8000, 2)).to(cuda)
+    voxels, coords, num, pid = gen.generate_voxel_with_id(pts, empty_mean=True)
+    feats = voxels.sum(dim=1) / num.clamp_min(1).unsqueeze(1).float() * 0 + voxels[:, 0]   # first point
+    idx = torch.cat([torch.zeros_like(coords[:, :1]), coords], dim=1).contiguous()
+    x = spconv.SparseConvTensor(feats.half(), idx, gen.grid_size, 1)
+    y = spconv.SubMConv3d(4, 16, 3).to(cuda).half()(x)
+    assert y.features.shape == (voxels.shape[0], 16)
+    back = gather_features_by_pc_voxel_id(y.features, pid, invalid_value=-1)
+    assert back.shape == (8000, 16) and bool((back[pid < 0] == -1).all())
+    assert torch.equal(back[pid >= 0], y.features[pid[pid >= 0]])
