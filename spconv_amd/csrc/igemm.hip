@@ -1347,7 +1347,7 @@ __host__ __device__ inline int plan2_wg(int w) { return 8 + kW2Rec * w; }
 __host__ __device__ inline int plan2_kf(int G) { return 8 + kW2Rec * G; }
 __host__ __device__ inline int plan2_seg(int G, int kv) { return 8 + kW2Rec * G + kv + 1; }
 // work list of the second stage: [0] items, then 2 ints per item: offset k | mode << 8, first
-// element inside a 64x64 tile.  At most kv * 128 items.
+// element inside a 64x64 tile.  At most kv * 256 items.
 __host__ __device__ inline int plan2_red(int G, int kv) { return plan2_seg(G, kv) + 3 * (G + kv); }
 
 __global__ void __launch_bounds__(kW2MaxG)
@@ -1433,7 +1433,7 @@ wgrad_plan2_kernel(const int32_t *__restrict__ num, int n_in, int kv, int subm, 
       // second-stage work list: block shape by segment count (see wgrad_reduce2_kernel)
       const int mode = kcount[k] >= 48 ? 0 : (kcount[k] >= 6 ? 1 : 2);
       ritems[k] = items;
-      items += (kWT * kWT) / (32 << (2 * mode));
+      items += (kWT * kWT) / (mode == 0 ? 16 : (mode == 1 ? 128 : 512));
     }
     kfirst[kv] = run;
     ritems[kv] = items;
@@ -1444,7 +1444,7 @@ wgrad_plan2_kernel(const int32_t *__restrict__ num, int n_in, int kv, int subm, 
   int32_t *rl = plan + plan2_red(G, kv);
   for (int k = 0; k < kv; ++k) {
     const int mode = kcount[k] >= 48 ? 0 : (kcount[k] >= 6 ? 1 : 2);
-    const int E = 32 << (2 * mode), cnt_items = (kWT * kWT) / E;
+    const int E = mode == 0 ? 16 : (mode == 1 ? 128 : 512), cnt_items = (kWT * kWT) / E;
     for (int q = tid; q < cnt_items; q += kW2MaxG) {
       rl[1 + 2 * (ritems[k] + q)] = k | (mode << 8);
       rl[2 + 2 * (ritems[k] + q)] = q * E;
@@ -1628,9 +1628,9 @@ igemm_bwd_kernel(const void *argA, const void *argB, const uint32_t *arg_mask,
 
 // dw[kk][k][c] = sum over the segments of offset k (deterministic: fixed assignment of
 // segments to threads, fixed summation order).  The work list (built with the plan) gives
-// every offset a block shape that fits its segment count -- 32 elements x 16 segment groups
+// every offset a block shape that fits its segment count -- 16 elements x 128 segment groups
 // for long lists, 128 x 4 or 512 x 1 for short ones -- so a SubM rulebook with one long and
-// 26 short lists runs ~340 blocks instead of 27 x 128.
+// 26 short lists runs ~460 blocks of useful work instead of 27 x 128 mostly idle ones.
 template <typename T>
 __global__ void __launch_bounds__(kRedThreads)
 wgrad_reduce2_kernel(Wgrad2Params p, T *__restrict__ dw) {
@@ -1643,23 +1643,56 @@ wgrad_reduce2_kernel(Wgrad2Params p, T *__restrict__ dw) {
   const int tile = blockIdx.y;
   for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
     const int k = rl[1 + 2 * it] & 0xff, mode = rl[1 + 2 * it] >> 8, e0 = rl[2 + 2 * it];
-    const int E = 32 << (2 * mode), S = kRedThreads / E;
     const int first = kf[k], nseg = kf[k + 1] - kf[k];
-    const int grp = threadIdx.x / E, el = threadIdx.x % E;
-    const int e = tile * (kWT * kWT) + e0 + el;  // element of [tiles][64*64]
-    float acc = 0.f;
-    {
-      const float *src = p.partial + static_cast<size_t>(first) * stride + e;
+    const float *base = p.partial + static_cast<size_t>(first) * stride + tile * (kWT * kWT) + e0;
+    if (mode == 0) {
+      // long list: 16 elements (4 lanes x float4) x 128 segment groups; with a few hundred
+      // segments every thread has all of its loads in flight at once.  Wave-level butterfly
+      // over the 16 groups of a wave, then 8 wave sums through LDS.
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      const int c4 = lane & 3, grp = wave * 16 + (lane >> 2);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float *src = base + c4 * 4;
       int ch = grp;
-      for (; ch + 7 * S < nseg; ch += 8 * S) {
-        float v[8];
+      for (; ch + 3 * 128 < nseg; ch += 4 * 128) {
+        float4 v[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = src[static_cast<size_t>(ch + u * S) * stride];
+        for (int u = 0; u < 4; ++u)
+          v[u] = *reinterpret_cast<const float4 *>(src + static_cast<size_t>(ch + u * 128) * stride);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += v[u];
+        for (int u = 0; u < 4; ++u) {
+          acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+        }
       }
-      for (; ch < nseg; ch += S) acc += src[static_cast<size_t>(ch) * stride];
+      for (; ch < nseg; ch += 128) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + static_cast<size_t>(ch) * stride);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+#pragma unroll
+      for (int d = 4; d < 64; d <<= 1) {
+        acc.x += __shfl_xor(acc.x, d, 64);
+        acc.y += __shfl_xor(acc.y, d, 64);
+        acc.z += __shfl_xor(acc.z, d, 64);
+        acc.w += __shfl_xor(acc.w, d, 64);
+      }
+      if (lane < 4) reinterpret_cast<float4 *>(red)[wave * 4 + lane] = acc;
+      __syncthreads();
+      if (threadIdx.x < 16) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < kRedThreads / 64; ++w) sum += red[w * 16 + threadIdx.x];
+        const int ee = e0 + threadIdx.x;
+        const int kk = (tile / p.tiles_c) * kWT + ee / kWT, c = (tile % p.tiles_c) * kWT + ee % kWT;
+        if (kk < p.K && c < p.C) store_f(dw + (static_cast<size_t>(kk) * p.kv + k) * p.C + c, sum);
+      }
+      __syncthreads();   // red[] is reused by the next item
+      continue;
     }
+    // short lists: 128 elements x 4 groups, or 512 x 1
+    const int E = mode == 1 ? 128 : 512, S = kRedThreads / E;
+    const int grp = threadIdx.x / E, el = threadIdx.x % E;
+    float acc = 0.f;
+    for (int ch = grp; ch < nseg; ch += S) acc += base[static_cast<size_t>(ch) * stride + el];
     if (S > 1) {
       red[threadIdx.x] = acc;
       __syncthreads();
@@ -1773,7 +1806,7 @@ int wgrad_groups(int n_in) {
 
 size_t wgrad_plan2_ints(int n_in, int kv) {
   const size_t G = wgrad_groups(n_in);
-  return 8 + kW2Rec * G + kv + 1 + 3 * (G + kv) + 1 + 2 * static_cast<size_t>(kv) * 128 + 8;
+  return 8 + kW2Rec * G + kv + 1 + 3 * (G + kv) + 1 + 2 * static_cast<size_t>(kv) * 256 + 8;
 }
 
 GemmParams dgrad_params(const void *dout, const void *weight, void *din, const int32_t *pair,
@@ -2047,7 +2080,7 @@ int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t 
       hipLaunchKernelGGL(wgrad_tr_kernel<false>, grid, dim3(kThreads), lds, s, q);
     else
       hipLaunchKernelGGL(wgrad_tr_kernel<true>, grid, dim3(kThreads), lds, s, q);
-    const dim3 rgrid2(kv * 128 < 512 ? kv * 128 : 512, ntile);   // block-stride over the work list
+    const dim3 rgrid2(kv * 256 < 512 ? kv * 256 : 512, ntile);   // block-stride over the work list
     if (dtype == SPX_F16)
       hipLaunchKernelGGL(wgrad_reduce2_kernel<h16>, rgrid2, dim3(kRedThreads), 0, s, q,
                          static_cast<h16 *>(dw));
@@ -2143,7 +2176,7 @@ int spx_igemm_bwd(const void *feat, const void *dout, const void *weight, void *
   const int ntile = q.tiles_c * q.tiles_k;
   const int rc = dtype == SPX_BF16 ? dispatch_bwd<1>(p, q, q.G * ntile, s) : dispatch_bwd<0>(p, q, q.G * ntile, s);
   if (rc) return rc;
-  const dim3 rgrid2(kv * 128 < 512 ? kv * 128 : 512, ntile);   // block-stride over the work list
+  const dim3 rgrid2(kv * 256 < 512 ? kv * 256 : 512, ntile);   // block-stride over the work list
   if (dtype == SPX_F16)
     hipLaunchKernelGGL(wgrad_reduce2_kernel<h16>, rgrid2, dim3(kRedThreads), 0, s, q, static_cast<h16 *>(dw));
   else
