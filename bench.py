@@ -177,7 +177,7 @@ def main():
     x.indice_dict["bench"] = net._make_indice_data(rb, indices, SHAPE, SHAPE, net.algo)
     num = rb.num_per_loc.cpu().numpy()
     P = int(n + 2 * num[:13].sum())                            # pairs incl. centre
-    bucket = GradBucket(net.parameters(), dtype=torch.float32) if world > 1 else None
+    bucket = GradBucket(net.parameters()) if world > 1 else None   # fp16 gradient, reduced in place
 
     def compute():
         net.weight.grad = None

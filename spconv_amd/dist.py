@@ -35,33 +35,62 @@ def shard_scenes(indices: torch.Tensor, features: torch.Tensor, batch_size: int,
 
 
 class GradBucket:
-    """Flat gradient bucket: one all-reduce for every parameter of a module."""
+    """One all-reduce for every parameter of a module.
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], dtype: torch.dtype = torch.float32):
+    * a single parameter (the benchmark layer): its ``.grad`` is reduced in place with
+      ``ReduceOp.AVG`` -- one RCCL call, no pack / scale / unpack kernels;
+    * several parameters: gradients are packed into one flat buffer (``dtype``, default the
+      first gradient's dtype), reduced once and copied back."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], dtype: Optional[torch.dtype] = None):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
-        dev = self.params[0].device if self.params else torch.device("cpu")
-        self.flat = torch.zeros(self.numel, dtype=dtype, device=dev)
+        self.dtype = dtype
+        self.flat: Optional[torch.Tensor] = None
+
+    def _ensure_flat(self) -> torch.Tensor:
+        if self.flat is None:
+            dev = self.params[0].device if self.params else torch.device("cpu")
+            dt = self.dtype or (self.params[0].dtype if self.params else torch.float32)
+            self.flat = torch.zeros(self.numel, dtype=dt, device=dev)
+        return self.flat
+
+    @staticmethod
+    def _reduce(t: torch.Tensor, group, average: bool) -> None:
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+            return
+        if average and dist.get_backend(group) == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)      # RCCL averages in the kernel
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            if average:
+                t.div_(dist.get_world_size(group))
 
     def all_reduce(self, group: Optional[dist.ProcessGroup] = None, average: bool = True):
-        """Packs .grad of every parameter, all-reduces once, unpacks in place."""
+        """All-reduces the gradients of every parameter (in place); returns the reduced buffer."""
+        if len(self.params) == 1 and self.params[0].grad is not None and (
+                self.dtype is None or self.dtype == self.params[0].grad.dtype):
+            g = self.params[0].grad
+            if not g.is_contiguous():
+                g = g.contiguous()
+                self.params[0].grad = g
+            self._reduce(g, group, average)
+            return g.view(-1)
+        flat = self._ensure_flat()
         off = 0
         for p in self.params:
             n = p.numel()
             if p.grad is None:
-                self.flat[off:off + n].zero_()
+                flat[off:off + n].zero_()
             else:
-                self.flat[off:off + n].copy_(p.grad.reshape(-1))
+                flat[off:off + n].copy_(p.grad.reshape(-1))
             off += n
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-            if average:
-                self.flat.div_(dist.get_world_size(group))
+        self._reduce(flat, group, average)
         off = 0
         for p in self.params:
             n = p.numel()
             if p.grad is None:
                 p.grad = torch.empty_like(p)
-            p.grad.copy_(self.flat[off:off + n].view_as(p))
+            p.grad.copy_(flat[off:off + n].view_as(p))
             off += n
-        return self.flat
+        return flat

@@ -55,7 +55,17 @@ def _worker(rank, world, port, out):
     dist.all_gather(gathered, torch.cat([g.reshape(-1) for g in local]))
     expect = torch.stack(gathered).mean(0)
     got = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
-    out[rank] = bool(torch.allclose(got, expect, atol=1e-6))
+    ok = bool(torch.allclose(got, expect, atol=1e-6))
+    # single parameter: reduced in place, no flat buffer (the benchmark layer's path)
+    lin = torch.nn.Linear(4, 3, bias=False)
+    lin(x).sum().backward()
+    mine = lin.weight.grad.clone()
+    b1 = GradBucket(lin.parameters())
+    b1.all_reduce(average=True)
+    g1 = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(g1, mine)
+    ok = ok and b1.flat is None and bool(torch.allclose(lin.weight.grad, torch.stack(g1).mean(0), atol=1e-6))
+    out[rank] = ok
     dist.barrier()
     dist.destroy_process_group()
 
