@@ -796,6 +796,10 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   const uint32_t wavemask =
       __builtin_amdgcn_readfirstlane(wm) | (spec ? (1u << p.identity_k) : 0u);
   if (lane == 0) lds_mask[wave] = wm;
+  // SubM: the identity step's weights go into stage 0 BEFORE the barrier that publishes the
+  // wave masks, so that one barrier serves both and the identity MFMAs can start as soon as
+  // their rows have arrived (they do not depend on the mask exchange at all)
+  if (spec) store_b(smem);
   __syncthreads();
   SPX_STAMP(2);   // mask words arrived, tile mask exchanged
   uint32_t tilemask = lds_mask[0] | lds_mask[1] | lds_mask[2] | lds_mask[3];
@@ -808,19 +812,11 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
     load_b(it0);
     load_idx(it0, Set0{});
     load_a(it0, Set0{});
+    store_b(smem);
+    __syncthreads();          // regular conv: the first step's weights could not be staged earlier
   }
   StepIt it1 = step_next(it0, nchunk);
   StepIt it2 = step_next(it1, nchunk);
-  // same issue order as a loop step (weights, pair words, rows), so that the wait counts the
-  // compiler derives at the loop header are the steady-state ones
-  load_idx(it1, Set1{});
-  store_b(smem);                // B(0) -> stage 0
-  __builtin_amdgcn_sched_barrier(0);   // pin the issue order: the scheduler must not sink load_b
-  load_b(it1);
-  __builtin_amdgcn_sched_barrier(0);
-  load_idx(it2, Set0{});        // idxr[0] has been consumed by load_a(it0): reuse it for step 2
-  __builtin_amdgcn_sched_barrier(0);
-  load_a(it1, Set1{});
 
   using acc_t = typename std::conditional<I8, i32x4, f32x4>::type;
   acc_t acc[NB][MB];
@@ -829,18 +825,13 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = acc_t{0, 0, 0, 0};
 
-  // ---- main loop: one step = one (offset, 64-wide reduction chunk), two steps per trip ---
-  // at step t (register set S = t & 1): areg[S] = gathered rows of step t, stage S of the
-  // ring = weights of step t, breg = weights of step t+1, idxr[S] = pair words of step t+2.
-  // Loads are unconditional (steps past the end read zero-sized resources).
-  auto step = [&](auto SET) __attribute__((always_inline)) {
+  // MFMAs of step `it` on register set S / weight stage S.  None of this wave's rows uses
+  // offset k (or the step does not exist): skipped.
+  auto compute = [&](const StepIt &it, auto SET) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
-    __syncthreads();   // stage 1-S is free (read at step t-1), stage S is complete
-    store_b(smem + (1 - S) * B_BYTES);
-    // none of this wave's rows uses offset k (or the step does not exist): skip the MFMAs
-    if (it0.k >= 0 && ((wavemask >> it0.k) & 1u)) {
+    if (it.k >= 0 && ((wavemask >> it.k) & 1u)) {
       const char *cur = smem + S * B_BYTES;
-      const int ksteps = (min(kRowBytes, static_cast<int>(rowB) - it0.chunk * kRowBytes) + 63) >> 6;  // 1 or 2
+      const int ksteps = (min(kRowBytes, static_cast<int>(rowB) - it.chunk * kRowBytes) + 63) >> 6;  // 1 or 2
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         if (ks < ksteps) {
@@ -855,6 +846,43 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
         }
       }
     }
+  };
+
+  // ---- first step, peeled: no barrier (stage 0 is complete, stage 1 untouched), and its MFMAs
+  // run before anything that waits for the pair words of the following steps.  Issue order as
+  // in a loop step (weights, pair words, rows) so that the loop-header wait counts are the
+  // steady-state ones.
+  load_idx(it1, Set1{});
+  __builtin_amdgcn_sched_barrier(0);
+  load_b(it1);
+  __builtin_amdgcn_sched_barrier(0);
+  load_idx(it2, Set0{});        // idxr[0] was consumed by load_a(it0): reuse it for step 2
+  __builtin_amdgcn_sched_barrier(0);
+  compute(it0, Set0{});
+  __builtin_amdgcn_sched_barrier(0);
+  load_a(it1, Set1{});
+  store_b(smem + B_BYTES);      // weights of step 1 -> stage 1 (published by step 1's barrier)
+  {
+    const StepIt it3 = step_next(it2, nchunk);
+    load_b(it2);
+    __builtin_amdgcn_sched_barrier(0);
+    load_idx(it3, Set1{});
+    __builtin_amdgcn_sched_barrier(0);
+    load_a(it2, Set0{});
+    it0 = it1;
+    it1 = it2;
+    it2 = it3;
+  }
+
+  // ---- main loop: one step = one (offset, 128-byte reduction piece), two steps per trip -----
+  // at step t (register set S = t & 1): areg[S] = gathered rows of step t, stage S of the
+  // ring = weights of step t, breg = weights of step t+1, idxr[S] = pair words of step t+2.
+  // Loads are unconditional (steps past the end read zero-sized resources).
+  auto step = [&](auto SET) __attribute__((always_inline)) {
+    constexpr int S = decltype(SET)::value;
+    __syncthreads();   // stage 1-S is free (read at step t-1), stage S is complete
+    store_b(smem + (1 - S) * B_BYTES);
+    compute(it0, SET);
     const StepIt it3 = step_next(it2, nchunk);
     load_b(it2);
     __builtin_amdgcn_sched_barrier(0);   // weights first: they are the first thing step t+1 waits for
@@ -865,10 +893,10 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
     it1 = it2;
     it2 = it3;
   };
-  SPX_STAMP(3);   // prologue done
+  SPX_STAMP(3);   // prologue + first step done
   while (it0.k >= 0) {
-    step(Set0{});
-    step(Set1{});   // may be a step past the end (no MFMAs, zero-sized loads): an early exit
+    step(Set1{});
+    step(Set0{});   // may be a step past the end (no MFMAs, zero-sized loads): an early exit
                     // here would cost the exact wait counts of the whole loop
   }
   SPX_STAMP(4);   // main loop done
