@@ -16,6 +16,9 @@
 //    are not coherent inside a launch).
 #include "common.h"
 
+#include <algorithm>
+#include <utility>
+
 namespace spx {
 namespace {
 
@@ -49,7 +52,8 @@ __device__ __forceinline__ int table_insert_min(const Table &t, hkey_t key, int3
                                         static_cast<unsigned long long>(key));
     if (prev == static_cast<unsigned long long>(-1LL) ||
         prev == static_cast<unsigned long long>(key)) {
-      atomicMin(&t.vals[slot], val);
+      // values start as 0xFFFFFFFF (one memset with the keys): unsigned min
+      atomicMin(reinterpret_cast<unsigned int *>(&t.vals[slot]), static_cast<unsigned int>(val));
       return static_cast<int>(slot);
     }
     slot = (slot + 1) & t.mask;
@@ -112,69 +116,65 @@ __device__ __forceinline__ bool in_range(const int (&c)[4], const int (&dims)[4]
 // ---------------------------------------------------------------- SubM
 
 __global__ void __launch_bounds__(kBlock)
-subm_insert_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table t) {
+subm_insert_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table t,
+                   int32_t *__restrict__ slot_of) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   int b, c[4];
   read_row(indices, i, g.ndim, b, c);
   // rows with a batch index outside [0, batch) ("deleted" points, docs/USAGE.md:150)
   // never match a neighbour query in the CPU path either; do not hash them.
-  if (b < 0 || b >= g.batch || !in_range(c, g.in_dims)) return;
-  table_insert_min(t, layout_key(b, c, g.in_dims), i);
+  int slot = -1;
+  if (b >= 0 && b < g.batch && in_range(c, g.in_dims))
+    slot = table_insert_min(t, layout_key(b, c, g.in_dims), i);
+  slot_of[i] = slot;
 }
 
-// One thread per voxel; loops over the kv offsets so that every store to
-// pair_fwd[k][.] / pair_bwd[k][.] is coalesced along the voxel axis and the
-// mask word is produced without atomics.
+// One thread per (voxel, offset k < kv/2): every probe chain is independent and there are only
+// kv/2 probes per voxel -- a hit at offset k from row o to row v is also the pair (kv-1-k) from
+// v to o (the mirror symmetry the CPU path uses, indices.py:1685-1696), written as a scattered
+// 4-byte store.  The tables are pre-filled with -1 and the masks with 0 (only hits write); the
+// mask bits are OR-ed in with atomicOr (commutative: the result does not depend on the order).
+// Duplicate coordinates: lookups only ever return the FIRST row of a coordinate
+// (unordered_map::insert keeps it, indices.py:1672), so a later duplicate never appears as the
+// found side; such a row keeps only its k > centre half, which it probes itself here.
 __global__ void __launch_bounds__(kBlock)
-subm_probe_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table t,
-                  int32_t *__restrict__ pair_fwd, int32_t *__restrict__ pair_bwd,
-                  uint32_t *__restrict__ mask, int words) {
+subm_probe3_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table t,
+                   const int32_t *__restrict__ slot_of, int32_t *__restrict__ pair_fwd,
+                   int32_t *__restrict__ pair_bwd, uint32_t *__restrict__ mask, int words,
+                   int32_t *__restrict__ native) {
   const int o = blockIdx.x * kBlock + threadIdx.x;
+  const int kv = g.kv, center = kv / 2;
+  int k = blockIdx.y;                         // 0 .. kv/2 (the last one is the identity offset)
   if (o >= n) return;
-  int b, c[4];
+  auto set = [&](int kk, int row, int val) __attribute__((always_inline)) {
+    pair_fwd[static_cast<size_t>(kk) * n + row] = val;
+    if (pair_bwd) pair_bwd[static_cast<size_t>(kv - 1 - kk) * n + row] = val;
+    atomicOr(&mask[static_cast<size_t>(row) * words + (kk >> 5)], 1u << (kk & 31));
+  };
+  if (k == center) {
+    set(center, o, o);
+    if (native) {                            // identity lists of ConvAlgo.Native (indices.py:1678-1682)
+      native[static_cast<size_t>(center) * n + o] = o;
+      native[static_cast<size_t>(kv + center) * n + o] = o;
+    }
+    return;
+  }
+  const int self = slot_of[o];
+  if (self < 0) return;
+  const bool first = t.vals[self] == o;
+  if (!first) k = kv - 1 - k;                 // a duplicate row only owns its k > centre half
+  int b, c[4], r[4], q[4];
   read_row(indices, o, g.ndim, b, c);
-  const bool bvalid = b >= 0 && b < g.batch;
-  const int kv = g.kv;
-  const int center = kv / 2;
-  // Duplicate coordinates: the CPU path only ever *finds* the first index of a
-  // coordinate (unordered_map::insert keeps it, indices.py:1672), so a later
-  // duplicate never appears as the found side.  In the dense table that side is
-  // the output for k < centre -> such rows keep only the k > centre half.
-  bool first_of_coord = false;
-  if (bvalid && in_range(c, g.in_dims)) {
-    const int self = table_lookup(t, layout_key(b, c, g.in_dims));
-    first_of_coord = self >= 0 && t.vals[self] == o;
-  }
-  int r[4] = {0, 0, 0, 0};
-  uint32_t mcur = 0;
-  for (int k = 0; k < kv; ++k) {
-    int v = -1;
-    if (k == center) {
-      v = o;
-    } else if (bvalid && (k > center || first_of_coord)) {
-      int q[4];
+  decode_offset(k, g.ksize, r);
 #pragma unroll
-      for (int d = 0; d < 4; ++d) q[d] = c[d] - g.padding[d] + r[d] * g.dilation[d];
-      if (in_range(q, g.in_dims)) {
-        const int slot = table_lookup(t, layout_key(b, q, g.in_dims));
-        if (slot >= 0) v = t.vals[slot];
-      }
-    }
-    pair_fwd[static_cast<size_t>(k) * n + o] = v;
-    if (pair_bwd) pair_bwd[static_cast<size_t>(kv - 1 - k) * n + o] = v;
-    if (v >= 0) mcur |= 1u << (k & 31);
-    if ((k & 31) == 31 || k == kv - 1) {
-      mask[static_cast<size_t>(o) * words + (k >> 5)] = mcur;
-      mcur = 0;
-    }
-    // odometer, last dim fastest (indices.py:114-127)
-#pragma unroll
-    for (int d = 3; d >= 0; --d) {
-      if (++r[d] < g.ksize[d]) break;
-      r[d] = 0;
-    }
-  }
+  for (int d = 0; d < 4; ++d) q[d] = c[d] - g.padding[d] + r[d] * g.dilation[d];
+  if (!in_range(q, g.in_dims)) return;
+  const int slot = table_lookup(t, layout_key(b, q, g.in_dims));
+  if (slot < 0) return;
+  const int v = t.vals[slot];
+  set(k, o, v);
+  if (first) set(kv - 1 - k, v, o);
 }
 
 // ------------------------------------------------- block-level primitives
@@ -813,6 +813,7 @@ size_t spx_subm_rulebook_ws_bytes(int n, int kv) {
   b += align_up(cap * sizeof(hkey_t), 256) + align_up(cap * sizeof(int32_t), 256);
   b += 2 * align_up(static_cast<size_t>(kv) * nblk * sizeof(int32_t), 256);
   b += 256;  // scratch totals when num_per_loc is NULL
+  b += align_up(static_cast<size_t>(n > 0 ? n : 1) * sizeof(int32_t), 256);   // hash slot of every row
   return b;
 }
 
@@ -841,8 +842,6 @@ int spx_subm_rulebook(const int32_t *indices, int n, int ndim, int batch_size,
                            padding, dilation);
   const int words = div_up(kv, 32);
   if (num_per_loc) SPX_HIP(hipMemsetAsync(num_per_loc, 0, sizeof(int32_t) * kv, s));
-  if (pair_native)
-    SPX_HIP(hipMemsetAsync(pair_native, 0xFF, sizeof(int32_t) * 2 * static_cast<size_t>(kv) * n, s));
   if (n == 0) return 0;
 
   const uint32_t cap = table_capacity(n);
@@ -855,16 +854,35 @@ int spx_subm_rulebook(const int32_t *indices, int n, int ndim, int batch_size,
   int32_t *blockcount = cv.take<int32_t>(static_cast<size_t>(kv) * nblk);
   int32_t *blockoff = cv.take<int32_t>(static_cast<size_t>(kv) * nblk);
   int32_t *scratch_totals = cv.take<int32_t>(64);
+  int32_t *slot_of = cv.take<int32_t>(n);
 
-  SPX_HIP(hipMemsetAsync(t.keys, 0xFF, sizeof(hkey_t) * cap, s));
-  SPX_HIP(hipMemsetAsync(t.vals, 0x7F, sizeof(int32_t) * cap, s));
+  // keys and values are adjacent in the workspace: one fill
+  SPX_HIP(hipMemsetAsync(t.keys, 0xFF, reinterpret_cast<char *>(t.vals + cap) - reinterpret_cast<char *>(t.keys), s));
+  SPX_HIP(hipMemsetAsync(mask, 0, sizeof(uint32_t) * static_cast<size_t>(n) * words, s));
   const dim3 grid(div_up(n, kBlock));
-  hipLaunchKernelGGL(subm_insert_kernel, grid, dim3(kBlock), 0, s, indices, n, g, t);
-  hipLaunchKernelGGL(subm_probe_kernel, grid, dim3(kBlock), 0, s, indices, n, g, t, pair_fwd,
-                     pair_bwd, mask, words);
+  hipLaunchKernelGGL(subm_insert_kernel, grid, dim3(kBlock), 0, s, indices, n, g, t, slot_of);
+  {
+    // -1 fill of every table; callers that carve them out of one buffer get ONE fill
+    std::pair<char *, size_t> f[3];
+    int nf = 0;
+    const size_t tb = sizeof(int32_t) * static_cast<size_t>(kv) * n;
+    f[nf++] = {reinterpret_cast<char *>(pair_fwd), tb};
+    if (pair_bwd) f[nf++] = {reinterpret_cast<char *>(pair_bwd), tb};
+    if (pair_native) f[nf++] = {reinterpret_cast<char *>(pair_native), 2 * tb};
+    std::sort(f, f + nf);
+    for (int i = 0; i < nf;) {
+      char *b0 = f[i].first;
+      size_t len = f[i].second;
+      int j = i + 1;
+      while (j < nf && f[j].first == b0 + len) len += f[j++].second;
+      SPX_HIP(hipMemsetAsync(b0, 0xFF, len, s));
+      i = j;
+    }
+  }
+  hipLaunchKernelGGL(subm_probe3_kernel, dim3(div_up(n, kBlock), kv / 2 + 1), dim3(kBlock), 0, s, indices,
+                     n, g, t, slot_of, pair_fwd, pair_bwd, mask, words, pair_native);
   SPX_LAUNCH_CHECK();
   if (pair_native) {
-    hipLaunchKernelGGL(subm_center_list_kernel, grid, dim3(kBlock), 0, s, pair_native, kv, n);
     // num_per_loc: counts only for k < kv/2 (indices.py:1685,1692)
     int32_t *totals = num_per_loc ? num_per_loc : scratch_totals;
     SPX_CHECK(num_per_loc || kv / 2 <= 64, "num_per_loc required for kv > 128");
@@ -905,8 +923,7 @@ int spx_conv_rulebook_count(const int32_t *indices, int n_in, int ndim, int batc
   if (n_in == 0) return 0;
   ConvWs w = carve_conv_ws(ws, n_in, ndim, ksize, stride, transposed);
   const size_t cap = static_cast<size_t>(w.t.mask) + 1;
-  SPX_HIP(hipMemsetAsync(w.t.keys, 0xFF, sizeof(hkey_t) * cap, s));
-  SPX_HIP(hipMemsetAsync(w.t.vals, 0x7F, sizeof(int32_t) * cap, s));
+  SPX_HIP(hipMemsetAsync(w.t.keys, 0xFF, reinterpret_cast<char *>(w.t.vals + cap) - reinterpret_cast<char *>(w.t.keys), s));
   const dim3 grid1(div_up(n_in, kBlock), g.kv);
   hipLaunchKernelGGL(conv_stage1_kernel, grid1, dim3(kBlock), 0, s, indices, n_in, g, transposed,
                      w.t, w.slot_of);
@@ -1086,8 +1103,7 @@ int spx_point2voxel(const float *points, int n, int nfeat, int ndim, const float
   }
   P2VWs w = carve_p2v_ws(ws, n, max_voxels);
   const size_t cap = static_cast<size_t>(w.t.mask) + 1;
-  SPX_HIP(hipMemsetAsync(w.t.keys, 0xFF, sizeof(hkey_t) * cap, s));
-  SPX_HIP(hipMemsetAsync(w.t.vals, 0x7F, sizeof(int32_t) * cap, s));
+  SPX_HIP(hipMemsetAsync(w.t.keys, 0xFF, reinterpret_cast<char *>(w.t.vals + cap) - reinterpret_cast<char *>(w.t.keys), s));
   SPX_HIP(hipMemsetAsync(w.slot_vid, 0xFF, sizeof(int32_t) * cap, s));
   const dim3 gp(div_up(n, kBlock));
   hipLaunchKernelGGL(p2v_insert_kernel, gp, dim3(kBlock), 0, s, points, n, nfeat, g, w.t, w.slot_of);

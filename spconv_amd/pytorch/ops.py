@@ -135,10 +135,13 @@ def build_rulebook(indices: torch.Tensor, batch_size: int, spatial_shape: List[i
     stream = _stream(indices)
     i32 = dict(dtype=torch.int32, device=dev)
     if subm:
-        pair_fwd = torch.empty((kv, n_in), **i32)
-        pair_bwd = torch.empty((kv, n_in), **i32) if need_bwd_table else None
+        # the -1 filled tables live in ONE buffer, so that the library needs a single fill
+        tb = kv * n_in
+        buf = torch.empty(((4 if need_bwd_table else 3) * tb,), **i32)
+        pair_fwd = buf[:tb].view(kv, n_in)
+        native = buf[tb:3 * tb].view(2, kv, n_in)
+        pair_bwd = buf[3 * tb:].view(kv, n_in) if need_bwd_table else None
         mask = torch.empty((n_in, words), **i32)
-        native = torch.empty((2, kv, n_in), **i32)
         num = torch.empty((kv,), **i32)
         ws = _ws(L.spx_subm_rulebook_ws_bytes(n_in, kv), dev)
         _lib.check(L.spx_subm_rulebook(indices.data_ptr(), n_in, ndim, batch_size,
