@@ -493,6 +493,13 @@ __device__ __forceinline__ ACC mfma_step(const uint4 &a, const uint4 &b, ACC c) 
   if constexpr (DT == 2) {
     return __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a),
                                                  __builtin_bit_cast(i32x4, b), c, 0, 0, 0);
+  } else if constexpr (DT == 3) {
+    // fp32: four v_mfma_f32_16x16x4_f32 (exact fp32, one element of the 16-byte piece each; the
+    // reduction index of element t of lane group g is 4 g + t on BOTH operands)
+    const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[t], fb[t], c, 0, 0, 0);
+    return c;
   } else {
     return mfma16<DT == 1>(a, b, c);
   }
@@ -533,7 +540,8 @@ __device__ __forceinline__ void load_dwords(uint32_t (&d)[N], __amdgpu_buffer_rs
   }
 }
 
-// DT: 0 = f16, 1 = bf16, 2 = int8 (i32 accumulate, quantised epilogue; forward only).  All
+// DT: 0 = f16, 1 = bf16, 2 = int8 (i32 accumulate, quantised epilogue; forward only), 3 = fp32
+// (v_mfma_f32_16x16x4_f32, exact fp32 at 1/16 of the 16-bit MFMA rate).  All
 // addressing is in BYTES: a step contracts one 128-byte piece of the rows (64 16-bit or 128
 // 8-bit reduction elements), a lane feeds 16 bytes per MFMA to either instruction family.
 // Kernel arguments: the 16 dwords every wave needs before its first load are separate scalar
@@ -603,12 +611,15 @@ __device__ __forceinline__ void unpack_gemm_args(GemmParams &p, const void *argA
 
 template <int COUT, int MB, int DT, bool BT>
 __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
-  constexpr bool BF16 = DT == 1, I8 = DT == 2;
-  constexpr int ES = I8 ? 1 : 2;                        // bytes per element
+  constexpr bool BF16 = DT == 1, I8 = DT == 2, F32 = DT == 3;
+  constexpr int ES = I8 ? 1 : (F32 ? 4 : 2);            // bytes per element
   static_assert(!(I8 && BT), "int8 is forward only");
   constexpr int NB = COUT / 16;
   constexpr int TM = 64 * MB;                           // rows per workgroup: 4 waves x MB x 16
-  constexpr int BROWS = BT ? 2 * ((COUT + 63) / 64) : (COUT + 31) / 32;
+  // 16-byte weight vectors staged per thread: [COUT][128 B] row-wise (forward), or the
+  // transposing read of dgrad (pairs of reduction rows x 8 channels for 16-bit, one reduction
+  // row x 4 channels for fp32)
+  constexpr int BROWS = !BT ? (COUT + 31) / 32 : (F32 ? (COUT + 31) / 32 : 2 * ((COUT + 63) / 64));
   // one-element arrays captured by the lambdas below defeat SROA in hipcc 7.2 (the whole
   // parameter block then lives in scratch): keep every register array at >= 2 elements
   constexpr int BA = BROWS < 2 ? 2 : BROWS;
@@ -676,11 +687,12 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   } else {
 #pragma unroll
     for (int j = 0; j < BROWS; ++j) {
-      const int d = 2 * r0 + (j & 1);                   // reduction row inside the chunk
-      const int n = (j >> 1) * 64 + slot * 8;
-      const uint32_t o = static_cast<uint32_t>(d) * static_cast<uint32_t>(p.strideD) * 2u + n * 2u;
+      // reduction row inside the chunk, first of the 16 / ES channels of this vector
+      const int d = F32 ? r0 : 2 * r0 + (j & 1);
+      const int n = F32 ? j * 32 + slot * 4 : (j >> 1) * 64 + slot * 8;
+      const uint32_t o = (static_cast<uint32_t>(d) * static_cast<uint32_t>(p.strideD) + n) * ES;
       boff[j] = n < COUT ? o : kOob;
-      boff_tail[j] = d * 2 < ctail ? 0u : kOob;
+      boff_tail[j] = d * ES < ctail ? 0u : kOob;
     }
   }
 
@@ -728,7 +740,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
     const int kb = p.b_reverse ? p.kv - 1 - k : k;
     uint32_t so = static_cast<uint32_t>(kb) * static_cast<uint32_t>(p.strideK) * ES;
     if constexpr (!BT) so += static_cast<uint32_t>(it.chunk) * kRowBytes;
-    else so += static_cast<uint32_t>(it.chunk) * kCK * static_cast<uint32_t>(p.strideD) * 2u;
+    else so += static_cast<uint32_t>(it.chunk) * (kRowBytes / ES) * static_cast<uint32_t>(p.strideD) * ES;
     const __amdgpu_buffer_rsrc_t r = make_rsrc(p.B, it.k >= 0 ? w_bytes : 0u);
 #pragma unroll
     for (int j = 0; j < BROWS; ++j)
@@ -741,6 +753,17 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
         const int n = r0 + 32 * j;
         if (COUT >= 32 * (j + 1) || n < COUT)    // compile-time true except for COUT == 16
           *reinterpret_cast<u32x4 *>(ldsB + swzB(n, slot)) = breg[j];
+      }
+    } else if constexpr (F32) {
+      // transpose: element (reduction row r0, channel n) lands in row n, byte column 4 * r0
+#pragma unroll
+      for (int j = 0; j < BROWS; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int n = j * 32 + slot * 4 + e;
+          if (COUT >= 32 * (j + 1) || n < COUT)
+            *reinterpret_cast<uint32_t *>(ldsB + swzB(n, r0 >> 2) + (r0 & 3) * 4) = breg[j][e];
+        }
       }
     } else {
       // transpose: the (d even, d odd) halves of channel n land in row n, reduction column 2*r0
@@ -904,20 +927,22 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   // ---- epilogue: CPL consecutive channels per lane, stored straight from registers; rows past
   // the end have an out-of-range offset and are dropped by the buffer unit.
   if constexpr (!I8) {
-    // bias/activation, fp32 -> 16 bit (packed converts)
-    const uint16_t *bias = static_cast<const uint16_t *>(p.bias);
-    const bool plain = bias == nullptr && p.act == SPX_ACT_NONE;   // uniform: training path
-    const __amdgpu_buffer_rsrc_t rO = make_rsrc(p.out, static_cast<uint32_t>(p.n_dst) * (COUT * 2u));
+    // bias/activation; fp32 -> 16 bit with packed converts, or fp32 as it is
+    const bool plain = p.bias == nullptr && p.act == SPX_ACT_NONE;   // uniform: training path
+    const __amdgpu_buffer_rsrc_t rO = make_rsrc(p.out, static_cast<uint32_t>(p.n_dst) * (COUT * ES));
     float bv[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; ++q) bv[q] = 0.f;
-    if (bias) {
+    if (p.bias) {
 #pragma unroll
-      for (int q = 0; q < CPL; ++q) bv[q] = to_float<BF16>(bias[lgrp * CPL + q]);
+      for (int q = 0; q < CPL; ++q) {
+        if constexpr (F32) bv[q] = static_cast<const float *>(p.bias)[lgrp * CPL + q];
+        else bv[q] = to_float<BF16>(static_cast<const uint16_t *>(p.bias)[lgrp * CPL + q]);
+      }
     }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
-      uint32_t d[CPL / 2];
+      uint32_t d[F32 ? CPL : CPL / 2];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
@@ -927,12 +952,17 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
             v0 = apply_act(v0 + bv[nb * 4 + 2 * h], p.act, p.act_alpha);
             v1 = apply_act(v1 + bv[nb * 4 + 2 * h + 1], p.act, p.act_alpha);
           }
-          d[nb * 2 + h] = pack2<BF16>(v0, v1);
+          if constexpr (F32) {
+            d[nb * 4 + 2 * h] = __builtin_bit_cast(uint32_t, v0);
+            d[nb * 4 + 2 * h + 1] = __builtin_bit_cast(uint32_t, v1);
+          } else {
+            d[nb * 2 + h] = pack2<BF16>(v0, v1);
+          }
         }
       }
       const uint32_t vo = grow[mb] < 0 ? kOob
-                                       : static_cast<uint32_t>(grow[mb]) * (COUT * 2u) + lgrp * (CPL * 2u);
-      store_dwords<CPL / 2>(d, rO, vo);
+                                       : static_cast<uint32_t>(grow[mb]) * (COUT * ES) + lgrp * (CPL * ES);
+      store_dwords<(F32 ? CPL : CPL / 2)>(d, rO, vo);
     }
   } else {
     // int8 inference epilogue (reference numerics: test/test_all_algo.py:272-287):
@@ -1634,6 +1664,114 @@ wgrad_tr_kernel(Wgrad2Params p) {
   wgrad_tr_body<BF16, 2>(p, blockIdx.x);
 }
 
+// fp32 wgrad on v_mfma_f32_16x16x4_f32 over the same balanced segments.  Each lane feeds ONE
+// element per operand, so the tiles are read from LDS as they lie ([pair][channel], row stride
+// 80 floats: the two rows a 32-lane ds_read_b32 group touches fall on disjoint bank halves) and
+// no transposition is needed.  64-pair chunks, one LDS stage, next chunk's rows in flight
+// during the MFMAs.
+constexpr int kW3J = 64;          // pairs per chunk
+constexpr int kW3Stride = 80;     // floats per LDS row
+
+__global__ void __launch_bounds__(kThreads)
+wgrad_f32_kernel(Wgrad2Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *sD = reinterpret_cast<float *>(smem);
+  float *sF = sD + kW3J * kW3Stride;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 15, lgrp = lane >> 4;
+  const int wk = wave >> 1, wc = wave & 1;
+  const int ntile = p.tiles_k * p.tiles_c;
+  const int w = blockIdx.x / ntile, tile = blockIdx.x - w * ntile;
+  const int kk0 = (tile / p.tiles_c) * kWT, c0 = (tile % p.tiles_c) * kWT;
+  const int32_t *__restrict__ rec = p.plan2 + plan2_wg(w);
+  const int32_t *__restrict__ segs = p.plan2 + plan2_seg(p.G, p.kv);
+  const int seg_lo = rec[0], nseg = rec[1];
+  const uint32_t rowD = static_cast<uint32_t>(p.K) * 4u, rowF = static_cast<uint32_t>(p.C) * 4u;
+  const __amdgpu_buffer_rsrc_t rD = make_rsrc(p.dout, static_cast<uint32_t>(p.n_out) * rowD);
+  const __amdgpu_buffer_rsrc_t rF = make_rsrc(p.feat, static_cast<uint32_t>(p.n_in) * rowF);
+  const uint32_t list_bytes = static_cast<uint32_t>(p.n_in) * 4u;
+  // load role: 16-byte slot `slot` (4 channels) of rows r0 + 16 q (q = 0..3) of both tiles
+  const int slot = tid & 15, r0 = tid >> 4;
+  const uint32_t dcol = kk0 + slot * 4 < p.K ? static_cast<uint32_t>(kk0 + slot * 4) * 4u : kOob;
+  const uint32_t fcol = c0 + slot * 4 < p.C ? static_cast<uint32_t>(c0 + slot * 4) * 4u : kOob;
+
+  for (int si = 0; si < nseg; ++si) {
+    int k, begin, end;
+    if (si == 0) {
+      k = rec[2];
+      begin = rec[3];
+      end = rec[4];
+    } else {
+      k = segs[3 * (seg_lo + si)];
+      begin = segs[3 * (seg_lo + si) + 1];
+      end = segs[3 * (seg_lo + si) + 2];
+    }
+    const bool identity = p.subm && k == p.kv / 2;
+    const __amdgpu_buffer_rsrc_t rIn =
+        make_rsrc(p.native + static_cast<size_t>(k) * p.n_in, list_bytes);
+    const __amdgpu_buffer_rsrc_t rOut =
+        make_rsrc(p.native + static_cast<size_t>(p.kv + k) * p.n_in, list_bytes);
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 dv[4], fv[4];
+    auto load_rows = [&](int base) __attribute__((always_inline)) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int j = base + r0 + 16 * q;
+        const bool ok = j < end;
+        uint32_t ii = static_cast<uint32_t>(j), oi = static_cast<uint32_t>(j);
+        if (!identity) {
+          const uint32_t vo = ok ? static_cast<uint32_t>(j) * 4u : kOob;
+          ii = __builtin_amdgcn_raw_buffer_load_b32(rIn, vo, 0, 0);
+          oi = __builtin_amdgcn_raw_buffer_load_b32(rOut, vo, 0, 0);
+        }
+        dv[q] = __builtin_amdgcn_raw_buffer_load_b128(rD, ok ? (oi * rowD + dcol) | (dcol & kOob) : kOob, 0, 0);
+        fv[q] = __builtin_amdgcn_raw_buffer_load_b128(rF, ok ? (ii * rowF + fcol) | (fcol & kOob) : kOob, 0, 0);
+      }
+    };
+    load_rows(begin);
+    for (int base = begin; base < end; base += kW3J) {
+      __syncthreads();   // the previous chunk's fragment reads are done
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        *reinterpret_cast<u32x4 *>(sD + (r0 + 16 * q) * kW3Stride + slot * 4) = dv[q];
+        *reinterpret_cast<u32x4 *>(sF + (r0 + 16 * q) * kW3Stride + slot * 4) = fv[q];
+      }
+      __syncthreads();
+      load_rows(base + kW3J);          // in flight during the MFMAs (out of range past the end)
+#pragma unroll 4
+      for (int ks = 0; ks < kW3J / 4; ++ks) {
+        const int row = (ks * 4 + lgrp) * kW3Stride;
+        float fa[2], fb[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) fa[a] = sD[row + wk * 32 + a * 16 + lrow];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) fb[b] = sF[row + wc * 32 + b * 16 + lrow];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+      }
+    }
+    float *dst = p.partial + (static_cast<size_t>(seg_lo + si) * ntile + tile) * (kWT * kWT);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int kk = wk * 32 + a * 16 + lgrp * 4 + e;
+          const int c = wc * 32 + b * 16 + lrow;
+          dst[kk * kWT + c] = acc[a][b][e];
+        }
+    __syncthreads();
+  }
+}
+
 // Backward of one layer in ONE launch: workgroups [0, n_dgrad) run the dgrad tiles, the rest
 // the wgrad ranges.  The two halves only share read-only inputs; at ~100k voxels each of them
 // is latency-bound with idle issue slots and idle HBM bandwidth, so running them side by side
@@ -1752,8 +1890,8 @@ bias_act_kernel(T *__restrict__ out, const T *__restrict__ bias, long long total
 int elem_bytes(int dtype) { return dtype == SPX_F32 ? 4 : (dtype == SPX_I8 ? 1 : 2); }
 
 bool mfma_ok(int dtype, int cin, int cout, int kv, const uint32_t *mask) {
-  if (dtype != SPX_F16 && dtype != SPX_BF16) return false;
-  if (cin % 8 != 0) return false;
+  if (dtype != SPX_F16 && dtype != SPX_BF16 && dtype != SPX_F32) return false;
+  if (cin % (dtype == SPX_F32 ? 4 : 8) != 0) return false;     // 16-byte lane pieces
   if (kv > 32) return false;
   (void)mask;
   return cout == 16 || cout == 32 || cout == 64 || cout == 128 || cout == 256;
@@ -1785,9 +1923,24 @@ int dispatch_gather_gemm(const GemmParams &p, hipStream_t s) {
   return -1;
 }
 
+// fp32 tensors: the same kernel on v_mfma_f32_16x16x4_f32 (128-row tiles; no v3 fallback)
+int dispatch_gather_gemm_f32(const GemmParams &p, hipStream_t s) {
+  switch (p.COUT) {
+    case 16: return launch_v4<16, 2, 3>(p, s);
+    case 32: return launch_v4<32, 2, 3>(p, s);
+    case 64: return launch_v4<64, 2, 3>(p, s);
+    case 128: return launch_v4<128, 2, 3>(p, s);
+    case 256: return launch_v4<256, 1, 3>(p, s);
+  }
+  return -1;
+}
+
 int run_gather_gemm(const GemmParams &p, int dtype, hipStream_t s) {
   if (p.n_dst == 0) return 0;
-  if (mfma_ok(dtype, p.CIN, p.COUT, p.kv, p.mask))
+  static const int f32_mfma = env_int("SPX_F32_MFMA", 1);         // tuning knob (A/B runs)
+  if (dtype == SPX_F32 && f32_mfma && mfma_ok(dtype, p.CIN, p.COUT, p.kv, p.mask) && v4_ok(p, 4, 4))
+    return dispatch_gather_gemm_f32(p, s);
+  if (dtype != SPX_F32 && mfma_ok(dtype, p.CIN, p.COUT, p.kv, p.mask))
     return dtype == SPX_BF16 ? dispatch_gather_gemm<true>(p, s) : dispatch_gather_gemm<false>(p, s);
   const long long total = static_cast<long long>(p.n_dst) * p.COUT;
   const dim3 grid(static_cast<unsigned>((total + kThreads - 1) / kThreads));
@@ -2085,7 +2238,12 @@ int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t 
   const bool small_offsets = static_cast<unsigned long long>(n_out) * K * 2ull < 0x7fff0000ull &&
                              static_cast<unsigned long long>(n_in) * C * 2ull < 0x7fff0000ull &&
                              static_cast<unsigned long long>(n_in) * 4ull < 0x7fff0000ull;
-  if (mfma && wgrad_version >= 2 && small_offsets) {
+  static const int f32_mfma = env_int("SPX_F32_MFMA", 1);         // tuning knob (A/B runs)
+  const bool f32_path = dtype == SPX_F32 && f32_mfma && C % 4 == 0 && K % 4 == 0 &&
+                        static_cast<unsigned long long>(n_out) * K * 4ull < 0x7fff0000ull &&
+                        static_cast<unsigned long long>(n_in) * C * 4ull < 0x7fff0000ull &&
+                        static_cast<unsigned long long>(n_in) * 4ull < 0x7fff0000ull;
+  if (f32_path || (mfma && wgrad_version >= 2 && small_offsets)) {
     Wgrad2Params q{};
     q.feat = feat;
     q.dout = dout;
@@ -2104,12 +2262,17 @@ int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t 
     q.G = wgrad_groups(n_in);
     const dim3 grid(static_cast<unsigned>(q.G) * ntile);
     const size_t lds = 2 * 2 * kW2J * 128;    // two stages x two operand tiles
-    if (dtype == SPX_F16)
+    if (dtype == SPX_F32)
+      hipLaunchKernelGGL(wgrad_f32_kernel, grid, dim3(kThreads), 2 * kW3J * kW3Stride * sizeof(float), s, q);
+    else if (dtype == SPX_F16)
       hipLaunchKernelGGL(wgrad_tr_kernel<false>, grid, dim3(kThreads), lds, s, q);
     else
       hipLaunchKernelGGL(wgrad_tr_kernel<true>, grid, dim3(kThreads), lds, s, q);
     const dim3 rgrid2(kv * 256 < 512 ? kv * 256 : 512, ntile);   // block-stride over the work list
-    if (dtype == SPX_F16)
+    if (dtype == SPX_F32)
+      hipLaunchKernelGGL(wgrad_reduce2_kernel<float>, rgrid2, dim3(kRedThreads), 0, s, q,
+                         static_cast<float *>(dw));
+    else if (dtype == SPX_F16)
       hipLaunchKernelGGL(wgrad_reduce2_kernel<h16>, rgrid2, dim3(kRedThreads), 0, s, q,
                          static_cast<h16 *>(dw));
     else
