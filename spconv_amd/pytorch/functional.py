@@ -61,7 +61,7 @@ class _NativeConvBase(Function):
         try:
             din, dw = ops.indice_conv_backward(features, filters, grad_output, indice_pairs,
                                                indice_pair_num, cls._inverse, cls._subm,
-                                               algo=ctx.algo)
+                                               algo=ctx.algo, need_din=ctx.needs_input_grad[0])
         except Exception:
             _report("indice_conv_backward", feat=features.shape, w=filters.shape,
                     pair=indice_pairs.shape, do=grad_output.shape)
@@ -170,7 +170,8 @@ class SparseImplicitGemmFunction(Function):
                 features, filters, grad_output, pair_fwd, pair_bwd, ctx.pair_mask_fwd_splits,
                 ctx.pair_mask_bwd_splits, ctx.mask_argsort_fwd_splits,
                 ctx.mask_argsort_bwd_splits, mask_output_fwd=ctx.mask_out, masks=ctx.masks,
-                mask_width=ctx.mask_width, is_subm=ctx.is_subm, fp32_accum=ctx.fp32_accum)
+                mask_width=ctx.mask_width, is_subm=ctx.is_subm, fp32_accum=ctx.fp32_accum,
+                need_din=ctx.needs_input_grad[0])
         except Exception:
             _report("implicit_gemm_backward", feat=features.shape, w=filters.shape,
                     pair=pair_fwd.shape, issubm=ctx.is_subm, do=grad_output.shape)

@@ -298,6 +298,33 @@ def igemm_fwd_int8(features: torch.Tensor, filters: torch.Tensor, pair: torch.Te
     return out
 
 
+_MFMA_COUT = (16, 32, 64, 128, 256)
+
+
+def _lane_mult(dtype: torch.dtype) -> int:
+    """Channels per 16-byte MFMA lane piece: reduction lengths must be a multiple of this."""
+    return 4 if dtype == torch.float32 else 8
+
+
+def _round_cout(c: int) -> int:
+    """Smallest output width the MFMA kernels are instantiated for (0: none, generic kernel)."""
+    for v in _MFMA_COUT:
+        if c <= v:
+            return v
+    return 0
+
+
+def _pad_last(t: torch.Tensor, to: int) -> torch.Tensor:
+    return t if t.shape[-1] == to else torch.nn.functional.pad(t, (0, to - t.shape[-1]))
+
+
+def _pad_first(t: torch.Tensor, to: int) -> torch.Tensor:
+    if t.shape[0] == to:
+        return t
+    pad = [0, 0] * (t.ndim - 1) + [0, to - t.shape[0]]
+    return torch.nn.functional.pad(t, pad)
+
+
 def igemm_fwd(features: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
               mask: Optional[torch.Tensor], argsort: Optional[torch.Tensor], n_out: int,
               identity_k: int = -1, bias: Optional[torch.Tensor] = None,
@@ -305,11 +332,24 @@ def igemm_fwd(features: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
     """out[o] = act(bias + sum_k feat[pair[k][o]] @ W[:, k, :].T); filters KRSC."""
     _check_feat(features, filters)
     L = _lib.load()
+    K0, C0 = filters.shape[0], filters.shape[-1]
+    assert features.shape[1] == C0, "channel size mismatch"
+    kv = filters.numel() // (K0 * C0)
+    # Shapes the MFMA kernels are not instantiated for (a backbone's first layer has 3-5 input
+    # channels; widths like 48 or 96) are zero-padded to the next supported shape instead of
+    # falling to the one-thread-per-output generic kernel (two orders of magnitude slower): the
+    # extra columns cost a few bytes per row and contribute exact zeros.
+    C = -(-C0 // _lane_mult(features.dtype)) * _lane_mult(features.dtype)
+    K = _round_cout(K0) if kv <= 32 else K0
+    if K and (C != C0 or K != K0):
+        features = _pad_last(features, C)
+        filters = _pad_first(_pad_last(filters, C), K)
+        if bias is not None:
+            bias = _pad_last(bias, K)
+    else:
+        C, K = C0, K0
     features = features.contiguous()
     filters = filters.contiguous()
-    K, C = filters.shape[0], filters.shape[-1]
-    kv = filters.numel() // (K * C)
-    assert features.shape[1] == C, "channel size mismatch"
     out = torch.empty((n_out, K), dtype=features.dtype, device=features.device)
     if bias is not None:
         bias = bias.to(features.dtype).contiguous()
@@ -317,7 +357,7 @@ def igemm_fwd(features: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
                                _ptr(pair), _ptr(mask), _ptr(argsort), features.shape[0], n_out,
                                C, K, kv, _dtype_code(features), identity_k, _ptr(bias),
                                int(act_type), float(act_alpha), _stream(features)))
-    return out
+    return out if K == K0 else out[:, :K0].contiguous()
 
 
 def igemm_dgrad(out_bp: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
@@ -326,17 +366,25 @@ def igemm_dgrad(out_bp: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
     """din[i] = sum_k dout[pair[k][i]] @ W[:, k, :] (SubM: pass the forward table, subm=True)."""
     _check_feat(out_bp, filters)
     L = _lib.load()
+    K0, C0 = filters.shape[0], filters.shape[-1]
+    kv = filters.numel() // (K0 * C0)
+    # same padding rule as igemm_fwd: here K is the reduction length and C the output width
+    K = -(-K0 // _lane_mult(out_bp.dtype)) * _lane_mult(out_bp.dtype)
+    C = _round_cout(C0) if kv <= 32 else C0
+    if C and (C != C0 or K != K0):
+        out_bp = _pad_last(out_bp, K)
+        filters = _pad_first(_pad_last(filters, C), K)
+    else:
+        C, K = C0, K0
     out_bp = out_bp.contiguous()
     filters = filters.contiguous()
-    K, C = filters.shape[0], filters.shape[-1]
-    kv = filters.numel() // (K * C)
     din = torch.empty((n_in, C), dtype=out_bp.dtype, device=out_bp.device)
     code = _dtype_code(out_bp)
     ws = _ws(L.spx_igemm_dgrad_ws_bytes(C, K, kv, code), out_bp.device)
     _lib.check(L.spx_igemm_dgrad(out_bp.data_ptr(), filters.data_ptr(), din.data_ptr(), _ptr(pair),
                                  _ptr(mask), _ptr(argsort), out_bp.shape[0], n_in, C, K, kv, code,
                                  int(subm), ws.data_ptr(), ws.numel(), _stream(out_bp)))
-    return din
+    return din if C == C0 else din[:, :C0].contiguous()
 
 
 def wgrad_plan(num_per_loc: torch.Tensor, n_in: int, kv: int, subm: bool) -> torch.Tensor:
@@ -355,26 +403,35 @@ def igemm_wgrad(features: torch.Tensor, out_bp: torch.Tensor, filters_shape, nat
     """dW[:, k, :] = sum_j dout[native[1][k][j]].T (x) feat[native[0][k][j]]."""
     _require_gpu(features, "features")
     L = _lib.load()
-    features = features.contiguous()
-    out_bp = out_bp.contiguous()
-    K, C = filters_shape[0], filters_shape[-1]
-    kv = int(np.prod(filters_shape)) // (K * C)
+    K0, C0 = filters_shape[0], filters_shape[-1]
+    kv = int(np.prod(filters_shape)) // (K0 * C0)
+    m = _lane_mult(features.dtype)
+    C, K = -(-C0 // m) * m, -(-K0 // m) * m          # the MFMA wgrad needs whole lane pieces
+    features = _pad_last(features, C).contiguous()
+    out_bp = _pad_last(out_bp, K).contiguous()
     n_in = native.shape[2]
-    dw = torch.empty(tuple(filters_shape), dtype=features.dtype, device=features.device)
+    shape = (K,) + tuple(filters_shape[1:-1]) + (C,)
+    dw = torch.empty(shape, dtype=features.dtype, device=features.device)
     ws = _ws(L.spx_igemm_wgrad_ws_bytes(n_in, C, K, kv), features.device)
     _lib.check(L.spx_igemm_wgrad(features.data_ptr(), out_bp.data_ptr(), dw.data_ptr(),
                                  native.data_ptr(), num_per_loc.data_ptr(), _ptr(plan), n_in,
                                  out_bp.shape[0], C, K, kv, _dtype_code(features), int(subm),
                                  ws.data_ptr(), ws.numel(), _stream(features)))
-    return dw
+    return dw if (C == C0 and K == K0) else dw[:K0, ..., :C0].contiguous()
 
 
 def igemm_bwd(features: torch.Tensor, out_bp: torch.Tensor, filters: torch.Tensor,
               table: torch.Tensor, mask: Optional[torch.Tensor], argsort: Optional[torch.Tensor],
               native: torch.Tensor, num_per_loc: torch.Tensor, subm: bool,
-              plan: Optional[torch.Tensor] = None):
-    """(din, dW) of one layer from one launch (+ the wgrad second stage)."""
+              plan: Optional[torch.Tensor] = None, need_din: bool = True):
+    """(din, dW) of one layer from one launch (+ the wgrad second stage).  need_din=False (the
+    input does not require grad: a network's first layer) computes dW only and returns None."""
     _check_feat(out_bp, filters)
+    K0, C0 = filters.shape[0], filters.shape[-1]
+    m = _lane_mult(out_bp.dtype)
+    if not need_din or K0 % m or C0 not in _MFMA_COUT:
+        din = igemm_dgrad(out_bp, filters, table, mask, argsort, features.shape[0], subm) if need_din else None
+        return din, igemm_wgrad(features, out_bp, filters.shape, native, num_per_loc, subm, plan)
     L = _lib.load()
     features = features.contiguous()
     out_bp = out_bp.contiguous()
@@ -487,7 +544,7 @@ def _backward_pair(dgrad_fn, wgrad_fn, ref: torch.Tensor):
 def indice_conv_backward(features: torch.Tensor, filters: torch.Tensor, out_bp: torch.Tensor,
                          indice_pairs: torch.Tensor, indice_pair_num: torch.Tensor,
                          inverse: bool = False, subm: bool = False,
-                         algo: ConvAlgo = ConvAlgo.Native, timer=None):
+                         algo: ConvAlgo = ConvAlgo.Native, timer=None, need_din: bool = True):
     """ConvAlgo.Native backward (ops.py:1103-1447): returns (din, dfilters)."""
     _check_feat(features, filters)
     rb: Optional[Rulebook] = rulebook_of(indice_pairs)
@@ -512,9 +569,9 @@ def indice_conv_backward(features: torch.Tensor, filters: torch.Tensor, out_bp: 
         native = rb.native_swapped() if rb is not None else torch.stack(
             [indice_pairs[1], indice_pairs[0]]).contiguous()
     plan = _plan_of(rb)
-    if native.shape[2] == n_in and not BWD_OVERLAP:
+    if (native.shape[2] == n_in and not BWD_OVERLAP) or not need_din:
         return igemm_bwd(features, out_bp, filters, table, mask, argsort, native, indice_pair_num,
-                         subm, plan)
+                         subm, plan, need_din)
     return _backward_pair(
         lambda: igemm_dgrad(out_bp, filters, table, mask, argsort, n_in, subm),
         lambda: igemm_wgrad(features, out_bp, filters.shape, native, indice_pair_num, subm, plan),
@@ -563,7 +620,7 @@ def implicit_gemm_backward(features: torch.Tensor, filters: torch.Tensor, out_bp
                            mask_argsort_bwd_splits: List[torch.Tensor],
                            mask_output_fwd: Optional[torch.Tensor], masks: List[np.ndarray],
                            mask_width: int, is_subm: bool, timer=None,
-                           fp32_accum: Optional[bool] = None):
+                           fp32_accum: Optional[bool] = None, need_din: bool = True):
     """Masked implicit GEMM backward (ops.py:1667-1896): returns (din, dfilters)."""
     rb: Optional[Rulebook] = rulebook_of(pair_fwd)
     n_in = features.shape[0]
@@ -578,8 +635,9 @@ def implicit_gemm_backward(features: torch.Tensor, filters: torch.Tensor, out_bp
     else:
         table, mask = pair_bwd, pair_mask_bwd_splits[0]
         argsort = rb.argsort_bwd if rb is not None else None
-    if native.shape[2] == n_in and not BWD_OVERLAP:
-        return igemm_bwd(features, out_bp, filters, table, mask, argsort, native, num, is_subm, plan)
+    if (native.shape[2] == n_in and not BWD_OVERLAP) or not need_din:
+        return igemm_bwd(features, out_bp, filters, table, mask, argsort, native, num, is_subm, plan,
+                         need_din)
     return _backward_pair(
         lambda: igemm_dgrad(out_bp, filters, table, mask, argsort, n_in, is_subm),
         lambda: igemm_wgrad(features, out_bp, filters.shape, native, num, is_subm, plan),
