@@ -261,6 +261,34 @@ int spx_point2voxel(const float *points, int n, int nfeat, int ndim, const float
                     int32_t *num_per_voxel, long long *pc_voxel_id, int *n_voxels_h, void *ws,
                     size_t ws_bytes, spx_stream_t stream);
 
+/* ---------------------------------------------------------------- hash table */
+
+/* Fixed-size hash table over caller-owned storage.  Replaces
+ * spconv/csrc/hash/core.py HashTable as driven by spconv/pytorch/hash.py:29-170.
+ *   table_keys [capacity] (4- or 8-byte integers, all-ones = empty; initialise with
+ *   spx_hash_clear), table_vals [capacity] (4- or 8-byte items, copied bit for bit)
+ *   insert: values may be NULL (key only); query: is_empty[i] = 1 where the key is absent;
+ *   insert_exist: writes values only where the key is already present;
+ *   assign_arange: every present key gets its rank in SLOT order as value, *count_out (an integer
+ *   of the key width) receives the number of keys; items: entries in the same order.
+ * ws >= spx_hash_ws_bytes(capacity) for assign_arange / items. */
+size_t spx_hash_ws_bytes(int capacity);
+int spx_hash_clear(void *table_keys, int capacity, int key_bytes, spx_stream_t stream);
+int spx_hash_insert(void *table_keys, void *table_vals, int capacity, int key_bytes, int val_bytes,
+                    const void *keys, const void *values, int n, spx_stream_t stream);
+int spx_hash_query(void *table_keys, void *table_vals, int capacity, int key_bytes, int val_bytes,
+                   const void *keys, void *values_out, unsigned char *is_empty, int n,
+                   spx_stream_t stream);
+int spx_hash_insert_exist(void *table_keys, void *table_vals, int capacity, int key_bytes,
+                          int val_bytes, const void *keys, const void *values,
+                          unsigned char *is_empty, int n, spx_stream_t stream);
+int spx_hash_assign_arange(void *table_keys, void *table_vals, int capacity, int key_bytes,
+                           int val_bytes, void *count_out, void *ws, size_t ws_bytes,
+                           spx_stream_t stream);
+int spx_hash_items(void *table_keys, void *table_vals, int capacity, int key_bytes, int val_bytes,
+                   void *keys_out, void *vals_out, int max_out, void *count_out, void *ws,
+                   size_t ws_bytes, spx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

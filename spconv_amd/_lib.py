@@ -65,6 +65,16 @@ SIGNATURES = {
                                        ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                                        c_int_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        vp, vp, vp, vp, c_int_p, vp, ctypes.c_size_t, vp]),
+    "spx_hash_ws_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "spx_hash_clear": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp]),
+    "spx_hash_insert": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int, vp]),
+    "spx_hash_query": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_int, vp]),
+    "spx_hash_insert_exist": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp,
+                                             ctypes.c_int, vp]),
+    "spx_hash_assign_arange": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp,
+                                              ctypes.c_size_t, vp]),
+    "spx_hash_items": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int, vp,
+                                      vp, ctypes.c_size_t, vp]),
     "spx_bias_act_inplace": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_float, vp]),
 }

@@ -799,6 +799,138 @@ P2VWs carve_p2v_ws(void *ws, int n, int max_voxels) {
   return w;
 }
 
+// ------------------------------------------------------------- user hash table
+// Fixed-size open-addressing table over caller-owned key / value arrays (SURVEY.md section 8f
+// row 4; replaces spconv/csrc/hash/core.py HashTable as used by spconv/pytorch/hash.py).  Keys
+// are 32- or 64-bit integers (all-ones = empty), values are opaque 4- or 8-byte items.
+// assign_arange / items walk the table in SLOT order (count -> scan -> assign), so their result
+// is a pure function of the set of keys -- the reference's GPU table numbers entries in atomic
+// arrival order.
+template <typename K> struct UKey;
+template <> struct UKey<uint32_t> { static __device__ __forceinline__ uint32_t empty() { return 0xffffffffu; } };
+template <> struct UKey<unsigned long long> {
+  static __device__ __forceinline__ unsigned long long empty() { return ~0ull; }
+};
+
+template <typename K>
+__device__ __forceinline__ uint32_t user_hash(K k) {
+  return hash_key(static_cast<hkey_t>(k));
+}
+
+template <typename K>
+__device__ __forceinline__ int user_find(const K *keys, int cap, K key, bool insert) {
+  uint32_t slot = user_hash(key) % static_cast<uint32_t>(cap);
+  for (int probe = 0; probe < cap; ++probe) {
+    if (insert) {
+      const K prev = atomicCAS(const_cast<K *>(&keys[slot]), UKey<K>::empty(), key);
+      if (prev == UKey<K>::empty() || prev == key) return static_cast<int>(slot);
+    } else {
+      const K cur = keys[slot];
+      if (cur == key) return static_cast<int>(slot);
+      if (cur == UKey<K>::empty()) return -1;
+    }
+    slot = slot + 1 == static_cast<uint32_t>(cap) ? 0u : slot + 1;
+  }
+  return -1;
+}
+
+// op 0: insert (values optional), 1: query, 2: insert only where the key exists
+template <typename K, typename V>
+__global__ void __launch_bounds__(kBlock)
+user_hash_kernel(K *__restrict__ tkeys, V *__restrict__ tvals, int cap, const K *__restrict__ keys,
+                 V *__restrict__ values, unsigned char *__restrict__ is_empty, int n, int op) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const K key = keys[i];
+  if (op == 0) {
+    const int slot = user_find(tkeys, cap, key, true);
+    if (slot >= 0 && values) tvals[slot] = values[i];
+  } else {
+    const int slot = user_find(tkeys, cap, key, false);
+    if (is_empty) is_empty[i] = slot < 0 ? 1 : 0;
+    if (slot >= 0) {
+      if (op == 1) values[i] = tvals[slot];
+      else tvals[slot] = values[i];
+    }
+  }
+}
+
+template <typename K>
+__global__ void __launch_bounds__(kBlock)
+user_count_kernel(const K *__restrict__ tkeys, int cap, int32_t *__restrict__ blockcount) {
+  __shared__ int lds_wave[kBlock / 64];
+  const int begin = blockIdx.x * kItems;
+  int cnt = 0;
+#pragma unroll
+  for (int it = 0; it < kItems / kBlock; ++it) {
+    const int e = begin + it * kBlock + threadIdx.x;
+    cnt += __popcll(__ballot(e < cap && tkeys[e] != UKey<K>::empty()));
+  }
+  if ((threadIdx.x & 63) == 0) lds_wave[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int sum = 0;
+    for (int w = 0; w < kBlock / 64; ++w) sum += lds_wave[w];
+    blockcount[blockIdx.x] = sum;
+  }
+}
+
+// mode 0: tvals[slot] = rank (assign_arange); mode 1: (keys_out, vals_out)[rank] = entry (items)
+template <typename K, typename V>
+__global__ void __launch_bounds__(kBlock)
+user_walk_kernel(const K *__restrict__ tkeys, V *__restrict__ tvals, int cap,
+                 const int32_t *__restrict__ blockoff, int mode, K *__restrict__ keys_out,
+                 V *__restrict__ vals_out, int max_out) {
+  __shared__ int lds_wave[kBlock / 64];
+  const int begin = blockIdx.x * kItems;
+  int running = blockoff[blockIdx.x];
+  for (int it = 0; it < kItems / kBlock; ++it) {
+    const int e = begin + it * kBlock + threadIdx.x;
+    const bool used = e < cap && tkeys[e] != UKey<K>::empty();
+    int total;
+    const int rank = block_rank(used, total, lds_wave);
+    if (used) {
+      const int r = running + rank;
+      if (mode == 0) {
+        tvals[e] = static_cast<V>(r);
+      } else if (r < max_out) {
+        keys_out[r] = tkeys[e];
+        vals_out[r] = tvals[e];
+      }
+    }
+    running += total;
+  }
+}
+
+template <typename T>
+__global__ void user_store_count_kernel(const int32_t *total, T *count_out) { *count_out = static_cast<T>(*total); }
+
+template <typename K, typename V>
+int user_hash_dispatch2(int what, void *tkeys, void *tvals, int cap, const void *keys, void *values,
+                        unsigned char *is_empty, int n, void *keys_out, void *vals_out, int max_out,
+                        void *count_out, void *ws, hipStream_t s) {
+  K *tk = static_cast<K *>(tkeys);
+  V *tv = static_cast<V *>(tvals);
+  if (what <= 2) {
+    if (n > 0)
+      hipLaunchKernelGGL((user_hash_kernel<K, V>), dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, tk, tv, cap,
+                         static_cast<const K *>(keys), static_cast<V *>(values), is_empty, n, what);
+  } else {
+    const int nblk = div_up(cap, kItems);
+    Carver cv(ws);
+    int32_t *blockcount = cv.take<int32_t>(nblk);
+    int32_t *blockoff = cv.take<int32_t>(nblk);
+    int32_t *total = cv.take<int32_t>(1);
+    hipLaunchKernelGGL((user_count_kernel<K>), dim3(nblk), dim3(kBlock), 0, s, tk, cap, blockcount);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kBlock), 0, s, blockcount, blockoff, nblk, total);
+    hipLaunchKernelGGL((user_walk_kernel<K, V>), dim3(nblk), dim3(kBlock), 0, s, tk, tv, cap, blockoff,
+                       what == 3 ? 0 : 1, static_cast<K *>(keys_out), static_cast<V *>(vals_out), max_out);
+    if (count_out) hipLaunchKernelGGL((user_store_count_kernel<K>), dim3(1), dim3(1), 0, s, total, static_cast<K *>(count_out));
+  }
+  SPX_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace
 }  // namespace spx
 
@@ -1144,6 +1276,70 @@ int spx_point2voxel(const float *points, int n, int nfeat, int ndim, const float
   SPX_HIP(hipStreamSynchronize(s));
   *n_voxels_h = host_n;
   return 0;
+}
+
+/* what: 0 insert, 1 query, 2 insert_exist_keys, 3 assign_arange, 4 items */
+static int user_hash_call(int what, void *tkeys, void *tvals, int cap, int key_bytes, int val_bytes,
+                          const void *keys, void *values, unsigned char *is_empty, int n, void *keys_out,
+                          void *vals_out, int max_out, void *count_out, void *ws, size_t ws_bytes,
+                          spx_stream_t stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  SPX_CHECK(tkeys && tvals && cap > 0, "hash table storage required");
+  SPX_CHECK((key_bytes == 4 || key_bytes == 8) && (val_bytes == 4 || val_bytes == 8),
+            "keys and values must be 4 or 8 bytes wide");
+  if (what >= 3) SPX_CHECK(ws && ws_bytes >= spx_hash_ws_bytes(cap), "workspace too small");
+#define SPX_UH(KT, VT) \
+  return user_hash_dispatch2<KT, VT>(what, tkeys, tvals, cap, keys, values, is_empty, n, keys_out, vals_out, \
+                                     max_out, count_out, ws, s)
+  if (key_bytes == 4 && val_bytes == 4) SPX_UH(uint32_t, uint32_t);
+  if (key_bytes == 4 && val_bytes == 8) SPX_UH(uint32_t, unsigned long long);
+  if (key_bytes == 8 && val_bytes == 4) SPX_UH(unsigned long long, uint32_t);
+  SPX_UH(unsigned long long, unsigned long long);
+#undef SPX_UH
+}
+
+size_t spx_hash_ws_bytes(int capacity) {
+  const int nblk = div_up(capacity > 0 ? capacity : 1, kItems);
+  return 2 * align_up(static_cast<size_t>(nblk) * sizeof(int32_t), 256) + 512;
+}
+
+int spx_hash_clear(void *table_keys, int capacity, int key_bytes, spx_stream_t stream) {
+  SPX_CHECK(table_keys && capacity > 0 && (key_bytes == 4 || key_bytes == 8), "bad hash table");
+  SPX_HIP(hipMemsetAsync(table_keys, 0xFF, static_cast<size_t>(capacity) * key_bytes,
+                         static_cast<hipStream_t>(stream)));
+  return 0;
+}
+
+int spx_hash_insert(void *table_keys, void *table_vals, int capacity, int key_bytes, int val_bytes,
+                    const void *keys, const void *values, int n, spx_stream_t stream) {
+  return user_hash_call(0, table_keys, table_vals, capacity, key_bytes, val_bytes, keys,
+                        const_cast<void *>(values), nullptr, n, nullptr, nullptr, 0, nullptr, nullptr, 0, stream);
+}
+
+int spx_hash_query(void *table_keys, void *table_vals, int capacity, int key_bytes, int val_bytes,
+                   const void *keys, void *values_out, unsigned char *is_empty, int n, spx_stream_t stream) {
+  return user_hash_call(1, table_keys, table_vals, capacity, key_bytes, val_bytes, keys, values_out, is_empty,
+                        n, nullptr, nullptr, 0, nullptr, nullptr, 0, stream);
+}
+
+int spx_hash_insert_exist(void *table_keys, void *table_vals, int capacity, int key_bytes, int val_bytes,
+                          const void *keys, const void *values, unsigned char *is_empty, int n,
+                          spx_stream_t stream) {
+  return user_hash_call(2, table_keys, table_vals, capacity, key_bytes, val_bytes, keys,
+                        const_cast<void *>(values), is_empty, n, nullptr, nullptr, 0, nullptr, nullptr, 0, stream);
+}
+
+int spx_hash_assign_arange(void *table_keys, void *table_vals, int capacity, int key_bytes, int val_bytes,
+                           void *count_out, void *ws, size_t ws_bytes, spx_stream_t stream) {
+  return user_hash_call(3, table_keys, table_vals, capacity, key_bytes, val_bytes, nullptr, nullptr, nullptr, 0,
+                        nullptr, nullptr, 0, count_out, ws, ws_bytes, stream);
+}
+
+int spx_hash_items(void *table_keys, void *table_vals, int capacity, int key_bytes, int val_bytes,
+                   void *keys_out, void *vals_out, int max_out, void *count_out, void *ws, size_t ws_bytes,
+                   spx_stream_t stream) {
+  return user_hash_call(4, table_keys, table_vals, capacity, key_bytes, val_bytes, nullptr, nullptr, nullptr, 0,
+                        keys_out, vals_out, max_out, count_out, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -1,6 +1,6 @@
 """``import spconv_amd.pytorch as spconv`` -- the reference's ``spconv.pytorch`` namespace
 (``spconv/pytorch/__init__.py:1-41``) for the convolution hot path."""
-from spconv_amd.pytorch import conv, core, functional, modules, ops, pool
+from spconv_amd.pytorch import conv, core, functional, hash, modules, ops, pool, utils
 from spconv_amd.pytorch.conv import (SparseConv1d, SparseConv2d, SparseConv3d, SparseConv4d,
                                      SparseConvolution, SparseConvTranspose1d,
                                      SparseConvTranspose2d, SparseConvTranspose3d,

@@ -252,3 +252,89 @@ indice_subm_conv = SubMConvFunction.apply
 indice_maxpool = SparseMaxPoolFunction.apply
 indice_maxpool_implicit_gemm = SparseMaxPoolImplicitGemmFunction.apply
 indice_avgpool_implicit_gemm = SparseAvgPoolImplicitGemmFunction.apply
+
+
+# ------------------------------------------------------------------ sparse add
+_MAX_INT32 = 2147483647
+
+
+def _indice_to_scalar(indices: torch.Tensor, shape: List[int]) -> torch.Tensor:
+    """Row-major linear index of (batch, *coords) rows (reference functional.py:430-436)."""
+    assert indices.shape[1] == len(shape)
+    out = torch.zeros_like(indices[:, 0])
+    for d, extent in enumerate(shape):
+        out = out * extent + indices[:, d]
+    return out.contiguous()
+
+
+def _like_first(first, features, indices, indice_dict=None):
+    from spconv_amd.pytorch.core import SparseConvTensor
+    res = SparseConvTensor(features, indices, first.spatial_shape, first.batch_size,
+                           benchmark=first.benchmark)
+    if indice_dict is not None:
+        res.indice_dict = indice_dict
+    res.benchmark_record = first.benchmark_record
+    res._timer = first._timer
+    res.thrust_allocator = first.thrust_allocator
+    return res
+
+
+def sparse_add_hash_based(*tens):
+    """Sum of sparse tensors with different coordinate sets (reference functional.py:439-499):
+    the union of the coordinates is numbered through a hash table.  indice_dict is dropped unless
+    one operand already holds every output coordinate."""
+    from spconv_amd.pytorch.hash import HashTable
+    first = tens[0]
+    for ten in tens:
+        assert ten.spatial_shape == first.spatial_shape
+        assert ten.batch_size == first.batch_size
+        assert ten.features.shape[1] == first.features.shape[1]
+    sizes = [t.features.shape[0] for t in tens]
+    biggest = max(range(len(tens)), key=lambda i: sizes[i])
+    shape = [first.batch_size, *first.spatial_shape]
+    big = int(np.prod(shape)) >= _MAX_INT32
+    k_type = torch.int64 if big else torch.int32
+    table = HashTable(first.features.device, k_type, torch.int32, max(2 * sum(sizes), 2))
+    scalars = []
+    for ten in tens:
+        scalar = _indice_to_scalar(ten.indices.long() if big else ten.indices, shape)
+        scalars.append(scalar)
+        table.insert(scalar)
+    count_val = int(table.assign_arange_().item())
+    feat = first.features
+    out_features = torch.zeros([count_val, feat.shape[1]], dtype=feat.dtype, device=feat.device)
+    out_indices = torch.zeros([count_val, first.indices.shape[1]], dtype=first.indices.dtype,
+                              device=first.indices.device)
+    for ten, scalar in zip(tens, scalars):
+        rows = table.query(scalar)[0].long()
+        out_features.index_add_(0, rows, ten.features)
+        out_indices[rows] = ten.indices
+    keep = tens[biggest].indice_dict if count_val == sizes[biggest] else None
+    return _like_first(first, out_features, out_indices, keep)
+
+
+def sparse_add(*tens):
+    """Same sum through sort + unique (reference functional.py:502-545 goes through torch.sparse):
+    output rows are ordered by coordinate."""
+    first = tens[0]
+    for ten in tens:
+        assert ten.spatial_shape == first.spatial_shape
+        assert ten.batch_size == first.batch_size
+        assert ten.features.shape[1] == first.features.shape[1]
+    sizes = [t.features.shape[0] for t in tens]
+    biggest = max(range(len(tens)), key=lambda i: sizes[i])
+    shape = [first.batch_size, *first.spatial_shape]
+    scalars = torch.cat([_indice_to_scalar(t.indices.long(), shape) for t in tens])
+    uniq, inverse = torch.unique(scalars, sorted=True, return_inverse=True)
+    feats = torch.cat([t.features for t in tens])
+    out_features = torch.zeros([uniq.shape[0], feats.shape[1]], dtype=feats.dtype, device=feats.device)
+    out_features.index_add_(0, inverse, feats)
+    cols = []
+    rest = uniq
+    for extent in reversed(shape):
+        cols.append(rest % extent)
+        rest = rest // extent
+    out_indices = torch.stack(cols[::-1], dim=1).to(first.indices.dtype).contiguous()
+    keep = tens[biggest].indice_dict if uniq.shape[0] == sizes[biggest] else None
+    return _like_first(first, out_features, out_indices, keep)
+
