@@ -1772,8 +1772,8 @@ wgrad_f32_kernel(Wgrad2Params p) {
   }
 }
 
-// Backward of one layer in ONE launch: workgroups [0, n_dgrad) run the dgrad tiles, the rest
-// the wgrad ranges.  The two halves only share read-only inputs; at ~100k voxels each of them
+// Backward of one layer in ONE launch: the wgrad ranges (the longer, streaming workgroups)
+// are dispatched first, the dgrad tiles after them.  The two halves only share read-only inputs; at ~100k voxels each of them
 // is latency-bound with idle issue slots and idle HBM bandwidth, so running them side by side
 // on the same CUs costs little more than the slower one -- and one kernel boundary (~1.7 us)
 // disappears.  (Two HIP streams were tried first: the fork/join costs more than it buys.)
@@ -1782,13 +1782,18 @@ __global__ void __launch_bounds__(kThreads, COUT <= 64 ? 4 : 2)   // 4 waves/SIM
 igemm_bwd_kernel(const void *argA, const void *argB, const uint32_t *arg_mask,
                  const int32_t *arg_argsort, const int32_t *arg_pair, int n_dst, int n_src, int CIN,
                  int kv, int identity_k, int b_reverse, GemmRest rest, int n_dgrad, Wgrad2Params wp) {
-  if (static_cast<int>(blockIdx.x) < n_dgrad) {
+  // n_dgrad > 0: dgrad tiles first, then the wgrad ranges; n_dgrad < 0: the wgrad ranges
+  // (-n_dgrad - 1 ... encoded as ~count) first
+  const int nw = n_dgrad < 0 ? ~n_dgrad : 0;          // wgrad workgroups placed first
+  const int b = static_cast<int>(blockIdx.x);
+  const bool is_dgrad = n_dgrad < 0 ? b >= nw : b < n_dgrad;
+  if (is_dgrad) {
     GemmParams p;
     unpack_gemm_args(p, argA, argB, arg_mask, arg_argsort, arg_pair, n_dst, n_src, CIN, kv,
                      identity_k, b_reverse, rest);
-    igemm_v4_body<COUT, MB, DT, true>(p, blockIdx.x);
+    igemm_v4_body<COUT, MB, DT, true>(p, n_dgrad < 0 ? b - nw : b);
   } else {
-    wgrad_tr_body<DT == 1, 1>(wp, static_cast<int>(blockIdx.x) - n_dgrad);
+    wgrad_tr_body<DT == 1, 1>(wp, n_dgrad < 0 ? b : b - n_dgrad);
   }
 }
 
@@ -1979,6 +1984,12 @@ size_t wgrad_plan_ints(int n_in, int kv) {
 int wgrad_groups(int n_in) {
   static const int forced = env_int("SPX_WGRAD_G", 0);   // tuning knob
   int g = forced > 0 ? forced : 384;
+  if (forced <= 0) {
+    // backward shares its launch with ceil(n / 128) dgrad tiles: when both halves fit the 1024
+    // resident workgroup slots of the chip together there is no second dispatch round
+    const int room = 1024 - div_up(n_in > 0 ? n_in : 1, 128);
+    if (room >= 128 && room < g) g = room;
+  }
   const int chunks = div_up(n_in > 0 ? n_in : 1, 128);
   if (g > 2 * chunks) g = 2 * chunks;
   if (g > kW2MaxG - 1) g = kW2MaxG - 1;   // the plan kernel needs thread G for the end marker
@@ -2043,9 +2054,11 @@ constexpr size_t bwd_smem_bytes() {
 template <int COUT, int MB, int DT>
 int launch_bwd(const GemmParams &p, const Wgrad2Params &q, int n_wgrad_blocks, hipStream_t s) {
   const int n_dgrad = div_up(p.n_dst, 64 * MB);
+  static const int wgrad_first = env_int("SPX_BWD_WGRAD_FIRST", 1);   // tuning knob (A/B runs)
   hipLaunchKernelGGL((igemm_bwd_kernel<COUT, MB, DT>), dim3(n_dgrad + n_wgrad_blocks), dim3(kThreads),
                      (bwd_smem_bytes<COUT, MB>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,
-                     p.n_src, p.CIN, p.kv, p.identity_k, p.b_reverse, rest_of(p), n_dgrad, q);
+                     p.n_src, p.CIN, p.kv, p.identity_k, p.b_reverse, rest_of(p),
+                     wgrad_first ? ~n_wgrad_blocks : n_dgrad, q);
   SPX_LAUNCH_CHECK();
   return 0;
 }
