@@ -140,9 +140,6 @@ def main():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     import spconv_amd.pytorch as spconv
     from spconv_amd.dist import GradBucket
     from spconv_amd.pytorch import ops
@@ -205,6 +202,12 @@ def main():
                   file=sys.stderr)
             graph = None
             torch.cuda.synchronize()
+
+    # the process group comes up AFTER the capture, so that no RCCL helper thread can touch the
+    # device while the stream is capturing
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     def step():
         if graph is not None:

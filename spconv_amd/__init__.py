@@ -17,5 +17,6 @@ def install_as_spconv() -> None:
     import spconv_amd.pytorch as sp
     sys.modules.setdefault("spconv", spconv_amd)
     sys.modules.setdefault("spconv.pytorch", sp)
-    for name in ("core", "conv", "functional", "ops", "modules", "pool", "hash", "utils"):
+    for name in ("core", "conv", "functional", "ops", "modules", "pool", "hash", "utils", "tables",
+                 "identity"):
         sys.modules.setdefault(f"spconv.pytorch.{name}", getattr(sp, name))

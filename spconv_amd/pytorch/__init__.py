@@ -1,6 +1,6 @@
 """``import spconv_amd.pytorch as spconv`` -- the reference's ``spconv.pytorch`` namespace
 (``spconv/pytorch/__init__.py:1-41``) for the convolution hot path."""
-from spconv_amd.pytorch import conv, core, functional, hash, modules, ops, pool, utils
+from spconv_amd.pytorch import conv, core, functional, hash, identity, modules, ops, pool, tables, utils
 from spconv_amd.pytorch.conv import (SparseConv1d, SparseConv2d, SparseConv3d, SparseConv4d,
                                      SparseConvolution, SparseConvTranspose1d,
                                      SparseConvTranspose2d, SparseConvTranspose3d,
@@ -9,6 +9,8 @@ from spconv_amd.pytorch.conv import (SparseConv1d, SparseConv2d, SparseConv3d, S
                                      SparseInverseConv4d, SubMConv1d, SubMConv2d, SubMConv3d,
                                      SubMConv4d)
 from spconv_amd.pytorch.core import ConvAlgo, SparseConvTensor
+from spconv_amd.pytorch.identity import Identity
+from spconv_amd.pytorch.tables import AddTable, AddTableMisaligned, ConcatTable, JoinTable
 from spconv_amd.pytorch.pool import (SparseAvgPool1d, SparseAvgPool2d, SparseAvgPool3d,
                                      SparseGlobalAvgPool, SparseGlobalMaxPool, SparseMaxPool1d,
                                      SparseMaxPool2d, SparseMaxPool3d, SparseMaxPool4d)

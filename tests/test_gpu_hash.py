@@ -70,3 +70,6 @@ def test_sparse_add_misaligned(cuda, fn_name):
     a.indice_dict["k"] = object()
     same = getattr(Fsp, fn_name)(a, a.replace_feature(a.features * 2))
     assert same.features.shape[0] == a.features.shape[0] and "k" in same.indice_dict
+    # the module form (tables.py:69-80 of the reference) is the same operation
+    via_module = spconv.AddTableMisaligned()(tens)
+    assert torch.equal(via_module.indices, Fsp.sparse_add_hash_based(*tens).indices)

@@ -116,3 +116,43 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(d, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, os.path.join(d, f)
                 assert "liboracle" not in text, os.path.join(d, f)
+
+
+def test_table_modules_combine_aligned_tensors():
+    """tables.py of the reference: JoinTable / AddTable / ConcatTable, Identity."""
+    x = _x()
+    y = x.replace_feature(x.features * 2)
+    j = spconv.JoinTable()([x, y])
+    assert j.features.shape == (6, 8) and torch.equal(j.features[:, 4:], y.features)
+    assert j.indices is x.indices and j.indice_dict is x.indice_dict
+    a = spconv.AddTable()([x, y, y])
+    assert torch.equal(a.features, 5 * x.features)
+    other = _x(n=5)
+    with pytest.raises(AssertionError, match="AddTableMisaligned"):
+        spconv.AddTable()([x, other])
+    with pytest.raises(AssertionError, match="JoinTable"):
+        spconv.JoinTable()([x, other])
+    ct = spconv.ConcatTable().add(spconv.Identity()).add(spconv.Identity())
+    outs = ct(x)
+    assert len(outs) == 2 and outs[0] is x and outs[1] is x
+    assert ct.input_spatial_size([3, 3, 3]) == [3, 3, 3]
+    assert spconv.JoinTable().input_spatial_size(7) == 7
+
+
+def test_install_as_spconv_aliases_every_submodule():
+    import importlib
+    import sys
+    import spconv_amd
+    saved = {k: v for k, v in sys.modules.items() if k == "spconv" or k.startswith("spconv.")}
+    try:
+        spconv_amd.install_as_spconv()
+        for name in ("core", "conv", "functional", "ops", "modules", "pool", "hash", "utils", "tables",
+                     "identity"):
+            m = importlib.import_module(f"spconv.pytorch.{name}")
+            assert m.__name__ == f"spconv_amd.pytorch.{name}"
+        import spconv.pytorch as sp
+        assert sp.SubMConv3d is spconv.SubMConv3d and sp.AddTable is spconv.AddTable
+    finally:
+        for k in [k for k in sys.modules if k == "spconv" or k.startswith("spconv.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
