@@ -1,9 +1,12 @@
 // Rulebook ("indice pair") builder for gfx950.
 //
 // Design (MI355X-first, not a translation of the reference kernels):
-//  * one open-addressing hash table (int64 key -> int32 value) in global memory;
-//    at 2x load headroom it is ~2.4 MB per 100k voxels and stays resident in
-//    the 4 MiB XCD-local L2, so probes are L2 hits, not HBM reads;
+//  * one open-addressing hash table in global memory.  Whenever the key space (batch x grid
+//    volume) fits 32 bits -- every configuration in BASELINE.json does -- a slot is ONE 64-bit
+//    word {key32 : value32}: an insert is a single atomicCAS (plus an atomicMin only when a
+//    duplicate key has to lower the value) and a probe is a single 8-byte load.  Larger key
+//    spaces use separate int64 key / int32 value arrays.  At 2x load headroom the packed table
+//    is 2 MB per 100k voxels and stays in the 4 MiB XCD-local L2;
 //  * NO order-dependent atomics anywhere: duplicate keys are resolved with
 //    atomicMin (smallest index wins == the CPU path's unordered_map::insert),
 //    the dense tables are written by the thread that owns the row (coalesced
@@ -27,10 +30,13 @@ constexpr int kItems = 2048;  // entries per block in count/scatter passes (8 x 
 typedef long long hkey_t;      // EMPTY == -1
 
 struct Table {
-  hkey_t *keys;
-  int32_t *vals;
-  uint32_t mask;  // capacity - 1 (capacity is a power of two)
+  hkey_t *keys;    // wide: keys[cap].  packed: slots[cap], slot = (key32 << 32) | value32
+  int32_t *vals;   // wide: vals[cap].  packed: the low halves of the slots (stride 2)
+  uint32_t mask;   // capacity - 1 (capacity is a power of two)
+  int packed;      // 1 when every key fits 32 bits
 };
+
+constexpr unsigned long long kEmptySlot = ~0ull;
 
 __device__ __forceinline__ uint32_t hash_key(hkey_t k) {
   // murmur3 fmix64
@@ -43,10 +49,43 @@ __device__ __forceinline__ uint32_t hash_key(hkey_t k) {
   return static_cast<uint32_t>(x);
 }
 
+__device__ __forceinline__ uint32_t hash_key32(uint32_t x) {
+  // murmur3 fmix32
+  x ^= x >> 16;
+  x *= 0x85ebca6bu;
+  x ^= x >> 13;
+  x *= 0xc2b2ae35u;
+  x ^= x >> 16;
+  return x;
+}
+
+// Value stored in a slot returned by table_insert_min.
+__device__ __forceinline__ int32_t table_val(const Table &t, int slot) {
+  return t.vals[static_cast<size_t>(slot) << t.packed];
+}
+
 // Inserts key (if absent) and lowers its value to min(value, val). Returns the slot.
 __device__ __forceinline__ int table_insert_min(const Table &t, hkey_t key, int32_t val) {
+  if (t.packed) {
+    unsigned long long *slots = reinterpret_cast<unsigned long long *>(t.keys);
+    const uint32_t k32 = static_cast<uint32_t>(key);
+    const unsigned long long want =
+        (static_cast<unsigned long long>(k32) << 32) | static_cast<uint32_t>(val);
+    uint32_t slot = hash_key32(k32) & t.mask;
+    for (uint32_t probe = 0; probe <= t.mask; ++probe) {  // bounded: the table is never full
+      const unsigned long long prev = atomicCAS(&slots[slot], kEmptySlot, want);
+      if (prev == kEmptySlot) return static_cast<int>(slot);
+      if (static_cast<uint32_t>(prev >> 32) == k32) {
+        // same key: the word only ever decreases, so a value already <= ours stays
+        if (static_cast<uint32_t>(prev) > static_cast<uint32_t>(val)) atomicMin(&slots[slot], want);
+        return static_cast<int>(slot);
+      }
+      slot = (slot + 1) & t.mask;
+    }
+    return -1;
+  }
   uint32_t slot = hash_key(key) & t.mask;
-  for (uint32_t probe = 0; probe <= t.mask; ++probe) {  // bounded: the table is never full
+  for (uint32_t probe = 0; probe <= t.mask; ++probe) {
     unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long *>(&t.keys[slot]),
                                         static_cast<unsigned long long>(-1LL),
                                         static_cast<unsigned long long>(key));
@@ -61,11 +100,24 @@ __device__ __forceinline__ int table_insert_min(const Table &t, hkey_t key, int3
   return -1;
 }
 
-__device__ __forceinline__ int table_lookup(const Table &t, hkey_t key) {
+// Value of key, or -1 when absent (values are row indices / positions, never negative).
+__device__ __forceinline__ int32_t table_find(const Table &t, hkey_t key) {
+  if (t.packed) {
+    const unsigned long long *slots = reinterpret_cast<const unsigned long long *>(t.keys);
+    const uint32_t k32 = static_cast<uint32_t>(key);
+    uint32_t slot = hash_key32(k32) & t.mask;
+    for (uint32_t probe = 0; probe <= t.mask; ++probe) {
+      const unsigned long long v = slots[slot];
+      if (static_cast<uint32_t>(v >> 32) == k32 && v != kEmptySlot) return static_cast<int32_t>(v);
+      if (v == kEmptySlot) return -1;
+      slot = (slot + 1) & t.mask;
+    }
+    return -1;
+  }
   uint32_t slot = hash_key(key) & t.mask;
   for (uint32_t probe = 0; probe <= t.mask; ++probe) {
-    hkey_t k = t.keys[slot];
-    if (k == key) return static_cast<int>(slot);
+    const hkey_t k = t.keys[slot];
+    if (k == key) return t.vals[slot];
     if (k == -1LL) return -1;
     slot = (slot + 1) & t.mask;
   }
@@ -162,7 +214,7 @@ subm_probe3_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table t,
   }
   const int self = slot_of[o];
   if (self < 0) return;
-  const bool first = t.vals[self] == o;
+  const bool first = table_val(t, self) == o;
   if (!first) k = kv - 1 - k;                 // a duplicate row only owns its k > centre half
   int b, c[4], r[4], q[4];
   read_row(indices, o, g.ndim, b, c);
@@ -170,9 +222,8 @@ subm_probe3_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table t,
 #pragma unroll
   for (int d = 0; d < 4; ++d) q[d] = c[d] - g.padding[d] + r[d] * g.dilation[d];
   if (!in_range(q, g.in_dims)) return;
-  const int slot = table_lookup(t, layout_key(b, q, g.in_dims));
-  if (slot < 0) return;
-  const int v = t.vals[slot];
+  const int v = table_find(t, layout_key(b, q, g.in_dims));
+  if (v < 0) return;
   set(k, o, v);
   if (first) set(kv - 1 - k, v, o);
 }
@@ -351,14 +402,14 @@ conv_stage1_kernel(const int32_t *__restrict__ indices, int n, Geom g, int trans
   slot_of[pos] = slot;
 }
 
-__device__ __forceinline__ bool is_first_seen(const int32_t *slot_of, const int32_t *vals,
+__device__ __forceinline__ bool is_first_seen(const int32_t *slot_of, const Table &t,
                                               size_t pos, bool inb, int &slot) {
   slot = inb ? slot_of[pos] : -1;
-  return slot >= 0 && vals[slot] == static_cast<int32_t>(pos);
+  return slot >= 0 && table_val(t, slot) == static_cast<int32_t>(pos);
 }
 
 __global__ void __launch_bounds__(kBlock)
-conv_count_first_kernel(const int32_t *__restrict__ slot_of, const int32_t *__restrict__ vals,
+conv_count_first_kernel(const int32_t *__restrict__ slot_of, Table t,
                         int n, int nblk, int32_t *__restrict__ blockcount) {
   __shared__ int lds_wave[kBlock / 64];
   const int k = blockIdx.y, blk = blockIdx.x;
@@ -368,7 +419,7 @@ conv_count_first_kernel(const int32_t *__restrict__ slot_of, const int32_t *__re
   for (int it = 0; it < kItems / kBlock; ++it) {
     const int e = begin + it * kBlock + threadIdx.x;
     int slot;
-    const bool pred = is_first_seen(slot_of, vals, static_cast<size_t>(k) * n + e, e < n, slot);
+    const bool pred = is_first_seen(slot_of, t, static_cast<size_t>(k) * n + e, e < n, slot);
     cnt += __popcll(__ballot(pred));
   }
   if ((threadIdx.x & 63) == 0) lds_wave[threadIdx.x >> 6] = cnt;
@@ -383,7 +434,7 @@ conv_count_first_kernel(const int32_t *__restrict__ slot_of, const int32_t *__re
 // Numbers outputs in first-seen order and writes their coordinates.
 __global__ void __launch_bounds__(kBlock)
 conv_assign_kernel(const int32_t *__restrict__ indices, int n, Geom g, int transposed,
-                   const int32_t *__restrict__ slot_of, const int32_t *__restrict__ vals,
+                   const int32_t *__restrict__ slot_of, Table t,
                    int nblk, const int32_t *__restrict__ blockoff,
                    int32_t *__restrict__ slot_out, int32_t *__restrict__ out_indices) {
   __shared__ int lds_wave[kBlock / 64];
@@ -396,7 +447,7 @@ conv_assign_kernel(const int32_t *__restrict__ indices, int n, Geom g, int trans
   for (int it = 0; it < kItems / kBlock; ++it) {
     const int e = begin + it * kBlock + threadIdx.x;
     int slot;
-    const bool first = is_first_seen(slot_of, vals, static_cast<size_t>(k) * n + e, e < n, slot);
+    const bool first = is_first_seen(slot_of, t, static_cast<size_t>(k) * n + e, e < n, slot);
     int total;
     const int rank = block_rank(first, total, lds_wave);
     if (first) {
@@ -548,6 +599,35 @@ uint32_t table_capacity(size_t entries) {
   return static_cast<uint32_t>(cap);
 }
 
+// True when every key of a (batch, dims[0..3]) layout is below 0xFFFFFFFF: the table then keeps
+// key and value in one 64-bit slot.
+bool keys_fit_u32(long long batch, const int *dims, int ndims) {
+  unsigned long long v = batch > 0 ? static_cast<unsigned long long>(batch) : 1ull;
+  for (int d = 0; d < ndims; ++d) {
+    const unsigned long long e = dims[d] > 0 ? static_cast<unsigned long long>(dims[d]) : 1ull;
+    if (v > 0xFFFFFFFFull / e) return false;
+    v *= e;
+  }
+  return v <= 0xFFFFFFFFull;   // largest key is v - 1 <= 0xFFFFFFFE
+}
+
+// Places a table of `cap` slots at `mem` (room for the wide form: 12 bytes per slot).
+void table_place(Table &t, hkey_t *keys, int32_t *vals, uint32_t cap, bool packed) {
+  t.keys = keys;
+  t.vals = packed ? reinterpret_cast<int32_t *>(keys) : vals;
+  t.mask = cap - 1;
+  t.packed = packed ? 1 : 0;
+}
+
+// Empties the table: every byte 0xFF (keys -1, values 0xFFFFFFFF, packed slots ~0).
+hipError_t table_clear(const Table &t, hipStream_t s) {
+  const size_t cap = static_cast<size_t>(t.mask) + 1;
+  const size_t bytes = t.packed ? cap * sizeof(unsigned long long)
+                                : static_cast<size_t>(reinterpret_cast<char *>(t.vals + cap) -
+                                                      reinterpret_cast<char *>(t.keys));
+  return hipMemsetAsync(t.keys, 0xFF, bytes, s);
+}
+
 size_t conv_max_out(int n_in, int ndim, const int *ksize, const int *stride, int transposed) {
   // SpconvOps.get_handcrafted_max_act_out (all.py:1557-1578): N * prod(ceil(k/s)),
   // transposed: kv * N (ops.py:569-570).
@@ -568,16 +648,17 @@ struct ConvWs {
 };
 
 ConvWs carve_conv_ws(void *ws, int n_in, int ndim, const int *ksize, const int *stride,
-                     int transposed) {
+                     int transposed, bool packed = false) {
   int kv = 1;
   for (int i = 0; i < ndim; ++i) kv *= ksize[i];
   const uint32_t cap = table_capacity(conv_max_out(n_in, ndim, ksize, stride, transposed));
   ConvWs w;
   w.nblk = div_up(n_in > 0 ? n_in : 1, kItems);
   Carver cv(ws);
-  w.t.keys = cv.take<hkey_t>(cap);
-  w.t.vals = cv.take<int32_t>(cap);
-  w.t.mask = cap - 1;
+  {
+    hkey_t *keys = cv.take<hkey_t>(cap);
+    table_place(w.t, keys, cv.take<int32_t>(cap), cap, packed);
+  }
   w.slot_out = cv.take<int32_t>(cap);
   w.slot_of = cv.take<int32_t>(static_cast<size_t>(kv) * (n_in > 0 ? n_in : 1));
   w.blockcount = cv.take<int32_t>(static_cast<size_t>(kv) * w.nblk);
@@ -659,7 +740,7 @@ p2v_insert_kernel(const float *__restrict__ pts, int n, int nfeat, P2VGeom g, Ta
 }
 
 __global__ void __launch_bounds__(kBlock)
-p2v_count_first_kernel(const int32_t *__restrict__ slot_of, const int32_t *__restrict__ vals, int n,
+p2v_count_first_kernel(const int32_t *__restrict__ slot_of, Table t, int n,
                        int32_t *__restrict__ blockcount) {
   __shared__ int lds_wave[kBlock / 64];
   const int begin = blockIdx.x * kItems;
@@ -668,7 +749,7 @@ p2v_count_first_kernel(const int32_t *__restrict__ slot_of, const int32_t *__res
   for (int it = 0; it < kItems / kBlock; ++it) {
     const int e = begin + it * kBlock + threadIdx.x;
     const int slot = e < n ? slot_of[e] : -1;
-    cnt += __popcll(__ballot(slot >= 0 && vals[slot] == e));
+    cnt += __popcll(__ballot(slot >= 0 && table_val(t, slot) == e));
   }
   if ((threadIdx.x & 63) == 0) lds_wave[threadIdx.x >> 6] = cnt;
   __syncthreads();
@@ -681,7 +762,7 @@ p2v_count_first_kernel(const int32_t *__restrict__ slot_of, const int32_t *__res
 
 __global__ void __launch_bounds__(kBlock)
 p2v_assign_kernel(const float *__restrict__ pts, int n, int nfeat, P2VGeom g,
-                  const int32_t *__restrict__ slot_of, const int32_t *__restrict__ vals,
+                  const int32_t *__restrict__ slot_of, Table t,
                   const int32_t *__restrict__ blockoff, int max_voxels,
                   int32_t *__restrict__ slot_vid, int32_t *__restrict__ indices) {
   __shared__ int lds_wave[kBlock / 64];
@@ -690,7 +771,7 @@ p2v_assign_kernel(const float *__restrict__ pts, int n, int nfeat, P2VGeom g,
   for (int it = 0; it < kItems / kBlock; ++it) {
     const int e = begin + it * kBlock + threadIdx.x;
     const int slot = e < n ? slot_of[e] : -1;
-    const bool first = slot >= 0 && vals[slot] == e;
+    const bool first = slot >= 0 && table_val(t, slot) == e;
     int total;
     const int rank = block_rank(first, total, lds_wave);
     if (first) {
@@ -772,15 +853,16 @@ struct P2VWs {
   size_t bytes;
 };
 
-P2VWs carve_p2v_ws(void *ws, int n, int max_voxels) {
+P2VWs carve_p2v_ws(void *ws, int n, int max_voxels, bool packed = false) {
   const uint32_t cap = table_capacity(n > 0 ? n : 1);
   const size_t np = n > 0 ? n : 1;
   P2VWs w;
   w.nblk = div_up(static_cast<int>(np), kItems);
   Carver cv(ws);
-  w.t.keys = cv.take<hkey_t>(cap);
-  w.t.vals = cv.take<int32_t>(cap);
-  w.t.mask = cap - 1;
+  {
+    hkey_t *keys = cv.take<hkey_t>(cap);
+    table_place(w.t, keys, cv.take<int32_t>(cap), cap, packed);
+  }
   w.slot_vid = cv.take<int32_t>(cap);
   w.slot_of = cv.take<int32_t>(np);
   w.blockcount = cv.take<int32_t>(w.nblk);
@@ -980,16 +1062,16 @@ int spx_subm_rulebook(const int32_t *indices, int n, int ndim, int batch_size,
   const int nblk = div_up(n, kItems);
   Carver cv(ws);
   Table t;
-  t.keys = cv.take<hkey_t>(cap);
-  t.vals = cv.take<int32_t>(cap);
-  t.mask = cap - 1;
+  {
+    hkey_t *keys = cv.take<hkey_t>(cap);
+    table_place(t, keys, cv.take<int32_t>(cap), cap, keys_fit_u32(g.batch, g.in_dims, 4));
+  }
   int32_t *blockcount = cv.take<int32_t>(static_cast<size_t>(kv) * nblk);
   int32_t *blockoff = cv.take<int32_t>(static_cast<size_t>(kv) * nblk);
   int32_t *scratch_totals = cv.take<int32_t>(64);
   int32_t *slot_of = cv.take<int32_t>(n);
 
-  // keys and values are adjacent in the workspace: one fill
-  SPX_HIP(hipMemsetAsync(t.keys, 0xFF, reinterpret_cast<char *>(t.vals + cap) - reinterpret_cast<char *>(t.keys), s));
+  SPX_HIP(table_clear(t, s));   // keys and values are adjacent in the workspace: one fill
   SPX_HIP(hipMemsetAsync(mask, 0, sizeof(uint32_t) * static_cast<size_t>(n) * words, s));
   const dim3 grid(div_up(n, kBlock));
   hipLaunchKernelGGL(subm_insert_kernel, grid, dim3(kBlock), 0, s, indices, n, g, t, slot_of);
@@ -1053,14 +1135,14 @@ int spx_conv_rulebook_count(const int32_t *indices, int n_in, int ndim, int batc
             "workspace too small");
   *n_out_h = 0;
   if (n_in == 0) return 0;
-  ConvWs w = carve_conv_ws(ws, n_in, ndim, ksize, stride, transposed);
-  const size_t cap = static_cast<size_t>(w.t.mask) + 1;
-  SPX_HIP(hipMemsetAsync(w.t.keys, 0xFF, reinterpret_cast<char *>(w.t.vals + cap) - reinterpret_cast<char *>(w.t.keys), s));
+  ConvWs w = carve_conv_ws(ws, n_in, ndim, ksize, stride, transposed,
+                           keys_fit_u32(g.batch, g.out_dims, 4));
+  SPX_HIP(table_clear(w.t, s));
   const dim3 grid1(div_up(n_in, kBlock), g.kv);
   hipLaunchKernelGGL(conv_stage1_kernel, grid1, dim3(kBlock), 0, s, indices, n_in, g, transposed,
                      w.t, w.slot_of);
   const dim3 grid2(w.nblk, g.kv);
-  hipLaunchKernelGGL(conv_count_first_kernel, grid2, dim3(kBlock), 0, s, w.slot_of, w.t.vals, n_in,
+  hipLaunchKernelGGL(conv_count_first_kernel, grid2, dim3(kBlock), 0, s, w.slot_of, w.t, n_in,
                      w.nblk, w.blockcount);
   hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kBlock), 0, s, w.blockcount, w.blockoff,
                      g.kv * w.nblk, w.d_nout);
@@ -1091,12 +1173,13 @@ int spx_conv_rulebook_fill(const int32_t *indices, int n_in, int ndim, int batch
   if (pair_native && n_in > 0)
     SPX_HIP(hipMemsetAsync(pair_native, 0xFF, sizeof(int32_t) * 2 * static_cast<size_t>(kv) * n_in, s));
   if (n_in == 0) return 0;
-  ConvWs w = carve_conv_ws(ws, n_in, ndim, ksize, stride, transposed);
+  ConvWs w = carve_conv_ws(ws, n_in, ndim, ksize, stride, transposed,
+                           keys_fit_u32(g.batch, g.out_dims, 4));   // as spx_conv_rulebook_count
   if (n_out > 0)
     SPX_HIP(hipMemsetAsync(pair_fwd, 0xFF, sizeof(int32_t) * static_cast<size_t>(kv) * n_out, s));
   const dim3 grid2(w.nblk, kv);
   hipLaunchKernelGGL(conv_assign_kernel, grid2, dim3(kBlock), 0, s, indices, n_in, g, transposed,
-                     w.slot_of, w.t.vals, w.nblk, w.blockoff, w.slot_out, out_indices);
+                     w.slot_of, w.t, w.nblk, w.blockoff, w.slot_out, out_indices);
   const dim3 grid1(div_up(n_in, kBlock), kv);
   hipLaunchKernelGGL(conv_stage2_kernel, grid1, dim3(kBlock), 0, s, w.slot_of, w.slot_out, n_in,
                      n_out, pair_fwd, pair_bwd);
@@ -1233,18 +1316,18 @@ int spx_point2voxel(const float *points, int n, int nfeat, int ndim, const float
     g.lo[j] = j < ndim ? coors_range[j] : 0.f;
     g.grid[j] = j < ndim ? grid_size[j] : 1;
   }
-  P2VWs w = carve_p2v_ws(ws, n, max_voxels);
+  P2VWs w = carve_p2v_ws(ws, n, max_voxels, keys_fit_u32(1, g.grid, 4));
   const size_t cap = static_cast<size_t>(w.t.mask) + 1;
-  SPX_HIP(hipMemsetAsync(w.t.keys, 0xFF, reinterpret_cast<char *>(w.t.vals + cap) - reinterpret_cast<char *>(w.t.keys), s));
+  SPX_HIP(table_clear(w.t, s));
   SPX_HIP(hipMemsetAsync(w.slot_vid, 0xFF, sizeof(int32_t) * cap, s));
   const dim3 gp(div_up(n, kBlock));
   hipLaunchKernelGGL(p2v_insert_kernel, gp, dim3(kBlock), 0, s, points, n, nfeat, g, w.t, w.slot_of);
-  hipLaunchKernelGGL(p2v_count_first_kernel, dim3(w.nblk), dim3(kBlock), 0, s, w.slot_of, w.t.vals, n,
+  hipLaunchKernelGGL(p2v_count_first_kernel, dim3(w.nblk), dim3(kBlock), 0, s, w.slot_of, w.t, n,
                      w.blockcount);
   hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kBlock), 0, s, w.blockcount, w.blockoff, w.nblk, w.total);
   hipLaunchKernelGGL(p2v_clamp_count_kernel, dim3(1), dim3(1), 0, s, w.total, max_voxels, w.n_voxels);
   hipLaunchKernelGGL(p2v_assign_kernel, dim3(w.nblk), dim3(kBlock), 0, s, points, n, nfeat, g, w.slot_of,
-                     w.t.vals, w.blockoff, max_voxels, w.slot_vid, indices);
+                     w.t, w.blockoff, max_voxels, w.slot_vid, indices);
   hipLaunchKernelGGL(p2v_point_vid_kernel, gp, dim3(kBlock), 0, s, w.slot_of, w.slot_vid, n, pc_voxel_id,
                      w.key32);
   // stable sort of the points by voxel id (4 x 8-bit LSD passes, as mask_argsort)

@@ -38,6 +38,22 @@ def test_point2voxel_bit_exact(cuda, n, max_voxels, max_points, empty_mean):
         assert (rpid == -1).any() and rc.max() == max_points      # caps and range checks are exercised
 
 
+def test_point2voxel_grid_beyond_32_bits(cuda):
+    """A grid with more than 2**32 cells takes the wide-key form of the hash table."""
+    from spconv_amd.pytorch.utils import PointToVoxel
+    vsize, rng_xyz = [0.003, 0.004, 0.004], [0, -4, -2, 8, 4, 2]      # 2667 x 2000 x 1000 cells
+    gen = PointToVoxel(vsize, rng_xyz, 4, 30000, 4, device=cuda)
+    assert int(np.prod(np.asarray(gen.grid_size, dtype=np.int64))) > 2 ** 32
+    pts = _cloud(20000, 5)
+    pts[:10000, :3] = pts[10000:, :3] + 1e-4                          # several points per voxel
+    v, i, c, pid = gen.generate_voxel_with_id(torch.from_numpy(pts).to(cuda), True, True)
+    rv, ri, rc, rpid = oracle.point2voxel(pts, gen.vsize, gen.coors_range, gen.grid_size, 30000, 4, True)
+    np.testing.assert_array_equal(i.cpu().numpy(), ri)
+    np.testing.assert_array_equal(c.cpu().numpy(), rc)
+    np.testing.assert_array_equal(pid.cpu().numpy(), rpid)
+    np.testing.assert_array_equal(v.cpu().numpy(), rv)
+
+
 def test_point2voxel_feeds_a_sparse_conv(cuda):
     """points -> voxels -> mean features -> SparseConvTensor -> SubMConv3d: the pipeline of
     docs/USAGE.md (indices ZYX, batch column prepended)."""

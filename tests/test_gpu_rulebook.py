@@ -58,6 +58,33 @@ def test_subm_duplicates_and_deleted_rows(cuda):
     assert_rulebook_equal(rb, ref, True)
 
 
+def _far_corner_scene(shape, n, bs, seed):
+    """Dense cluster next to the far corner of a grid whose volume does not fit 32 bits: linear
+    keys exceed 2**32, which takes the wide (int64 key) form of the hash table."""
+    idx = dense_scene([30, 30, 30], n, bs, seed)
+    idx[:, 1:] += np.asarray(shape, dtype=np.int32) - 12
+    return np.ascontiguousarray(idx)
+
+
+def test_subm_key_space_beyond_32_bits(cuda):
+    shape = [3000, 2500, 2000]                       # 1.5e10 cells per scene
+    idx = _far_corner_scene(shape, 400, 2, seed=2)
+    assert int(idx[:, 1].max()) * shape[1] * shape[2] > 2 ** 32
+    ref = oracle_rulebook(idx, 2, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True)
+    assert ref["num"].sum() > idx.shape[0]
+    rb, _ = gpu_rulebook(idx, 2, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True, need_bwd_table=True)
+    assert_rulebook_equal(rb, ref, True)
+
+
+def test_conv_key_space_beyond_32_bits(cuda):
+    shape = [4000, 4000, 4000]                       # stride 2 -> 8e9 output cells
+    idx = _far_corner_scene(shape, 400, 1, seed=4)
+    ref = oracle_rulebook(idx, 1, shape, [3] * 3, [2] * 3, [1] * 3, [1] * 3, False)
+    rb, out_shape = gpu_rulebook(idx, 1, shape, [3] * 3, [2] * 3, [1] * 3, [1] * 3, False)
+    assert list(out_shape) == [2000] * 3
+    assert_rulebook_equal(rb, ref, False)
+
+
 def test_subm_empty(cuda):
     idx = np.zeros((0, 4), dtype=np.int32)
     rb, _ = gpu_rulebook(idx, 1, [8, 8, 8], [3] * 3, [1] * 3, [1] * 3, [1] * 3, True)
