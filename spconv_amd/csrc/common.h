@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "../../include/spconv_amd.h"
 
@@ -13,6 +14,12 @@ constexpr int kWave = 64;
 constexpr int kMaxNdim = SPX_MAX_NDIM;
 
 void set_error(const char *fmt, ...);
+
+// Integer tuning knob from the environment (A/B measurements; defaults are the shipped choice).
+inline int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int div_up(int a, int b) { return (a + b - 1) / b; }

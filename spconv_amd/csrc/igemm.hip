@@ -423,11 +423,6 @@ constexpr size_t gemm_smem_bytes() {
   return stage > outb ? stage : outb;
 }
 
-int env_int(const char *name, int dflt) {
-  const char *v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
-
 template <int COUT, bool BF16>
 int launch_gather_gemm(const GemmParams &p, hipStream_t s) {
   const int ntiles = div_up(p.n_dst, kTileM);
