@@ -269,6 +269,10 @@ def main():
                        "GBps": round(ab[k] / (v * 1e-3) / 1e9, 1)} for k, v in {**groups, **alone}.items()}
         dom = max(groups, key=groups.get)
         achieved = ab[dom] / (groups[dom] * 1e-3) / 1e9
+        # stricter count for the fused backward launch: dout is read once for both gradients
+        # (dout + feat + din + pair table + Native lists of P pairs + W + dW)
+        strict = {"fwd": ab["fwd"],
+                  "bwd": s * n * K + 2 * s * n * C + 4 * 27 * n + 8 * P + 2 * s * 27 * C * K}
         total_bytes = ab["fwd"] + ab["bwd"]
         result = {
             "metric": "active-voxels/sec fwd+bwd, 3x3x3 SubMConv3d C=64, ~100k voxels/scene",
@@ -285,7 +289,9 @@ def main():
                          "traffic": pmc_traffic(dom, args),
                          "kernel": {"fwd": "igemm_v4_kernel<64,2,f16,fwd>",
                                     "bwd": "igemm_bwd_kernel<64,2,f16> + wgrad_reduce2_kernel"}[dom],
-                         "algorithmic_bytes": ab[dom], "ms": round(groups[dom], 5)},
+                         "algorithmic_bytes": ab[dom], "ms": round(groups[dom], 5),
+                         "shared_input_bytes": strict[dom],
+                         "shared_input_frac": round(strict[dom] / (groups[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "kernels": kernels,
             "step_GBps_algorithmic": round(total_bytes / (ms_per_step * 1e-3) / 1e9, 1),
             "eager_device_ms_per_step": round(t_eager, 5),
