@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sort", action="store_true", help="mask_argsort the rulebook rows")
+    ap.add_argument("--graph-steps", type=int, default=8,
+                    help="steps captured per hipGraph at N = 1 (a replay boundary costs ~5 us; with N > 1 "
+                         "the gradient all-reduce follows every step, so one step per replay)")
     return ap.parse_args()
 
 
@@ -183,7 +186,9 @@ def main():
         y.features.backward(dout)
 
     launch = "eager"
-    graph = None
+    graph = None          # one step per replay
+    graph_u = None        # U steps per replay (N = 1 only)
+    U = max(1, args.graph_steps) if world == 1 else 1
     if not args.no_graph:
         try:
             side = torch.cuda.Stream()
@@ -196,12 +201,19 @@ def main():
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 compute()
+            if U > 1:
+                graph_u = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_u):
+                    for _ in range(U):
+                        compute()
             launch = "hipgraph"
         except Exception as e:  # capture unsupported -> eager launches, same work
             print(f"[bench] graph capture failed ({type(e).__name__}: {e}); using eager launches",
                   file=sys.stderr)
-            graph = None
+            graph = graph_u = None
             torch.cuda.synchronize()
+    if graph_u is None:
+        U = 1
 
     # the process group comes up AFTER the capture, so that no RCCL helper thread can touch the
     # device while the stream is capturing
@@ -222,17 +234,32 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
+    def run_steps(k):
+        """Exactly k steps: whole U-step replays, then single steps."""
+        if graph_u is not None:
+            for _ in range(k // U):
+                graph_u.replay()
+            k = k % U
+        for _ in range(k):
+            step()
+
+    run_steps(args.warmup)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    single_replay_ms = None
+    if graph_u is not None:          # the same K steps with one step per replay, for reference
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        single_replay_ms = (time.perf_counter() - t1) / args.steps * 1e3
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -283,6 +310,7 @@ def main():
                                    f"voxels/scene in {SHAPE[2]}x{SHAPE[1]}x{SHAPE[0]} (BASELINE configs[1]), "
                                    f"1 scene per GPU, rulebook reused via indice_key",
                        "voxels_per_gpu": n, "pairs_per_voxel": round(P / n, 4), "launch": launch,
+                       "steps_per_replay": U if launch == "hipgraph" else None,
                        "mask_sort": bool(args.sort), "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -295,6 +323,7 @@ def main():
             "kernels": kernels,
             "step_GBps_algorithmic": round(total_bytes / (ms_per_step * 1e-3) / 1e9, 1),
             "eager_device_ms_per_step": round(t_eager, 5),
+            "ms_per_step_one_step_per_replay": None if single_replay_ms is None else round(single_replay_ms, 5),
             "rulebook_ms": round(statistics.median(rule_ms), 4),
         }
         if world == 1 and not args.no_cpu_baseline:
