@@ -20,3 +20,12 @@ def install_as_spconv() -> None:
     for name in ("core", "conv", "functional", "ops", "modules", "pool", "hash", "utils", "tables",
                  "identity"):
         sys.modules.setdefault(f"spconv.pytorch.{name}", getattr(sp, name))
+    # the quantization package tree (spconv.pytorch.quantization.intrinsic.qat, ...)
+    import importlib
+    import pkgutil
+    import spconv_amd.pytorch.quantization as q
+    sys.modules.setdefault("spconv.pytorch.quantization", q)
+    for info in pkgutil.walk_packages(q.__path__, q.__name__ + "."):
+        mod = importlib.import_module(info.name)
+        sys.modules.setdefault(info.name.replace("spconv_amd.", "spconv.", 1), mod)
+    sys.modules.setdefault("spconv.constants", importlib.import_module("spconv_amd.constants"))

@@ -8,6 +8,9 @@ SAVED_WEIGHT_LAYOUT = os.getenv("SPCONV_SAVED_WEIGHT_LAYOUT", "")
 # run dgrad and wgrad of one layer on two HIP streams (they are independent).  Off by default:
 # measured on MI355X the fork/join costs more than the overlap buys (57.2 vs 64.7 us per step)
 BWD_OVERLAP = os.getenv("SPCONV_AMD_BWD_OVERLAP", "0") == "1"
+# spconv/constants.py:112: skip the constructor checks of SparseConvTensor while torch.fx traces a
+# model (its arguments are Proxies then)
+SPCONV_FX_TRACE_MODE = os.getenv("SPCONV_FX_TRACE_MODE", "0") == "1"
 ALL_WEIGHT_IS_KRSC = True
 FILTER_HWIO = False
 

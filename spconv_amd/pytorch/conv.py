@@ -460,3 +460,25 @@ for _n in (1, 2, 3, 4):
     globals()[f"SubMConv{_n}d"] = _named(
         _subm_cls(_n, f"{_n}-d submanifold convolution (reference conv.py:1155-1308)."),
         f"SubMConv{_n}d")
+
+
+# reference conv.py:1291-1308: the concrete layer classes quantization patterns are keyed on
+DEFAULT_SPARSE_CONV_TYPES = {
+    globals()[f"{_kind}{_n}d"]
+    for _kind in ("SubMConv", "SparseConv", "SparseInverseConv", "SparseConvTranspose")
+    for _n in (1, 2, 3, 4)
+}
+
+
+def conv_ctor_kwargs(conv: "SparseConvolution") -> dict:
+    """Constructor arguments that rebuild ``conv`` as a plain SparseConvolution (or a subclass
+    taking the same arguments): used by the quantization modules' from_float / to_float."""
+    return dict(ndim=conv.ndim, in_channels=conv.in_channels, out_channels=conv.out_channels,
+                kernel_size=conv.kernel_size, stride=conv.stride, padding=conv.padding,
+                dilation=conv.dilation, groups=conv.groups, bias=conv.bias is not None
+                if not callable(conv.bias) else True,
+                subm=conv.subm, output_padding=conv.output_padding, transposed=conv.transposed,
+                inverse=conv.inverse, indice_key=conv.indice_key, algo=conv.algo,
+                fp32_accum=conv.fp32_accum, record_voxel_count=conv.record_voxel_count,
+                act_type=conv.act_type, act_alpha=conv.act_alpha, act_beta=conv.act_beta,
+                name=conv.name)

@@ -14,6 +14,9 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 import torch
+import torch.fx
+
+from spconv_amd.constants import SPCONV_FX_TRACE_MODE
 
 
 class ConvAlgo(Enum):
@@ -127,7 +130,13 @@ def scatter_nd(indices: torch.Tensor, updates: torch.Tensor, shape: Sequence[int
     return ret
 
 
-class SparseConvTensor:
+def _under_fx_trace(*values) -> bool:
+    return SPCONV_FX_TRACE_MODE or any(isinstance(v, torch.fx.Proxy) for v in values)
+
+
+class SparseConvTensor(metaclass=torch.fx.ProxyableClassMeta):
+    # ProxyableClassMeta (reference core.py:24-31,132): constructing the tensor from fx Proxies
+    # while a model is traced records the construction in the graph
     def __init__(self, features: torch.Tensor, indices: torch.Tensor,
                  spatial_shape: Union[List[int], np.ndarray], batch_size: int,
                  grid: Optional[torch.Tensor] = None, voxel_num: Optional[torch.Tensor] = None,
@@ -141,12 +150,13 @@ class SparseConvTensor:
         ``grid``/``voxel_num`` are carried along, ``benchmark`` records per-layer wall time,
         ``permanent_thrust_allocator``/``enable_timer`` have no effect here.
         """
-        ndim = indices.shape[1] - 1
-        assert features.ndim == 2
-        assert indices.ndim == 2
-        assert len(spatial_shape) == ndim, "spatial shape must equal to ndim"
-        assert indices.dtype == torch.int32, "only support int32"
-        assert batch_size > 0
+        if not _under_fx_trace(features, indices, batch_size):
+            ndim = indices.shape[1] - 1
+            assert features.ndim == 2
+            assert indices.ndim == 2
+            assert len(spatial_shape) == ndim, "spatial shape must equal to ndim"
+            assert indices.dtype == torch.int32, "only support int32"
+            assert batch_size > 0
         self._features = features
         self.indices = indices
         self.spatial_shape = [int(v) for v in spatial_shape]
@@ -172,6 +182,9 @@ class SparseConvTensor:
         if self.is_quantized:
             return self.features.q_scale()
         raise ValueError("sparse tensor must be quantized")
+
+    def dequantize(self) -> "SparseConvTensor":
+        return self.replace_feature(self.features.dequantize())
 
     def _like(self, features: torch.Tensor, indice_dict) -> "SparseConvTensor":
         t = SparseConvTensor(features, self.indices, self.spatial_shape, self.batch_size,

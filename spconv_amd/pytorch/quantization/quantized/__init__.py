@@ -1,1 +1,1 @@
-from spconv_amd.pytorch.quantization.quantized.conv import SparseConv  # noqa: F401
+from .conv import SparseConv  # noqa: F401

@@ -13,9 +13,12 @@ from typing import List, Optional, Tuple, Union
 
 import torch
 
-from spconv_amd.pytorch.conv import SparseConvolution
+from torch.ao.nn.quantized.modules.utils import _quantize_weight
+
+from spconv_amd.pytorch.conv import SparseConvolution, conv_ctor_kwargs
 from spconv_amd.pytorch.core import ConvAlgo, SparseConvTensor
 from spconv_amd.pytorch.ops import Activation
+from spconv_amd.pytorch.quantization.utils import fuse_spconv_bn_weights
 
 
 class SparseConv(SparseConvolution):
@@ -30,12 +33,13 @@ class SparseConv(SparseConvolution):
                  indice_key: Optional[str] = None, algo: Optional[ConvAlgo] = None,
                  fp32_accum: Optional[bool] = None, record_voxel_count: bool = False,
                  act_type=Activation.None_, act_alpha: float = 0, act_beta: float = 0,
-                 device=None, dtype=None):
+                 name=None, device=None, dtype=None):
         super().__init__(ndim, in_channels, out_channels, kernel_size, stride, padding, dilation,
                          groups, bias=False, subm=subm, output_padding=output_padding,
                          transposed=transposed, inverse=inverse, indice_key=indice_key, algo=algo,
                          fp32_accum=fp32_accum, record_voxel_count=record_voxel_count,
-                         act_type=act_type, act_alpha=act_alpha, act_beta=act_beta, device=device)
+                         act_type=act_type, act_alpha=act_alpha, act_beta=act_beta, name=name,
+                         device=device)
         self.scale = 1.0
         self.zero_point = 0
         self.eval()
@@ -75,6 +79,76 @@ class SparseConv(SparseConvolution):
         except Exception:   # dtype casts do not apply to quantised tensors
             pass
         return self
+
+    # ---- serialisation (reference quantized/conv.py:120-148): weight / bias / scale / zero_point
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        destination[prefix + "weight"] = self._weight
+        destination[prefix + "bias"] = self._bias
+        destination[prefix + "scale"] = torch.tensor(self.scale)
+        destination[prefix + "zero_point"] = torch.tensor(self.zero_point)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys,
+                              unexpected_keys, error_msgs):
+        self.set_weight_bias(state_dict.pop(prefix + "weight"), state_dict.pop(prefix + "bias"))
+        self.scale = float(state_dict.pop(prefix + "scale"))
+        self.zero_point = int(state_dict.pop(prefix + "zero_point"))
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, False, missing_keys,
+                                      unexpected_keys, error_msgs)
+
+    # ---- conversion from float / QAT / reference modules (reference quantized/conv.py:153-258)
+    _FLOAT_MODULE = SparseConvolution
+
+    @classmethod
+    def get_qconv(cls, mod, activation_post_process, weight_post_process=None):
+        """Quantised module from a float conv ``mod`` and its observers."""
+        if weight_post_process is None:
+            weight_post_process = mod.qconfig.weight()
+        weight_post_process = weight_post_process.to(mod.weight.device)
+        weight_post_process(mod.weight)
+        assert weight_post_process.dtype == torch.qint8, "Weight observer must have a dtype of qint8"
+        qweight = _quantize_weight(mod.weight.float(), weight_post_process)
+        kw = conv_ctor_kwargs(mod)
+        kw.pop("bias")
+        qconv = cls(**kw, device=mod.weight.device)
+        qconv.set_weight_bias(qweight, None if mod.bias is None else mod.bias.detach().float())
+        if activation_post_process is None or activation_post_process.dtype == torch.float:
+            return qconv
+        act_scale, act_zp = activation_post_process.calculate_qparams()
+        qconv.scale = float(act_scale)
+        qconv.zero_point = int(act_zp)
+        return qconv
+
+    @classmethod
+    def from_float(cls, mod):
+        """From an observed float module (PTQ), a fused float container, or a QAT module."""
+        import torch.ao.nn.intrinsic as nni
+        if hasattr(mod, "weight_fake_quant"):                         # QAT module
+            if hasattr(mod, "bn"):                                    # conv + bn trained together
+                mod.weight, mod.bias = fuse_spconv_bn_weights(
+                    mod.weight, mod.bias, mod.bn.running_mean, mod.bn.running_var, mod.bn.eps,
+                    mod.bn.weight, mod.bn.bias)
+            assert hasattr(mod, "activation_post_process"), "Input QAT module must have observer attached"
+            return cls.get_qconv(mod, mod.activation_post_process, mod.weight_fake_quant)
+        assert isinstance(mod, (SparseConvolution, nni._FusedModule)),             f"nnq.{cls.__name__}.from_float only works for sparse convolutions but got: {type(mod)}"
+        assert hasattr(mod, "qconfig"), "Input float module must have qconfig defined."
+        act_pp = getattr(mod, "activation_post_process", None)
+        qconfig = mod.qconfig
+        if isinstance(mod, nni._FusedModule):
+            mod = mod[0]
+        return cls.get_qconv(mod, act_pp, qconfig.weight())
+
+    @classmethod
+    def from_reference(cls, ref_qconv, output_scale, output_zero_point):
+        """From a reference quantised module (``quantized.reference.SpConv``)."""
+        kw = conv_ctor_kwargs(ref_qconv)
+        kw.pop("bias")
+        qconv = cls(**kw, device=ref_qconv.weight.device)
+        qconv.set_weight_bias(ref_qconv.get_quantized_weight(),
+                              None if ref_qconv.bias is None else ref_qconv.bias.detach().float())
+        qconv.scale = float(output_scale)
+        qconv.zero_point = int(output_zero_point)
+        return qconv
 
     @classmethod
     def from_float_conv(cls, conv: SparseConvolution, output_scale: float) -> "SparseConv":

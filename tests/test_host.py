@@ -152,6 +152,10 @@ def test_install_as_spconv_aliases_every_submodule():
             assert m.__name__ == f"spconv_amd.pytorch.{name}"
         import spconv.pytorch as sp
         assert sp.SubMConv3d is spconv.SubMConv3d and sp.AddTable is spconv.AddTable
+        from spconv.pytorch.quantization.intrinsic.qat import SparseConvBnReLU   # noqa: F401
+        from spconv.pytorch.quantization.intrinsic.modules import SpconvBnAddReLUNd   # noqa: F401
+        import spconv.pytorch.quantization as spq
+        assert callable(spq.get_spconv_backend_config)
     finally:
         for k in [k for k in sys.modules if k == "spconv" or k.startswith("spconv.")]:
             del sys.modules[k]
