@@ -1546,6 +1546,7 @@ __device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, int block) 
   const int32_t *__restrict__ rec = p.plan2 + plan2_wg(w);     // uniform address: scalar loads
   const int32_t *__restrict__ segs = p.plan2 + plan2_seg(p.G, p.kv);
   const int seg_lo = rec[0], nseg = rec[1];
+  SPX_STAMP(0);
 
   const uint32_t rowD = static_cast<uint32_t>(p.K) * 2u, rowF = static_cast<uint32_t>(p.C) * 2u;
   const __amdgpu_buffer_rsrc_t rD = make_rsrc(p.dout, static_cast<uint32_t>(p.n_out) * rowD);
@@ -1610,6 +1611,7 @@ __device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, int block) 
     load_words(begin);
     load_rows(begin);
     load_words(begin + kW2J);
+    if (si == 0) SPX_STAMP(1);   // first rows issued
     int stage = 0;
     for (int base = begin; base < end; base += kW2J, stage ^= (STAGES - 1)) {
       char *sD = smem + stage * (2 * TILE_B);
@@ -1637,6 +1639,7 @@ __device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, int block) 
           for (int b = 0; b < 2; ++b) acc[a][b] = mfma16<BF16>(fa[a], fb[b], acc[a][b]);
       }
     }
+    if (si == nseg - 1) SPX_STAMP(4);   // last chunk loop done
     // D[i = kk][j = c]: lane holds c = lane & 15, kk = (lane >> 4) * 4 + reg
     float *dst = p.partial + (static_cast<size_t>(seg_lo + si) * ntile + tile) * (kWT * kWT);
 #pragma unroll
@@ -1651,6 +1654,11 @@ __device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, int block) 
         }
     __syncthreads();  // both stages are rewritten by the next segment
   }
+  SPX_STAMP(6);
+#ifdef SPX_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  SPX_STAMP(7);
+#endif
 }
 
 template <bool BF16>
