@@ -2088,9 +2088,10 @@ int spx_igemm_fwd(const void *feat, const void *weight, void *out, const int32_t
                   const uint32_t *mask, const int32_t *argsort, int n_in, int n_out, int C,
                   int K, int kv, int dtype, int identity_k, const void *bias, int act,
                   float act_alpha, spx_stream_t stream) {
-  SPX_CHECK(feat && weight && out, "null tensor pointer");
-  SPX_CHECK(pair || kv == 1, "pair table required");
   SPX_CHECK(C > 0 && K > 0 && kv > 0 && n_in >= 0 && n_out >= 0, "bad sizes");
+  if (n_out == 0) return 0;                                   // empty scene: nothing to write
+  SPX_CHECK((feat || n_in == 0) && weight && out, "null tensor pointer");
+  SPX_CHECK(pair || kv == 1, "pair table required");
   GemmParams p{};
   p.A = feat;
   p.B = weight;
@@ -2119,9 +2120,10 @@ int spx_igemm_fwd_int8(const void *feat, const void *weight, void *out, const in
                        int K, int kv, int identity_k, const float *scale, const float *bias,
                        const void *add, float add_scale, int out_dtype, int act, float act_alpha,
                        spx_stream_t stream) {
-  SPX_CHECK(feat && weight && out, "null tensor pointer");
-  SPX_CHECK(pair || kv == 1, "pair table required");
   SPX_CHECK(C > 0 && K > 0 && kv > 0 && n_in >= 0 && n_out >= 0, "bad sizes");
+  if (n_out == 0) return 0;                                   // empty scene: nothing to write
+  SPX_CHECK((feat || n_in == 0) && weight && out, "null tensor pointer");
+  SPX_CHECK(pair || kv == 1, "pair table required");
   // the reference has the same restriction (test/test_all_algo.py:376-377)
   SPX_CHECK(C % 16 == 0, "int8 needs in_channels %% 16 == 0, got %d", C);
   SPX_CHECK(K == 16 || K == 32 || K == 64 || K == 128 || K == 256,
@@ -2177,7 +2179,8 @@ int spx_igemm_dgrad(const void *dout, const void *weight, void *din, const int32
                     int K, int kv, int dtype, int subm, void *ws, size_t ws_bytes,
                     spx_stream_t stream) {
   (void)ws; (void)ws_bytes;
-  SPX_CHECK(dout && weight && din, "null tensor pointer");
+  if (n_in == 0) return 0;                                    // empty input: no gradient rows
+  SPX_CHECK((dout || n_out == 0) && weight && din, "null tensor pointer");
   SPX_CHECK(pair || kv == 1, "pair table required");
   const GemmParams p = dgrad_params(dout, weight, din, pair, mask, argsort, n_out, n_in, C, K, kv, subm);
   return run_gather_gemm(p, dtype, static_cast<hipStream_t>(stream));
@@ -2221,9 +2224,14 @@ int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t 
                     int K, int kv, int dtype, int subm, void *ws, size_t ws_bytes,
                     spx_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
-  SPX_CHECK(feat && dout && dw && ws, "null tensor pointer");
-  SPX_CHECK(pair_native && num_per_loc, "Native pair lists and counts are required");
+  SPX_CHECK(dw && C > 0 && K > 0, "null tensor pointer");
   SPX_CHECK(kv >= 1 && kv <= 128, "kernel volume %d not supported by wgrad (max 128)", kv);
+  if (n_in == 0 || n_out == 0) {                              // no pairs: the gradient is zero
+    SPX_HIP(hipMemsetAsync(dw, 0, static_cast<size_t>(K) * kv * C * elem_bytes(dtype), s));
+    return 0;
+  }
+  SPX_CHECK(feat && dout && ws, "null tensor pointer");
+  SPX_CHECK(pair_native && num_per_loc, "Native pair lists and counts are required");
   SPX_CHECK(ws_bytes >= spx_igemm_wgrad_ws_bytes(n_in, C, K, kv), "workspace too small");
   WgradParams p{};
   p.feat = feat;
@@ -2339,6 +2347,15 @@ int spx_igemm_bwd(const void *feat, const void *dout, const void *weight, void *
                   int n_in, int n_out, int C, int K, int kv, int dtype, int subm, void *ws,
                   size_t ws_bytes, spx_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n_in == 0 || n_out == 0) {                              // empty scene: din empty / zero, dW zero
+    SPX_CHECK(dw && C > 0 && K > 0 && kv > 0, "null tensor pointer");
+    SPX_HIP(hipMemsetAsync(dw, 0, static_cast<size_t>(K) * kv * C * elem_bytes(dtype), s));
+    if (n_in > 0) {
+      SPX_CHECK(din, "null tensor pointer");
+      SPX_HIP(hipMemsetAsync(din, 0, static_cast<size_t>(n_in) * C * elem_bytes(dtype), s));
+    }
+    return 0;
+  }
   SPX_CHECK(feat && dout && weight && din && dw && ws, "null tensor pointer");
   SPX_CHECK(pair_native && num_per_loc, "Native pair lists and counts are required");
   SPX_CHECK(pair || kv == 1, "pair table required");

@@ -235,3 +235,108 @@ def test_lidar_like_scene_fp16(cuda):
         _check("out", out, out_ref, 2e-3)
         _check("din", din, din_ref, 2e-3)
         _check("dw", dw, dw_ref, 2e-3)
+
+
+def _oracle_fwd_bwd(idx, bs, shape, ksize, stride, pad, dil, subm, f, w, dout_fn):
+    ref = oracle_rulebook(idx, bs, shape, ksize, stride, pad, dil, subm)
+    dout = dout_fn(ref["n_out"])
+    out = oracle.indice_conv(f, w, torch.from_numpy(ref["pair"]), torch.from_numpy(ref["num"]), ref["n_out"],
+                             subm=subm)
+    din, dw = oracle.indice_conv_backward(f, w, dout, torch.from_numpy(ref["pair"]),
+                                          torch.from_numpy(ref["num"]), subm=subm)
+    return ref, dout, out, din, dw
+
+
+@pytest.mark.parametrize("subm", [True, False])
+def test_ragged_batch_with_an_empty_scene(cuda, subm):
+    """Scenes of very different sizes in one batch, one of them empty (batch id 1 never occurs)
+    and one holding a single voxel: rulebook bit-exact, features within tolerance."""
+    shape, bs, C, K = [16, 18, 20], 4, 32, 32
+    parts = [dense_scene(shape, 1800, 1, 1), dense_scene(shape, 1, 1, 2), dense_scene(shape, 300, 1, 3)]
+    for b, p in zip((0, 2, 3), parts):
+        p[:, 0] = b
+    idx = np.ascontiguousarray(np.concatenate(parts))
+    idx = idx[np.random.default_rng(0).permutation(idx.shape[0])]            # scenes interleaved
+    rng = np.random.default_rng(1)
+    f = _rounded(rng.uniform(-1, 1, (idx.shape[0], C)).astype(np.float32), torch.float16)
+    w = _rounded(rng.uniform(-1, 1, (K, 3, 3, 3, C)).astype(np.float32), torch.float16)
+    stride, pad = ([1] * 3, [1] * 3) if subm else ([2] * 3, [1] * 3)
+    ref, dout, out, din, dw = _oracle_fwd_bwd(
+        idx, bs, shape, [3] * 3, stride, pad, [1] * 3, subm, f, w,
+        lambda n: _rounded(rng.uniform(-0.2, 0.2, (n, K)).astype(np.float32), torch.float16))
+    rb, gout, gdin, gdw = _run_gpu(cuda, idx, bs, shape, [3] * 3, stride, pad, [1] * 3, subm, False, f, w, dout,
+                                   torch.float16)
+    from util import assert_rulebook_equal
+    assert_rulebook_equal(rb, ref, subm)
+    assert not (to_np(rb.out_indices)[:, 0] == 1).any()
+    _check("out", gout, out, TOL[torch.float16])
+    _check("din", gdin, din, TOL[torch.float16])
+    _check("dw", gdw, dw, TOL[torch.float16])
+
+
+def test_single_voxel_and_zero_voxels(cuda):
+    """n = 1 (one workgroup, one row) and n = 0 (every kernel is a no-op, outputs are empty,
+    the weight gradient is exactly zero)."""
+    from spconv_amd.pytorch import ops
+    shape, C, K = [8, 8, 8], 16, 32
+    w = torch.randn(K, 3, 3, 3, C, device=cuda).half()
+    one = np.array([[0, 3, 4, 5]], dtype=np.int32)
+    rb, _ = gpu_rulebook(one, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True)
+    f = torch.randn(1, C, device=cuda).half()
+    out = ops.igemm_fwd(f, w, rb.pair_fwd, rb.mask_fwd, None, 1, 13)
+    want = f.float() @ w[:, 1, 1, 1, :].float().t()
+    assert torch.allclose(out.float(), want, atol=2e-2, rtol=2e-3)
+    din, dw = ops.igemm_bwd(f, out, w, rb.pair_fwd, rb.mask_fwd, None, rb.pair_native, rb.num_per_loc, True,
+                            ops._plan_of(rb))
+    assert torch.allclose(din.float(), out.float() @ w[:, 1, 1, 1, :].float(), atol=5e-1, rtol=5e-3)
+    centre = dw[:, 1, 1, 1, :].float()
+    assert torch.allclose(centre, out.float().t() @ f.float(), atol=5e-2, rtol=5e-3)
+    dw_off = dw.float().clone()
+    dw_off[:, 1, 1, 1, :] = 0
+    assert float(dw_off.abs().max()) == 0.0                        # no neighbours: only the centre tap
+    empty = np.zeros((0, 4), dtype=np.int32)
+    rb0, _ = gpu_rulebook(empty, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True)
+    f0 = torch.zeros(0, C, device=cuda).half()
+    out0 = ops.igemm_fwd(f0, w, rb0.pair_fwd, rb0.mask_fwd, None, 0, 13)
+    assert out0.shape == (0, K)
+    dw0 = ops.igemm_wgrad(f0, out0, w.shape, rb0.pair_native, rb0.num_per_loc, True, None)
+    assert dw0.shape == w.shape and float(dw0.float().abs().max()) == 0.0
+    # the same through the module + autograd: an empty scene yields an empty output and zero gradients
+    import spconv_amd.pytorch as spconv
+    net = spconv.SubMConv3d(C, K, 3, bias=True).to(cuda).half()
+    x = spconv.SparseConvTensor(f0.clone().requires_grad_(True), torch.zeros(0, 4, dtype=torch.int32, device=cuda),
+                                shape, 1)
+    y = net(x)
+    assert y.features.shape == (0, K)
+    y.features.sum().backward()
+    assert net.weight.grad is not None and float(net.weight.grad.float().abs().max()) == 0.0
+
+
+def test_one_million_voxels_identity_and_linearity(cuda):
+    """Size-independent properties at a size the oracle does not reach (1 M voxels, batch 8):
+    an identity centre tap reproduces the input bit-for-bit, the op is linear in the features,
+    and the rulebook obeys the SubM mirror symmetry."""
+    from spconv_amd.pytorch import ops
+    shape, bs, C = [40, 400, 400], 8, 32
+    idx = scene(shape, 125_000, bs, seed=7)
+    rb, _ = gpu_rulebook(idx, bs, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True)
+    n = idx.shape[0]
+    assert n == 1_000_000
+    pf = rb.pair_fwd
+    # mirror symmetry: pair[k][o] = v  <=>  pair[26-k][v] = o  (checked on a sample of offsets)
+    for k in (0, 5, 12):
+        o = torch.nonzero(pf[k] >= 0).flatten()
+        v = pf[k][o].long()
+        assert torch.equal(pf[26 - k][v].long(), o)
+    assert torch.equal(pf[13], torch.arange(n, device=cuda, dtype=torch.int32))
+    g = torch.Generator(device="cpu").manual_seed(0)
+    f1 = torch.randn(n, C, generator=g).to(cuda).half()
+    f2 = torch.randn(n, C, generator=g).to(cuda).half()
+    w = torch.zeros(C, 3, 3, 3, C, device=cuda).half()
+    w[:, 1, 1, 1, :] = torch.eye(C, device=cuda).half()
+    assert torch.equal(ops.igemm_fwd(f1, w, pf, rb.mask_fwd, None, n, 13), f1)
+    wr = (torch.randn(C, 3, 3, 3, C, generator=g) * 0.1).to(cuda).half()
+    a = ops.igemm_fwd(f1, wr, pf, rb.mask_fwd, None, n, 13).float()
+    b = ops.igemm_fwd(f2, wr, pf, rb.mask_fwd, None, n, 13).float()
+    ab = ops.igemm_fwd((f1.float() + f2.float()).half(), wr, pf, rb.mask_fwd, None, n, 13).float()
+    assert float((ab - (a + b)).abs().max()) < 2e-2 * float((a + b).abs().max())
