@@ -1399,9 +1399,12 @@ struct Wgrad2Params {
 __host__ __device__ inline int plan2_wg(int w) { return 8 + kW2Rec * w; }
 __host__ __device__ inline int plan2_kf(int G) { return 8 + kW2Rec * G; }
 __host__ __device__ inline int plan2_seg(int G, int kv) { return 8 + kW2Rec * G + kv + 1; }
-// work list of the second stage: [0] items, then 2 ints per item: offset k | mode << 8, first
-// element inside a 64x64 tile.  At most kv * 256 items.
-__host__ __device__ inline int plan2_red(int G, int kv) { return plan2_seg(G, kv) + 3 * (G + kv); }
+// work list of the second stage: [0] items, then (16-byte aligned) 4 ints per item: offset k |
+// mode << 8, first element inside a 64x64 tile, first segment of k, segments of k -- everything a
+// block needs comes with ONE scalar load.  At most kv * 256 items.
+__host__ __device__ inline int plan2_red(int G, int kv) {
+  return (plan2_seg(G, kv) + 3 * (G + kv) + 3) & ~3;
+}
 
 __global__ void __launch_bounds__(kW2MaxG)
 wgrad_plan2_kernel(const int32_t *__restrict__ num, int n_in, int kv, int subm, int G,
@@ -1499,8 +1502,11 @@ wgrad_plan2_kernel(const int32_t *__restrict__ num, int n_in, int kv, int subm, 
     const int mode = kcount[k] >= 48 ? 0 : (kcount[k] >= 6 ? 1 : 2);
     const int E = mode == 0 ? 16 : (mode == 1 ? 128 : 512), cnt_items = (kWT * kWT) / E;
     for (int q = tid; q < cnt_items; q += kW2MaxG) {
-      rl[1 + 2 * (ritems[k] + q)] = k | (mode << 8);
-      rl[2 + 2 * (ritems[k] + q)] = q * E;
+      int32_t *item = rl + 4 + 4 * (ritems[k] + q);
+      item[0] = k | (mode << 8);
+      item[1] = q * E;
+      item[2] = kfirst[k];
+      item[3] = kcount[k];
     }
   }
 }
@@ -1809,15 +1815,14 @@ template <typename T>
 __global__ void __launch_bounds__(kRedThreads)
 wgrad_reduce2_kernel(Wgrad2Params p, T *__restrict__ dw) {
   __shared__ float red[kRedThreads];
-  const int32_t *__restrict__ kf = p.plan2 + plan2_kf(p.G);
   const int32_t *__restrict__ rl = p.plan2 + plan2_red(p.G, p.kv);
   const int nitems = rl[0];
   const int ntile = p.tiles_k * p.tiles_c;
   const size_t stride = static_cast<size_t>(ntile) * (kWT * kWT);
   const int tile = blockIdx.y;
   for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
-    const int k = rl[1 + 2 * it] & 0xff, mode = rl[1 + 2 * it] >> 8, e0 = rl[2 + 2 * it];
-    const int first = kf[k], nseg = kf[k + 1] - kf[k];
+    const int4 item = *reinterpret_cast<const int4 *>(rl + 4 + 4 * it);    // uniform: one s_load_dwordx4
+    const int k = item.x & 0xff, mode = item.x >> 8, e0 = item.y, first = item.z, nseg = item.w;
     const float *base = p.partial + static_cast<size_t>(first) * stride + tile * (kWT * kWT) + e0;
     if (mode == 0) {
       // long list: 16 elements (4 lanes x float4) x 128 segment groups; with a few hundred
@@ -2001,7 +2006,7 @@ int wgrad_groups(int n_in) {
 
 size_t wgrad_plan2_ints(int n_in, int kv) {
   const size_t G = wgrad_groups(n_in);
-  return 8 + kW2Rec * G + kv + 1 + 3 * (G + kv) + 1 + 2 * static_cast<size_t>(kv) * 256 + 8;
+  return 8 + kW2Rec * G + kv + 1 + 3 * (G + kv) + 4 + 4 + 4 * static_cast<size_t>(kv) * 256 + 8;
 }
 
 GemmParams dgrad_params(const void *dout, const void *weight, void *din, const int32_t *pair,
