@@ -340,3 +340,65 @@ def test_one_million_voxels_identity_and_linearity(cuda):
     b = ops.igemm_fwd(f2, wr, pf, rb.mask_fwd, None, n, 13).float()
     ab = ops.igemm_fwd((f1.float() + f2.float()).half(), wr, pf, rb.mask_fwd, None, n, 13).float()
     assert float((ab - (a + b)).abs().max()) < 2e-2 * float((a + b).abs().max())
+
+
+@pytest.mark.timeout(600)
+def test_tensors_beyond_two_gigabytes(cuda):
+    """Maximum sizes: 17 M voxels x 64 fp16 channels = 2.18 GB per feature tensor, past the 32-bit
+    byte offsets the fast kernels address with -- the library must switch to its 64-bit-offset
+    kernels.  A fully occupied 41 x 644 x 644 block in raster order makes every expected value
+    analytic: neighbour index = row + dz*Y*X + dy*X + dx, pair counts = products of (extent - |d|)."""
+    from spconv_amd.pytorch import ops
+    Z, Y, X, C = 41, 644, 644, 64
+    n = Z * Y * X
+    assert n * C * 2 > 2 ** 31
+    zz, yy, xx = torch.meshgrid(torch.arange(Z, dtype=torch.int32), torch.arange(Y, dtype=torch.int32),
+                                torch.arange(X, dtype=torch.int32), indexing="ij")
+    idx = torch.stack([torch.zeros_like(zz), zz, yy, xx], dim=-1).reshape(n, 4).contiguous().to(cuda)
+    del zz, yy, xx
+    rb, _ = ops.build_rulebook(idx, 1, [Z, Y, X], [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True)
+    num = rb.num_per_loc.cpu().numpy()
+    offs = [(a - 1, b - 1, c - 1) for a in range(3) for b in range(3) for c in range(3)]
+    for k in range(13):
+        dz, dy, dx = offs[k]
+        assert num[k] == (Z - abs(dz)) * (Y - abs(dy)) * (X - abs(dx)), k
+    g = torch.Generator().manual_seed(0)
+    f = torch.empty(n, C, dtype=torch.float16, device=cuda).uniform_(-1, 1)
+    w = (torch.rand(C, 3, 3, 3, C, generator=g) * 2 - 1).to(cuda).half()
+    out = ops.igemm_fwd(f, w, rb.pair_fwd, rb.mask_fwd, None, n, 13)
+    rows = torch.randint(0, n, (4096,), generator=g).to(cuda)
+    rows[:8] = torch.tensor([0, 1, X, Y * X, n - 1, n - 2, n - X, n - Y * X])     # corners / faces
+    z, y, x = rows // (Y * X), (rows // X) % Y, rows % X
+
+    def expect(feat, weight_of):
+        acc = torch.zeros(rows.shape[0], C, device=cuda)
+        for k, (dz, dy, dx) in enumerate(offs):
+            ok = ((z + dz >= 0) & (z + dz < Z) & (y + dy >= 0) & (y + dy < Y) & (x + dx >= 0) & (x + dx < X))
+            src = (rows + dz * Y * X + dy * X + dx).clamp(0, n - 1)
+            acc += (feat[src].float() * ok[:, None]) @ weight_of(k)
+        return acc
+    want = expect(f, lambda k: w.reshape(C, 27, C)[:, k, :].float().t())
+    got = out[rows].float()
+    assert float((got - want).abs().max() / want.abs().max()) < 3e-3
+    # dgrad: din[i] = sum_k dout[i - offset_k] W_k  ==  forward with the mirrored offset and W_k^T
+    dout = torch.empty(n, C, dtype=torch.float16, device=cuda).uniform_(-0.2, 0.2)
+    din = ops.igemm_dgrad(dout, w, rb.pair_fwd, rb.mask_fwd, None, n, True)
+    want = expect(dout, lambda k: w.reshape(C, 27, C)[:, 26 - k, :].float())
+    assert float((din[rows].float() - want).abs().max() / want.abs().max()) < 3e-3
+    del din, out
+    # wgrad on three offsets: dW_k = dout[out rows]^T f[in rows], rows of the pair list are analytic
+    dw = ops.igemm_wgrad(f, dout, w.shape, rb.pair_native, rb.num_per_loc, True, ops._plan_of(rb))
+    for k in (0, 13, 22):
+        dz, dy, dx = offs[k]
+        shift = dz * Y * X + dy * X + dx
+        o = torch.arange(n, device=cuda)
+        oz, oy, ox = o // (Y * X), (o // X) % Y, o % X
+        ok = ((oz + dz >= 0) & (oz + dz < Z) & (oy + dy >= 0) & (oy + dy < Y) & (ox + dx >= 0) & (ox + dx < X))
+        o = o[ok]
+        del oz, oy, ox, ok
+        want_k = torch.zeros(C, C, device=cuda)
+        for a in range(0, o.shape[0], 2_000_000):
+            oo = o[a:a + 2_000_000]
+            want_k += dout[oo].float().t() @ f[oo + shift].float()
+        got_k = dw.reshape(C, 27, C)[:, k, :].float()
+        assert float((got_k - want_k).abs().max() / want_k.abs().max()) < 5e-3, k
