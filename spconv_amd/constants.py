@@ -3,6 +3,10 @@ import os
 
 # spconv/constants.py:119-121: sort output rows by mask so that whole tiles skip offsets.
 SPCONV_DO_SORT = os.getenv("SPCONV_DO_SORT", "1") == "1"
+# The layer modules sort only when SPCONV_DO_SORT=1 is set EXPLICITLY: here the sort costs ~170 us
+# per rulebook and buys ~2.5 us per kernel at 100k voxels, so unlike the
+# reference it is not the default; ops.get_indice_pairs_implicit_gemm keeps the reference default.
+MODULE_DO_SORT = os.getenv("SPCONV_DO_SORT", "") == "1"
 # spconv/constants.py:36: layout of checkpoints produced by spconv 1.x / 2.1 ("KRSC", "RSKC", "RSCK").
 SAVED_WEIGHT_LAYOUT = os.getenv("SPCONV_SAVED_WEIGHT_LAYOUT", "")
 # run dgrad and wgrad of one layer on two HIP streams (they are independent).  Off by default:

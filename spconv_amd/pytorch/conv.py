@@ -26,7 +26,7 @@ from torch.nn import init
 from torch.nn.init import calculate_gain
 from torch.nn.parameter import Parameter
 
-from spconv_amd.constants import SAVED_WEIGHT_LAYOUT, SPCONV_DO_SORT
+from spconv_amd.constants import MODULE_DO_SORT, SAVED_WEIGHT_LAYOUT
 from spconv_amd.pytorch import functional as Fsp
 from spconv_amd.pytorch import ops
 from spconv_amd.pytorch.core import (ConvAlgo, ImplicitGemmIndiceData, IndiceData, Rulebook,
@@ -324,7 +324,7 @@ class SparseConvolution(SparseModule):
             rb, _ = ops.build_rulebook(indices, batch_size, spatial_shape, self.kernel_size,
                                        self.stride, self.padding, self.dilation,
                                        self.output_padding, self.subm, self.transposed,
-                                       do_sort=False)
+                                       do_sort=MODULE_DO_SORT)
             if input.benchmark:
                 torch.cuda.synchronize()
                 out_tensor.benchmark_record[name]["indice_gen_time"].append(time.time() - t)

@@ -18,7 +18,6 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from spconv_amd.pytorch import ops
-from spconv_amd.pytorch.core import ConvAlgo
 
 import torch.amp as _amp
 

@@ -9,7 +9,6 @@ from __future__ import annotations
 import sys
 from collections import OrderedDict
 
-import torch
 from torch import nn
 
 from spconv_amd.pytorch.core import SparseConvTensor

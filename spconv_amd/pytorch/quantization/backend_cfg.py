@@ -19,8 +19,6 @@ import operator
 from typing import Dict, List, Optional, Tuple, Type
 
 import torch
-import torch.ao.nn.intrinsic as nni
-import torch.ao.nn.quantized.reference as nnqr
 import torch.nn.functional as F
 from torch import nn
 from torch.ao.quantization.backend_config import (BackendConfig, BackendPatternConfig, DTypeConfig,
