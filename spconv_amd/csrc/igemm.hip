@@ -555,7 +555,7 @@ struct GemmRest {
   int out_dtype;
 };
 
-template <int COUT, int MB, int DT, bool BT>
+template <int COUT, int MB, int DT, bool BT, int NKS = 2>
 __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block);
 __device__ __forceinline__ void unpack_gemm_args(GemmParams &p, const void *argA, const void *argB,
                                                  const uint32_t *arg_mask, const int32_t *arg_argsort,
@@ -563,7 +563,11 @@ __device__ __forceinline__ void unpack_gemm_args(GemmParams &p, const void *argA
                                                  int kv, int identity_k, int b_reverse,
                                                  const GemmRest &rest);
 
-template <int COUT, int MB, int DT, bool BT>
+// NKS = 1: rows of at most 64 bytes (16 / 32 16-bit channels): the second half of every 128-byte
+// piece is empty, so its loads and MFMAs are not emitted at all -- the dense-scene kernels are
+// bound by vector-memory INSTRUCTIONS (16 clocks each in the address unit, whatever the lanes
+// fetch), and a dead load costs as much as a live one.
+template <int COUT, int MB, int DT, bool BT, int NKS = 2>
 __global__ void __launch_bounds__(kThreads)
 igemm_v4_kernel(const void *argA, const void *argB, const uint32_t *arg_mask,
                 const int32_t *arg_argsort, const int32_t *arg_pair, int n_dst, int n_src, int CIN,
@@ -571,7 +575,7 @@ igemm_v4_kernel(const void *argA, const void *argB, const uint32_t *arg_mask,
   GemmParams p;
   unpack_gemm_args(p, argA, argB, arg_mask, arg_argsort, arg_pair, n_dst, n_src, CIN, kv, identity_k,
                    b_reverse, rest);
-  igemm_v4_body<COUT, MB, DT, BT>(p, blockIdx.x);
+  igemm_v4_body<COUT, MB, DT, BT, NKS>(p, blockIdx.x);
 }
 
 __device__ __forceinline__ void unpack_gemm_args(GemmParams &p, const void *argA, const void *argB,
@@ -604,7 +608,7 @@ __device__ __forceinline__ void unpack_gemm_args(GemmParams &p, const void *argA
   p.out_dtype = rest.out_dtype;
 }
 
-template <int COUT, int MB, int DT, bool BT>
+template <int COUT, int MB, int DT, bool BT, int NKS>
 __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   constexpr bool BF16 = DT == 1, I8 = DT == 2, F32 = DT == 3;
   constexpr int ES = I8 ? 1 : (F32 ? 4 : 2);            // bytes per element
@@ -663,9 +667,10 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   // zero on BOTH operands).  Bitwise on purpose: a ?: between two arrays becomes a pointer
   // select that pins them (and the parameter block) in scratch.
   const int ctail = static_cast<int>(rowB) - (nchunk - 1) * kRowBytes;   // bytes in the last chunk
-  uint32_t aoff[2], aoff_tail[2];
+  constexpr int AK = NKS < 2 ? 2 : NKS;                 // (register arrays stay at >= 2 elements)
+  uint32_t aoff[AK], aoff_tail[AK];
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
+  for (int ks = 0; ks < NKS; ++ks) {
     const int c = ks * 64 + lgrp * 16;                  // byte inside the 128-byte piece
     aoff[ks] = static_cast<uint32_t>(c);
     aoff_tail[ks] = c < ctail ? 0u : kOob;
@@ -693,7 +698,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
 
   int idxr[2][MB];
   uint32_t identr[2] = {0u, 0u};   // wave-uniform: idxr[S] stands for the identity offset
-  u32x4 areg[2][MB][2];
+  u32x4 areg[2][MB][AK];
   u32x4 breg[BA];
 
   // Straight-line on purpose (no branch around a load): the compiler's s_waitcnt counts stay
@@ -722,7 +727,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
                            (static_cast<uint32_t>(idxr[S][mb]) & ~identr[S]);
       const uint32_t rbase = idx * rowB;                                   // -1 -> >= kOob
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < NKS; ++ks) {
         const uint32_t lo = aoff[ks] | (aoff_tail[ks] & tail);
         const uint32_t vo = min(rbase + lo, kOob) | (lo & kOob);
         areg[S][mb][ks] = __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0);
@@ -851,7 +856,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
       const char *cur = smem + S * B_BYTES;
       const int ksteps = (min(kRowBytes, static_cast<int>(rowB) - it.chunk * kRowBytes) + 63) >> 6;  // 1 or 2
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < NKS; ++ks) {
         if (ks < ksteps) {
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) {
@@ -1052,14 +1057,20 @@ template <int COUT, int MB, int DT>
 int launch_v4(const GemmParams &p, hipStream_t s) {
   const int ntiles = div_up(p.n_dst, 64 * MB);
   const GemmRest r = rest_of(p);
-  if (DT == 2 || p.strideD == 1)
-    hipLaunchKernelGGL((igemm_v4_kernel<COUT, MB, DT, false>), dim3(ntiles), dim3(kThreads),
-                       (v4_smem_bytes<COUT, MB>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,
-                       p.n_src, p.CIN, p.kv, p.identity_k, p.b_reverse, r);
-  else if constexpr (DT != 2)
-    hipLaunchKernelGGL((igemm_v4_kernel<COUT, MB, DT, true>), dim3(ntiles), dim3(kThreads),
-                       (v4_smem_bytes<COUT, MB>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,
-                       p.n_src, p.CIN, p.kv, p.identity_k, p.b_reverse, r);
+  constexpr int es = DT == 2 ? 1 : (DT == 3 ? 4 : 2);
+  const bool half = p.CIN * es <= 64;        // narrow rows: only the first 64 bytes of a piece exist
+#define SPX_LAUNCH_V4(BTV, NKSV)                                                                     \
+  hipLaunchKernelGGL((igemm_v4_kernel<COUT, MB, DT, BTV, NKSV>), dim3(ntiles), dim3(kThreads),          \
+                     (v4_smem_bytes<COUT, MB>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,      \
+                     p.n_src, p.CIN, p.kv, p.identity_k, p.b_reverse, r)
+  if (DT == 2 || p.strideD == 1) {
+    if (half) SPX_LAUNCH_V4(false, 1);
+    else SPX_LAUNCH_V4(false, 2);
+  } else if constexpr (DT != 2) {
+    if (half) SPX_LAUNCH_V4(true, 1);
+    else SPX_LAUNCH_V4(true, 2);
+  }
+#undef SPX_LAUNCH_V4
   SPX_LAUNCH_CHECK();
   return 0;
 }
@@ -1786,7 +1797,7 @@ wgrad_f32_kernel(Wgrad2Params p) {
 // is latency-bound with idle issue slots and idle HBM bandwidth, so running them side by side
 // on the same CUs costs little more than the slower one -- and one kernel boundary (~1.7 us)
 // disappears.  (Two HIP streams were tried first: the fork/join costs more than it buys.)
-template <int COUT, int MB, int DT>
+template <int COUT, int MB, int DT, int NKS = 2>
 __global__ void __launch_bounds__(kThreads, COUT <= 64 ? 4 : 2)   // 4 waves/SIMD: 1024 resident workgroups
 igemm_bwd_kernel(const void *argA, const void *argB, const uint32_t *arg_mask,
                  const int32_t *arg_argsort, const int32_t *arg_pair, int n_dst, int n_src, int CIN,
@@ -1800,7 +1811,7 @@ igemm_bwd_kernel(const void *argA, const void *argB, const uint32_t *arg_mask,
     GemmParams p;
     unpack_gemm_args(p, argA, argB, arg_mask, arg_argsort, arg_pair, n_dst, n_src, CIN, kv,
                      identity_k, b_reverse, rest);
-    igemm_v4_body<COUT, MB, DT, true>(p, n_dgrad < 0 ? b - nw : b);
+    igemm_v4_body<COUT, MB, DT, true, NKS>(p, n_dgrad < 0 ? b - nw : b);
   } else {
     wgrad_tr_body<DT == 1, 1>(wp, n_dgrad < 0 ? b : b - n_dgrad);
   }
@@ -2066,10 +2077,16 @@ template <int COUT, int MB, int DT>
 int launch_bwd(const GemmParams &p, const Wgrad2Params &q, int n_wgrad_blocks, hipStream_t s) {
   const int n_dgrad = div_up(p.n_dst, 64 * MB);
   static const int wgrad_first = env_int("SPX_BWD_WGRAD_FIRST", 1);   // tuning knob (A/B runs)
-  hipLaunchKernelGGL((igemm_bwd_kernel<COUT, MB, DT>), dim3(n_dgrad + n_wgrad_blocks), dim3(kThreads),
-                     (bwd_smem_bytes<COUT, MB>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,
-                     p.n_src, p.CIN, p.kv, p.identity_k, p.b_reverse, rest_of(p),
-                     wgrad_first ? ~n_wgrad_blocks : n_dgrad, q);
+  if (p.CIN * 2 <= 64)     // dgrad's reduction rows (dout channels) fit half a piece
+    hipLaunchKernelGGL((igemm_bwd_kernel<COUT, MB, DT, 1>), dim3(n_dgrad + n_wgrad_blocks), dim3(kThreads),
+                       (bwd_smem_bytes<COUT, MB>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,
+                       p.n_src, p.CIN, p.kv, p.identity_k, p.b_reverse, rest_of(p),
+                       wgrad_first ? ~n_wgrad_blocks : n_dgrad, q);
+  else
+    hipLaunchKernelGGL((igemm_bwd_kernel<COUT, MB, DT, 2>), dim3(n_dgrad + n_wgrad_blocks), dim3(kThreads),
+                       (bwd_smem_bytes<COUT, MB>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,
+                       p.n_src, p.CIN, p.kv, p.identity_k, p.b_reverse, rest_of(p),
+                       wgrad_first ? ~n_wgrad_blocks : n_dgrad, q);
   SPX_LAUNCH_CHECK();
   return 0;
 }
