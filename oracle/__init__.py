@@ -60,6 +60,8 @@ def lib() -> ctypes.CDLL:
         fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, _I32P, ctypes.c_int,
                        ctypes.c_int, ctypes.c_int]
         fn.restype = None
+    L.orc_set_omp_threads.argtypes = [ctypes.c_int]
+    L.orc_set_omp_threads.restype = None
     for name in ("orc_scatter_add_f32", "orc_scatter_add_f64", "orc_scatter_add_f32_omp"):
         fn = getattr(L, name)
         fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, _I32P, ctypes.c_int, ctypes.c_int]
@@ -454,3 +456,8 @@ def point2voxel(points: np.ndarray, vsize_zyx, coors_range_zyx, grid_size_zyx, m
                            pid.ctypes.data_as(ctypes.c_void_p))
     return voxels[:nv], indices[:nv], num[:nv], pid
 
+
+
+def set_omp_threads(n: int) -> None:
+    """Threads used by the faithful-omp gather / scatter variants (``omp=True``)."""
+    lib().orc_set_omp_threads(int(n))

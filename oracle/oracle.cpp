@@ -20,6 +20,9 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <limits>
 #include <unordered_map>
 
@@ -276,6 +279,15 @@ void orc_scatter_add_f64(double *out, const double *in, const int32_t *inds,
     double *o = out + size_t(inds[i]) * channel;
     for (int j = 0; j < channel; ++j) o[j] = o[j] + buf[j];
   }
+}
+
+// Thread count of the faithful-omp variants below (bench.py's cpu_baseline leg).
+void orc_set_omp_threads(int n) {
+#ifdef _OPENMP
+  omp_set_num_threads(n > 0 ? n : 1);
+#else
+  (void)n;
+#endif
 }
 
 // "faithful-omp" variants (what a source CUMM_CPU_ONLY_BUILD with -fopenmp
