@@ -165,6 +165,69 @@ __device__ __forceinline__ bool in_range(const int (&c)[4], const int (&dims)[4]
   return ok;
 }
 
+// ------------------------------------------------------------ range fills
+// Every "memset" of a rulebook build in ONE launch: on a host-bound pipeline (a single scene per
+// step) a rulebook is a dozen launches of ~6 us of host time each, and hipMemsetAsync costs a
+// launch like any kernel.  Ranges are 4-byte aligned multiples of 4 bytes; the 16-byte aligned
+// middle of each goes out as dwordx4 stores.
+constexpr int kMaxFills = 8;
+struct FillJobs {
+  uint32_t *ptr[kMaxFills];
+  unsigned long long words[kMaxFills];
+  uint32_t value[kMaxFills];
+  int n;
+};
+
+__global__ void __launch_bounds__(kBlock)
+fill_ranges_kernel(FillJobs jobs) {
+  const unsigned long long t = static_cast<unsigned long long>(blockIdx.x) * kBlock + threadIdx.x;
+  const unsigned long long T = static_cast<unsigned long long>(gridDim.x) * kBlock;
+  for (int j = 0; j < jobs.n; ++j) {
+    uint32_t *p = jobs.ptr[j];
+    const unsigned long long w = jobs.words[j];
+    const uint32_t v = jobs.value[j];
+    unsigned long long head = (4 - ((reinterpret_cast<uintptr_t>(p) >> 2) & 3)) & 3;
+    if (head > w) head = w;
+    const unsigned long long body = (w - head) >> 2, tail = (w - head) & 3;
+    if (t < head) p[t] = v;
+    uint4 *q = reinterpret_cast<uint4 *>(p + head);
+    const uint4 vv = make_uint4(v, v, v, v);
+    for (unsigned long long i = t; i < body; i += T) q[i] = vv;
+    if (t < tail) p[head + 4 * body + t] = v;
+  }
+}
+
+struct FillList {
+  FillJobs jobs;
+  FillList() { jobs.n = 0; }
+  // adjacent ranges with the same value merge (tables carved from one buffer: one range)
+  void add(void *ptr, size_t bytes, uint32_t value) {
+    if (!ptr || bytes == 0) return;
+    uint32_t *p = static_cast<uint32_t *>(ptr);
+    for (int j = 0; j < jobs.n; ++j) {
+      if (jobs.value[j] != value) continue;
+      if (jobs.ptr[j] + jobs.words[j] == p) { jobs.words[j] += bytes / 4; return; }
+      if (p + bytes / 4 == jobs.ptr[j]) { jobs.ptr[j] = p; jobs.words[j] += bytes / 4; return; }
+    }
+    jobs.ptr[jobs.n] = p;
+    jobs.words[jobs.n] = bytes / 4;
+    jobs.value[jobs.n] = value;
+    ++jobs.n;
+  }
+  hipError_t launch(hipStream_t s) const {
+    if (jobs.n == 0) return hipSuccess;
+    unsigned long long most = 0;
+    for (int j = 0; j < jobs.n; ++j) most = jobs.words[j] > most ? jobs.words[j] : most;
+    // 16 words (four dwordx4) per thread of the longest range, at most 2048 workgroups
+    unsigned long long blocks = (most + 16ull * kBlock - 1) / (16ull * kBlock);
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(fill_ranges_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, s, jobs);
+    return hipGetLastError();
+  }
+};
+
+void table_fill(FillList &f, const Table &t);
+
 // ---------------------------------------------------------------- SubM
 
 __global__ void __launch_bounds__(kBlock)
@@ -497,6 +560,32 @@ mask_from_table_kernel(const int32_t *__restrict__ table, int kv, int n, int wor
   }
 }
 
+// Both masks of a regular-conv rulebook in one launch: rows [0, n_a) of table a, then rows of b.
+__global__ void __launch_bounds__(kBlock)
+mask_from_tables_kernel(const int32_t *__restrict__ ta, int n_a, uint32_t *__restrict__ ma,
+                        const int32_t *__restrict__ tb, int n_b, uint32_t *__restrict__ mb,
+                        int kv, int words) {
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  const int32_t *table = ta;
+  uint32_t *mask = ma;
+  int n = n_a;
+  if (i >= n_a) {
+    i -= n_a;
+    table = tb;
+    mask = mb;
+    n = n_b;
+  }
+  if (i >= n) return;
+  uint32_t mcur = 0;
+  for (int k = 0; k < kv; ++k) {
+    if (table[static_cast<size_t>(k) * n + i] >= 0) mcur |= 1u << (k & 31);
+    if ((k & 31) == 31 || k == kv - 1) {
+      mask[static_cast<size_t>(i) * words + (k >> 5)] = mcur;
+      mcur = 0;
+    }
+  }
+}
+
 // ------------------------------------------------------- mask argsort (a9)
 // Stable LSD radix sort of (mask word, row) with 8-bit digits built from the
 // same count -> scan -> scatter primitives.  words == 1 only (kv <= 32).
@@ -617,6 +706,15 @@ void table_place(Table &t, hkey_t *keys, int32_t *vals, uint32_t cap, bool packe
   t.vals = packed ? reinterpret_cast<int32_t *>(keys) : vals;
   t.mask = cap - 1;
   t.packed = packed ? 1 : 0;
+}
+
+// The table's bytes as a 0xFF range of a FillList (see table_clear).
+void table_fill(FillList &f, const Table &t) {
+  const size_t cap = static_cast<size_t>(t.mask) + 1;
+  const size_t bytes = t.packed ? cap * sizeof(unsigned long long)
+                                : static_cast<size_t>(reinterpret_cast<char *>(t.vals + cap) -
+                                                      reinterpret_cast<char *>(t.keys));
+  f.add(t.keys, bytes, 0xFFFFFFFFu);
 }
 
 // Empties the table: every byte 0xFF (keys -1, values 0xFFFFFFFF, packed slots ~0).
@@ -1055,7 +1153,6 @@ int spx_subm_rulebook(const int32_t *indices, int n, int ndim, int batch_size,
   const Geom g = make_geom(ndim, batch_size, spatial_shape, spatial_shape, ksize, stride,
                            padding, dilation);
   const int words = div_up(kv, 32);
-  if (num_per_loc) SPX_HIP(hipMemsetAsync(num_per_loc, 0, sizeof(int32_t) * kv, s));
   if (n == 0) return 0;
 
   const uint32_t cap = table_capacity(n);
@@ -1071,29 +1168,21 @@ int spx_subm_rulebook(const int32_t *indices, int n, int ndim, int batch_size,
   int32_t *scratch_totals = cv.take<int32_t>(64);
   int32_t *slot_of = cv.take<int32_t>(n);
 
-  SPX_HIP(table_clear(t, s));   // keys and values are adjacent in the workspace: one fill
-  // two atomicOr per hit beat a separate mask-from-table pass (measured: 108 vs 118 us at cfg 2)
-  SPX_HIP(hipMemsetAsync(mask, 0, sizeof(uint32_t) * static_cast<size_t>(n) * words, s));
+  // every fill of this build in one launch: hash table, masks, counts, -1 tables (callers that
+  // carve the tables out of one buffer get one contiguous range)
+  FillList fills;
+  table_fill(fills, t);
+  fills.add(mask, sizeof(uint32_t) * static_cast<size_t>(n) * words, 0u);
+  if (num_per_loc) fills.add(num_per_loc, sizeof(int32_t) * kv, 0u);
+  {
+    const size_t tb = sizeof(int32_t) * static_cast<size_t>(kv) * n;
+    fills.add(pair_fwd, tb, 0xFFFFFFFFu);
+    if (pair_bwd) fills.add(pair_bwd, tb, 0xFFFFFFFFu);
+    if (pair_native) fills.add(pair_native, 2 * tb, 0xFFFFFFFFu);
+  }
+  SPX_HIP(fills.launch(s));
   const dim3 grid(div_up(n, kBlock));
   hipLaunchKernelGGL(subm_insert_kernel, grid, dim3(kBlock), 0, s, indices, n, g, t, slot_of);
-  {
-    // -1 fill of every table; callers that carve them out of one buffer get ONE fill
-    std::pair<char *, size_t> f[3];
-    int nf = 0;
-    const size_t tb = sizeof(int32_t) * static_cast<size_t>(kv) * n;
-    f[nf++] = {reinterpret_cast<char *>(pair_fwd), tb};
-    if (pair_bwd) f[nf++] = {reinterpret_cast<char *>(pair_bwd), tb};
-    if (pair_native) f[nf++] = {reinterpret_cast<char *>(pair_native), 2 * tb};
-    std::sort(f, f + nf);
-    for (int i = 0; i < nf;) {
-      char *b0 = f[i].first;
-      size_t len = f[i].second;
-      int j = i + 1;
-      while (j < nf && f[j].first == b0 + len) len += f[j++].second;
-      SPX_HIP(hipMemsetAsync(b0, 0xFF, len, s));
-      i = j;
-    }
-  }
   hipLaunchKernelGGL(subm_probe3_kernel, dim3(div_up(n, kBlock), kv / 2 + 1), dim3(kBlock), 0, s, indices,
                      n, g, t, slot_of, pair_fwd, pair_bwd, mask, words, pair_native);
   SPX_LAUNCH_CHECK();
@@ -1170,26 +1259,28 @@ int spx_conv_rulebook_fill(const int32_t *indices, int n_in, int ndim, int batch
             "workspace too small");
   SPX_CHECK(pair_fwd && pair_bwd && out_indices, "out_indices, pair_fwd and pair_bwd are required");
   const int kv = g.kv, words = div_up(kv, 32);
-  if (num_per_loc) SPX_HIP(hipMemsetAsync(num_per_loc, 0, sizeof(int32_t) * kv, s));
+  FillList fills;                                           // every fill of this call: one launch
+  if (num_per_loc) fills.add(num_per_loc, sizeof(int32_t) * kv, 0u);
   if (pair_native && n_in > 0)
-    SPX_HIP(hipMemsetAsync(pair_native, 0xFF, sizeof(int32_t) * 2 * static_cast<size_t>(kv) * n_in, s));
+    fills.add(pair_native, sizeof(int32_t) * 2 * static_cast<size_t>(kv) * n_in, 0xFFFFFFFFu);
+  if (n_in > 0 && n_out > 0)
+    fills.add(pair_fwd, sizeof(int32_t) * static_cast<size_t>(kv) * n_out, 0xFFFFFFFFu);
+  SPX_HIP(fills.launch(s));
   if (n_in == 0) return 0;
   ConvWs w = carve_conv_ws(ws, n_in, ndim, ksize, stride, transposed,
                            keys_fit_u32(g.batch, g.out_dims, 4));   // as spx_conv_rulebook_count
-  if (n_out > 0)
-    SPX_HIP(hipMemsetAsync(pair_fwd, 0xFF, sizeof(int32_t) * static_cast<size_t>(kv) * n_out, s));
   const dim3 grid2(w.nblk, kv);
   hipLaunchKernelGGL(conv_assign_kernel, grid2, dim3(kBlock), 0, s, indices, n_in, g, transposed,
                      w.slot_of, w.t, w.nblk, w.blockoff, w.slot_out, out_indices);
   const dim3 grid1(div_up(n_in, kBlock), kv);
   hipLaunchKernelGGL(conv_stage2_kernel, grid1, dim3(kBlock), 0, s, w.slot_of, w.slot_out, n_in,
                      n_out, pair_fwd, pair_bwd);
-  if (mask_fwd && n_out > 0)
-    hipLaunchKernelGGL(mask_from_table_kernel, dim3(div_up(n_out, kBlock)), dim3(kBlock), 0, s,
-                       pair_fwd, kv, n_out, words, mask_fwd);
-  if (mask_bwd)
-    hipLaunchKernelGGL(mask_from_table_kernel, dim3(div_up(n_in, kBlock)), dim3(kBlock), 0, s,
-                       pair_bwd, kv, n_in, words, mask_bwd);
+  {
+    const int na = mask_fwd ? n_out : 0, nb = mask_bwd ? n_in : 0;
+    if (na + nb > 0)
+      hipLaunchKernelGGL(mask_from_tables_kernel, dim3(div_up(na + nb, kBlock)), dim3(kBlock), 0, s, pair_fwd,
+                         na, mask_fwd, pair_bwd, nb, mask_bwd, kv, words);
+  }
   SPX_LAUNCH_CHECK();
   if (pair_native) {
     SPX_CHECK(num_per_loc, "num_per_loc is required with pair_native");

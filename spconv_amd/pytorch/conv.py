@@ -324,7 +324,8 @@ class SparseConvolution(SparseModule):
             rb, _ = ops.build_rulebook(indices, batch_size, spatial_shape, self.kernel_size,
                                        self.stride, self.padding, self.dilation,
                                        self.output_padding, self.subm, self.transposed,
-                                       do_sort=MODULE_DO_SORT)
+                                       do_sort=MODULE_DO_SORT,
+                                       need_native=torch.is_grad_enabled() or self.algo == ConvAlgo.Native)
             if input.benchmark:
                 torch.cuda.synchronize()
                 out_tensor.benchmark_record[name]["indice_gen_time"].append(time.time() - t)

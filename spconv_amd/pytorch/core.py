@@ -45,8 +45,8 @@ class Rulebook:
         self.pair_bwd = pair_bwd
         self.mask_fwd = mask_fwd
         self.mask_bwd = mask_bwd
-        self.pair_native = pair_native
-        self.num_per_loc = num_per_loc
+        self._pair_native = pair_native     # None: built on first use (see pair_native)
+        self._num_per_loc = num_per_loc
         self.n_in = n_in
         self.n_out = n_out
         self.kv = kv
@@ -55,6 +55,24 @@ class Rulebook:
         self.argsort_bwd = argsort_bwd
         self.wgrad_plan = None          # built lazily by ops._plan_of
         self._native_swapped = None
+
+    def _ensure_native(self) -> None:
+        """Inference builds only the dense tables; the ConvAlgo.Native lists (consumed by wgrad
+        and by the Native-layout API) are derived from them when something asks."""
+        if self._pair_native is None:
+            from spconv_amd.pytorch import ops
+            table = self.pair_fwd if self.subm else self.pair_bwd
+            self._pair_native, self._num_per_loc = ops._native_from_table(table, self.subm)
+
+    @property
+    def pair_native(self) -> torch.Tensor:
+        self._ensure_native()
+        return self._pair_native
+
+    @property
+    def num_per_loc(self) -> torch.Tensor:
+        self._ensure_native()
+        return self._num_per_loc
 
     def native_swapped(self) -> torch.Tensor:
         """Native lists with in/out roles exchanged (inverse convolution)."""

@@ -114,8 +114,10 @@ def build_rulebook(indices: torch.Tensor, batch_size: int, spatial_shape: List[i
                    ksize: List[int], stride: List[int], padding: List[int],
                    dilation: List[int], out_padding: List[int], subm: bool = False,
                    transpose: bool = False, need_bwd_table: bool = False,
-                   do_sort: bool = False) -> Tuple[Rulebook, List[int]]:
-    """One call builds every artefact (dense tables, masks, Native lists)."""
+                   do_sort: bool = False, need_native: bool = True) -> Tuple[Rulebook, List[int]]:
+    """One call builds every artefact (dense tables, masks, Native lists).  need_native=False
+    (inference) leaves the ConvAlgo.Native lists out -- three launches and two thirds of the
+    fill traffic -- and the Rulebook derives them from the tables if they are asked for later."""
     _require_gpu(indices, "indices")
     assert indices.dtype == torch.int32 and indices.ndim == 2
     L = _lib.load()
@@ -137,17 +139,18 @@ def build_rulebook(indices: torch.Tensor, batch_size: int, spatial_shape: List[i
     if subm:
         # the -1 filled tables live in ONE buffer, so that the library needs a single fill
         tb = kv * n_in
-        buf = torch.empty(((4 if need_bwd_table else 3) * tb,), **i32)
+        nat = 2 if need_native else 0
+        buf = torch.empty(((1 + nat + (1 if need_bwd_table else 0)) * tb,), **i32)
         pair_fwd = buf[:tb].view(kv, n_in)
-        native = buf[tb:3 * tb].view(2, kv, n_in)
-        pair_bwd = buf[3 * tb:].view(kv, n_in) if need_bwd_table else None
+        native = buf[tb:3 * tb].view(2, kv, n_in) if need_native else None
+        pair_bwd = buf[(1 + nat) * tb:].view(kv, n_in) if need_bwd_table else None
         mask = torch.empty((n_in, words), **i32)
-        num = torch.empty((kv,), **i32)
+        num = torch.empty((kv,), **i32) if need_native else None
         ws = _ws(L.spx_subm_rulebook_ws_bytes(n_in, kv), dev)
         _lib.check(L.spx_subm_rulebook(indices.data_ptr(), n_in, ndim, batch_size,
                                        _lib.ints(spatial_shape), _lib.ints(ksize),
                                        _lib.ints(dilation), pair_fwd.data_ptr(), _ptr(pair_bwd),
-                                       mask.data_ptr(), native.data_ptr(), num.data_ptr(),
+                                       mask.data_ptr(), _ptr(native), _ptr(num),
                                        ws.data_ptr(), ws.numel(), stream))
         rb = Rulebook(indices, pair_fwd, pair_bwd, mask, mask, native, num, n_in, n_in, kv, True)
     else:
@@ -167,12 +170,12 @@ def build_rulebook(indices: torch.Tensor, batch_size: int, spatial_shape: List[i
         pair_bwd = torch.empty((kv, n_in), **i32)
         mask_fwd = torch.empty((n_out, words), **i32)
         mask_bwd = torch.empty((n_in, words), **i32)
-        native = torch.empty((2, kv, n_in), **i32)
-        num = torch.empty((kv,), **i32)
+        native = torch.empty((2, kv, n_in), **i32) if need_native else None
+        num = torch.empty((kv,), **i32) if need_native else None
         _lib.check(L.spx_conv_rulebook_fill(indices.data_ptr(), n_in, ndim, batch_size, *args,
                                             n_out, out_indices.data_ptr(), pair_fwd.data_ptr(),
                                             pair_bwd.data_ptr(), mask_fwd.data_ptr(),
-                                            mask_bwd.data_ptr(), native.data_ptr(), num.data_ptr(),
+                                            mask_bwd.data_ptr(), _ptr(native), _ptr(num),
                                             ws.data_ptr(), ws.numel(), stream))
         rb = Rulebook(out_indices, pair_fwd, pair_bwd, mask_fwd, mask_bwd, native, num, n_in,
                       n_out, kv, False)

@@ -183,3 +183,21 @@ def test_full_size_properties_cfg2(cuda):
         assert np.all(np.diff(native[0, kk, :num[kk]]) > 0)
     ref = oracle_rulebook(idx, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True)
     assert_rulebook_equal(rb, ref, True)
+
+
+@pytest.mark.parametrize("subm", [True, False])
+def test_native_lists_built_on_demand_equal_the_builder(cuda, subm):
+    """Inference rulebooks skip the ConvAlgo.Native lists (need_native=False); when something asks
+    for them later they are derived from the dense tables and must equal what the builder writes."""
+    shape, bs = [20, 22, 24], 2
+    idx = dense_scene(shape, 2500, bs, seed=13)
+    args = ([3] * 3, [1] * 3, [1] * 3, [1] * 3, True) if subm else ([3] * 3, [2] * 3, [1] * 3, [1] * 3, False)
+    full, _ = gpu_rulebook(idx, bs, shape, *args)
+    lazy, _ = gpu_rulebook(idx, bs, shape, *args, need_native=False)
+    assert lazy._pair_native is None and lazy._num_per_loc is None
+    np.testing.assert_array_equal(to_np(lazy.pair_fwd), to_np(full.pair_fwd))
+    np.testing.assert_array_equal(to_np(lazy.mask_fwd), to_np(full.mask_fwd))
+    np.testing.assert_array_equal(to_np(lazy.num_per_loc), to_np(full.num_per_loc))       # built here
+    np.testing.assert_array_equal(to_np(lazy.pair_native), to_np(full.pair_native))
+    ref = oracle_rulebook(idx, bs, shape, *args)
+    assert_rulebook_equal(lazy, ref, subm)
