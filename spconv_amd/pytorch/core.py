@@ -205,6 +205,14 @@ class SparseConvTensor(metaclass=torch.fx.ProxyableClassMeta):
         return self.replace_feature(self.features.dequantize())
 
     def _like(self, features: torch.Tensor, indice_dict) -> "SparseConvTensor":
+        if not isinstance(features, torch.fx.Proxy):
+            # hot path (every layer makes one): skip the constructor's checks and the fx metaclass
+            # call -- same coordinates, same bookkeeping, new features
+            t = object.__new__(SparseConvTensor)
+            t.__dict__.update(self.__dict__)
+            t._features = features
+            t.indice_dict = {} if indice_dict is None else indice_dict
+            return t
         t = SparseConvTensor(features, self.indices, self.spatial_shape, self.batch_size,
                              self.grid, self.voxel_num, indice_dict, self.benchmark)
         t.benchmark_record = self.benchmark_record

@@ -87,7 +87,9 @@ def _require_gpu(t: torch.Tensor, what: str) -> None:
 
 
 def _stream(t: torch.Tensor) -> int:
-    return torch.cuda.current_stream(t.device).cuda_stream
+    """Raw hipStream_t of torch's current stream on t's device (the C call, not the Stream object:
+    this runs for every kernel launch)."""
+    return torch._C._cuda_getCurrentRawStream(t.device.index)
 
 
 def _ptr(t: Optional[torch.Tensor]):
