@@ -2225,8 +2225,8 @@ int spx_wgrad_plan(const int32_t *num_per_loc, int n_in, int kv, int subm, int32
                    spx_stream_t stream) {
   SPX_CHECK(num_per_loc && plan, "null pointer");
   SPX_CHECK(kv >= 1 && kv <= 128, "kernel volume %d not supported by wgrad (max 128)", kv);
-  hipLaunchKernelGGL(wgrad_plan_kernel, dim3(1), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
-                     num_per_loc, n_in, kv, subm, wgrad_chunk(n_in), plan);
+  // the first-generation item list (front of the buffer) is only read by the fallback kernels of
+  // spx_igemm_wgrad, which build it themselves when they run: one launch less per rulebook
   int32_t *plan2 = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(plan) + plan1_bytes(n_in, kv));
   hipLaunchKernelGGL(wgrad_plan2_kernel, dim3(1), dim3(kW2MaxG), 0, static_cast<hipStream_t>(stream),
                      num_per_loc, n_in, kv, subm, wgrad_groups(n_in), plan2);
@@ -2329,6 +2329,15 @@ int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t 
                          static_cast<b16 *>(dw));
     SPX_LAUNCH_CHECK();
     return 0;
+  }
+  {
+    // fallback kernels (odd channel counts, tensors beyond 32-bit offsets): their item list is
+    // built here, behind the partials (spx_wgrad_plan does not write it)
+    int32_t *plan1 = reinterpret_cast<int32_t *>(static_cast<char *>(ws) + ws_bytes -
+                                                 spx_wgrad_plan_bytes(n_in, kv));
+    hipLaunchKernelGGL(wgrad_plan_kernel, dim3(1), dim3(kThreads), 0, s, num_per_loc, n_in, kv, subm,
+                       wgrad_chunk(n_in), plan1);
+    p.plan = plan1;
   }
   {
     // upper bound of work items is nchunks * kv * ntile; the kernels loop over the real count
