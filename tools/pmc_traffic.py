@@ -40,7 +40,8 @@ def main():
         if not m:
             continue
         short = f"{m.group(1)}<{m.group(2)}>"
-        if m.group(1) == "igemm_v4_kernel" and m.group(2).strip().endswith("false"):
+        targs = [a.strip() for a in m.group(2).split(",")]      # <COUT, MB, DT, BT, NKS>
+        if m.group(1) == "igemm_v4_kernel" and len(targs) > 3 and targs[3] == "false":
             groups["fwd"].append((short, b))
         elif m.group(1) in ("igemm_bwd_kernel", "wgrad_reduce2_kernel"):
             groups["bwd"].append((short, b))
