@@ -108,3 +108,33 @@ class SparseReLU(nn.ReLU):
 
 class SparseIdentity(nn.Identity):
     forward = _on_features(nn.Identity)
+
+
+class PrintTensorMeta(nn.Module):
+    """Debug layer: prints min / max / mean of the (features of the) tensor passing through
+    (reference modules.py:186-193)."""
+
+    def forward(self, x):
+        ft = x.features if isinstance(x, SparseConvTensor) else x
+        print(ft.min(), ft.max(), ft.mean())
+        return x
+
+
+class PrintCurrentTime(nn.Module):
+    """Debug layer: prints the wall time since construction, after draining the GPU queue
+    (reference modules.py:195-208)."""
+
+    def __init__(self) -> None:
+        super().__init__()
+        import time
+        self._time = time
+        self.first_time = time.time()
+
+    def forward(self, x, msg="", reset: bool = False):
+        import torch
+        if reset:
+            self.first_time = self._time.time()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        print(msg, self._time.time() - self.first_time)
+        return x

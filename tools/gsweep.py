@@ -18,7 +18,7 @@ else:
     shape = [40, 1280, 1600]
     idx_np = (synthetic.lidar_like_scene if kind == "lidar" else synthetic.uniform_scene)(shape, n, 1, seed=0)
 idx = torch.from_numpy(np.ascontiguousarray(idx_np)).to(dev); n = idx.shape[0]
-C = 64
+C = int(os.environ.get("GS_CHANNELS", "64"))
 f = (torch.rand(n, C, device=dev) * 2 - 1).half(); d = ((torch.rand(n, C, device=dev) * 2 - 1) * 0.2).half()
 w = (torch.rand(C, 3, 3, 3, C, device=dev) * 2 - 1).half()
 rb, _ = ops.build_rulebook(idx, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True)
