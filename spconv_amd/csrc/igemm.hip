@@ -1930,7 +1930,8 @@ int dispatch_gather_gemm(const GemmParams &p, hipStream_t s) {
     // for 128 output channels, whose 128-row variant holds 64 accumulator registers per lane and
     // drops to two waves per SIMD (measured at C = K = 128: 28 vs 37 us at 100 k uniform voxels,
     // 56 vs 75 us at 200 k, equal on dense scenes)
-    const int mb = mb_forced ? mb_forced : ((p.n_dst <= 64 * 1024 || p.COUT == 128) ? 1 : 2);
+    // (threshold: at 50 k rows 128-row tiles already win at every width, sparse and dense)
+    const int mb = mb_forced ? mb_forced : ((p.n_dst <= 32 * 1024 || p.COUT == 128) ? 1 : 2);
     switch (p.COUT) {
       case 16: return mb == 1 ? launch_v4<16, 1, BF16 ? 1 : 0>(p, s) : launch_v4<16, 2, BF16 ? 1 : 0>(p, s);
       case 32: return mb == 1 ? launch_v4<32, 1, BF16 ? 1 : 0>(p, s) : launch_v4<32, 2, BF16 ? 1 : 0>(p, s);
