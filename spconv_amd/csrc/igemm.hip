@@ -2010,12 +2010,13 @@ int wgrad_groups(int n_in) {
   if (forced <= 0) {
     // backward shares its launch with ceil(n / 128) dgrad tiles: when both halves fit the 1024
     // resident workgroup slots of the chip together there is no second dispatch round
-    // (41.3 vs 44.7 us per step at 100 k voxels).  Beyond ~115 k voxels the dgrad tiles alone fill
-    // the slots: few, long wgrad ranges then take the fewest slots from them -- 128 ranges beat
-    // 384 by 7-13 % from 125 k to 400 k voxels on sparse and dense scenes alike (tools/gsweep.py)
+    // (41.3 vs 44.7 us per step at 100 k voxels).  Beyond ~115 k voxels 384 stays: 128 ranges are
+    // 7-13 % faster at C = 64 (the dgrad tiles alone fill the slots there), but the ranges become
+    // chains of > 100 chunks and double the launch time of 16 / 32-channel layers, which is what
+    // the large levels of a backbone are (igemm_bwd_kernel<32>: 158 -> 294 us at 450 k voxels);
+    // the plan is built per rulebook, without knowing the layer widths that will use it
     const int room = 1024 - div_up(n_in > 0 ? n_in : 1, 128);
-    if (room < 128) g = 128;
-    else if (room < g) g = room;
+    if (room >= 128 && room < g) g = room;
   }
   const int chunks = div_up(n_in > 0 ? n_in : 1, 128);
   if (g > 2 * chunks) g = 2 * chunks;
