@@ -1563,6 +1563,7 @@ __device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, int block) 
   const int32_t *__restrict__ rec = p.plan2 + plan2_wg(w);     // uniform address: scalar loads
   const int32_t *__restrict__ segs = p.plan2 + plan2_seg(p.G, p.kv);
   const int seg_lo = rec[0], nseg = rec[1];
+  const bool live = kk0 + wk * 32 < p.K && c0 + wc * 32 < p.C;   // wave-uniform
   SPX_STAMP(0);
 
   const uint32_t rowD = static_cast<uint32_t>(p.K) * 2u, rowF = static_cast<uint32_t>(p.C) * 2u;
@@ -1642,6 +1643,7 @@ __device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, int block) 
       __syncthreads();   // stage complete; the other stage was last read one iteration ago
       load_rows(base + kW2J);         // in flight during the MFMAs (out of range past the end)
       load_words(base + 2 * kW2J);
+      if (live)                       // (waves whose 32 x 32 quadrant lies outside K x C idle)
 #pragma unroll
       for (int ks = 0; ks < kW2J / 32; ++ks) {
         const int row0 = ks * 32 + lgrp * 8;
