@@ -1,10 +1,11 @@
-"""``spconv.pytorch.identity.Identity`` (reference ``spconv/pytorch/identity.py:10-15``)."""
-from torch.nn import Module
+"""``spconv.pytorch.identity.Identity``: pass-through layer that also answers the
+``input_spatial_size`` query of the reference's shape-inference helpers
+(reference ``spconv/pytorch/identity.py``)."""
+import torch
 
 
-class Identity(Module):
-    def forward(self, input):
-        return input
-
-    def input_spatial_size(self, out_size):
+class Identity(torch.nn.Identity):
+    @staticmethod
+    def input_spatial_size(out_size):
+        """A pass-through layer needs an input as large as its output."""
         return out_size

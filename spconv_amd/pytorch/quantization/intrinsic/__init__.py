@@ -1,2 +1,6 @@
-from .modules import (SpconvAddReLUNd, SpconvBnAddReLUNd, SpconvBnNd, SpconvBnReLUNd,  # noqa: F401
-                      SpconvReLUNd, _FusedSparseModule)
+"""Fused float containers (``modules``), their QAT (``qat``) and int8 (``quantized``) forms."""
+from . import modules as _m
+
+__all__ = ["SpconvReLUNd", "SpconvBnNd", "SpconvBnReLUNd", "SpconvAddReLUNd", "SpconvBnAddReLUNd",
+           "_FusedSparseModule"]
+globals().update({name: getattr(_m, name) for name in __all__})
