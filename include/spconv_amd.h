@@ -79,9 +79,13 @@ int spx_subm_rulebook(const int32_t *indices, int n, int ndim, int batch_size,
                       int32_t *pair_native, int32_t *num_per_loc,
                       void *ws, size_t ws_bytes, spx_stream_t stream);
 
-/* Scratch bytes for the two-phase regular/transposed conv rulebook. */
+/* Scratch bytes for the two-phase regular/transposed conv rulebook.  The output hash table is
+ * sized for N * prod_i ceil(k_i * gcd(d_i, s_i) / s_i) distinct outputs (kv * N when transposed):
+ * SpconvOps.get_handcrafted_max_act_out (all.py:1557-1578) with dilation taken into account;
+ * `dilation` may be NULL (= all ones).  spx_conv_rulebook_count fails loudly if the bound is
+ * ever exceeded. */
 size_t spx_conv_rulebook_ws_bytes(int n_in, int ndim, const int *ksize, const int *stride,
-                                  int transposed);
+                                  const int *dilation, int transposed);
 
 /* Regular / transposed conv rulebook, phase 1: hash the candidate output
  * coordinates and count the distinct ones.  Replaces stage1 + unique

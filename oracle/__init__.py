@@ -282,33 +282,6 @@ def indice_conv_backward(features: torch.Tensor, filters: torch.Tensor,
 
 
 # --------------------------------------------------------------------------
-# int8 inference epilogue (test/test_all_algo.py:272-287,
-# quantization/quantized/conv.py:368-378)
-# --------------------------------------------------------------------------
-def int8_conv_ref(feat_i8: np.ndarray, w_i8: np.ndarray, pair: np.ndarray,
-                  num_per_loc: np.ndarray, num_act_out: int, subm: bool,
-                  scale: np.ndarray, bias: np.ndarray,
-                  add: Optional[np.ndarray] = None, add_scale: float = 0.0,
-                  relu: bool = False) -> np.ndarray:
-    """q_out = clip(round(act(acc_i32*scale[k] + bias[k] + add*add_scale)), -128, 127)."""
-    K = w_i8.shape[0]
-    w = w_i8.reshape(K, -1, w_i8.shape[-1]).astype(np.int32)
-    kv = w.shape[1]
-    acc = np.zeros((num_act_out, K), dtype=np.int32)
-    counts = native_counts(num_per_loc, kv, subm, feat_i8.shape[0])
-    for k in range(kv):
-        c = counts[k]
-        a = feat_i8[pair[0, k, :c]].astype(np.int32)
-        np.add.at(acc, pair[1, k, :c], a @ w[:, k].T)
-    r = acc.astype(np.float32) * scale.astype(np.float32) + bias.astype(np.float32)
-    if add is not None:
-        r = r + add.astype(np.float32) * np.float32(add_scale)
-    if relu:
-        r = np.maximum(r, 0)
-    return np.clip(np.round(r), -128, 127).astype(np.int8)
-
-
-# --------------------------------------------------------------------------
 # the reference's own test oracle: dense conv on the scattered dense input
 # (test/test_conv.py:83-109,286-357)
 # --------------------------------------------------------------------------

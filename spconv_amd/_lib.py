@@ -32,7 +32,7 @@ SIGNATURES = {
                                          c_int_p, c_int_p, vp, vp, vp, vp, vp, vp,
                                          ctypes.c_size_t, vp]),
     "spx_conv_rulebook_ws_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, c_int_p, c_int_p,
-                                                     ctypes.c_int]),
+                                                     c_int_p, ctypes.c_int]),
     "spx_conv_rulebook_count": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
                                 + [c_int_p] * 6 + [ctypes.c_int, vp, ctypes.c_size_t, c_int_p, vp]),
     "spx_conv_rulebook_fill": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]

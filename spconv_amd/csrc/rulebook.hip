@@ -451,7 +451,7 @@ __device__ __forceinline__ bool conv_out_coord(const Geom &g, const int (&c)[4],
 // (k * n + i); remember the slot so later passes do not re-probe.
 __global__ void __launch_bounds__(kBlock)
 conv_stage1_kernel(const int32_t *__restrict__ indices, int n, Geom g, int transposed,
-                   Table t, int32_t *__restrict__ slot_of) {
+                   Table t, int32_t *__restrict__ slot_of, int32_t *__restrict__ overflow) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   const int k = blockIdx.y;
   if (i >= n) return;
@@ -460,8 +460,10 @@ conv_stage1_kernel(const int32_t *__restrict__ indices, int n, Geom g, int trans
   decode_offset(k, g.ksize, r);
   const size_t pos = static_cast<size_t>(k) * n + i;
   int slot = -1;
-  if (b >= 0 && b < g.batch && conv_out_coord(g, c, r, transposed, q))
+  if (b >= 0 && b < g.batch && conv_out_coord(g, c, r, transposed, q)) {
     slot = table_insert_min(t, layout_key(b, q, g.out_dims), static_cast<int32_t>(pos));
+    if (slot < 0) *overflow = 1;          // table full: reported by spx_conv_rulebook_count
+  }
   slot_of[pos] = slot;
 }
 
@@ -726,13 +728,29 @@ hipError_t table_clear(const Table &t, hipStream_t s) {
   return hipMemsetAsync(t.keys, 0xFF, bytes, s);
 }
 
-size_t conv_max_out(int n_in, int ndim, const int *ksize, const int *stride, int transposed) {
-  // SpconvOps.get_handcrafted_max_act_out (all.py:1557-1578): N * prod(ceil(k/s)),
-  // transposed: kv * N (ops.py:569-570).
+int gcd_int(int a, int b) {
+  while (b) {
+    const int t = a % b;
+    a = b;
+    b = t;
+  }
+  return a < 0 ? -a : a;
+}
+
+size_t conv_max_out(int n_in, int ndim, const int *ksize, const int *stride, const int *dilation,
+                    int transposed) {
+  // Upper bound of distinct outputs.  The reference's SpconvOps.get_handcrafted_max_act_out
+  // (all.py:1557-1578) uses N * prod(ceil(k/s)), which ignores dilation: along one axis an input
+  // reaches the outputs o with o*s = c + p - r*d, and r*d mod s repeats with period s / gcd(d, s),
+  // so up to ceil(k * gcd(d, s) / s) offsets r hit a multiple of s (k = 3, s = 2, d = 2: all 3,
+  // not 2).  Transposed: kv * N (ops.py:569-570).
   size_t kv = 1, m = 1;
   for (int i = 0; i < ndim; ++i) {
     kv *= ksize[i];
-    m *= static_cast<size_t>((ksize[i] + stride[i] - 1) / stride[i]);
+    const int g = gcd_int(dilation ? dilation[i] : 1, stride[i]);
+    size_t per = (static_cast<size_t>(ksize[i]) * g + stride[i] - 1) / stride[i];
+    if (per > static_cast<size_t>(ksize[i])) per = ksize[i];
+    m *= per;
   }
   if (transposed || m > kv) m = kv;
   return m * static_cast<size_t>(n_in);
@@ -746,10 +764,10 @@ struct ConvWs {
 };
 
 ConvWs carve_conv_ws(void *ws, int n_in, int ndim, const int *ksize, const int *stride,
-                     int transposed, bool packed = false) {
+                     const int *dilation, int transposed, bool packed = false) {
   int kv = 1;
   for (int i = 0; i < ndim; ++i) kv *= ksize[i];
-  const uint32_t cap = table_capacity(conv_max_out(n_in, ndim, ksize, stride, transposed));
+  const uint32_t cap = table_capacity(conv_max_out(n_in, ndim, ksize, stride, dilation, transposed));
   ConvWs w;
   w.nblk = div_up(n_in > 0 ? n_in : 1, kItems);
   Carver cv(ws);
@@ -761,7 +779,7 @@ ConvWs carve_conv_ws(void *ws, int n_in, int ndim, const int *ksize, const int *
   w.slot_of = cv.take<int32_t>(static_cast<size_t>(kv) * (n_in > 0 ? n_in : 1));
   w.blockcount = cv.take<int32_t>(static_cast<size_t>(kv) * w.nblk);
   w.blockoff = cv.take<int32_t>(static_cast<size_t>(kv) * w.nblk);
-  w.d_nout = cv.take<int32_t>(1);
+  w.d_nout = cv.take<int32_t>(2);      // [0] number of outputs, [1] hash-table overflow flag
   w.bytes = cv.off;
   return w;
 }
@@ -1205,9 +1223,9 @@ int spx_subm_rulebook(const int32_t *indices, int n, int ndim, int batch_size,
 }
 
 size_t spx_conv_rulebook_ws_bytes(int n_in, int ndim, const int *ksize, const int *stride,
-                                  int transposed) {
+                                  const int *dilation, int transposed) {
   if (ndim < 1 || ndim > kMaxNdim) return 0;
-  return carve_conv_ws(nullptr, n_in, ndim, ksize, stride, transposed).bytes + 256;
+  return carve_conv_ws(nullptr, n_in, ndim, ksize, stride, dilation, transposed).bytes + 256;
 }
 
 int spx_conv_rulebook_count(const int32_t *indices, int n_in, int ndim, int batch_size,
@@ -1221,26 +1239,29 @@ int spx_conv_rulebook_count(const int32_t *indices, int n_in, int ndim, int batc
   if (check_geom(ndim, n_in, g.kv)) return -1;
   for (int i = 0; i < ndim; ++i)
     SPX_CHECK(out_shape[i] > 0 && stride[i] > 0, "bad output shape / stride at dim %d", i);
-  SPX_CHECK(ws_bytes >= spx_conv_rulebook_ws_bytes(n_in, ndim, ksize, stride, transposed),
+  SPX_CHECK(ws_bytes >= spx_conv_rulebook_ws_bytes(n_in, ndim, ksize, stride, dilation, transposed),
             "workspace too small");
   *n_out_h = 0;
   if (n_in == 0) return 0;
-  ConvWs w = carve_conv_ws(ws, n_in, ndim, ksize, stride, transposed,
+  ConvWs w = carve_conv_ws(ws, n_in, ndim, ksize, stride, dilation, transposed,
                            keys_fit_u32(g.batch, g.out_dims, 4));
   SPX_HIP(table_clear(w.t, s));
+  SPX_HIP(hipMemsetAsync(w.d_nout, 0, 2 * sizeof(int32_t), s));
   const dim3 grid1(div_up(n_in, kBlock), g.kv);
   hipLaunchKernelGGL(conv_stage1_kernel, grid1, dim3(kBlock), 0, s, indices, n_in, g, transposed,
-                     w.t, w.slot_of);
+                     w.t, w.slot_of, w.d_nout + 1);
   const dim3 grid2(w.nblk, g.kv);
   hipLaunchKernelGGL(conv_count_first_kernel, grid2, dim3(kBlock), 0, s, w.slot_of, w.t, n_in,
                      w.nblk, w.blockcount);
   hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kBlock), 0, s, w.blockcount, w.blockoff,
                      g.kv * w.nblk, w.d_nout);
   SPX_LAUNCH_CHECK();
-  int32_t host_n = 0;
-  SPX_HIP(hipMemcpyAsync(&host_n, w.d_nout, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  int32_t host_n[2] = {0, 0};
+  SPX_HIP(hipMemcpyAsync(host_n, w.d_nout, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   SPX_HIP(hipStreamSynchronize(s));
-  *n_out_h = host_n;
+  SPX_CHECK(host_n[1] == 0, "output hash table overflow: more distinct outputs than the bound %zu",
+            conv_max_out(n_in, ndim, ksize, stride, dilation, transposed));
+  *n_out_h = host_n[0];
   return 0;
 }
 
@@ -1255,7 +1276,7 @@ int spx_conv_rulebook_fill(const int32_t *indices, int n_in, int ndim, int batch
   SPX_CHECK(ndim >= 1 && ndim <= kMaxNdim, "ndim must be in [1,4], got %d", ndim);
   const Geom g = make_geom(ndim, batch_size, in_shape, out_shape, ksize, stride, padding, dilation);
   if (check_geom(ndim, n_in, g.kv)) return -1;
-  SPX_CHECK(ws_bytes >= spx_conv_rulebook_ws_bytes(n_in, ndim, ksize, stride, transposed),
+  SPX_CHECK(ws_bytes >= spx_conv_rulebook_ws_bytes(n_in, ndim, ksize, stride, dilation, transposed),
             "workspace too small");
   SPX_CHECK(pair_fwd && pair_bwd && out_indices, "out_indices, pair_fwd and pair_bwd are required");
   const int kv = g.kv, words = div_up(kv, 32);
@@ -1267,7 +1288,7 @@ int spx_conv_rulebook_fill(const int32_t *indices, int n_in, int ndim, int batch
     fills.add(pair_fwd, sizeof(int32_t) * static_cast<size_t>(kv) * n_out, 0xFFFFFFFFu);
   SPX_HIP(fills.launch(s));
   if (n_in == 0) return 0;
-  ConvWs w = carve_conv_ws(ws, n_in, ndim, ksize, stride, transposed,
+  ConvWs w = carve_conv_ws(ws, n_in, ndim, ksize, stride, dilation, transposed,
                            keys_fit_u32(g.batch, g.out_dims, 4));   // as spx_conv_rulebook_count
   const dim3 grid2(w.nblk, kv);
   hipLaunchKernelGGL(conv_assign_kernel, grid2, dim3(kBlock), 0, s, indices, n_in, g, transposed,

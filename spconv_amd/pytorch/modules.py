@@ -6,7 +6,6 @@ assign_name_for_sparse_modules).
 """
 from __future__ import annotations
 
-import sys
 from collections import OrderedDict
 
 from torch import nn
@@ -33,39 +32,44 @@ def is_sparse_conv(module) -> bool:
 
 
 class SparseSequential(SparseModule):
-    """nn.Sequential that applies dense modules to ``.features`` of a SparseConvTensor."""
+    """Ordered container: sparse modules receive the SparseConvTensor, any other module is
+    applied to its ``.features`` matrix.
 
-    def __init__(self, *args, **kwargs):
+    Construction follows ``nn.Sequential`` (positional modules numbered from "0", or one ordered
+    mapping of names to modules) and additionally accepts named modules as keyword arguments,
+    as the reference container does (modules.py:59-145)."""
+
+    def __init__(self, *modules, **named):
         super().__init__()
-        if len(args) == 1 and isinstance(args[0], OrderedDict):
-            for key, module in args[0].items():
-                self.add_module(key, module)
+        if len(modules) == 1 and isinstance(modules[0], OrderedDict):
+            entries = list(modules[0].items())
         else:
-            for idx, module in enumerate(args):
-                self.add_module(str(idx), module)
-        for name, module in kwargs.items():
-            if sys.version_info < (3, 6):
-                raise ValueError("kwargs only supported in py36+")
-            if name in self._modules:
-                raise ValueError("name exists.")
-            self.add_module(name, module)
+            entries = [(str(i), m) for i, m in enumerate(modules)]
+        for key, m in entries + list(named.items()):
+            self._register(key, m)
 
-    def __getitem__(self, idx):
-        if not (-len(self) <= idx < len(self)):
-            raise IndexError("index {} is out of range".format(idx))
-        if idx < 0:
-            idx += len(self)
-        return list(self._modules.values())[idx]
+    def _register(self, key, module):
+        if key in self._modules:
+            raise ValueError(f"a module named {key!r} is already part of this SparseSequential")
+        self.add_module(key, module)
 
     def __len__(self):
         return len(self._modules)
 
+    def __getitem__(self, idx):
+        n = len(self._modules)
+        if isinstance(idx, slice):
+            return SparseSequential(OrderedDict(list(self._modules.items())[idx]))
+        if not -n <= idx < n:
+            raise IndexError(f"index {idx} is out of range for a SparseSequential of {n} modules")
+        return list(self._modules.values())[idx % n]
+
+    def __iter__(self):
+        return iter(self._modules.values())
+
     def add(self, module, name=None):
-        if name is None:
-            name = str(len(self._modules))
-            if name in self._modules:
-                raise KeyError("name exists")
-        self.add_module(name, module)
+        """Appends `module` under `name` (default: its position)."""
+        self._register(str(len(self._modules)) if name is None else name, module)
 
     def forward(self, input):
         for module in self._modules.values():

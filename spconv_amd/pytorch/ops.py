@@ -159,7 +159,7 @@ def build_rulebook(indices: torch.Tensor, batch_size: int, spatial_shape: List[i
         args = (_lib.ints(spatial_shape), _lib.ints(out_shape), _lib.ints(ksize), _lib.ints(stride),
                 _lib.ints(padding), _lib.ints(dilation), int(transpose))
         ws = _ws(L.spx_conv_rulebook_ws_bytes(n_in, ndim, _lib.ints(ksize), _lib.ints(stride),
-                                              int(transpose)), dev)
+                                              _lib.ints(dilation), int(transpose)), dev)
         n_out_c = ctypes.c_int(0)
         _lib.check(L.spx_conv_rulebook_count(indices.data_ptr(), n_in, ndim, batch_size, *args,
                                              ws.data_ptr(), ws.numel(), ctypes.byref(n_out_c),
@@ -234,7 +234,9 @@ def get_indice_pairs_implicit_gemm(indices: torch.Tensor, batch_size: int,
     """Returns the reference's 9-tuple (ops.py:347-359):
     (out_inds, num_inds_per_loc, pair_fwd, pair_bwd, pair_mask_fwd_splits, pair_mask_bwd_splits,
      mask_argsort_fwd_splits, mask_argsort_bwd_splits, masks)."""
-    assert algo in (ConvAlgo.MaskImplicitGemm, ConvAlgo.MaskSplitImplicitGemm), "TODO"
+    if algo not in (ConvAlgo.MaskImplicitGemm, ConvAlgo.MaskSplitImplicitGemm):
+        raise ValueError(f"get_indice_pairs_implicit_gemm builds the masked implicit-GEMM tables; algo {algo} "
+                         f"(ConvAlgo.Native) goes through get_indice_pairs")
     kv = _kv(ksize)
     rb, _ = build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation,
                            out_padding, subm, transpose, need_bwd_table=subm and is_train,

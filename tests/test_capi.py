@@ -72,7 +72,7 @@ def test_conv_out_shape_matches_oracle(lib):
 
 def test_workspace_size_queries(lib):
     assert lib.spx_subm_rulebook_ws_bytes(100_000, 27) > 100_000 * 2 * 12
-    assert lib.spx_conv_rulebook_ws_bytes(100_000, 3, _lib.ints([3] * 3), _lib.ints([2] * 3), 0) > 0
+    assert lib.spx_conv_rulebook_ws_bytes(100_000, 3, _lib.ints([3] * 3), _lib.ints([2] * 3), _lib.ints([1] * 3), 0) > 0
     assert lib.spx_igemm_dgrad_ws_bytes(64, 64, 27, _lib.DTYPE_F16) == 0   # transpose is in-kernel
     assert lib.spx_wgrad_plan_bytes(100_000, 27) > 27 * 8
     assert lib.spx_igemm_wgrad_ws_bytes(100_000, 64, 64, 27) % 256 == 0

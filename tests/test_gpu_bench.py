@@ -1,0 +1,45 @@
+"""bench.py end to end on the GPU box: the JSON contract, and the N > 1 launcher on one device
+(two ranks over gloo share cuda:0 -- the control flow of the multi-GPU run without a second GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, extra_env=None, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(extra_env or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env,
+                         capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_bench_single_gpu_contract(cuda):
+    r = _run(["--steps", "16", "--warmup", "8", "--no-cpu-baseline", "--scenes", "4"])
+    assert r["n_gpus"] == 1 and r["steps"] == 16 and r["warmup"] == 8
+    assert r["unit"] == "voxels/s" and r["value"] > 0 and r["scaling"] == "weak"
+    for key in ("roofline", "roofline_cold", "roofline_warm"):
+        assert r[key]["bound"] == "hbm" and 0 < r[key]["frac"] < 1.0
+    assert r["config"]["scenes_rotated"] == 4
+
+
+def test_bench_gpus_2_spawns_two_ranks(cuda):
+    r = _run(["--gpus", "2", "--steps", "6", "--warmup", "2", "--scenes", "2"],
+             {"BENCH_DIST_BACKEND": "gloo", "BENCH_ONE_DEVICE": "1"})
+    assert r["n_gpus"] == 2
+    assert r["config"]["ranks_seen"] == 2 and r["config"]["parallelism"] == "dp2"
+    assert r["config"]["dist_backend"] == "gloo"
+
+
+def test_bench_config4_two_ranks(cuda):
+    r = _run(["--gpus", "2", "--config", "4", "--steps", "2", "--warmup", "1", "--voxels", "20000",
+              "--scenes", "1"], {"BENCH_DIST_BACKEND": "gloo", "BENCH_ONE_DEVICE": "1"})
+    assert r["n_gpus"] == 2 and r["config"]["ranks_seen"] == 2
+    assert len(r["config"]["layer_voxels"]) == 13

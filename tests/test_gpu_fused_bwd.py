@@ -1,0 +1,197 @@
+"""Parity of the path bench.py times: module forward + the FUSED backward launch
+(`spx_igemm_bwd` -> `igemm_bwd_kernel` dgrad tiles + wgrad ranges + second stage) against the CPU
+oracle at the BASELINE configurations' full sizes.
+
+The fused launch plans its wgrad ranges from the scene size (`wgrad_groups`), so small cases do not
+exercise the configuration the benchmark runs; these tests do:
+
+* cfg 2   -- 100 000 uniform voxels in 40x1280x1600, C = K = 64, fp16 and bf16;
+* cfg 2b  -- the reference's real-LiDAR fixture coordinates (125 562 voxels, 6.28 pairs/voxel;
+             test/test_multi_impl.py:224-341 uses the same fixture with CPU-Native as oracle);
+* cfg 3   -- backward of the stride-2 chain 16 -> 32 -> 64 -> 128 on the fixture;
+* cfg 4   -- one training step of the SECOND-style backbone over 4 scenes: every conv layer's
+             forward, input gradient and weight gradient against the oracle evaluated on that
+             layer's actual (GPU-produced, fp16) inputs, so errors do not compound.
+
+Tolerances (relative to the largest reference magnitude, see util.rel_err; element-wise check with
+an absolute floor via util.assert_close_elementwise): fp16 2e-3, bf16 1.2e-2."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from util import (assert_close_elementwise, assert_rulebook_equal, gpu_rulebook, oracle_rulebook,
+                  rel_err, scene)
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float16: 2e-3, torch.bfloat16: 1.2e-2}
+K3, ONE = [3] * 3, [1] * 3
+
+
+def _rounded(a, dtype):
+    return torch.from_numpy(a).to(dtype).to(torch.float32)
+
+
+def _check3(tag, got, ref, tol):
+    for name, g, r in zip(("out", "din", "dw"), got, ref):
+        e = rel_err(g.float().cpu().numpy(), r.numpy())
+        assert e <= tol, f"{tag} {name}: rel err {e:.3e} > {tol:.1e}"
+        assert_close_elementwise(g.float().cpu().numpy(), r.numpy(), tol, name=f"{tag} {name}")
+
+
+def _fused_subm(cuda, idx, shape, C, K, dtype, seed):
+    """Module forward + fused backward of one SubMConv3d; returns (rulebook, (out, din, dw))."""
+    import spconv_amd.pytorch as spconv
+    rng = np.random.default_rng(seed)
+    n = idx.shape[0]
+    f = _rounded(rng.uniform(-1, 1, (n, C)).astype(np.float32), dtype)
+    w = _rounded(rng.uniform(-1, 1, (K, 3, 3, 3, C)).astype(np.float32), dtype)
+    dout = _rounded(rng.uniform(-0.2, 0.2, (n, K)).astype(np.float32), dtype)
+    net = spconv.SubMConv3d(C, K, 3, bias=False, indice_key="t").to(cuda, dtype)
+    with torch.no_grad():
+        net.weight.copy_(w.to(cuda, dtype))
+    net.train()
+    feats = f.to(cuda, dtype).requires_grad_(True)
+    x = spconv.SparseConvTensor(feats, torch.from_numpy(idx).to(cuda), shape, 1)
+    y = net(x)
+    y.features.backward(dout.to(cuda, dtype))
+    torch.cuda.synchronize()
+    rb = y.indice_dict["t"].rulebook
+    return rb, (f, w, dout), (y.features.detach(), feats.grad, net.weight.grad)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_cfg2_full_size_fused_bwd_vs_oracle(cuda, dtype):
+    shape = [40, 1280, 1600]
+    idx = scene(shape, 100_000, 1, 0)
+    rb, (f, w, dout), got = _fused_subm(cuda, idx, shape, 64, 64, dtype, seed=0)
+    ref = oracle_rulebook(idx, 1, shape, K3, ONE, ONE, ONE, True)
+    assert_rulebook_equal(rb, ref, True)
+    out_ref = oracle.indice_conv(f, w, ref["pair"], ref["num"], ref["n_out"], subm=True)
+    din_ref, dw_ref = oracle.indice_conv_backward(f, w, dout, ref["pair"], ref["num"], subm=True)
+    _check3(f"cfg2 {dtype}", got, (out_ref, din_ref, dw_ref), TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_cfg2b_lidar_fixture_fused_bwd_vs_oracle(cuda, dtype):
+    from golden import lidar_scene
+    idx, shape = lidar_scene()
+    rb, (f, w, dout), got = _fused_subm(cuda, idx, shape, 64, 64, dtype, seed=1)
+    ref = oracle_rulebook(idx, 1, shape, K3, ONE, ONE, ONE, True)
+    assert_rulebook_equal(rb, ref, True)
+    assert int(idx.shape[0] + 2 * ref["num"][:13].sum()) == 788_888
+    out_ref = oracle.indice_conv(f, w, ref["pair"], ref["num"], ref["n_out"], subm=True)
+    din_ref, dw_ref = oracle.indice_conv_backward(f, w, dout, ref["pair"], ref["num"], subm=True)
+    _check3(f"cfg2b {dtype}", got, (out_ref, din_ref, dw_ref), TOL[dtype])
+
+
+def test_cfg2_sorted_rows_fused_bwd_vs_oracle(cuda):
+    """The same launch with mask-sorted row order (SPCONV_DO_SORT / bench.py --sort)."""
+    from spconv_amd.pytorch import ops
+    shape = [40, 1280, 1600]
+    idx = scene(shape, 100_000, 1, 3)
+    rng = np.random.default_rng(3)
+    f = _rounded(rng.uniform(-1, 1, (idx.shape[0], 64)).astype(np.float32), torch.float16)
+    w = _rounded(rng.uniform(-1, 1, (64, 3, 3, 3, 64)).astype(np.float32), torch.float16)
+    dout = _rounded(rng.uniform(-0.2, 0.2, (idx.shape[0], 64)).astype(np.float32), torch.float16)
+    ref = oracle_rulebook(idx, 1, shape, K3, ONE, ONE, ONE, True)
+    rb, _ = gpu_rulebook(idx, 1, shape, K3, ONE, ONE, ONE, True, do_sort=True)
+    fg, wg, dg = (t.to(cuda).half() for t in (f, w, dout))
+    out = ops.igemm_fwd(fg, wg, rb.pair_fwd, rb.mask_fwd, rb.argsort_fwd, rb.n_out, 13)
+    din, dw = ops.igemm_bwd(fg, dg, wg, rb.pair_fwd, rb.mask_fwd, rb.argsort_fwd, rb.pair_native,
+                            rb.num_per_loc, True, ops._plan_of(rb))
+    out_ref = oracle.indice_conv(f, w, ref["pair"], ref["num"], ref["n_out"], subm=True)
+    din_ref, dw_ref = oracle.indice_conv_backward(f, w, dout, ref["pair"], ref["num"], subm=True)
+    _check3("cfg2 sorted", (out, din, dw), (out_ref, din_ref, dw_ref), 2e-3)
+
+
+class _Tap:
+    """Records what every sparse conv layer of a network saw in one training step."""
+
+    def __init__(self, net):
+        from spconv_amd.utils.nets import conv_layers
+        self.layers = conv_layers(net)
+        self.rec = {}
+        self.handles = [m.register_forward_hook(self._hook) for m in self.layers]
+
+    def _hook(self, mod, args, out):
+        x = args[0]
+        fin, fout = x.features, out.features
+        if fin.requires_grad:
+            fin.retain_grad()
+        fout.retain_grad()
+        self.rec[id(mod)] = dict(idx=x.indices, shape=list(x.spatial_shape), bs=x.batch_size, fin=fin,
+                                 fout=fout, out_idx=out.indices, out_shape=list(out.spatial_shape))
+
+    def close(self):
+        for h in self.handles:
+            h.remove()
+
+
+def _check_layers_vs_oracle(tap, tol, first_has_din=False):
+    """Every conv layer of the step: coordinates bit-exact, forward / dgrad / wgrad within tol of
+    the oracle evaluated on the layer's own inputs."""
+    for li, m in enumerate(tap.layers):
+        r = tap.rec[id(m)]
+        idx = r["idx"].cpu().numpy()
+        ref = oracle_rulebook(idx, r["bs"], r["shape"], m.kernel_size, m.stride, m.padding, m.dilation,
+                              m.subm)
+        np.testing.assert_array_equal(r["out_idx"].cpu().numpy(), ref["out_inds"])
+        assert r["out_shape"] == list(ref["out_shape"])
+        f = r["fin"].detach().float().cpu()
+        w = m.weight.detach().float().cpu()
+        dout = r["fout"].grad.detach().float().cpu()
+        assert torch.isfinite(dout).all() and float(dout.abs().max()) > 0, f"layer {li}: degenerate gradient"
+        out_ref = oracle.indice_conv(f, w, ref["pair"], ref["num"], ref["n_out"], subm=m.subm)
+        din_ref, dw_ref = oracle.indice_conv_backward(f, w, dout, ref["pair"], ref["num"], subm=m.subm)
+        tag = f"layer {li} ({m.in_channels}->{m.out_channels}, {'subm' if m.subm else 'conv'}, n={idx.shape[0]})"
+        e = rel_err(r["fout"].detach().float().cpu().numpy(), out_ref.numpy())
+        assert e <= tol, f"{tag} out: {e:.3e}"
+        e = rel_err(m.weight.grad.float().cpu().numpy(), dw_ref.numpy())
+        assert e <= tol, f"{tag} dw: {e:.3e}"
+        if r["fin"].grad is not None and (li > 0 or first_has_din):
+            e = rel_err(r["fin"].grad.float().cpu().numpy(), din_ref.numpy())
+            assert e <= tol, f"{tag} din: {e:.3e}"
+
+
+def test_cfg3_chain_backward_on_lidar_fixture_vs_oracle(cuda):
+    """Backward of BASELINE config 3 (regular-conv rulebooks, fused dgrad + wgrad on pair_bwd and the
+    Native lists) on the reference fixture; forward-only coverage lives in test_gpu_modules.py."""
+    import spconv_amd.pytorch as spconv
+    from golden import lidar_scene
+    from spconv_amd.utils.nets import downsample_chain
+    idx, shape = lidar_scene()
+    torch.manual_seed(3)
+    net = downsample_chain().to(cuda).half().train()
+    tap = _Tap(net)
+    f = torch.randn(idx.shape[0], 16).half().to(cuda).requires_grad_(True)
+    y = net(spconv.SparseConvTensor(f, torch.from_numpy(idx).to(cuda), shape, 1))
+    g = (torch.rand(y.features.shape, device=cuda) - 0.5).half() * 0.4
+    y.features.backward(g)
+    torch.cuda.synchronize()
+    _check_layers_vs_oracle(tap, 2e-3, first_has_din=True)
+    tap.close()
+
+
+@pytest.mark.timeout(900)
+def test_cfg4_backbone_step_fused_bwd_vs_oracle(cuda):
+    """One training step of the SECOND-style backbone (BatchNorm + ReLU, fp16) over a batch of 4
+    LiDAR-density scenes of 100 k voxels: all 13 sparse conv layers against the oracle."""
+    import spconv_amd.pytorch as spconv
+    from spconv_amd.utils import synthetic
+    from spconv_amd.utils.nets import SECOND_SHAPE, second_backbone
+    bs = 4
+    idx = synthetic.lidar_like_scene(SECOND_SHAPE, 100_000, bs, seed=11)
+    torch.manual_seed(4)
+    net = second_backbone(4).to(cuda).half().train()
+    tap = _Tap(net)
+    f = torch.randn(idx.shape[0], 4).half().to(cuda)
+    y = net(spconv.SparseConvTensor(f, torch.from_numpy(idx).to(cuda), SECOND_SHAPE, bs))
+    # (a mean-of-squares loss would put 1/N-sized gradients below fp16's subnormal range)
+    g = (torch.rand(y.features.shape, device=cuda) - 0.5).half() * 0.2
+    y.features.backward(g)
+    torch.cuda.synchronize()
+    assert len(tap.layers) == 13
+    _check_layers_vs_oracle(tap, 3e-3)
+    tap.close()

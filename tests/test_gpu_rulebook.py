@@ -115,6 +115,22 @@ def test_conv_rulebook_bit_exact(cuda, shape, n, bs, ksize, stride, pad, dil, tr
     assert_rulebook_equal(rb, ref, False)
 
 
+def test_conv_dilation_sharing_a_factor_with_stride(cuda):
+    """k = 3, s = 2, d = 2, p = 2: an input whose coordinates are all even reaches all 27 outputs,
+    not the prod(ceil(k/s)) = 8 the reference's hand-crafted bound assumes; with stride-aligned,
+    well separated inputs the number of distinct outputs is 27 N.  The output hash table must be
+    sized for that (no silently dropped pairs)."""
+    shape = [64, 64, 64]
+    rng = np.random.default_rng(5)
+    g = np.stack(np.unravel_index(rng.choice(10 * 10 * 10, 600, replace=False), (10, 10, 10)), -1)
+    idx = np.concatenate([np.zeros((600, 1), np.int64), 6 * g + 2], 1).astype(np.int32)   # even, 6 apart
+    ks, st, pd, dl = [3] * 3, [2] * 3, [2] * 3, [2] * 3
+    ref = oracle_rulebook(idx, 1, shape, ks, st, pd, dl, False)
+    assert ref["n_out"] == 27 * 600
+    rb, _ = gpu_rulebook(idx, 1, shape, ks, st, pd, dl, False)
+    assert_rulebook_equal(rb, ref, False)
+
+
 def test_conv_points_vanish_raises(cuda):
     """ops.py:260-262: zero active outputs is an error, with the reference's message."""
     idx = np.array([[0, 7, 3, 3]], dtype=np.int32)

@@ -1,4 +1,7 @@
 """CPU: host-side logic of the drop-in API (no kernels run)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -160,3 +163,28 @@ def test_install_as_spconv_aliases_every_submodule():
         for k in [k for k in sys.modules if k == "spconv" or k.startswith("spconv.")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_bench_gpus_flag_becomes_a_launcher(tmp_path):
+    """`bench.py --gpus N` without a launcher's environment re-executes itself under
+    torch.distributed.run with N ranks on 127.0.0.1 (BENCH_DRY_LAUNCH prints the command)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["BENCH_DRY_LAUNCH"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "7",
+                          "--warmup", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    cmd = json.loads(out.stdout.strip().splitlines()[-1])["launch"]
+    assert "torch.distributed.run" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    tail = cmd[cmd.index(os.path.join(root, "bench.py")) + 1:]
+    assert tail == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    # under a launcher (WORLD_SIZE set) it must NOT spawn again
+    import bench
+    os.environ["WORLD_SIZE"] = "4"
+    try:
+        bench.maybe_spawn(bench.parse(["--gpus", "4"]), ["--gpus", "4"])
+    finally:
+        del os.environ["WORLD_SIZE"]

@@ -58,6 +58,29 @@ def assert_rulebook_equal(rb, ref, subm, check_bwd=True):
 
 
 def rel_err(a, ref):
+    """NORM-WISE relative error: max |a - ref| / max |ref|.  This is the bound a GEMM-shaped
+    kernel can promise (an output element that is a cancelling sum of large terms has an error
+    relative to the terms, not to itself); the element-wise statement north_star makes for fp32
+    ("within 1e-3 rel") is checked by `assert_close_elementwise` below with an absolute floor."""
     a = np.asarray(a, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     return float(np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-12))
+
+
+def assert_close_elementwise(a, ref, rtol, floor_frac=None, name=""):
+    """Element-wise |a - ref| <= rtol * |ref| + floor, floor = floor_frac * rms(ref): every
+    element within rtol of ITS OWN reference value, except that elements much smaller than the
+    tensor's typical magnitude (cancelling sums) are held to an absolute floor instead.
+    floor_frac defaults to rtol (i.e. the floor is the error allowed on a typical element)."""
+    a = np.asarray(a, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    if ref.size == 0:
+        return
+    rms = float(np.sqrt(np.mean(ref * ref)))
+    floor = (rtol if floor_frac is None else floor_frac) * max(rms, 1e-30)
+    bad = np.abs(a - ref) > rtol * np.abs(ref) + 4.0 * floor
+    if bad.any():
+        i = np.unravel_index(np.argmax(np.abs(a - ref) * bad), a.shape)
+        raise AssertionError(f"{name}: {int(bad.sum())} of {a.size} elements outside rtol {rtol:g} "
+                             f"(+ floor {4 * floor:.3g}); worst at {i}: got {a[i]:.6g}, want {ref[i]:.6g}")
