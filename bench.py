@@ -720,7 +720,7 @@ def run_net(args, D: Dist):
         kind = args.scene or "lidar"
         batches = [make_scene(kind, voxels, seed=rank * S + si, batch=bs, shape=nets.SECOND_SHAPE)
                    for si in range(S)]
-        name = "SECOND-style VoxelBackBone8x (13 sparse convs + BatchNorm1d + ReLU)"
+        name = "SECOND-style VoxelBackBone8x (12 sparse convs + BatchNorm1d + ReLU)"
     data = []
     for idx_np, shape in batches:
         ind = torch.from_numpy(idx_np).to(dev)
@@ -766,6 +766,7 @@ def run_net(args, D: Dist):
                          n_in=x.features.shape[0], n_out=out.features.shape[0]))
     hs = [m.register_forward_hook(hook) for m in nets.conv_layers(net)]
     cnt[0] = 0
+    bucket = None        # rank 0 only from here on: no collective in this bookkeeping step
     step()
     for h in hs:
         h.remove()
