@@ -5,15 +5,23 @@
 // tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
 // this library; the product (spconv_amd/) never does.
 //
-// The reference (traveller59/spconv v2.3.8) cannot be built here: its C++ is
-// generated at import time by `pccm` and includes headers of the unvendored
-// `cumm` package.  Every function below therefore
-// restates the generated code operation-for-operation and cites the generator
-// lines it follows.  Parity status: numerical results of the path are pinned
-// by the reference's own test oracle (dense torch conv3d, test/test_conv.py:
-// 247-357, re-run in tests/test_oracle.py); the *order* of rulebook entries is
-// "parity unpinned" by any reference test (they reconcile by coordinate,
-// test/test_all_algo.py:152-160) and is defined here by restating the CPU loops.
+// The reference (traveller59/spconv v2.3.8) cannot be built with its own build system here: its
+// C++ is assembled at import time by `pccm` and includes headers of the unvendored `cumm` package
+// (SURVEY.md section 8c).  Every function below therefore restates the generated code
+// operation-for-operation and cites the generator lines it follows.
+//
+// Parity status -- PINNED:
+//  * rulebook (pairs, counts, output coordinates, their ORDER): pinned by executing the
+//    reference's own CPU generators.  oracle/refbuild/render.py loads
+//    /root/reference/spconv/csrc/sparse/indices.py where it lies, collects the reference's C++
+//    text of ConvOutLocIter / SparseConvIndicesCPU and compiles it (against small stand-ins for
+//    the cumm value types, refbuild/tv_shim.h) into oracle/_ref/libspconv_ref.so.  This
+//    restatement equals that library bit-for-bit on every committed vector
+//    (tests/golden/ref_*.npz, ref_digests.json incl. the real-LiDAR fixture and BASELINE
+//    configs 1-3) and on a randomised 1-d..4-d sweep (tests/test_oracle.py);
+//  * numerical results of the path: pinned by the reference's own test oracle (dense torch
+//    conv3d, test/test_conv.py:247-357, re-run in tests/test_oracle.py) and its numpy per-offset
+//    formula (test/test_all_algo.py:222-288).
 //
 // Build: see oracle/Makefile (g++ -O3 -shared -fPIC).
 

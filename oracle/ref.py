@@ -1,0 +1,87 @@
+"""ctypes front of `oracle/_ref/libspconv_ref.so`: the reference's OWN CPU rulebook generators
+(`SparseConvIndicesCPU.generate_subm_conv_inds` / `generate_conv_inds`, csrc/sparse/indices.py:
+1639-1778, and `ConvOutLocIter`, :76-269), rendered from the reference's source file where it lies
+and compiled by `make -C oracle ref` (see refbuild/render.py for what is and is not reference text).
+
+TEST INFRASTRUCTURE: pins the restatement in oracle.cpp and generates tests/golden/ref_*.npz.  The
+library exists wherever it was built (`oracle/_ref/` travels to the GPU box with the snapshot; it is
+git-ignored); `available()` says whether it does.  Buffers are prepared as the reference's Python
+driver prepares them for its CPU branch (pytorch/ops.py:186-196,311-326): pairs filled with -1,
+counts zeroed, `out_inds` sized kv * N and cut to the returned count.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Optional, Sequence
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "_ref", "libspconv_ref.so")
+REFERENCE = os.environ.get("SPCONV_REFERENCE", "/root/reference")
+_lib: Optional[ctypes.CDLL] = None
+
+
+def can_build() -> bool:
+    return os.path.isfile(os.path.join(REFERENCE, "spconv", "csrc", "sparse", "indices.py"))
+
+
+def build(force: bool = False) -> Optional[str]:
+    """Renders + compiles the reference code when /root/reference is present; returns the path
+    of the library, or None when it can neither be built nor found."""
+    global _lib
+    if can_build() and (force or not os.path.isfile(LIB)):
+        if force:
+            subprocess.run(["make", "-C", HERE, "clean-ref"], check=True, capture_output=True)
+        subprocess.run(["make", "-C", HERE, "ref"], check=True, capture_output=True)
+        _lib = None
+    return LIB if os.path.isfile(LIB) else None
+
+
+def available() -> bool:
+    return os.path.isfile(LIB)
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not available():
+            raise FileNotFoundError(f"{LIB} not built (needs /root/reference: make -C oracle ref)")
+        _lib = ctypes.CDLL(LIB)
+        ip = ctypes.POINTER(ctypes.c_int)
+        _lib.ref_generate_inds.restype = ctypes.c_int
+        _lib.ref_generate_inds.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                           ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                           ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + [ip] * 6
+    return _lib
+
+
+def _ints(v: Sequence[int]):
+    return (ctypes.c_int * len(v))(*[int(x) for x in v])
+
+
+def get_indice_pairs(indices: np.ndarray, batch_size: int, spatial_shape, ksize, stride, padding,
+                     dilation, out_padding=None, subm: bool = False, transpose: bool = False):
+    """Same return shape as oracle.get_indice_pairs: (out_inds, pair [2, kv, N], num [kv], out_shape)."""
+    import oracle
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    n, ndim = indices.shape[0], indices.shape[1] - 1
+    kv = int(np.prod(ksize))
+    if subm:
+        out_shape = list(spatial_shape)
+    else:
+        out_shape = oracle.conv_out_shape(spatial_shape, ksize, stride, padding, dilation, out_padding,
+                                          transpose)
+    pair = np.full((2, kv, n), -1, dtype=np.int32)
+    num = np.zeros((kv,), dtype=np.int32)
+    out_inds = indices.copy() if subm else np.empty((max(kv * n, 1), ndim + 1), dtype=np.int32)
+    rc = lib().ref_generate_inds(ndim, int(subm), int(transpose), indices.ctypes.data, n,
+                                 pair.ctypes.data, n, out_inds.ctypes.data, out_inds.shape[0],
+                                 num.ctypes.data, int(batch_size), _ints(spatial_shape), _ints(out_shape),
+                                 _ints(ksize), _ints(stride if not subm else [1] * ndim),
+                                 _ints(padding if not subm else [0] * ndim), _ints(dilation))
+    if rc < 0:
+        raise RuntimeError(f"reference generator failed (rc {rc})")
+    return np.ascontiguousarray(out_inds[:rc]), pair, num, list(out_shape)

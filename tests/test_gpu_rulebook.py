@@ -217,3 +217,40 @@ def test_native_lists_built_on_demand_equal_the_builder(cuda, subm):
     np.testing.assert_array_equal(to_np(lazy.pair_native), to_np(full.pair_native))
     ref = oracle_rulebook(idx, bs, shape, *args)
     assert_rulebook_equal(lazy, ref, subm)
+
+
+# ---- against vectors produced by executing the reference's own CPU code (oracle/_ref) --------
+from golden import digest, load_ref_case, ref_big_inputs, ref_case_names, ref_digests  # noqa: E402
+
+
+@pytest.mark.parametrize("name", ref_case_names())
+def test_gpu_rulebook_equals_reference_executed_vectors(cuda, name):
+    import oracle
+    c = load_ref_case(name)
+    rb, out_shape = gpu_rulebook(c["indices"], c["bs"], c["shape"], c["ksize"], c["stride"], c["pad"], c["dil"],
+                                 c["subm"], c["transposed"])
+    assert list(out_shape) == c["out_shape"]
+    n_in, n_out = c["indices"].shape[0], c["out_inds"].shape[0]
+    fwd, bwd, mfwd, mbwd = oracle.dense_tables(c["pair"], c["num"], n_in, n_out, c["subm"])
+    ref = dict(out_inds=c["out_inds"], pair=c["pair"], num=c["num"], fwd=fwd, bwd=bwd, mfwd=mfwd, mbwd=mbwd,
+               n_in=n_in, n_out=n_out)
+    assert_rulebook_equal(rb, ref, c["subm"])
+
+
+def test_gpu_rulebook_equals_reference_digests_at_baseline_sizes(cuda):
+    """config 1 / 2 scenes, the real-LiDAR fixture as SubM and as config 3's stride-2 chain: the
+    SHA-256 of what the HIP builder returns equals the digest of what spconv's CPU code produced."""
+    want = ref_digests()
+    for name in ("cfg1_subm", "cfg2_subm", "fixture_subm"):
+        idx, shape = ref_big_inputs(name)
+        rb, _ = gpu_rulebook(idx, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True)
+        got = (digest(to_np(rb.out_indices)), digest(to_np(rb.pair_native)), digest(to_np(rb.num_per_loc)))
+        assert got == (want[name]["out_inds"], want[name]["pair"], want[name]["num"]), name
+    cur, cur_shape = ref_big_inputs("fixture_chain_l0")
+    for level in range(3):
+        w = want[f"fixture_chain_l{level}"]
+        rb, out_shape = gpu_rulebook(cur, 1, cur_shape, [3] * 3, [2] * 3, [1] * 3, [1] * 3, False)
+        assert rb.n_out == w["n_out"] and list(out_shape) == w["out_shape"]
+        got = (digest(to_np(rb.out_indices)), digest(to_np(rb.pair_native)), digest(to_np(rb.num_per_loc)))
+        assert got == (w["out_inds"], w["pair"], w["num"]), f"chain level {level}"
+        cur, cur_shape = to_np(rb.out_indices), list(out_shape)

@@ -235,3 +235,73 @@ def test_pool_oracle_matches_dense_torch_pooling():
     np.testing.assert_array_equal(cnt, np.rint(c[0][sel][0]).astype(np.int32))
     np.testing.assert_allclose(avg, (s[0][sel] / c[0][sel]).T, rtol=1e-6)
 
+
+
+# ---------------------------------------------------------------------------------------------
+# The restatement against the REFERENCE'S OWN CPU CODE: committed vectors produced by executing
+# spconv's generate_subm_conv_inds / generate_conv_inds (tests/golden/make_ref_golden.py), and --
+# where oracle/_ref was built (this container, and the GPU box it travels to) -- the live library.
+# ---------------------------------------------------------------------------------------------
+from golden import digest, load_ref_case, ref_big_inputs, ref_case_names, ref_digests  # noqa: E402
+
+
+@pytest.mark.parametrize("name", ref_case_names())
+def test_oracle_rulebook_equals_reference_executed_vectors(name):
+    c = load_ref_case(name)
+    out_inds, pair, num, out_shape = oracle.get_indice_pairs(
+        c["indices"], c["bs"], c["shape"], c["ksize"], c["stride"], c["pad"], c["dil"], None, c["subm"],
+        c["transposed"])
+    assert list(out_shape) == c["out_shape"]
+    np.testing.assert_array_equal(out_inds, c["out_inds"])
+    np.testing.assert_array_equal(num, c["num"])
+    np.testing.assert_array_equal(pair, c["pair"])
+
+
+def test_oracle_rulebook_equals_reference_digests_at_baseline_sizes():
+    """config 1 / config 2 scenes and the real-LiDAR fixture (SubM and the stride-2 chain of config 3):
+    SHA-256 of every artefact equals the digest of what the reference's code produced."""
+    want = ref_digests()
+    for name in ("cfg1_subm", "cfg2_subm", "fixture_subm"):
+        idx, shape = ref_big_inputs(name)
+        assert digest(idx) == want[name]["input"], f"{name}: input generator drifted"
+        out_inds, pair, num, _ = oracle.get_indice_pairs(idx, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3,
+                                                         None, True, False)
+        assert (digest(out_inds), digest(pair), digest(num)) == (
+            want[name]["out_inds"], want[name]["pair"], want[name]["num"]), name
+    cur, cur_shape = ref_big_inputs("fixture_chain_l0")
+    for level in range(3):
+        w = want[f"fixture_chain_l{level}"]
+        assert digest(cur) == w["input"]
+        out_inds, pair, num, out_shape = oracle.get_indice_pairs(cur, 1, cur_shape, [3] * 3, [2] * 3, [1] * 3,
+                                                                 [1] * 3, None, False, False)
+        assert out_inds.shape[0] == w["n_out"] and list(out_shape) == w["out_shape"]
+        assert (digest(out_inds), digest(pair), digest(num)) == (w["out_inds"], w["pair"], w["num"]), level
+        cur, cur_shape = out_inds, list(out_shape)
+
+
+def test_oracle_rulebook_equals_live_reference_library():
+    """Randomised sweep against oracle/_ref/libspconv_ref.so when it is present."""
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("oracle/_ref not built here (needs /root/reference: make -C oracle ref)")
+    from spconv_amd.utils import synthetic
+    rng = np.random.default_rng(2024)
+    for trial in range(40):
+        nd = int(rng.integers(1, 5))
+        shape = [int(v) for v in rng.integers(6, 20 if nd > 2 else 60, nd)]
+        bs = int(rng.integers(1, 4))
+        n = int(min(rng.integers(1, 800), np.prod(shape) // 2))
+        subm = bool(rng.integers(0, 2))
+        transposed = (not subm) and bool(rng.integers(0, 3) == 0)
+        ksize = [int(v) for v in (rng.choice([1, 3, 5], nd) if subm else rng.integers(1, 4, nd))]
+        stride = [1] * nd if subm else [int(v) for v in rng.integers(1, 4, nd)]
+        dil = [int(v) for v in rng.integers(1, 3, nd)]
+        pad = [int(v) for v in rng.integers(0, 3, nd)]
+        idx = synthetic.uniform_scene(shape, n, bs, seed=trial)
+        try:
+            want = ref.get_indice_pairs(idx, bs, shape, ksize, stride, pad, dil, None, subm, transposed)
+        except (ValueError, RuntimeError):
+            continue
+        got = oracle.get_indice_pairs(idx, bs, shape, ksize, stride, pad, dil, None, subm, transposed)
+        for a, b in zip(got[:3], want[:3]):
+            np.testing.assert_array_equal(a, b, err_msg=f"trial {trial}: {shape} k{ksize} s{stride} p{pad} d{dil}")
