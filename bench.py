@@ -439,6 +439,7 @@ def run_layer(args, D: Dist):
         sc.x = spconv.SparseConvTensor(sc.feats, sc.indices, sc.shape, 1)
         sc.x.indice_dict["bench"] = net._make_indice_data(sc.rb, sc.indices, sc.shape, sc.shape, net.algo)
         ops._plan_of(sc.rb)
+        sc.tp = ops.tile_plan(sc.rb, "fwd")          # dense neighbourhoods: spatial tiles + halo lists
         num = sc.rb.num_per_loc.cpu().numpy()
         sc.P = int(sc.n + 2 * num[:13].sum())                      # pairs incl. centre
         scenes.append(sc)
@@ -545,16 +546,18 @@ def run_layer(args, D: Dist):
     def groups_for(pick):
         def fwd(i):
             sc = scenes[pick(i)]
-            ops.igemm_fwd(sc.feats.detach(), w, sc.rb.pair_fwd, sc.rb.mask_fwd, sc.rb.argsort_fwd, sc.n, 13)
+            ops.igemm_fwd(sc.feats.detach(), w, sc.rb.pair_fwd, sc.rb.mask_fwd, sc.rb.argsort_fwd, sc.n, 13,
+                          plan=sc.tp)
 
         def bwd(i):
             sc = scenes[pick(i)]
             ops.igemm_bwd(sc.feats.detach(), sc.dout, w, sc.rb.pair_fwd, sc.rb.mask_fwd, sc.rb.argsort_fwd,
-                          sc.rb.pair_native, sc.rb.num_per_loc, True, plan[pick(i)])
+                          sc.rb.pair_native, sc.rb.num_per_loc, True, plan[pick(i)], tile_plan=sc.tp)
 
         def dgrad(i):
             sc = scenes[pick(i)]
-            ops.igemm_dgrad(sc.dout, w, sc.rb.pair_fwd, sc.rb.mask_fwd, sc.rb.argsort_fwd, sc.n, True)
+            ops.igemm_dgrad(sc.dout, w, sc.rb.pair_fwd, sc.rb.mask_fwd, sc.rb.argsort_fwd, sc.n, True,
+                            plan=sc.tp)
 
         def wgrad(i):
             sc = scenes[pick(i)]
@@ -566,6 +569,13 @@ def run_layer(args, D: Dist):
     t_cold = groups_for(lambda i: i % S)
     t_warm = groups_for(lambda i: 0) if S > 1 else t_cold
     t_eager = event_time_ms(lambda i: compute(scenes[i % S]), iters=20, warm=5)
+    t_plan_dev = None
+    if tiled:            # building a plan (spatial sort + halo lists): once per rulebook, like the rulebook itself
+
+        def replan(i):
+            scenes[0].rb.tile_plans.clear()
+            ops.tile_plan(scenes[0].rb, "fwd")
+        t_plan_dev = round(event_time_ms(replan, iters=10, warm=2), 4)
     s = scenes[0].feats.element_size()
     P = sum(sc.P for sc in scenes) / S
     ab = algorithmic_bytes(n_mean, n_mean, C, K, 27, s)
@@ -574,7 +584,10 @@ def run_layer(args, D: Dist):
     strict = {"fwd": ab["fwd"], "bwd": s * n_mean * K + 2 * s * n_mean * C + 4 * 27 * n_mean + 8 * P
               + 2 * s * 27 * C * K}
     dt = args.dtype
-    kname = {"fwd": f"igemm_v4_kernel<{K},2,{dt},fwd>", "bwd": f"igemm_bwd_kernel<{C},2,{dt}> + wgrad_reduce2_kernel"}
+    tiled = scenes[0].tp is not None
+    kname = ({"fwd": f"igemm_halo_kernel<{K},{dt},fwd>",
+              "bwd": f"igemm_halo_kernel<{C},{dt},dgrad> + wgrad_tr_kernel + wgrad_reduce2_kernel"} if tiled else
+             {"fwd": f"igemm_v4_kernel<{K},2,{dt},fwd>", "bwd": f"igemm_bwd_kernel<{C},2,{dt}> + wgrad_reduce2_kernel"})
     tkey = f"{kind}-{dt}-c{C}-n{voxels}"
 
     def roof(t, label):
@@ -602,7 +615,8 @@ def run_layer(args, D: Dist):
                                f"{S} distinct scenes per GPU visited round-robin, rulebook reused via indice_key",
                    "voxels_per_gpu": int(n_mean), "pairs_per_voxel": round(P / n_mean, 4), "launch": launch,
                    "steps_per_replay": U if launch == "hipgraph" else None, "scenes_rotated": S,
-                   "mask_sort": bool(args.sort), "parallelism": f"dp{world}", "ranks_seen": ranks_seen,
+                   "mask_sort": bool(args.sort), "tile_plan": tiled, "parallelism": f"dp{world}",
+                   "ranks_seen": ranks_seen,
                    "dist_backend": D.backend if world > 1 else None},
         "roofline": r_cold, "roofline_cold": r_cold, "roofline_warm": r_warm,
         "kernels": ktable(t_cold), "kernels_warm": ktable(t_warm),
@@ -614,6 +628,7 @@ def run_layer(args, D: Dist):
         "ms_per_step_one_step_per_replay": None if single_replay_ms is None else round(single_replay_ms, 5),
         "rulebook_ms": round(statistics.median(rule_ms), 4),
         "rulebook_device_ms": round(t_rule_dev, 4),
+        "tile_plan_device_ms": t_plan_dev,
     }
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline_layer(scenes[0].idx_np, scenes[0].shape, C, K, seed=1)

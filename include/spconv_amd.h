@@ -166,6 +166,30 @@ int spx_igemm_fwd_int8(const void *feat, const void *weight, void *out, const in
                        const void *add, float add_scale, int out_dtype, int act, float act_alpha,
                        spx_stream_t stream);
 
+/* ---- tile plans: the dense-neighbourhood path ------------------------------------------------
+ * The reference sorts the rows of a rulebook by mask (SpconvOps.sort_1d_by_key_allocator,
+ * all.py:935-991, on by default through SPCONV_DO_SORT) so that its implicit-GEMM tiles skip
+ * offsets; here the rows are ordered SPATIALLY instead, which lets a tile stage the unique source
+ * rows of all its pairs once in LDS (csrc/tileplan.hip, csrc/igemm.hip: igemm_halo_kernel).
+ * A plan belongs to one pair table [kv, n_dst] (kv <= 32) and the coordinates of its destination
+ * rows: pair_fwd + out_indices for the forward pass (and, for SubM, for dgrad as well),
+ * pair_bwd + the input indices for the dgrad of a regular convolution. */
+size_t spx_tile_plan_bytes(int n_dst, int kv);
+size_t spx_tile_plan_ws_bytes(int n_dst);
+int spx_tile_plan_build(const int32_t *dst_indices, int n_dst, int ndim, int batch_size,
+                        const int *dst_shape, const int32_t *pair, int kv, int32_t *plan, void *ws,
+                        size_t ws_bytes, spx_stream_t stream);
+
+/* spx_igemm_fwd / spx_igemm_dgrad over a tile plan: same results (bit-identical), dense scenes
+ * run ~2x faster.  16-bit dtypes with C <= 64 (forward) / K <= 64 (dgrad) and output widths
+ * 16 / 32 / 64 take the halo kernel, everything else falls back to the plain kernels. */
+int spx_igemm_fwd_tiled(const void *feat, const void *weight, void *out, const int32_t *pair,
+                        const int32_t *plan, int n_in, int n_out, int C, int K, int kv, int dtype,
+                        const void *bias, int act, float act_alpha, spx_stream_t stream);
+int spx_igemm_dgrad_tiled(const void *dout, const void *weight, void *din, const int32_t *pair,
+                          const int32_t *plan, int n_out, int n_in, int C, int K, int kv, int dtype,
+                          int subm, spx_stream_t stream);
+
 /* Scratch for dgrad (always 0: the weight transpose happens inside the kernel). */
 size_t spx_igemm_dgrad_ws_bytes(int C, int K, int kv, int dtype);
 

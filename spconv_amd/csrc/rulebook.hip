@@ -242,7 +242,7 @@ subm_insert_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table t,
   int slot = -1;
   if (b >= 0 && b < g.batch && in_range(c, g.in_dims))
     slot = table_insert_min(t, layout_key(b, c, g.in_dims), i);
-  slot_of[i] = slot;
+  if (slot_of) slot_of[i] = slot;
 }
 
 // One thread per (voxel, offset k < kv/2): every probe chain is independent and there are only
@@ -423,6 +423,209 @@ subm_center_list_kernel(int32_t *__restrict__ native, int kv, int n) {
   const size_t c = static_cast<size_t>(kv / 2) * n + i;
   native[c] = i;
   native[static_cast<size_t>(kv) * n + c] = i;
+}
+
+// ------------------------------------------------ SubM, second generation
+// One thread per voxel.  The thread issues the probes of a whole chunk of offsets before it looks
+// at any of them (independent 8-byte loads in flight together) and OWNS column o of every table:
+// each entry -- hit or -1 -- is written exactly once, coalesced along the voxel axis.  Compared
+// with subm_probe3_kernel this needs no -1 pre-fill of the tables (34 MB at 100 k voxels), no
+// scattered mirror stores, no atomicOr on the masks and no slot_of round trip; it probes all kv
+// offsets of a voxel instead of kv/2, which costs less than what it removes.  The per-block hit
+// counts of the offsets above the centre (= the lengths of the ConvAlgo.Native lists, see
+// subm_lists_kernel) fall out of the same pass.
+constexpr int kProbeChunk = 9;
+
+// linear-probe walk of a packed table starting from an already loaded first slot word
+__device__ __forceinline__ int32_t packed_resolve(const unsigned long long *slots, uint32_t tmask,
+                                                  uint32_t key32, uint32_t slot,
+                                                  unsigned long long v) {
+  for (uint32_t probe = 0; probe <= tmask; ++probe) {
+    if (v == kEmptySlot) return -1;
+    if (static_cast<uint32_t>(v >> 32) == key32) return static_cast<int32_t>(v);
+    slot = (slot + 1) & tmask;
+    v = slots[slot];
+  }
+  return -1;
+}
+
+template <bool PACKED>
+__global__ void __launch_bounds__(kBlock)
+subm_probe_all_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table t,
+                      int32_t *__restrict__ pair_fwd, int32_t *__restrict__ pair_bwd,
+                      uint32_t *__restrict__ mask, int words, int32_t *__restrict__ blockcount,
+                      int nblk) {
+  __shared__ int lds_cnt[64];                 // hits of offset centre+1+j in this block (kv <= 128)
+  const int o = blockIdx.x * kBlock + threadIdx.x;
+  const int kv = g.kv, center = kv / 2;
+  if (threadIdx.x < 64) lds_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const bool live = o < n;
+  int b = -1, c[4] = {0, 0, 0, 0};
+  if (live) read_row(indices, o, g.ndim, b, c);
+  const bool hashed = live && b >= 0 && b < g.batch && in_range(c, g.in_dims);
+  const unsigned long long *slots = reinterpret_cast<const unsigned long long *>(t.keys);
+  // the first row of this coordinate (duplicates: the smallest index won the slot); its first
+  // slot word travels with the first chunk's loads
+  const hkey_t own_key = layout_key(b, c, g.in_dims);
+  const uint32_t own_slot = hash_key32(static_cast<uint32_t>(own_key)) & t.mask;
+  unsigned long long own_word = kEmptySlot;
+  if (PACKED && hashed) own_word = slots[own_slot];
+  bool first = false;
+  uint32_t mword = 0;
+  int r[4] = {0, 0, 0, 0};                    // offset odometer (ConvOutLocIter::operator++)
+  for (int k0 = 0; k0 < kv; k0 += kProbeChunk) {
+    uint32_t key32[kProbeChunk], slot0[kProbeChunk];
+    unsigned long long word[kProbeChunk];
+    bool act[kProbeChunk];
+    hkey_t wide[PACKED ? 1 : kProbeChunk];
+#pragma unroll
+    for (int j = 0; j < kProbeChunk; ++j) {
+      const int k = k0 + j;
+      int q[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) q[d] = c[d] - g.padding[d] + r[d] * g.dilation[d];
+      act[j] = hashed && k < kv && k != center && in_range(q, g.in_dims);
+      const hkey_t wkey = layout_key(b, q, g.in_dims);
+      if (!PACKED) wide[j] = wkey;
+      key32[j] = static_cast<uint32_t>(wkey);
+      slot0[j] = hash_key32(key32[j]) & t.mask;
+      word[j] = kEmptySlot;
+      if (PACKED && act[j]) word[j] = slots[slot0[j]];
+      if (++r[3] >= g.ksize[3]) {             // ++r with carry, last dimension fastest
+        r[3] = 0;
+        if (++r[2] >= g.ksize[2]) {
+          r[2] = 0;
+          if (++r[1] >= g.ksize[1]) {
+            r[1] = 0;
+            ++r[0];
+          }
+        }
+      }
+    }
+    if (k0 == 0) {
+      int own = -1;
+      if (hashed) own = PACKED ? packed_resolve(slots, t.mask, static_cast<uint32_t>(own_key), own_slot, own_word)
+                                 : table_find(t, own_key);
+      first = own == o;
+    }
+#pragma unroll
+    for (int j = 0; j < kProbeChunk; ++j) {
+      const int k = k0 + j;
+      const bool kin = k < kv;               // (no break: the loop must unroll, the arrays are registers)
+      int res = -1;
+      if (k == center) {
+        res = live ? o : -1;
+      } else if (act[j] && (first || k > center)) {
+        // a row that is not the first of its coordinate keeps only its k > centre half
+        // (unordered_map::insert kept the first one, indices.py:1672: lookups never return it)
+        res = PACKED ? packed_resolve(slots, t.mask, key32[j], slot0[j], word[j]) : table_find(t, wide[PACKED ? 0 : j]);
+      }
+      if (live && kin) {
+        pair_fwd[static_cast<size_t>(k) * n + o] = res;
+        if (pair_bwd) pair_bwd[static_cast<size_t>(kv - 1 - k) * n + o] = res;
+      }
+      if (res >= 0) mword |= 1u << (k & 31);
+      if (live && kin && ((k & 31) == 31 || k == kv - 1)) {
+        mask[static_cast<size_t>(o) * words + (k >> 5)] = mword;
+        mword = 0;
+      }
+      if (blockcount && kin && k > center) {
+        const unsigned long long bal = __ballot(res >= 0);
+        if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&lds_cnt[k - center - 1], __popcll(bal));
+      }
+    }
+  }
+  if (blockcount) {
+    __syncthreads();
+    // list L (< kv/2) is read off row kv-1-L of the table: offset centre+1+j <-> list kv/2-1-j
+    if (threadIdx.x < kv / 2)
+      blockcount[static_cast<size_t>(kv / 2 - 1 - threadIdx.x) * nblk + blockIdx.x] = lds_cnt[threadIdx.x];
+  }
+}
+
+// ConvAlgo.Native lists of a SubM rulebook from the finished table, in the CPU loop's order
+// (ascending input row inside a list, indices.py:1685-1696): blockIdx.y = list L < kv/2 (and its
+// mirror kv-1-L with the roles swapped), or kv/2 = the identity list.  The block's output offset
+// is the sum of the 256-voxel hit counts the probe kernel left (no separate scan launch); block 0
+// of a list also writes num_per_loc[L].  Positions past a list's length are set to -1 here
+// (ops.py:191-193 starts from a -1 filled tensor), so the caller's buffer needs no pre-fill.
+__global__ void __launch_bounds__(kBlock)
+subm_lists_kernel(const int32_t *__restrict__ pair_fwd, int kv, int n, int nblk256,
+                  const int32_t *__restrict__ blockcount, int32_t *__restrict__ native,
+                  int32_t *__restrict__ num_per_loc, int num_len) {
+  __shared__ int lds_wave[kBlock / 64];
+  __shared__ int lds_red[2][kBlock / 64];
+  const int list = blockIdx.y, blk = blockIdx.x;
+  const int begin = blk * kItems;
+  const size_t plane = static_cast<size_t>(kv) * n;
+  if (list == kv / 2) {                        // identity lists (indices.py:1678-1682)
+    // counts exist for k < kv/2 only (indices.py:1685,1692); the rest of num_per_loc reads 0
+    if (blk == 0)
+      for (int i = kv / 2 + threadIdx.x; i < num_len; i += kBlock) num_per_loc[i] = 0;
+    if (!native) return;
+    for (int it = 0; it < kItems / kBlock; ++it) {
+      const int e = begin + it * kBlock + threadIdx.x;
+      if (e < n) {
+        native[static_cast<size_t>(list) * n + e] = e;
+        native[plane + static_cast<size_t>(list) * n + e] = e;
+      }
+    }
+    return;
+  }
+  // prefix of the hit counts before this block's first 256-voxel group, and the list total
+  const int32_t *cnt = blockcount + static_cast<size_t>(list) * nblk256;
+  const int first_group = blk * (kItems / kBlock);
+  int before = 0, all = 0;
+  for (int i = threadIdx.x; i < nblk256; i += kBlock) {
+    const int v = cnt[i];
+    all += v;
+    if (i < first_group) before += v;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    before += __shfl_xor(before, d, 64);
+    all += __shfl_xor(all, d, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    lds_red[0][threadIdx.x >> 6] = before;
+    lds_red[1][threadIdx.x >> 6] = all;
+  }
+  __syncthreads();
+  before = all = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) {
+    before += lds_red[0][w];
+    all += lds_red[1][w];
+  }
+  if (blk == 0 && threadIdx.x == 0 && num_per_loc) num_per_loc[list] = all;
+  if (!native) return;
+  const int32_t *row = pair_fwd + static_cast<size_t>(kv - 1 - list) * n;
+  int32_t *in_k = native + static_cast<size_t>(list) * n;
+  int32_t *out_k = native + plane + static_cast<size_t>(list) * n;
+  int32_t *in_m = native + static_cast<size_t>(kv - 1 - list) * n;
+  int32_t *out_m = native + plane + static_cast<size_t>(kv - 1 - list) * n;
+  int running = before;
+  for (int it = 0; it < kItems / kBlock; ++it) {
+    const int e = begin + it * kBlock + threadIdx.x;
+    const int v = e < n ? row[e] : -1;
+    int total;
+    const int rank = block_rank(v >= 0, total, lds_wave);
+    if (v >= 0) {
+      const int j = running + rank;
+      in_k[j] = e;
+      out_k[j] = v;
+      in_m[j] = v;
+      out_m[j] = e;
+    }
+    running += total;
+    if (e < n && e >= all) {                   // tail of the list: this block's own position range
+      in_k[e] = -1;
+      out_k[e] = -1;
+      in_m[e] = -1;
+      out_m[e] = -1;
+    }
+  }
 }
 
 // ------------------------------------------------ regular / transposed conv
@@ -1185,6 +1388,36 @@ int spx_subm_rulebook(const int32_t *indices, int n, int ndim, int batch_size,
   int32_t *blockoff = cv.take<int32_t>(static_cast<size_t>(kv) * nblk);
   int32_t *scratch_totals = cv.take<int32_t>(64);
   int32_t *slot_of = cv.take<int32_t>(n);
+  const dim3 grid(div_up(n, kBlock));
+  static const int version = env_int("SPX_SUBM_V", 2);          // tuning knob (A/B runs)
+  const int nblk256 = div_up(n, kBlock);
+  // second generation: 4 launches (table fill, insert, probe, lists), no table pre-fills.  Its
+  // 256-voxel hit counts live where the first generation keeps its 2048-entry counts
+  // (blockcount .. blockoff are contiguous: 2 * kv * nblk ints >= (kv / 2) * nblk256)
+  const bool gen2 = version >= 2 && kv <= 128 && nblk256 <= 16384 &&
+                    static_cast<size_t>(kv / 2) * nblk256 <= 2 * static_cast<size_t>(kv) * nblk;
+  if (gen2) {
+    FillList fills;
+    table_fill(fills, t);
+    SPX_HIP(fills.launch(s));
+    hipLaunchKernelGGL(subm_insert_kernel, grid, dim3(kBlock), 0, s, indices, n, g, t,
+                       static_cast<int32_t *>(nullptr));
+    const bool lists = pair_native || num_per_loc;
+    if (t.packed)
+      hipLaunchKernelGGL(subm_probe_all_kernel<true>, grid, dim3(kBlock), 0, s, indices, n, g, t, pair_fwd,
+                         pair_bwd, mask, words, (lists && kv > 1) ? blockcount : nullptr, nblk256);
+    else
+      hipLaunchKernelGGL(subm_probe_all_kernel<false>, grid, dim3(kBlock), 0, s, indices, n, g, t, pair_fwd,
+                         pair_bwd, mask, words, (lists && kv > 1) ? blockcount : nullptr, nblk256);
+    if (lists) {
+      SPX_CHECK(!pair_native || num_per_loc || kv / 2 <= 64, "num_per_loc required for kv > 128");
+      hipLaunchKernelGGL(subm_lists_kernel, dim3(nblk, kv / 2 + 1), dim3(kBlock), 0, s, pair_fwd, kv, n,
+                         nblk256, blockcount, pair_native, num_per_loc ? num_per_loc : scratch_totals,
+                         num_per_loc ? kv : 0);
+    }
+    SPX_LAUNCH_CHECK();
+    return 0;
+  }
 
   // every fill of this build in one launch: hash table, masks, counts, -1 tables (callers that
   // carve the tables out of one buffer get one contiguous range)
@@ -1199,7 +1432,6 @@ int spx_subm_rulebook(const int32_t *indices, int n, int ndim, int batch_size,
     if (pair_native) fills.add(pair_native, 2 * tb, 0xFFFFFFFFu);
   }
   SPX_HIP(fills.launch(s));
-  const dim3 grid(div_up(n, kBlock));
   hipLaunchKernelGGL(subm_insert_kernel, grid, dim3(kBlock), 0, s, indices, n, g, t, slot_of);
   hipLaunchKernelGGL(subm_probe3_kernel, dim3(div_up(n, kBlock), kv / 2 + 1), dim3(kBlock), 0, s, indices,
                      n, g, t, slot_of, pair_fwd, pair_bwd, mask, words, pair_native);

@@ -362,8 +362,9 @@ class SparseConvolution(SparseModule):
             else:
                 table, mask, argsort = rb.pair_fwd, rb.mask_fwd, rb.argsort_fwd
                 ident = rb.kv // 2 if self.subm else -1
+            tp = ops.tile_plan(rb, "fwd") if (not self.inverse and argsort is None) else None
             out_features = ops.igemm_fwd(features, w, table, mask, argsort, num_out, ident,
-                                         bias_for_infer, act_type, act_alpha)
+                                         bias_for_infer, act_type, act_alpha, plan=tp)
         if bias_for_training is not None:
             out_features += bias_for_training
         if input.benchmark:

@@ -55,6 +55,13 @@ class Rulebook:
         self.argsort_bwd = argsort_bwd
         self.wgrad_plan = None          # built lazily by ops._plan_of
         self._native_swapped = None
+        # geometry of the two row sets (set by ops.build_rulebook) and the tile plans built from it
+        # on first use (ops.tile_plan: spatial row order + per-tile halo lists, csrc/tileplan.hip)
+        self.in_indices = None
+        self.in_shape = None
+        self.out_shape = None
+        self.batch_size = 1
+        self.tile_plans = {}
 
     def _ensure_native(self) -> None:
         """Inference builds only the dense tables; the ConvAlgo.Native lists (consumed by wgrad

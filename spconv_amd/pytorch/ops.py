@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes
 import functools
+import os
 import weakref
 from typing import List, Optional, Tuple
 
@@ -181,6 +182,7 @@ def build_rulebook(indices: torch.Tensor, batch_size: int, spatial_shape: List[i
                                             ws.data_ptr(), ws.numel(), stream))
         rb = Rulebook(out_indices, pair_fwd, pair_bwd, mask_fwd, mask_bwd, native, num, n_in,
                       n_out, kv, False)
+    rb.in_indices, rb.in_shape, rb.out_shape, rb.batch_size = indices, list(spatial_shape), list(out_shape), batch_size
     if do_sort and words == 1:
         rb.argsort_fwd = mask_argsort(rb.mask_fwd)
         if not subm:
@@ -197,6 +199,55 @@ def mask_argsort(mask: torch.Tensor) -> torch.Tensor:
     _lib.check(L.spx_mask_argsort(mask.data_ptr(), n, words, out.data_ptr(), ws.data_ptr(),
                                   ws.numel(), _stream(mask)))
     return out
+
+
+# ---------------------------------------------------------------- tile plans
+# SPCONV_AMD_TILE_PLAN: "auto" (default) = SubM rulebooks of >= 32 k rows whose neighbourhoods are
+# dense (real point clouds) get a plan on first use; "1" = every eligible table; "0" = never.
+_TILE_MODE = os.environ.get("SPCONV_AMD_TILE_PLAN", "auto")
+_TILE_MIN_ROWS = 32768
+
+
+def _halo_ok(dtype: torch.dtype, cin: int, cout: int, kv: int) -> bool:
+    """Shapes igemm_halo_kernel is instantiated for (csrc/igemm.hip)."""
+    return (dtype in (torch.float16, torch.bfloat16) and cin % 8 == 0 and cin * 2 <= 128
+            and cout in (16, 32, 64) and kv <= 32)
+
+
+def tile_plan(rb: Optional[Rulebook], direction: str) -> Optional[torch.Tensor]:
+    """Plan of a rulebook's table for the dense-neighbourhood kernel, or None when the plain kernel
+    is the better choice.  direction "fwd": pair_fwd over the output rows; "bwd": the table dgrad
+    reads (SubM: pair_fwd again -- one plan serves both passes; regular conv: pair_bwd over the
+    input rows).  Built once per rulebook and direction, cached on the rulebook."""
+    if rb is None or _TILE_MODE == "0" or rb.kv > 32 or rb.in_indices is None:
+        return None
+    if rb.subm:
+        direction = "fwd"
+    if direction in rb.tile_plans:
+        return rb.tile_plans[direction]
+    plan = None
+    if direction == "fwd":
+        table, mask, inds, shape, n_dst = rb.pair_fwd, rb.mask_fwd, rb.out_indices, rb.out_shape, rb.n_out
+    else:
+        table, mask, inds, shape, n_dst = rb.pair_bwd, rb.mask_bwd, rb.in_indices, rb.in_shape, rb.n_in
+    want = table is not None and n_dst > 0
+    if want and _TILE_MODE != "1":
+        want = rb.subm and n_dst >= _TILE_MIN_ROWS
+        if want:
+            # dense neighbourhoods?  share of rows with more than their own (centre) pair; one
+            # small reduction + read-back per rulebook (uniform-random scenes: ~3 %, LiDAR: ~100 %)
+            centre = 1 << (rb.kv // 2)
+            want = float((mask.view(-1) != centre).float().mean().item()) >= 0.5
+    if want:
+        L = _lib.load()
+        plan = torch.empty((L.spx_tile_plan_bytes(n_dst, rb.kv) // 4,), dtype=torch.int32, device=table.device)
+        ws = _ws(L.spx_tile_plan_ws_bytes(n_dst), table.device)
+        inds = inds.contiguous()
+        _lib.check(L.spx_tile_plan_build(inds.data_ptr(), n_dst, inds.shape[1] - 1, int(rb.batch_size),
+                                         _lib.ints(shape), table.data_ptr(), rb.kv, plan.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), _stream(table)))
+    rb.tile_plans[direction] = plan
+    return plan
 
 
 def attach_rulebook(t: torch.Tensor, rb: Rulebook) -> torch.Tensor:
@@ -335,13 +386,25 @@ def _pad_first(t: torch.Tensor, to: int) -> torch.Tensor:
 def igemm_fwd(features: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
               mask: Optional[torch.Tensor], argsort: Optional[torch.Tensor], n_out: int,
               identity_k: int = -1, bias: Optional[torch.Tensor] = None,
-              act_type: int = Activation.None_, act_alpha: float = 0.0) -> torch.Tensor:
-    """out[o] = act(bias + sum_k feat[pair[k][o]] @ W[:, k, :].T); filters KRSC."""
+              act_type: int = Activation.None_, act_alpha: float = 0.0,
+              plan: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[o] = act(bias + sum_k feat[pair[k][o]] @ W[:, k, :].T); filters KRSC.  `plan`: tile plan of
+    `pair` (ops.tile_plan) -> the dense-neighbourhood kernel, same results."""
     _check_feat(features, filters)
     L = _lib.load()
     K0, C0 = filters.shape[0], filters.shape[-1]
     assert features.shape[1] == C0, "channel size mismatch"
     kv = filters.numel() // (K0 * C0)
+    if plan is not None and _halo_ok(features.dtype, C0, K0, kv):
+        features, filters = features.contiguous(), filters.contiguous()
+        out = torch.empty((n_out, K0), dtype=features.dtype, device=features.device)
+        if bias is not None:
+            bias = bias.to(features.dtype).contiguous()
+        _lib.check(L.spx_igemm_fwd_tiled(features.data_ptr(), filters.data_ptr(), out.data_ptr(), pair.data_ptr(),
+                                         plan.data_ptr(), features.shape[0], n_out, C0, K0, kv,
+                                         _dtype_code(features), _ptr(bias), int(act_type), float(act_alpha),
+                                         _stream(features)))
+        return out
     # Shapes the MFMA kernels are not instantiated for (a backbone's first layer has 3-5 input
     # channels; widths like 48 or 96) are zero-padded to the next supported shape instead of
     # falling to the one-thread-per-output generic kernel (two orders of magnitude slower): the
@@ -369,12 +432,19 @@ def igemm_fwd(features: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
 
 def igemm_dgrad(out_bp: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
                 mask: Optional[torch.Tensor], argsort: Optional[torch.Tensor], n_in: int,
-                subm: bool) -> torch.Tensor:
+                subm: bool, plan: Optional[torch.Tensor] = None) -> torch.Tensor:
     """din[i] = sum_k dout[pair[k][i]] @ W[:, k, :] (SubM: pass the forward table, subm=True)."""
     _check_feat(out_bp, filters)
     L = _lib.load()
     K0, C0 = filters.shape[0], filters.shape[-1]
     kv = filters.numel() // (K0 * C0)
+    if plan is not None and _halo_ok(out_bp.dtype, K0, C0, kv):
+        out_bp, filters = out_bp.contiguous(), filters.contiguous()
+        din = torch.empty((n_in, C0), dtype=out_bp.dtype, device=out_bp.device)
+        _lib.check(L.spx_igemm_dgrad_tiled(out_bp.data_ptr(), filters.data_ptr(), din.data_ptr(), pair.data_ptr(),
+                                           plan.data_ptr(), out_bp.shape[0], n_in, C0, K0, kv,
+                                           _dtype_code(out_bp), int(subm), _stream(out_bp)))
+        return din
     # same padding rule as igemm_fwd: here K is the reduction length and C the output width
     K = -(-K0 // _lane_mult(out_bp.dtype)) * _lane_mult(out_bp.dtype)
     C = _round_cout(C0) if kv <= 32 else C0
@@ -430,12 +500,19 @@ def igemm_wgrad(features: torch.Tensor, out_bp: torch.Tensor, filters_shape, nat
 def igemm_bwd(features: torch.Tensor, out_bp: torch.Tensor, filters: torch.Tensor,
               table: torch.Tensor, mask: Optional[torch.Tensor], argsort: Optional[torch.Tensor],
               native: torch.Tensor, num_per_loc: torch.Tensor, subm: bool,
-              plan: Optional[torch.Tensor] = None, need_din: bool = True):
+              plan: Optional[torch.Tensor] = None, need_din: bool = True,
+              tile_plan: Optional[torch.Tensor] = None):
     """(din, dW) of one layer from one launch (+ the wgrad second stage).  need_din=False (the
-    input does not require grad: a network's first layer) computes dW only and returns None."""
+    input does not require grad: a network's first layer) computes dW only and returns None.
+    `tile_plan` (dense neighbourhoods): dgrad takes the halo kernel, wgrad its own launch -- there
+    the two halves are long enough that sharing a launch buys ~5 %, the halo kernel ~2x."""
     _check_feat(out_bp, filters)
     K0, C0 = filters.shape[0], filters.shape[-1]
     m = _lane_mult(out_bp.dtype)
+    kvf = filters.numel() // (K0 * C0)
+    if tile_plan is not None and need_din and _halo_ok(out_bp.dtype, K0, C0, kvf):
+        din = igemm_dgrad(out_bp, filters, table, mask, argsort, features.shape[0], subm, tile_plan)
+        return din, igemm_wgrad(features, out_bp, filters.shape, native, num_per_loc, subm, plan)
     if not need_din or K0 % m or C0 not in _MFMA_COUT:
         din = igemm_dgrad(out_bp, filters, table, mask, argsort, features.shape[0], subm) if need_din else None
         return din, igemm_wgrad(features, out_bp, filters.shape, native, num_per_loc, subm, plan)
@@ -517,8 +594,9 @@ def indice_conv(features: torch.Tensor, filters: torch.Tensor, indice_pairs: tor
         table, mask = rb.pair_bwd, rb.mask_bwd
     else:
         table, mask = _table_from_native(indice_pairs, indice_pair_num, num_activate_out, subm, inverse)
+    tp = tile_plan(rb, "fwd") if (rb is not None and not inverse and table is rb.pair_fwd) else None
     return igemm_fwd(features, filters, table, mask, None, num_activate_out,
-                     kv // 2 if subm else -1, bias, act_type, act_alpha)
+                     kv // 2 if subm else -1, bias, act_type, act_alpha, plan=tp)
 
 
 _SIDE_STREAMS = {}
@@ -576,9 +654,15 @@ def indice_conv_backward(features: torch.Tensor, filters: torch.Tensor, out_bp: 
         native = rb.native_swapped() if rb is not None else torch.stack(
             [indice_pairs[1], indice_pairs[0]]).contiguous()
     plan = _plan_of(rb)
+    tp = None
+    if rb is not None and need_din:
+        if table is rb.pair_fwd and (subm or inverse):
+            tp = tile_plan(rb, "fwd")
+        elif table is rb.pair_bwd and not subm:
+            tp = tile_plan(rb, "bwd")
     if (native.shape[2] == n_in and not BWD_OVERLAP) or not need_din:
         return igemm_bwd(features, out_bp, filters, table, mask, argsort, native, indice_pair_num,
-                         subm, plan, need_din)
+                         subm, plan, need_din, tile_plan=tp)
     return _backward_pair(
         lambda: igemm_dgrad(out_bp, filters, table, mask, argsort, n_in, subm),
         lambda: igemm_wgrad(features, out_bp, filters.shape, native, indice_pair_num, subm, plan),
@@ -614,8 +698,9 @@ def implicit_gemm(features: torch.Tensor, filters: torch.Tensor, pair_fwd: torch
         return out, None, -1
     if scale is not None or output_add is not None:
         raise NotImplementedError("scale / output_add belong to the int8 path")
+    tp = tile_plan(rb, "fwd") if (rb is not None and pair_fwd is rb.pair_fwd and argsort is None) else None
     out = igemm_fwd(features, filters, pair_fwd, mask, argsort, num_activate_out,
-                    kv // 2 if is_subm else -1, bias, act_type, act_alpha)
+                    kv // 2 if is_subm else -1, bias, act_type, act_alpha, plan=tp)
     return out, None, -1
 
 
@@ -642,9 +727,15 @@ def implicit_gemm_backward(features: torch.Tensor, filters: torch.Tensor, out_bp
     else:
         table, mask = pair_bwd, pair_mask_bwd_splits[0]
         argsort = rb.argsort_bwd if rb is not None else None
+    tp = None
+    if rb is not None and need_din and argsort is None:
+        if is_subm and table is rb.pair_fwd:
+            tp = tile_plan(rb, "fwd")
+        elif not is_subm and table is rb.pair_bwd:
+            tp = tile_plan(rb, "bwd")
     if (native.shape[2] == n_in and not BWD_OVERLAP) or not need_din:
         return igemm_bwd(features, out_bp, filters, table, mask, argsort, native, num, is_subm, plan,
-                         need_din)
+                         need_din, tile_plan=tp)
     return _backward_pair(
         lambda: igemm_dgrad(out_bp, filters, table, mask, argsort, n_in, is_subm),
         lambda: igemm_wgrad(features, out_bp, filters.shape, native, num, is_subm, plan),
