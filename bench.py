@@ -575,7 +575,9 @@ def run_layer(args, D: Dist):
         def replan(i):
             scenes[0].rb.tile_plans.clear()
             ops.tile_plan(scenes[0].rb, "fwd")
+        mode, ops._TILE_MODE = ops._TILE_MODE, "1"       # (skip the density read-back: time the build only)
         t_plan_dev = round(event_time_ms(replan, iters=10, warm=2), 4)
+        ops._TILE_MODE = mode
     s = scenes[0].feats.element_size()
     P = sum(sc.P for sc in scenes) / S
     ab = algorithmic_bytes(n_mean, n_mean, C, K, 27, s)
