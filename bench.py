@@ -444,6 +444,7 @@ def run_layer(args, D: Dist):
         sc.P = int(sc.n + 2 * num[:13].sum())                      # pairs incl. centre
         scenes.append(sc)
     n = scenes[0].n
+    tiled = scenes[0].tp is not None
     bucket = GradBucket(net.parameters()) if world > 1 else None   # fp16 gradient, reduced in place
 
     def compute(sc):
@@ -586,7 +587,6 @@ def run_layer(args, D: Dist):
     strict = {"fwd": ab["fwd"], "bwd": s * n_mean * K + 2 * s * n_mean * C + 4 * 27 * n_mean + 8 * P
               + 2 * s * 27 * C * K}
     dt = args.dtype
-    tiled = scenes[0].tp is not None
     kname = ({"fwd": f"igemm_halo_kernel<{K},{dt},fwd>",
               "bwd": f"igemm_halo_kernel<{C},{dt},dgrad> + wgrad_tr_kernel + wgrad_reduce2_kernel"} if tiled else
              {"fwd": f"igemm_v4_kernel<{K},2,{dt},fwd>", "bwd": f"igemm_bwd_kernel<{C},2,{dt}> + wgrad_reduce2_kernel"})

@@ -185,7 +185,8 @@ int spx_tile_plan_build(const int32_t *dst_indices, int n_dst, int ndim, int bat
  * 16 / 32 / 64 take the halo kernel, everything else falls back to the plain kernels. */
 int spx_igemm_fwd_tiled(const void *feat, const void *weight, void *out, const int32_t *pair,
                         const int32_t *plan, int n_in, int n_out, int C, int K, int kv, int dtype,
-                        const void *bias, int act, float act_alpha, spx_stream_t stream);
+                        int identity_k, const void *bias, int act, float act_alpha,
+                        spx_stream_t stream);
 int spx_igemm_dgrad_tiled(const void *dout, const void *weight, void *din, const int32_t *pair,
                           const int32_t *plan, int n_out, int n_in, int C, int K, int kv, int dtype,
                           int subm, spx_stream_t stream);

@@ -42,7 +42,7 @@ SIGNATURES = {
     "spx_tile_plan_ws_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "spx_tile_plan_build": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_int_p, vp,
                                            ctypes.c_int, vp, vp, ctypes.c_size_t, vp]),
-    "spx_igemm_fwd_tiled": (ctypes.c_int, [vp, vp, vp, vp, vp] + [ctypes.c_int] * 6
+    "spx_igemm_fwd_tiled": (ctypes.c_int, [vp, vp, vp, vp, vp] + [ctypes.c_int] * 7
                             + [vp, ctypes.c_int, ctypes.c_float, vp]),
     "spx_igemm_dgrad_tiled": (ctypes.c_int, [vp, vp, vp, vp, vp] + [ctypes.c_int] * 7 + [vp]),
     "spx_mask_argsort_ws_bytes": (ctypes.c_size_t, [ctypes.c_int]),

@@ -1103,7 +1103,7 @@ __global__ void __launch_bounds__(kThreads, 2)
 igemm_halo_kernel(const void *argA, const void *argB, const int32_t *plan_order,
                   const int32_t *plan_info, const int32_t *plan_halo, const uint16_t *plan_local,
                   const int32_t *arg_pair, int n_dst, int n_src, int CIN, int kv, int b_reverse,
-                  int ntiles, GemmRest rest) {
+                  int ntiles, int identity_k, GemmRest rest) {
   constexpr bool BF16 = DT == 1;
   constexpr int ES = 2, MB = 2, NB = COUT / 16, CPL = NB * 4;
   constexpr int B_BYTES = COUT * kRowBytes;
@@ -1183,9 +1183,17 @@ igemm_halo_kernel(const void *argA, const void *argB, const int32_t *plan_order,
   };
 
   // ---- prologue: first weights, slot table, halo ------------------------------------------------
+  // step order as in igemm_v4_kernel (SubM: the identity offset first, then ascending), so that
+  // both kernels add a row's terms in the same order and return bit-identical results
   uint32_t rest_bits = kmask;
-  int k0 = rest_bits ? __builtin_ctz(rest_bits) : -1;
-  rest_bits = rest_bits ? (rest_bits & (rest_bits - 1)) : 0u;
+  int k0;
+  if (identity_k >= 0) {
+    k0 = identity_k;
+    rest_bits &= ~(1u << identity_k);
+  } else {
+    k0 = rest_bits ? __builtin_ctz(rest_bits) : -1;
+    rest_bits = rest_bits ? (rest_bits & (rest_bits - 1)) : 0u;
+  }
   load_b(k0);
   int grow[MB];
 #pragma unroll
@@ -1347,7 +1355,8 @@ int launch_halo(const GemmParams &p, const PlanView &pv, hipStream_t s) {
   }                                                                                                      \
   hipLaunchKernelGGL((igemm_halo_kernel<COUT, DT, BTV, NKSV>), dim3(pv.ntiles), dim3(kThreads),           \
                      (halo_smem_bytes<COUT>()), s, p.A, p.B, pv.order, pv.tile_info, pv.halo_rows,        \
-                     pv.plocal, p.pair, p.n_dst, p.n_src, p.CIN, p.kv, p.b_reverse, pv.ntiles, r)
+                     pv.plocal, p.pair, p.n_dst, p.n_src, p.CIN, p.kv, p.b_reverse, pv.ntiles,            \
+                     p.identity_k, r)
   if (p.strideD == 1) {
     if (half) { SPX_LAUNCH_HALO(false, 1); }
     else { SPX_LAUNCH_HALO(false, 2); }
@@ -2507,7 +2516,8 @@ int spx_igemm_fwd_int8(const void *feat, const void *weight, void *out, const in
 
 int spx_igemm_fwd_tiled(const void *feat, const void *weight, void *out, const int32_t *pair,
                         const int32_t *plan, int n_in, int n_out, int C, int K, int kv, int dtype,
-                        const void *bias, int act, float act_alpha, spx_stream_t stream) {
+                        int identity_k, const void *bias, int act, float act_alpha,
+                        spx_stream_t stream) {
   SPX_CHECK(C > 0 && K > 0 && kv > 0 && n_in >= 0 && n_out >= 0, "bad sizes");
   if (n_out == 0) return 0;
   SPX_CHECK((feat || n_in == 0) && weight && out && pair && plan, "null tensor pointer");
@@ -2525,7 +2535,7 @@ int spx_igemm_fwd_tiled(const void *feat, const void *weight, void *out, const i
   p.CIN = C;
   p.COUT = K;
   p.kv = kv;
-  p.identity_k = -1;
+  p.identity_k = identity_k;
   p.act = act;
   p.act_alpha = act_alpha;
   return run_gather_gemm_planned(p, dtype, plan, static_cast<hipStream_t>(stream));
@@ -2536,8 +2546,7 @@ int spx_igemm_dgrad_tiled(const void *dout, const void *weight, void *din, const
                           int subm, spx_stream_t stream) {
   if (n_in == 0) return 0;
   SPX_CHECK((dout || n_out == 0) && weight && din && pair && plan, "null tensor pointer");
-  GemmParams p = dgrad_params(dout, weight, din, pair, nullptr, nullptr, n_out, n_in, C, K, kv, subm);
-  p.identity_k = -1;
+  const GemmParams p = dgrad_params(dout, weight, din, pair, nullptr, nullptr, n_out, n_in, C, K, kv, subm);
   return run_gather_gemm_planned(p, dtype, plan, static_cast<hipStream_t>(stream));
 }
 

@@ -402,7 +402,8 @@ def igemm_fwd(features: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
             bias = bias.to(features.dtype).contiguous()
         _lib.check(L.spx_igemm_fwd_tiled(features.data_ptr(), filters.data_ptr(), out.data_ptr(), pair.data_ptr(),
                                          plan.data_ptr(), features.shape[0], n_out, C0, K0, kv,
-                                         _dtype_code(features), _ptr(bias), int(act_type), float(act_alpha),
+                                         _dtype_code(features), int(identity_k), _ptr(bias), int(act_type),
+                                         float(act_alpha),
                                          _stream(features)))
         return out
     # Shapes the MFMA kernels are not instantiated for (a backbone's first layer has 3-5 input
