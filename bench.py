@@ -547,18 +547,19 @@ def run_layer(args, D: Dist):
     def groups_for(pick):
         def fwd(i):
             sc = scenes[pick(i)]
-            ops.igemm_fwd(sc.feats.detach(), w, sc.rb.pair_fwd, sc.rb.mask_fwd, sc.rb.argsort_fwd, sc.n, 13,
-                          plan=sc.tp)
+            pair, mask, order, to = ops.tables_of(sc.rb, "fwd", K)
+            ops.igemm_fwd(sc.feats.detach(), w, pair, mask, order, sc.n, 13, plan=sc.tp, tile_order=to)
 
         def bwd(i):
             sc = scenes[pick(i)]
-            ops.igemm_bwd(sc.feats.detach(), sc.dout, w, sc.rb.pair_fwd, sc.rb.mask_fwd, sc.rb.argsort_fwd,
-                          sc.rb.pair_native, sc.rb.num_per_loc, True, plan[pick(i)], tile_plan=sc.tp)
+            pair, mask, order, to = ops.tables_of(sc.rb, "fwd", C)
+            ops.igemm_bwd(sc.feats.detach(), sc.dout, w, pair, mask, order, sc.rb.pair_native,
+                          sc.rb.num_per_loc, True, plan[pick(i)], tile_plan=sc.tp, tile_order=to)
 
         def dgrad(i):
             sc = scenes[pick(i)]
-            ops.igemm_dgrad(sc.dout, w, sc.rb.pair_fwd, sc.rb.mask_fwd, sc.rb.argsort_fwd, sc.n, True,
-                            plan=sc.tp)
+            pair, mask, order, to = ops.tables_of(sc.rb, "fwd", C)
+            ops.igemm_dgrad(sc.dout, w, pair, mask, order, sc.n, True, plan=sc.tp, tile_order=to)
 
         def wgrad(i):
             sc = scenes[pick(i)]
@@ -570,6 +571,9 @@ def run_layer(args, D: Dist):
     t_cold = groups_for(lambda i: i % S)
     t_warm = groups_for(lambda i: 0) if S > 1 else t_cold
     t_eager = event_time_ms(lambda i: compute(scenes[i % S]), iters=20, warm=5)
+    t_sort_dev = None
+    if scenes[0].rb.argsort_fwd is not None:      # mask sort + tile-order table copies: once per rulebook
+        t_sort_dev = round(event_time_ms(lambda i: ops.sort_rulebook(scenes[0].rb), iters=10, warm=2), 4)
     t_plan_dev = None
     if tiled:            # building a plan (spatial sort + halo lists): once per rulebook, like the rulebook itself
 
@@ -617,7 +621,8 @@ def run_layer(args, D: Dist):
                                f"{S} distinct scenes per GPU visited round-robin, rulebook reused via indice_key",
                    "voxels_per_gpu": int(n_mean), "pairs_per_voxel": round(P / n_mean, 4), "launch": launch,
                    "steps_per_replay": U if launch == "hipgraph" else None, "scenes_rotated": S,
-                   "mask_sort": bool(args.sort), "tile_plan": tiled, "parallelism": f"dp{world}",
+                   "mask_sort": scenes[0].rb.argsort_fwd is not None, "tile_plan": tiled,
+                   "parallelism": f"dp{world}",
                    "ranks_seen": ranks_seen,
                    "dist_backend": D.backend if world > 1 else None},
         "roofline": r_cold, "roofline_cold": r_cold, "roofline_warm": r_warm,
@@ -631,6 +636,7 @@ def run_layer(args, D: Dist):
         "rulebook_ms": round(statistics.median(rule_ms), 4),
         "rulebook_device_ms": round(t_rule_dev, 4),
         "tile_plan_device_ms": t_plan_dev,
+        "mask_sort_device_ms": t_sort_dev,
     }
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline_layer(scenes[0].idx_np, scenes[0].shape, C, K, seed=1)

@@ -146,7 +146,7 @@ int spx_table_to_native(const int32_t *table, int subm, int kv, int n, int32_t *
  *   bias [K] (dtype) or NULL; act: spx_act (inference epilogue, conv.py:463-490)
  * Every row of `out` is written (no pre-zeroing needed, cf. convops.py:2128-2134). */
 int spx_igemm_fwd(const void *feat, const void *weight, void *out, const int32_t *pair,
-                  const uint32_t *mask, const int32_t *argsort, int n_in, int n_out,
+                  const uint32_t *mask, const int32_t *argsort, int tile_order, int n_in, int n_out,
                   int C, int K, int kv, int dtype, int identity_k, const void *bias,
                   int act, float act_alpha, spx_stream_t stream);
 
@@ -174,6 +174,14 @@ int spx_igemm_fwd_int8(const void *feat, const void *weight, void *out, const in
  * A plan belongs to one pair table [kv, n_dst] (kv <= 32) and the coordinates of its destination
  * rows: pair_fwd + out_indices for the forward pass (and, for SubM, for dgrad as well),
  * pair_bwd + the input indices for the dgrad of a regular convolution. */
+/* Copies of a pair table [kv, n] and its mask words in TILE ORDER (row t <- row order[t], order =
+ * spx_mask_argsort's output): with tile_order = 1, spx_igemm_fwd / _dgrad / _bwd read `pair` and
+ * `mask` by tile position and use `argsort` only for the operand / output rows, so a mask-sorted
+ * tile reads its table columns as contiguous runs.  (The reference reads its tables through
+ * mask_argsort, ops.py:1503-1530.) */
+int spx_permute_tables(const int32_t *pair, const uint32_t *mask, const int32_t *order, int kv, int n,
+                       int words, int32_t *pair_t, uint32_t *mask_t, spx_stream_t stream);
+
 size_t spx_tile_plan_bytes(int n_dst, int kv);
 size_t spx_tile_plan_ws_bytes(int n_dst);
 int spx_tile_plan_build(const int32_t *dst_indices, int n_dst, int ndim, int batch_size,
@@ -200,7 +208,7 @@ size_t spx_igemm_dgrad_ws_bytes(int C, int K, int kv, int dtype);
  * For SubM pass subm=1 with the FORWARD pair/mask (mirror symmetry
  * pair_bwd[k] == pair_fwd[kv-1-k]; the reference's reverse_mask, convops.py:2327-2345). */
 int spx_igemm_dgrad(const void *dout, const void *weight, void *din, const int32_t *pair,
-                    const uint32_t *mask, const int32_t *argsort, int n_out, int n_in,
+                    const uint32_t *mask, const int32_t *argsort, int tile_order, int n_out, int n_in,
                     int C, int K, int kv, int dtype, int subm, void *ws, size_t ws_bytes,
                     spx_stream_t stream);
 
@@ -234,7 +242,7 @@ int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t 
  * SubM), pair_native / num_per_loc / plan as for spx_igemm_wgrad, ws as spx_igemm_wgrad_ws_bytes.
  * Shapes the fused kernel does not cover fall back to the two separate calls internally. */
 int spx_igemm_bwd(const void *feat, const void *dout, const void *weight, void *din, void *dw,
-                  const int32_t *pair, const uint32_t *mask, const int32_t *argsort,
+                  const int32_t *pair, const uint32_t *mask, const int32_t *argsort, int tile_order,
                   const int32_t *pair_native, const int32_t *num_per_loc, const int32_t *plan,
                   int n_in, int n_out, int C, int K, int kv, int dtype, int subm, void *ws,
                   size_t ws_bytes, spx_stream_t stream);

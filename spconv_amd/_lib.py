@@ -51,18 +51,20 @@ SIGNATURES = {
     "spx_table_to_native_ws_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "spx_table_to_native": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp,
                                            ctypes.c_size_t, vp]),
-    "spx_igemm_fwd": (ctypes.c_int, [vp] * 6 + [ctypes.c_int] * 7 + [vp, ctypes.c_int,
+    "spx_igemm_fwd": (ctypes.c_int, [vp] * 6 + [ctypes.c_int] * 8 + [vp, ctypes.c_int,
                                                                      ctypes.c_float, vp]),
     "spx_igemm_fwd_int8": (ctypes.c_int, [vp] * 6 + [ctypes.c_int] * 6 + [vp, vp, vp, ctypes.c_float,
                                                                        ctypes.c_int, ctypes.c_int,
                                                                        ctypes.c_float, vp]),
     "spx_igemm_dgrad_ws_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),
-    "spx_igemm_dgrad": (ctypes.c_int, [vp] * 6 + [ctypes.c_int] * 7 + [vp, ctypes.c_size_t, vp]),
+    "spx_igemm_dgrad": (ctypes.c_int, [vp] * 6 + [ctypes.c_int] * 8 + [vp, ctypes.c_size_t, vp]),
     "spx_igemm_wgrad_ws_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),
     "spx_wgrad_plan_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "spx_wgrad_plan": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "spx_igemm_wgrad": (ctypes.c_int, [vp] * 6 + [ctypes.c_int] * 7 + [vp, ctypes.c_size_t, vp]),
-    "spx_igemm_bwd": (ctypes.c_int, [vp] * 11 + [ctypes.c_int] * 7 + [vp, ctypes.c_size_t, vp]),
+    "spx_igemm_bwd": (ctypes.c_int, [vp] * 8 + [ctypes.c_int] + [vp] * 3 + [ctypes.c_int] * 7
+                      + [vp, ctypes.c_size_t, vp]),
+    "spx_permute_tables": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]),
     "spx_maxpool_fwd": (ctypes.c_int, [vp] * 4 + [ctypes.c_int] * 5 + [vp]),
     "spx_maxpool_bwd": (ctypes.c_int, [vp] * 6 + [ctypes.c_int] * 4 + [vp]),
     "spx_avgpool_fwd": (ctypes.c_int, [vp] * 5 + [ctypes.c_int] * 4 + [vp]),

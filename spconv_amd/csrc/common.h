@@ -124,6 +124,10 @@ inline size_t plan_ints(int n_dst, int kv) {
   return kPlanHeader + nt * kTileRows + nt * 4 + nt * kHaloMax + (nt * kv * kTileRows + 1) / 2 + 64;
 }
 
+// stable LSD radix argsort shared by the tile plans and spx_mask_argsort (tileplan.hip)
+size_t radix_argsort_ws_bytes(int n);
+int radix_argsort(const uint32_t *keys, int n, int nbits, int32_t *order_out, void *ws, hipStream_t s);
+
 inline PlanView plan_view(const int32_t *plan, int n_dst, int kv) {
   const size_t nt = static_cast<size_t>((n_dst + kTileRows - 1) / kTileRows);
   PlanView v;

@@ -49,6 +49,8 @@ struct GemmParams {
   int n_src, n_dst, CIN, COUT, kv;
   int identity_k;         // offset whose pair is the identity, or -1
   int b_reverse;          // use weight slice kv-1-k for offset k (SubM dgrad)
+  int tile_order;         // pair / mask are stored in tile order (row t of the tables belongs to
+                          // destination row argsort[t]): rows sorted by mask keep coalesced table reads
   int act;
   float act_alpha;
   // int8 inference epilogue (igemm_v4_kernel<.., DT = 2, ..>): bias is fp32 here
@@ -56,7 +58,17 @@ struct GemmParams {
   const void *add;        // int8 [n_dst, COUT] residual input, or null
   float add_scale;
   int out_dtype;          // SPX_I8 / SPX_F16 / SPX_BF16 / SPX_F32
+  int dbg;                // ablation builds only (-DSPX_ABLATE, tools/dense_probe.py)
 };
+
+// Ablation switch of the measurement build (csrc/build_ablate.sh): which part of a step is left out
+// (results are wrong): 1 = weights staged once, 2 = also no per-step barrier, 3 = no MFMAs, 4 = no
+// gathered-row loads, 5 = no pair-word loads.  Compiles to nothing in the product build.
+#ifdef SPX_ABLATE
+#define SPX_ABL(p, v) ((p).dbg == (v))
+#else
+#define SPX_ABL(p, v) false
+#endif
 
 // ---- 16-bit <-> float helpers -------------------------------------------
 template <bool BF16> __device__ __forceinline__ float to_float(uint16_t v);
@@ -553,6 +565,7 @@ struct GemmRest {
   const void *add;
   float add_scale;
   int out_dtype;
+  int dbg;
 };
 
 template <int COUT, int MB, int DT, bool BT, int NKS = 2>
@@ -593,7 +606,8 @@ __device__ __forceinline__ void unpack_gemm_args(GemmParams &p, const void *argA
   p.CIN = CIN;
   p.kv = kv;
   p.identity_k = identity_k;
-  p.b_reverse = b_reverse;
+  p.b_reverse = b_reverse & 1;          // the launch packs (reverse, tile order) into one preloaded SGPR
+  p.tile_order = (b_reverse >> 1) & 1;
   p.out = rest.out;
   p.bias = rest.bias;
   p.strideK = rest.strideK;
@@ -606,6 +620,7 @@ __device__ __forceinline__ void unpack_gemm_args(GemmParams &p, const void *argA
   p.add = rest.add;
   p.add_scale = rest.add_scale;
   p.out_dtype = rest.out_dtype;
+  p.dbg = rest.dbg;
 }
 
 template <int COUT, int MB, int DT, bool BT, int NKS>
@@ -659,7 +674,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
     int g = -1;
     if (t < p.n_dst) g = p.argsort ? p.argsort[t] : t;
     grow[mb] = g;
-    goff[mb] = g < 0 ? kOob : static_cast<uint32_t>(g) * 4u;
+    goff[mb] = g < 0 ? kOob : static_cast<uint32_t>(p.tile_order ? t : g) * 4u;
   }
 
   // per-thread constant offsets.  *_tail is the out-of-range bit to OR in for the last
@@ -714,7 +729,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
     identr[S] = it.k == p.identity_k ? 0xffffffffu : 0u;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
-      idxr[S][mb] = static_cast<int>(__builtin_amdgcn_raw_buffer_load_b32(rP, goff[mb], 0, 0));
+      idxr[S][mb] = SPX_ABL(p, 5) ? grow[mb] : static_cast<int>(__builtin_amdgcn_raw_buffer_load_b32(rP, goff[mb], 0, 0));
   };
   auto load_a = [&](const StepIt &it, auto SET) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
@@ -730,7 +745,8 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
       for (int ks = 0; ks < NKS; ++ks) {
         const uint32_t lo = aoff[ks] | (aoff_tail[ks] & tail);
         const uint32_t vo = min(rbase + lo, kOob) | (lo & kOob);
-        areg[S][mb][ks] = __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0);
+        if (SPX_ABL(p, 4)) areg[S][mb][ks] = u32x4{vo, vo, vo, vo};
+        else areg[S][mb][ks] = __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0);
       }
     }
   };
@@ -863,8 +879,10 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
             const uint4 fa = *reinterpret_cast<const uint4 *>(
                 cur + swzB((lrow >> 2) * CPL + nb * 4 + (lrow & 3), ks * 4 + lgrp));
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-              acc[nb][mb] = mfma_step<DT>(fa, __builtin_bit_cast(uint4, areg[S][mb][ks]), acc[nb][mb]);
+            for (int mb = 0; mb < MB; ++mb) {
+              if (SPX_ABL(p, 3)) acc[nb][mb][0] += static_cast<decltype(acc[nb][mb][0] + 0)>(fa.x ^ areg[S][mb][ks][0]);
+              else acc[nb][mb] = mfma_step<DT>(fa, __builtin_bit_cast(uint4, areg[S][mb][ks]), acc[nb][mb]);
+            }
           }
         }
       }
@@ -903,11 +921,11 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   // Loads are unconditional (steps past the end read zero-sized resources).
   auto step = [&](auto SET) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
-    __syncthreads();   // stage 1-S is free (read at step t-1), stage S is complete
-    store_b(smem + (1 - S) * B_BYTES);
+    if (!SPX_ABL(p, 2)) __syncthreads();   // stage 1-S is free (read at step t-1), stage S is complete
+    if (!SPX_ABL(p, 1) && !SPX_ABL(p, 2)) store_b(smem + (1 - S) * B_BYTES);
     compute(it0, SET);
     const StepIt it3 = step_next(it2, nchunk);
-    load_b(it2);
+    if (!SPX_ABL(p, 1) && !SPX_ABL(p, 2)) load_b(it2);
     __builtin_amdgcn_sched_barrier(0);   // weights first: they are the first thing step t+1 waits for
     load_idx(it3, std::integral_constant<int, 1 - S>{});
     __builtin_amdgcn_sched_barrier(0);
@@ -1062,7 +1080,7 @@ int launch_v4(const GemmParams &p, hipStream_t s) {
 #define SPX_LAUNCH_V4(BTV, NKSV)                                                                     \
   hipLaunchKernelGGL((igemm_v4_kernel<COUT, MB, DT, BTV, NKSV>), dim3(ntiles), dim3(kThreads),          \
                      (v4_smem_bytes<COUT, MB>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,      \
-                     p.n_src, p.CIN, p.kv, p.identity_k, p.b_reverse, r)
+                     p.n_src, p.CIN, p.kv, p.identity_k, (p.b_reverse | (p.tile_order << 1)), r)
   if (DT == 2 || p.strideD == 1) {
     if (half) SPX_LAUNCH_V4(false, 1);
     else SPX_LAUNCH_V4(false, 2);
@@ -1103,7 +1121,9 @@ __global__ void __launch_bounds__(kThreads, 2)
 igemm_halo_kernel(const void *argA, const void *argB, const int32_t *plan_order,
                   const int32_t *plan_info, const int32_t *plan_halo, const uint16_t *plan_local,
                   const int32_t *arg_pair, int n_dst, int n_src, int CIN, int kv, int b_reverse,
-                  int ntiles, int identity_k, GemmRest rest) {
+                  int ntiles, int identity_k, GemmRest rest, int dbg) {
+  // dbg != 0 (SPX_HALO_DBG, measurements only, results are wrong): 1 = weights staged once, 2 = also no
+  // barrier per step, 3 = no MFMAs, 4 = no gathered-operand reads
   constexpr bool BF16 = DT == 1;
   constexpr int ES = 2, MB = 2, NB = COUT / 16, CPL = NB * 4;
   constexpr int B_BYTES = COUT * kRowBytes;
@@ -1262,10 +1282,10 @@ igemm_halo_kernel(const void *argA, const void *argB, const int32_t *plan_order,
   // stage `stage` of the ring holds this step's weights, breg the next step's (loaded a step ago)
   int stage = 0;
   while (k0 >= 0) {
-    store_b(smem + (1 - stage) * B_BYTES);        // (that stage was last read before the previous barrier)
+    if (dbg != 1 && dbg != 2) store_b(smem + (1 - stage) * B_BYTES);   // (last read before the previous barrier)
     const int k2 = rest_bits ? __builtin_ctz(rest_bits) : -1;
     rest_bits = rest_bits ? (rest_bits & (rest_bits - 1)) : 0u;
-    load_b(k2);
+    if (dbg != 1 && dbg != 2) load_b(k2);
     // gathered operand of this step from the halo (zero row for a missing pair)
     u32x4 areg[MB][NKS];
 #pragma unroll
@@ -1273,7 +1293,8 @@ igemm_halo_kernel(const void *argA, const void *argB, const int32_t *plan_order,
       const uint32_t s = slots[mb] < static_cast<uint32_t>(kHaloMax) ? slots[mb] : static_cast<uint32_t>(kHaloMax);
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks)
-        areg[mb][ks] = *reinterpret_cast<const u32x4 *>(ldsH + s * kRowBytes + (((ks * 4 + lgrp) ^ (s & 7)) << 4));
+        areg[mb][ks] = dbg == 4 ? u32x4{s, s, s, s}
+                                : *reinterpret_cast<const u32x4 *>(ldsH + s * kRowBytes + (((ks * 4 + lgrp) ^ (s & 7)) << 4));
     }
     if (spilled) {       // rare: pairs whose source row did not fit the halo come through the pair table
 #pragma unroll
@@ -1300,12 +1321,14 @@ igemm_halo_kernel(const void *argA, const void *argB, const int32_t *plan_order,
         const uint4 fa = *reinterpret_cast<const uint4 *>(
             cur + swzB((lrow >> 2) * CPL + nb * 4 + (lrow & 3), ks * 4 + lgrp));
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-          acc[nb][mb] = mfma16<BF16>(fa, __builtin_bit_cast(uint4, areg[mb][ks]), acc[nb][mb]);
+        for (int mb = 0; mb < MB; ++mb) {
+          if (dbg == 3) acc[nb][mb][0] += __builtin_bit_cast(float, fa.x ^ areg[mb][ks][0]);
+          else acc[nb][mb] = mfma16<BF16>(fa, __builtin_bit_cast(uint4, areg[mb][ks]), acc[nb][mb]);
+        }
       }
     }
-    __syncthreads();     // the other stage is complete; this stage's reads are done
-    stage ^= 1;
+    if (dbg != 2) __syncthreads();     // the other stage is complete; this stage's reads are done
+    if (dbg != 1 && dbg != 2) stage ^= 1;
     k0 = k1;
     k1 = k2;
 #pragma unroll
@@ -1356,7 +1379,8 @@ int launch_halo(const GemmParams &p, const PlanView &pv, hipStream_t s) {
   hipLaunchKernelGGL((igemm_halo_kernel<COUT, DT, BTV, NKSV>), dim3(pv.ntiles), dim3(kThreads),           \
                      (halo_smem_bytes<COUT>()), s, p.A, p.B, pv.order, pv.tile_info, pv.halo_rows,        \
                      pv.plocal, p.pair, p.n_dst, p.n_src, p.CIN, p.kv, p.b_reverse, pv.ntiles,            \
-                     p.identity_k, r)
+                     p.identity_k, r, dbg)
+  static const int dbg = env_int("SPX_HALO_DBG", 0);
   if (p.strideD == 1) {
     if (half) { SPX_LAUNCH_HALO(false, 1); }
     else { SPX_LAUNCH_HALO(false, 2); }
@@ -2236,6 +2260,10 @@ int dispatch_gather_gemm(const GemmParams &p, hipStream_t s) {
       case 256: return launch_v4<256, 1, BF16 ? 1 : 0>(p, s);
     }
   }
+  if (p.tile_order) {
+    set_error("tables in tile order need the direct-fragment kernel (tensor beyond 32-bit offsets?)");
+    return -1;
+  }
   switch (p.COUT) {
     case 16: return launch_gather_gemm<16, BF16>(p, s);
     case 32: return launch_gather_gemm<32, BF16>(p, s);
@@ -2266,6 +2294,10 @@ int run_gather_gemm(const GemmParams &p, int dtype, hipStream_t s) {
     return dispatch_gather_gemm_f32(p, s);
   if (dtype != SPX_F32 && mfma_ok(dtype, p.CIN, p.COUT, p.kv, p.mask))
     return dtype == SPX_BF16 ? dispatch_gather_gemm<true>(p, s) : dispatch_gather_gemm<false>(p, s);
+  if (p.tile_order) {
+    set_error("tables in tile order are supported by the MFMA kernels only (channel counts / kernel volume)");
+    return -1;
+  }
   const long long total = static_cast<long long>(p.n_dst) * p.COUT;
   const dim3 grid(static_cast<unsigned>((total + kThreads - 1) / kThreads));
   if (dtype == SPX_F32)
@@ -2383,6 +2415,8 @@ GemmRest rest_of(const GemmParams &p) {
   r.add = p.add;
   r.add_scale = p.add_scale;
   r.out_dtype = p.out_dtype;
+  static const int dbg = env_int("SPX_V4_DBG", 0);
+  r.dbg = dbg;
   return r;
 }
 
@@ -2400,12 +2434,12 @@ int launch_bwd(const GemmParams &p, const Wgrad2Params &q, int n_wgrad_blocks, h
   if (p.CIN * 2 <= 64)     // dgrad's reduction rows (dout channels) fit half a piece
     hipLaunchKernelGGL((igemm_bwd_kernel<COUT, MB, DT, 1>), dim3(n_dgrad + n_wgrad_blocks), dim3(kThreads),
                        (bwd_smem_bytes<COUT, MB>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,
-                       p.n_src, p.CIN, p.kv, p.identity_k, p.b_reverse, rest_of(p),
+                       p.n_src, p.CIN, p.kv, p.identity_k, (p.b_reverse | (p.tile_order << 1)), rest_of(p),
                        wgrad_first ? ~n_wgrad_blocks : n_dgrad, q);
   else
     hipLaunchKernelGGL((igemm_bwd_kernel<COUT, MB, DT, 2>), dim3(n_dgrad + n_wgrad_blocks), dim3(kThreads),
                        (bwd_smem_bytes<COUT, MB>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,
-                       p.n_src, p.CIN, p.kv, p.identity_k, p.b_reverse, rest_of(p),
+                       p.n_src, p.CIN, p.kv, p.identity_k, (p.b_reverse | (p.tile_order << 1)), rest_of(p),
                        wgrad_first ? ~n_wgrad_blocks : n_dgrad, q);
   SPX_LAUNCH_CHECK();
   return 0;
@@ -2430,7 +2464,7 @@ using namespace spx;
 extern "C" {
 
 int spx_igemm_fwd(const void *feat, const void *weight, void *out, const int32_t *pair,
-                  const uint32_t *mask, const int32_t *argsort, int n_in, int n_out, int C,
+                  const uint32_t *mask, const int32_t *argsort, int tile_order, int n_in, int n_out, int C,
                   int K, int kv, int dtype, int identity_k, const void *bias, int act,
                   float act_alpha, spx_stream_t stream) {
   SPX_CHECK(C > 0 && K > 0 && kv > 0 && n_in >= 0 && n_out >= 0, "bad sizes");
@@ -2455,6 +2489,7 @@ int spx_igemm_fwd(const void *feat, const void *weight, void *out, const int32_t
   p.kv = kv;
   p.identity_k = identity_k;
   p.b_reverse = 0;
+  p.tile_order = (tile_order && argsort) ? 1 : 0;
   p.act = act;
   p.act_alpha = act_alpha;
   return run_gather_gemm(p, dtype, static_cast<hipStream_t>(stream));
@@ -2556,14 +2591,15 @@ size_t spx_igemm_dgrad_ws_bytes(int C, int K, int kv, int dtype) {
 }
 
 int spx_igemm_dgrad(const void *dout, const void *weight, void *din, const int32_t *pair,
-                    const uint32_t *mask, const int32_t *argsort, int n_out, int n_in, int C,
+                    const uint32_t *mask, const int32_t *argsort, int tile_order, int n_out, int n_in, int C,
                     int K, int kv, int dtype, int subm, void *ws, size_t ws_bytes,
                     spx_stream_t stream) {
   (void)ws; (void)ws_bytes;
   if (n_in == 0) return 0;                                    // empty input: no gradient rows
   SPX_CHECK((dout || n_out == 0) && weight && din, "null tensor pointer");
   SPX_CHECK(pair || kv == 1, "pair table required");
-  const GemmParams p = dgrad_params(dout, weight, din, pair, mask, argsort, n_out, n_in, C, K, kv, subm);
+  GemmParams p = dgrad_params(dout, weight, din, pair, mask, argsort, n_out, n_in, C, K, kv, subm);
+  p.tile_order = (tile_order && argsort) ? 1 : 0;
   return run_gather_gemm(p, dtype, static_cast<hipStream_t>(stream));
 }
 
@@ -2732,7 +2768,7 @@ int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t 
 }
 
 int spx_igemm_bwd(const void *feat, const void *dout, const void *weight, void *din, void *dw,
-                  const int32_t *pair, const uint32_t *mask, const int32_t *argsort,
+                  const int32_t *pair, const uint32_t *mask, const int32_t *argsort, int tile_order,
                   const int32_t *pair_native, const int32_t *num_per_loc, const int32_t *plan,
                   int n_in, int n_out, int C, int K, int kv, int dtype, int subm, void *ws,
                   size_t ws_bytes, spx_stream_t stream) {
@@ -2751,7 +2787,8 @@ int spx_igemm_bwd(const void *feat, const void *dout, const void *weight, void *
   SPX_CHECK(pair || kv == 1, "pair table required");
   SPX_CHECK(ws_bytes >= spx_igemm_wgrad_ws_bytes(n_in, C, K, kv), "workspace too small");
   static const int fuse = env_int("SPX_BWD_FUSE", 1);             // tuning knob (A/B runs)
-  const GemmParams p = dgrad_params(dout, weight, din, pair, mask, argsort, n_out, n_in, C, K, kv, subm);
+  GemmParams p = dgrad_params(dout, weight, din, pair, mask, argsort, n_out, n_in, C, K, kv, subm);
+  p.tile_order = (tile_order && argsort) ? 1 : 0;
   const bool small_offsets = static_cast<unsigned long long>(n_out) * K * 2ull < 0x7fff0000ull &&
                              static_cast<unsigned long long>(n_in) * C * 2ull < 0x7fff0000ull &&
                              static_cast<unsigned long long>(n_in) * 4ull < 0x7fff0000ull;
@@ -2759,7 +2796,7 @@ int spx_igemm_bwd(const void *feat, const void *dout, const void *weight, void *
                        mfma_ok(dtype, p.CIN, p.COUT, kv, mask) && p.COUT <= 128 && v4_ok(p) &&
                        small_offsets && kv <= 128 && n_in > 0 && n_out > 0;
   if (!fusable) {
-    if (spx_igemm_dgrad(dout, weight, din, pair, mask, argsort, n_out, n_in, C, K, kv, dtype, subm,
+    if (spx_igemm_dgrad(dout, weight, din, pair, mask, argsort, tile_order, n_out, n_in, C, K, kv, dtype, subm,
                         nullptr, 0, stream))
       return -2;
     return spx_igemm_wgrad(feat, dout, dw, pair_native, num_per_loc, plan, n_in, n_out, C, K, kv, dtype,
@@ -2819,6 +2856,19 @@ int spx_bias_act_inplace(void *out, const void *bias, int n, int K, int dtype, i
   SPX_LAUNCH_CHECK();
   return 0;
 }
+
+#ifdef SPX_ABLATE
+// measurement build only: resident workgroups per CU the runtime reports for the two gather-GEMMs
+int spx_debug_occupancy(int *halo_wgs, int *v4_wgs) {
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_halo_kernel<64, 0, false, 2>),
+                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(halo_smem_bytes<64>()));
+  SPX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(halo_wgs, igemm_halo_kernel<64, 0, false, 2>, kThreads,
+                                                       halo_smem_bytes<64>()));
+  SPX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(v4_wgs, igemm_v4_kernel<64, 2, 0, false, 2>, kThreads,
+                                                       v4_smem_bytes<64, 2>()));
+  return 0;
+}
+#endif
 
 #ifdef SPX_TIMELINE
 // debug builds only: copies the timeline table (8192 workgroups x 8 stamps, uint64) to host memory

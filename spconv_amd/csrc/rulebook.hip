@@ -232,9 +232,12 @@ void table_fill(FillList &f, const Table &t);
 
 __global__ void __launch_bounds__(kBlock)
 subm_insert_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table t,
-                   int32_t *__restrict__ slot_of) {
+                   int32_t *__restrict__ slot_of, uint32_t *__restrict__ mask_zero = nullptr,
+                   int words = 0) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
+  if (mask_zero)      // the probe kernel ORs bits into the masks: clear them here (no fill launch)
+    for (int w = 0; w < words; ++w) mask_zero[static_cast<size_t>(i) * words + w] = 0u;
   int b, c[4];
   read_row(indices, i, g.ndim, b, c);
   // rows with a batch index outside [0, batch) ("deleted" points, docs/USAGE.md:150)
@@ -289,6 +292,70 @@ subm_probe3_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table t,
   if (v < 0) return;
   set(k, o, v);
   if (first) set(kv - 1 - k, v, o);
+}
+
+// Third form of the probe pass: as subm_probe3_kernel, but every thread probes an offset ABOVE the
+// centre (k' = kv-1-k), i.e. in the CPU loop's own orientation -- row o is the INPUT row i of list
+// L = kv-1-k' and the hit is the output row (indices.py:1685-1696).  The direct entry
+// pair_fwd[k'][o] then is the thread's own (coalesced, written whether hit or miss: that half of
+// the table needs no -1 pre-fill), only the mirror entry pair_fwd[L][found] = o is scattered, and the
+// hits of a block ARE the entries of list L that fall into the block's 256-voxel group: the block
+// leaves their count for subm_lists_kernel (no count / scan launches).  A row that is not the first
+// of its coordinate still owns its k' entries but writes no mirror entry (lookups return the first
+// row only), so the first-row test is needed on hits only.
+__global__ void __launch_bounds__(kBlock)
+subm_probe4_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table t,
+                   const int32_t *__restrict__ slot_of, int32_t *__restrict__ pair_fwd,
+                   int32_t *__restrict__ pair_bwd, uint32_t *__restrict__ mask, int words,
+                   int32_t *__restrict__ groupcount, int ngroups) {
+  __shared__ int lds_wave[kBlock / 64];
+  const int o = blockIdx.x * kBlock + threadIdx.x;
+  const int kv = g.kv, center = kv / 2;
+  const int list = blockIdx.y;                // 0 .. kv/2 - 1, or kv/2 = the identity offset
+  const int k = kv - 1 - list;                // probed offset (> centre), or the centre itself
+  auto set = [&](int kk, int row, int val) __attribute__((always_inline)) {
+    pair_fwd[static_cast<size_t>(kk) * n + row] = val;
+    if (pair_bwd) pair_bwd[static_cast<size_t>(kv - 1 - kk) * n + row] = val;
+  };
+  if (list == center) {
+    if (o < n) {
+      set(center, o, o);
+      atomicOr(&mask[static_cast<size_t>(o) * words + (center >> 5)], 1u << (center & 31));
+    }
+    return;
+  }
+  int v = -1;
+  int b = -1, c[4] = {0, 0, 0, 0};
+  if (o < n) {
+    read_row(indices, o, g.ndim, b, c);
+    if (b >= 0 && b < g.batch && in_range(c, g.in_dims)) {
+      int r[4], q[4];
+      decode_offset(k, g.ksize, r);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) q[d] = c[d] - g.padding[d] + r[d] * g.dilation[d];
+      if (in_range(q, g.in_dims)) v = table_find(t, layout_key(b, q, g.in_dims));
+    }
+    set(k, o, v);                             // own entry, hit or miss
+    if (v >= 0) {
+      atomicOr(&mask[static_cast<size_t>(o) * words + (k >> 5)], 1u << (k & 31));
+      const int self = slot_of[o];
+      if (self >= 0 && table_val(t, self) == o) {       // first row of its coordinate: mirror entry
+        set(list, v, o);
+        atomicOr(&mask[static_cast<size_t>(v) * words + (list >> 5)], 1u << (list & 31));
+      }
+    }
+  }
+  if (groupcount) {
+    const unsigned long long bal = __ballot(v >= 0);
+    if ((threadIdx.x & 63) == 0) lds_wave[threadIdx.x >> 6] = __popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int sum = 0;
+#pragma unroll
+      for (int w = 0; w < kBlock / 64; ++w) sum += lds_wave[w];
+      groupcount[static_cast<size_t>(list) * ngroups + blockIdx.x] = sum;
+    }
+  }
 }
 
 // ------------------------------------------------- block-level primitives
@@ -1347,6 +1414,8 @@ size_t spx_subm_rulebook_ws_bytes(int n, int kv) {
   b += 2 * align_up(static_cast<size_t>(kv) * nblk * sizeof(int32_t), 256);
   b += 256;  // scratch totals when num_per_loc is NULL
   b += align_up(static_cast<size_t>(n > 0 ? n : 1) * sizeof(int32_t), 256);   // hash slot of every row
+  // second generation: hit counts per (list, 256-voxel group)
+  b += align_up(static_cast<size_t>(kv / 2 + 1) * div_up(n > 0 ? n : 1, kBlock) * sizeof(int32_t), 256);
   return b;
 }
 
@@ -1388,15 +1457,40 @@ int spx_subm_rulebook(const int32_t *indices, int n, int ndim, int batch_size,
   int32_t *blockoff = cv.take<int32_t>(static_cast<size_t>(kv) * nblk);
   int32_t *scratch_totals = cv.take<int32_t>(64);
   int32_t *slot_of = cv.take<int32_t>(n);
-  const dim3 grid(div_up(n, kBlock));
-  static const int version = env_int("SPX_SUBM_V", 2);          // tuning knob (A/B runs)
   const int nblk256 = div_up(n, kBlock);
-  // second generation: 4 launches (table fill, insert, probe, lists), no table pre-fills.  Its
-  // 256-voxel hit counts live where the first generation keeps its 2048-entry counts
-  // (blockcount .. blockoff are contiguous: 2 * kv * nblk ints >= (kv / 2) * nblk256)
-  const bool gen2 = version >= 2 && kv <= 128 && nblk256 <= 16384 &&
-                    static_cast<size_t>(kv / 2) * nblk256 <= 2 * static_cast<size_t>(kv) * nblk;
+  int32_t *groupcount = cv.take<int32_t>(static_cast<size_t>(kv / 2 + 1) * nblk256);
+  const dim3 grid(div_up(n, kBlock));
+  static const int version = env_int("SPX_SUBM_V", 3);          // tuning knob (A/B runs)
+  // second generation: 4 launches (table fill, insert, probe, lists), no table pre-fills; beyond
+  // ~4 M voxels the lists kernel's in-block prefix over the group counts would dominate
+  // third form: fills (table, lower half of pair_fwd [+ pair_bwd's upper half]) -> insert (+ mask
+  // clear) -> probe4 (block-local list counts) -> lists: 4 launches, 11 MB of fills instead of 34
+  if (version >= 3 && kv > 1 && kv <= 128 && nblk256 <= 16384) {
+    FillList fills;
+    table_fill(fills, t);
+    {
+      const size_t half = sizeof(int32_t) * static_cast<size_t>(kv / 2) * n;      // rows k < centre
+      fills.add(pair_fwd, half, 0xFFFFFFFFu);
+      // pair_bwd[kv-1-kk] mirrors pair_fwd[kk]: its rows above the centre are the scattered ones
+      if (pair_bwd) fills.add(pair_bwd + static_cast<size_t>(kv / 2 + 1) * n, half, 0xFFFFFFFFu);
+    }
+    SPX_HIP(fills.launch(s));
+    hipLaunchKernelGGL(subm_insert_kernel, grid, dim3(kBlock), 0, s, indices, n, g, t, slot_of, mask, words);
+    const bool lists = pair_native || num_per_loc;
+    hipLaunchKernelGGL(subm_probe4_kernel, dim3(div_up(n, kBlock), kv / 2 + 1), dim3(kBlock), 0, s, indices, n,
+                       g, t, slot_of, pair_fwd, pair_bwd, mask, words, lists ? groupcount : nullptr, nblk256);
+    if (lists) {
+      SPX_CHECK(!pair_native || num_per_loc || kv / 2 <= 64, "num_per_loc required for kv > 128");
+      hipLaunchKernelGGL(subm_lists_kernel, dim3(nblk, kv / 2 + 1), dim3(kBlock), 0, s, pair_fwd, kv, n,
+                         nblk256, groupcount, pair_native, num_per_loc ? num_per_loc : scratch_totals,
+                         num_per_loc ? kv : 0);
+    }
+    SPX_LAUNCH_CHECK();
+    return 0;
+  }
+  const bool gen2 = version == 2 && kv <= 128 && nblk256 <= 16384;
   if (gen2) {
+    blockcount = groupcount;
     FillList fills;
     table_fill(fills, t);
     SPX_HIP(fills.launch(s));
@@ -1550,46 +1644,15 @@ int spx_conv_rulebook_fill(const int32_t *indices, int n_in, int ndim, int batch
   return 0;
 }
 
-size_t spx_mask_argsort_ws_bytes(int n) {
-  const int nblk = div_up(n > 0 ? n : 1, kItems);
-  size_t b = 0;
-  b += 2 * align_up(static_cast<size_t>(n > 0 ? n : 1) * sizeof(uint32_t), 256);  // key ping/pong
-  b += align_up(static_cast<size_t>(n > 0 ? n : 1) * sizeof(int32_t), 256);      // value pong
-  b += 2 * align_up(static_cast<size_t>(kRadix) * nblk * sizeof(int32_t), 256);
-  return b + 256;
-}
+size_t spx_mask_argsort_ws_bytes(int n) { return radix_argsort_ws_bytes(n) + 256; }
 
 int spx_mask_argsort(const uint32_t *mask, int n, int words, int32_t *argsort, void *ws,
                      size_t ws_bytes, spx_stream_t stream) {
-  hipStream_t s = static_cast<hipStream_t>(stream);
   SPX_CHECK(words == 1, "mask_argsort supports kernel volume <= 32 (words == 1), got %d", words);
   SPX_CHECK(ws_bytes >= spx_mask_argsort_ws_bytes(n), "workspace too small");
   if (n == 0) return 0;
-  const int nblk = div_up(n, kItems);
-  Carver cv(ws);
-  uint32_t *kA = cv.take<uint32_t>(n);
-  uint32_t *kB = cv.take<uint32_t>(n);
-  int32_t *vB = cv.take<int32_t>(n);
-  int32_t *hist = cv.take<int32_t>(static_cast<size_t>(kRadix) * nblk);
-  int32_t *hist_off = cv.take<int32_t>(static_cast<size_t>(kRadix) * nblk);
-  // 4 passes of 8 bits.  pass 0: mask -> (kA, argsort); 1: -> (kB, vB); 2: -> (kA, argsort);
-  // 3: -> (kB, vB) ... keep it to an even number of hops ending in `argsort`.
-  const uint32_t *kin = mask;
-  const int32_t *vin = nullptr;  // identity
-  uint32_t *kout[4] = {kB, kA, kB, kA};
-  int32_t *vout[4] = {vB, argsort, vB, argsort};
-  for (int pass = 0; pass < 4; ++pass) {
-    const int shift = pass * kRadixBits;
-    hipLaunchKernelGGL(radix_count_kernel, dim3(nblk), dim3(kBlock), 0, s, kin, n, shift, nblk, hist);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kBlock), 0, s, hist, hist_off, kRadix * nblk,
-                       static_cast<int32_t *>(nullptr));
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk), dim3(kBlock), 0, s, kin, vin, n, shift,
-                       nblk, hist_off, kout[pass], vout[pass]);
-    kin = kout[pass];
-    vin = vout[pass];
-  }
-  SPX_LAUNCH_CHECK();
-  return 0;
+  // stable argsort of the mask words (all.py:935-991 sorts the same keys with thrust)
+  return radix_argsort(mask, n, 32, argsort, ws, static_cast<hipStream_t>(stream));
 }
 
 int spx_native_to_table(const int32_t *pair_native, const int32_t *num_per_loc, int n_in,

@@ -271,7 +271,62 @@ int bits_of(unsigned v) {
   return b;
 }
 
+__global__ void __launch_bounds__(kBlock)
+permute_tables_kernel(const int32_t *__restrict__ pair, const uint32_t *__restrict__ mask,
+                      const int32_t *__restrict__ order, int kv, int n, int words,
+                      int32_t *__restrict__ pair_t, uint32_t *__restrict__ mask_t) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= n) return;
+  const int g = order[t];
+  const int k = blockIdx.y;
+  if (k < kv) {
+    pair_t[static_cast<size_t>(k) * n + t] = pair[static_cast<size_t>(k) * n + g];
+  } else {
+    for (int w = 0; w < words; ++w) mask_t[static_cast<size_t>(t) * words + w] = mask[static_cast<size_t>(g) * words + w];
+  }
+}
+
 }  // namespace
+
+size_t radix_argsort_ws_bytes(int n_in) {
+  const size_t n = n_in > 0 ? n_in : 1;
+  const size_t nblk = (n + kSortItems - 1) / kSortItems;
+  return 2 * align_up(n * 4, 256) + 2 * align_up(n * 4, 256) + 2 * align_up(kRadix * nblk * 4, 256) +
+         align_up(kRadix * 4, 256) + 256;
+}
+
+// Stable LSD radix argsort of n 32-bit keys on their low `nbits` bits: order_out[t] = index of the
+// t-th smallest key.  8-bit digits, three launches per pass (count, per-digit scan, scatter), all
+// of them wide (>= n / 512 workgroups).  `keys` is not modified.
+int radix_argsort(const uint32_t *keys, int n, int nbits, int32_t *order_out, void *ws, hipStream_t s) {
+  if (n <= 0) return 0;
+  const int nblk = div_up(n, kSortItems);
+  Carver cv(ws);
+  uint32_t *kA = cv.take<uint32_t>(n), *kB = cv.take<uint32_t>(n);
+  int32_t *vA = cv.take<int32_t>(n), *vB = cv.take<int32_t>(n);
+  (void)vB;
+  int32_t *hist = cv.take<int32_t>(static_cast<size_t>(kRadix) * nblk);
+  int32_t *hist_off = cv.take<int32_t>(static_cast<size_t>(kRadix) * nblk);
+  int32_t *totals = cv.take<int32_t>(kRadix);
+  const int passes = div_up(nbits > 0 ? nbits : 1, kRadixBits);
+  const uint32_t *kin = keys;
+  const int32_t *vin = nullptr;
+  for (int pass = 0; pass < passes; ++pass) {
+    const int shift = pass * kRadixBits;
+    // value buffers alternate so that the LAST pass writes order_out
+    int32_t *vout = ((passes - 1 - pass) & 1) ? vA : order_out;
+    uint32_t *kout = (pass & 1) ? kA : kB;
+    hipLaunchKernelGGL(plan_radix_count_kernel, dim3(nblk), dim3(kBlock), 0, s, kin, n, shift, nblk, hist);
+    hipLaunchKernelGGL(plan_radix_scan_kernel, dim3(kRadix), dim3(kBlock), 0, s, hist, hist_off, nblk, totals);
+    hipLaunchKernelGGL(plan_radix_scatter_kernel, dim3(nblk), dim3(kBlock), 0, s, kin, vin, n, shift, nblk,
+                       hist_off, totals, kout, vout);
+    kin = kout;
+    vin = vout;
+  }
+  SPX_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace spx
 
 using namespace spx;
@@ -282,9 +337,21 @@ size_t spx_tile_plan_bytes(int n_dst, int kv) { return plan_ints(n_dst > 0 ? n_d
 
 size_t spx_tile_plan_ws_bytes(int n_dst) {
   const size_t n = n_dst > 0 ? n_dst : 1;
-  const size_t nblk = (n + kSortItems - 1) / kSortItems;
-  return 2 * align_up(n * 4, 256) + 2 * align_up(n * 4, 256) + 2 * align_up(kRadix * nblk * 4, 256) +
-         align_up(kRadix * 4, 256) + 256;
+  return 2 * align_up(n * 4, 256) + align_up(radix_argsort_ws_bytes(n_dst), 256) + 256;
+}
+
+/* Copies of a pair table [kv, n] and its mask words [n, words] in TILE ORDER: row t of the copies
+ * belongs to destination row order[t] (order = spx_mask_argsort's output).  With them the
+ * gather-GEMM reads the tables of a sorted tile as contiguous 512-byte runs instead of 128
+ * scattered words (spx_igemm_* with tile_order = 1). */
+int spx_permute_tables(const int32_t *pair, const uint32_t *mask, const int32_t *order, int kv, int n,
+                       int words, int32_t *pair_t, uint32_t *mask_t, spx_stream_t stream) {
+  SPX_CHECK(pair && mask && order && pair_t && mask_t, "null pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(permute_tables_kernel, dim3(div_up(n, kBlock), kv + 1), dim3(kBlock), 0,
+                     static_cast<hipStream_t>(stream), pair, mask, order, kv, n, words, pair_t, mask_t);
+  SPX_LAUNCH_CHECK();
+  return 0;
 }
 
 int spx_tile_plan_build(const int32_t *dst_indices, int n_dst, int ndim, int batch_size,
@@ -296,13 +363,10 @@ int spx_tile_plan_build(const int32_t *dst_indices, int n_dst, int ndim, int bat
   SPX_CHECK(dst_indices && pair && plan && ws, "null pointer");
   SPX_CHECK(ws_bytes >= spx_tile_plan_ws_bytes(n_dst), "workspace too small");
   SPX_CHECK(n_dst > 0, "empty tensors need no plan");
-  const int nblk = div_up(n_dst, kSortItems);
   Carver cv(ws);
-  uint32_t *kA = cv.take<uint32_t>(n_dst), *kB = cv.take<uint32_t>(n_dst);
-  int32_t *vA = cv.take<int32_t>(n_dst), *vB = cv.take<int32_t>(n_dst);
-  int32_t *hist = cv.take<int32_t>(static_cast<size_t>(kRadix) * nblk);
-  int32_t *hist_off = cv.take<int32_t>(static_cast<size_t>(kRadix) * nblk);
-  int32_t *totals = cv.take<int32_t>(kRadix);
+  uint32_t *keys = cv.take<uint32_t>(n_dst);
+  int32_t *sorted = cv.take<int32_t>(n_dst);
+  void *sort_ws = cv.take<char>(radix_argsort_ws_bytes(n_dst));
   // key width: batch bits on top of an even number of Morton bits; coarsen the cells (>> sh) until
   // the key fits 24 bits = three 8-bit passes (cells of 2 x 2 are fine enough: measured on the
   // reference's LiDAR fixture, halo 1.45 x the tile rows at sh = 1 vs 1.43 at sh = 0)
@@ -314,22 +378,10 @@ int spx_tile_plan_build(const int32_t *dst_indices, int n_dst, int ndim, int bat
     mbits = 2 * cb;
     if (mbits + bbits <= 24 || cb == 0) break;
   }
-  const int passes = div_up(mbits + bbits > 0 ? mbits + bbits : 1, kRadixBits);
   hipLaunchKernelGGL(plan_keys_kernel, dim3(div_up(n_dst, kBlock)), dim3(kBlock), 0, s, dst_indices, n_dst,
-                     ndim, batch_size, sh, mbits, kA);
-  const uint32_t *kin = kA;
-  const int32_t *vin = nullptr;
-  uint32_t *kbuf[2] = {kB, kA};
-  int32_t *vbuf[2] = {vB, vA};
-  for (int pass = 0; pass < passes; ++pass) {
-    const int shift = pass * kRadixBits;
-    hipLaunchKernelGGL(plan_radix_count_kernel, dim3(nblk), dim3(kBlock), 0, s, kin, n_dst, shift, nblk, hist);
-    hipLaunchKernelGGL(plan_radix_scan_kernel, dim3(kRadix), dim3(kBlock), 0, s, hist, hist_off, nblk, totals);
-    hipLaunchKernelGGL(plan_radix_scatter_kernel, dim3(nblk), dim3(kBlock), 0, s, kin, vin, n_dst, shift, nblk,
-                       hist_off, totals, kbuf[pass & 1], vbuf[pass & 1]);
-    kin = kbuf[pass & 1];
-    vin = vbuf[pass & 1];
-  }
+                     ndim, batch_size, sh, mbits, keys);
+  if (radix_argsort(keys, n_dst, mbits + bbits, sorted, sort_ws, s)) return -2;
+  const int32_t *vin = sorted;
   const int ntiles = div_up(n_dst, kTileRows);
   const PlanView v = plan_view(plan, n_dst, kv);
   hipLaunchKernelGGL(plan_halo_kernel, dim3(ntiles), dim3(kBlock), 0, s, vin, n_dst, pair, kv,

@@ -357,14 +357,12 @@ class SparseConvolution(SparseModule):
                 output_add_scale=add_input.q_scale() if add_input is not None else 0.0)
         else:
             w = weight if weight.dtype == features.dtype else weight.to(features.dtype)
-            if self.inverse:
-                table, mask, argsort, ident = rb.pair_bwd, rb.mask_bwd, rb.argsort_bwd, -1
-            else:
-                table, mask, argsort = rb.pair_fwd, rb.mask_fwd, rb.argsort_fwd
-                ident = rb.kv // 2 if self.subm else -1
+            which = "bwd" if self.inverse else "fwd"
+            table, mask, argsort, tile_order = ops.tables_of(rb, which, w.shape[0])
+            ident = rb.kv // 2 if (self.subm and not self.inverse) else -1
             tp = ops.tile_plan(rb, "fwd") if (not self.inverse and argsort is None) else None
             out_features = ops.igemm_fwd(features, w, table, mask, argsort, num_out, ident,
-                                         bias_for_infer, act_type, act_alpha, plan=tp)
+                                         bias_for_infer, act_type, act_alpha, plan=tp, tile_order=tile_order)
         if bias_for_training is not None:
             out_features += bias_for_training
         if input.benchmark:

@@ -62,6 +62,10 @@ class Rulebook:
         self.out_shape = None
         self.batch_size = 1
         self.tile_plans = {}
+        # copies of the tables in mask-sorted tile order (ops.sort_rulebook): [pair, mask] per
+        # direction, None while unsorted; sort_decided: the automatic mode looked at this rulebook
+        self.sorted_tables = {}
+        self.sort_decided = False
 
     def _ensure_native(self) -> None:
         """Inference builds only the dense tables; the ConvAlgo.Native lists (consumed by wgrad

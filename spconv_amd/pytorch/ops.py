@@ -184,10 +184,65 @@ def build_rulebook(indices: torch.Tensor, batch_size: int, spatial_shape: List[i
                       n_out, kv, False)
     rb.in_indices, rb.in_shape, rb.out_shape, rb.batch_size = indices, list(spatial_shape), list(out_shape), batch_size
     if do_sort and words == 1:
-        rb.argsort_fwd = mask_argsort(rb.mask_fwd)
-        if not subm:
-            rb.argsort_bwd = mask_argsort(rb.mask_bwd)
+        sort_rulebook(rb)
     return rb, out_shape
+
+
+# SPCONV_AMD_SORT: "auto" (default) = SubM rulebooks of >= 32 k rows with dense neighbourhoods (real
+# point clouds) get their rows sorted by mask on first use -- what the reference does for every
+# rulebook (SPCONV_DO_SORT, on by default there): tiles of equal-mask rows skip the offsets none of
+# their rows has (LiDAR fixture: 14 steps per 128-row tile instead of 27); "0" = only when asked
+# (do_sort / SPCONV_DO_SORT=1).
+_SORT_MODE = os.environ.get("SPCONV_AMD_SORT", "auto")
+_SORT_MIN_ROWS = 32768
+
+
+def sort_rulebook(rb: Rulebook) -> None:
+    """argsort of the mask words + copies of the tables in that order (both directions of a
+    regular-conv rulebook).  The gather-GEMM then reads pair / mask by tile position."""
+    L = _lib.load()
+    rb.sort_decided = True
+    for which in (("fwd",) if rb.subm else ("fwd", "bwd")):
+        pair, mask = (rb.pair_fwd, rb.mask_fwd) if which == "fwd" else (rb.pair_bwd, rb.mask_bwd)
+        if pair is None or mask is None or mask.shape[1] != 1 or pair.shape[1] == 0:
+            continue
+        order = mask_argsort(mask)
+        pair_t, mask_t = torch.empty_like(pair), torch.empty_like(mask)
+        _lib.check(L.spx_permute_tables(pair.data_ptr(), mask.data_ptr(), order.data_ptr(), pair.shape[0],
+                                        pair.shape[1], mask.shape[1], pair_t.data_ptr(), mask_t.data_ptr(),
+                                        _stream(pair)))
+        if which == "fwd":
+            rb.argsort_fwd = order
+        else:
+            rb.argsort_bwd = order
+        rb.sorted_tables[which] = (pair_t, mask_t)
+
+
+def tables_of(rb: Rulebook, which: str, cout: int = 64):
+    """(pair, mask, argsort, tile_order) the gather-GEMM should read for `which` ("fwd": pair_fwd
+    over the output rows, "bwd": pair_bwd over the input rows).  Automatic mode decides here, once
+    per rulebook, whether the rows get sorted.  `cout`: output width of the GEMM (widths beyond the
+    MFMA instantiations take the generic kernel, which reads the tables by row)."""
+    if cout > _MFMA_COUT[-1] or rb.kv > 32:
+        return ((rb.pair_fwd, rb.mask_fwd, None, False) if which == "fwd"
+                else (rb.pair_bwd, rb.mask_bwd, None, False))
+    if not rb.sort_decided:
+        rb.sort_decided = True
+        if (_SORT_MODE == "auto" and rb.subm and rb.kv <= 32 and rb.kv > 1 and rb.n_out >= _SORT_MIN_ROWS
+                and rb.argsort_fwd is None):
+            # dense neighbourhoods?  share of rows with more than their own (centre) pair; one small
+            # reduction + read-back per rulebook (uniform-random scenes: ~3 %, LiDAR: ~100 %)
+            centre = 1 << (rb.kv // 2)
+            if float((rb.mask_fwd.view(-1) != centre).float().mean().item()) >= 0.5:
+                sort_rulebook(rb)
+    if which == "fwd":
+        pair, mask, order = rb.pair_fwd, rb.mask_fwd, rb.argsort_fwd
+    else:
+        pair, mask, order = rb.pair_bwd, rb.mask_bwd, rb.argsort_bwd
+    st = rb.sorted_tables.get(which)
+    if order is not None and st is not None:
+        return st[0], st[1], order, True
+    return pair, mask, order, False
 
 
 def mask_argsort(mask: torch.Tensor) -> torch.Tensor:
@@ -202,9 +257,12 @@ def mask_argsort(mask: torch.Tensor) -> torch.Tensor:
 
 
 # ---------------------------------------------------------------- tile plans
-# SPCONV_AMD_TILE_PLAN: "auto" (default) = SubM rulebooks of >= 32 k rows whose neighbourhoods are
-# dense (real point clouds) get a plan on first use; "1" = every eligible table; "0" = never.
-_TILE_MODE = os.environ.get("SPCONV_AMD_TILE_PLAN", "auto")
+# SPCONV_AMD_TILE_PLAN: "0" (default) = never; "auto" = SubM rulebooks of >= 32 k rows whose
+# neighbourhoods are dense get a plan on first use; "1" = every eligible table.  Off by default:
+# measured on the reference's LiDAR fixture the halo kernel needs 74 KB of LDS per workgroup (two
+# per CU) and runs 57 us where the plain kernel runs 41 us (three per CU) -- the gathered operand was
+# not what bounds the dense regime; mask-sorted rows (below) are.
+_TILE_MODE = os.environ.get("SPCONV_AMD_TILE_PLAN", "0")
 _TILE_MIN_ROWS = 32768
 
 
@@ -387,7 +445,7 @@ def igemm_fwd(features: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
               mask: Optional[torch.Tensor], argsort: Optional[torch.Tensor], n_out: int,
               identity_k: int = -1, bias: Optional[torch.Tensor] = None,
               act_type: int = Activation.None_, act_alpha: float = 0.0,
-              plan: Optional[torch.Tensor] = None) -> torch.Tensor:
+              plan: Optional[torch.Tensor] = None, tile_order: bool = False) -> torch.Tensor:
     """out[o] = act(bias + sum_k feat[pair[k][o]] @ W[:, k, :].T); filters KRSC.  `plan`: tile plan of
     `pair` (ops.tile_plan) -> the dense-neighbourhood kernel, same results."""
     _check_feat(features, filters)
@@ -395,7 +453,7 @@ def igemm_fwd(features: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
     K0, C0 = filters.shape[0], filters.shape[-1]
     assert features.shape[1] == C0, "channel size mismatch"
     kv = filters.numel() // (K0 * C0)
-    if plan is not None and _halo_ok(features.dtype, C0, K0, kv):
+    if plan is not None and not tile_order and _halo_ok(features.dtype, C0, K0, kv):
         features, filters = features.contiguous(), filters.contiguous()
         out = torch.empty((n_out, K0), dtype=features.dtype, device=features.device)
         if bias is not None:
@@ -425,7 +483,7 @@ def igemm_fwd(features: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
     if bias is not None:
         bias = bias.to(features.dtype).contiguous()
     _lib.check(L.spx_igemm_fwd(features.data_ptr(), filters.data_ptr(), out.data_ptr(),
-                               _ptr(pair), _ptr(mask), _ptr(argsort), features.shape[0], n_out,
+                               _ptr(pair), _ptr(mask), _ptr(argsort), int(tile_order), features.shape[0], n_out,
                                C, K, kv, _dtype_code(features), identity_k, _ptr(bias),
                                int(act_type), float(act_alpha), _stream(features)))
     return out if K == K0 else out[:, :K0].contiguous()
@@ -433,13 +491,13 @@ def igemm_fwd(features: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
 
 def igemm_dgrad(out_bp: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
                 mask: Optional[torch.Tensor], argsort: Optional[torch.Tensor], n_in: int,
-                subm: bool, plan: Optional[torch.Tensor] = None) -> torch.Tensor:
+                subm: bool, plan: Optional[torch.Tensor] = None, tile_order: bool = False) -> torch.Tensor:
     """din[i] = sum_k dout[pair[k][i]] @ W[:, k, :] (SubM: pass the forward table, subm=True)."""
     _check_feat(out_bp, filters)
     L = _lib.load()
     K0, C0 = filters.shape[0], filters.shape[-1]
     kv = filters.numel() // (K0 * C0)
-    if plan is not None and _halo_ok(out_bp.dtype, K0, C0, kv):
+    if plan is not None and not tile_order and _halo_ok(out_bp.dtype, K0, C0, kv):
         out_bp, filters = out_bp.contiguous(), filters.contiguous()
         din = torch.empty((n_in, C0), dtype=out_bp.dtype, device=out_bp.device)
         _lib.check(L.spx_igemm_dgrad_tiled(out_bp.data_ptr(), filters.data_ptr(), din.data_ptr(), pair.data_ptr(),
@@ -460,7 +518,7 @@ def igemm_dgrad(out_bp: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
     code = _dtype_code(out_bp)
     ws = _ws(L.spx_igemm_dgrad_ws_bytes(C, K, kv, code), out_bp.device)
     _lib.check(L.spx_igemm_dgrad(out_bp.data_ptr(), filters.data_ptr(), din.data_ptr(), _ptr(pair),
-                                 _ptr(mask), _ptr(argsort), out_bp.shape[0], n_in, C, K, kv, code,
+                                 _ptr(mask), _ptr(argsort), int(tile_order), out_bp.shape[0], n_in, C, K, kv, code,
                                  int(subm), ws.data_ptr(), ws.numel(), _stream(out_bp)))
     return din if C == C0 else din[:, :C0].contiguous()
 
@@ -502,7 +560,7 @@ def igemm_bwd(features: torch.Tensor, out_bp: torch.Tensor, filters: torch.Tenso
               table: torch.Tensor, mask: Optional[torch.Tensor], argsort: Optional[torch.Tensor],
               native: torch.Tensor, num_per_loc: torch.Tensor, subm: bool,
               plan: Optional[torch.Tensor] = None, need_din: bool = True,
-              tile_plan: Optional[torch.Tensor] = None):
+              tile_plan: Optional[torch.Tensor] = None, tile_order: bool = False):
     """(din, dW) of one layer from one launch (+ the wgrad second stage).  need_din=False (the
     input does not require grad: a network's first layer) computes dW only and returns None.
     `tile_plan` (dense neighbourhoods): dgrad takes the halo kernel, wgrad its own launch -- there
@@ -511,11 +569,12 @@ def igemm_bwd(features: torch.Tensor, out_bp: torch.Tensor, filters: torch.Tenso
     K0, C0 = filters.shape[0], filters.shape[-1]
     m = _lane_mult(out_bp.dtype)
     kvf = filters.numel() // (K0 * C0)
-    if tile_plan is not None and need_din and _halo_ok(out_bp.dtype, K0, C0, kvf):
+    if tile_plan is not None and not tile_order and need_din and _halo_ok(out_bp.dtype, K0, C0, kvf):
         din = igemm_dgrad(out_bp, filters, table, mask, argsort, features.shape[0], subm, tile_plan)
         return din, igemm_wgrad(features, out_bp, filters.shape, native, num_per_loc, subm, plan)
     if not need_din or K0 % m or C0 not in _MFMA_COUT:
-        din = igemm_dgrad(out_bp, filters, table, mask, argsort, features.shape[0], subm) if need_din else None
+        din = igemm_dgrad(out_bp, filters, table, mask, argsort, features.shape[0], subm,
+                          tile_order=tile_order) if need_din else None
         return din, igemm_wgrad(features, out_bp, filters.shape, native, num_per_loc, subm, plan)
     L = _lib.load()
     features = features.contiguous()
@@ -529,7 +588,7 @@ def igemm_bwd(features: torch.Tensor, out_bp: torch.Tensor, filters: torch.Tenso
     ws = _ws(L.spx_igemm_wgrad_ws_bytes(native.shape[2], C, K, kv), features.device)
     _lib.check(L.spx_igemm_bwd(features.data_ptr(), out_bp.data_ptr(), filters.data_ptr(),
                                din.data_ptr(), dw.data_ptr(), _ptr(table), _ptr(mask), _ptr(argsort),
-                               native.data_ptr(), num_per_loc.data_ptr(), _ptr(plan), n_in,
+                               int(tile_order), native.data_ptr(), num_per_loc.data_ptr(), _ptr(plan), n_in,
                                out_bp.shape[0], C, K, kv, _dtype_code(out_bp), int(subm),
                                ws.data_ptr(), ws.numel(), _stream(out_bp)))
     return din, dw
@@ -589,15 +648,16 @@ def indice_conv(features: torch.Tensor, filters: torch.Tensor, indice_pairs: tor
     _check_feat(features, filters)
     rb: Optional[Rulebook] = rulebook_of(indice_pairs)
     kv = indice_pairs.shape[1]
+    argsort, tile_order, tp = None, False, None
     if rb is not None and not inverse:
-        table, mask = rb.pair_fwd, rb.mask_fwd
+        table, mask, argsort, tile_order = tables_of(rb, "fwd", filters.shape[0])
+        tp = tile_plan(rb, "fwd") if argsort is None else None
     elif rb is not None and inverse and rb.pair_bwd is not None:
-        table, mask = rb.pair_bwd, rb.mask_bwd
+        table, mask, argsort, tile_order = tables_of(rb, "bwd", filters.shape[0])
     else:
         table, mask = _table_from_native(indice_pairs, indice_pair_num, num_activate_out, subm, inverse)
-    tp = tile_plan(rb, "fwd") if (rb is not None and not inverse and table is rb.pair_fwd) else None
-    return igemm_fwd(features, filters, table, mask, None, num_activate_out,
-                     kv // 2 if subm else -1, bias, act_type, act_alpha, plan=tp)
+    return igemm_fwd(features, filters, table, mask, argsort, num_activate_out,
+                     kv // 2 if subm else -1, bias, act_type, act_alpha, plan=tp, tile_order=tile_order)
 
 
 _SIDE_STREAMS = {}
@@ -635,37 +695,25 @@ def indice_conv_backward(features: torch.Tensor, filters: torch.Tensor, out_bp: 
     _check_feat(features, filters)
     rb: Optional[Rulebook] = rulebook_of(indice_pairs)
     n_in = features.shape[0]
-    if subm:
-        if rb is not None:
-            table, mask = rb.pair_fwd, rb.mask_fwd
-        else:
-            table, mask = _table_from_native(indice_pairs, indice_pair_num, n_in, True, False)
-        argsort = rb.argsort_fwd if rb is not None else None
+    argsort, tile_order, which = None, False, None
+    if rb is not None:
+        # dgrad gathers dout rows for every input row: SubM reads the forward table (mirrored
+        # weights), a regular conv the table indexed by its input rows, an inverse conv the forward one
+        which = "fwd" if (subm or inverse) else "bwd"
+        table, mask, argsort, tile_order = tables_of(rb, which, filters.shape[-1])
     else:
-        # dgrad gathers dout rows for every input row: the table indexed by the conv's input
-        if rb is not None and not inverse:
-            table, mask, argsort = rb.pair_bwd, rb.mask_bwd, rb.argsort_bwd
-        elif rb is not None and inverse:
-            table, mask, argsort = rb.pair_fwd, rb.mask_fwd, rb.argsort_fwd
-        else:
-            table, mask = _table_from_native(indice_pairs, indice_pair_num, n_in, False, not inverse)
-            argsort = None
+        table, mask = _table_from_native(indice_pairs, indice_pair_num, n_in, subm, (not subm) and (not inverse))
     native = indice_pairs
     if inverse:
         native = rb.native_swapped() if rb is not None else torch.stack(
             [indice_pairs[1], indice_pairs[0]]).contiguous()
     plan = _plan_of(rb)
-    tp = None
-    if rb is not None and need_din:
-        if table is rb.pair_fwd and (subm or inverse):
-            tp = tile_plan(rb, "fwd")
-        elif table is rb.pair_bwd and not subm:
-            tp = tile_plan(rb, "bwd")
+    tp = tile_plan(rb, which) if (rb is not None and need_din and argsort is None) else None
     if (native.shape[2] == n_in and not BWD_OVERLAP) or not need_din:
         return igemm_bwd(features, out_bp, filters, table, mask, argsort, native, indice_pair_num,
-                         subm, plan, need_din, tile_plan=tp)
+                         subm, plan, need_din, tile_plan=tp, tile_order=tile_order)
     return _backward_pair(
-        lambda: igemm_dgrad(out_bp, filters, table, mask, argsort, n_in, subm),
+        lambda: igemm_dgrad(out_bp, filters, table, mask, argsort, n_in, subm, tile_order=tile_order),
         lambda: igemm_wgrad(features, out_bp, filters.shape, native, indice_pair_num, subm, plan),
         features)
 
@@ -683,8 +731,10 @@ def implicit_gemm(features: torch.Tensor, filters: torch.Tensor, pair_fwd: torch
     the last two exist for signature parity (this wgrad does not consume tile masks)."""
     mask = pair_mask_fwd_splits[0] if pair_mask_fwd_splits else None
     rb: Optional[Rulebook] = rulebook_of(pair_fwd)
-    argsort = rb.argsort_fwd if rb is not None else None
+    argsort, tile_order = (rb.argsort_fwd if rb is not None else None), False
     kv = pair_fwd.shape[0]
+    if rb is not None and pair_fwd is rb.pair_fwd and features.dtype not in (torch.int8, torch.qint8):
+        pair_fwd, mask, argsort, tile_order = tables_of(rb, "fwd", filters.shape[0])
     if features.dtype in (torch.int8, torch.qint8):
         # int8 inference (ops.py:1540-1553,1631-1662): scale = per-channel multiplier, bias is
         # fp32 in output-quantised units, the residual input is scaled by add_scale / out_scale
@@ -701,7 +751,7 @@ def implicit_gemm(features: torch.Tensor, filters: torch.Tensor, pair_fwd: torch
         raise NotImplementedError("scale / output_add belong to the int8 path")
     tp = tile_plan(rb, "fwd") if (rb is not None and pair_fwd is rb.pair_fwd and argsort is None) else None
     out = igemm_fwd(features, filters, pair_fwd, mask, argsort, num_activate_out,
-                    kv // 2 if is_subm else -1, bias, act_type, act_alpha, plan=tp)
+                    kv // 2 if is_subm else -1, bias, act_type, act_alpha, plan=tp, tile_order=tile_order)
     return out, None, -1
 
 
@@ -722,23 +772,24 @@ def implicit_gemm_backward(features: torch.Tensor, filters: torch.Tensor, out_bp
     else:
         native, num = _native_from_table(pair_fwd if is_subm else pair_bwd, is_subm)
     plan = _plan_of(rb)
+    tile_order, tp = False, None
     if is_subm:
         table, mask = pair_fwd, pair_mask_fwd_splits[0]
         argsort = rb.argsort_fwd if rb is not None else None
+        if rb is not None and pair_fwd is rb.pair_fwd:
+            table, mask, argsort, tile_order = tables_of(rb, "fwd", filters.shape[-1])
+            tp = tile_plan(rb, "fwd") if (need_din and argsort is None) else None
     else:
         table, mask = pair_bwd, pair_mask_bwd_splits[0]
         argsort = rb.argsort_bwd if rb is not None else None
-    tp = None
-    if rb is not None and need_din and argsort is None:
-        if is_subm and table is rb.pair_fwd:
-            tp = tile_plan(rb, "fwd")
-        elif not is_subm and table is rb.pair_bwd:
-            tp = tile_plan(rb, "bwd")
+        if rb is not None and pair_bwd is rb.pair_bwd:
+            table, mask, argsort, tile_order = tables_of(rb, "bwd", filters.shape[-1])
+            tp = tile_plan(rb, "bwd") if (need_din and argsort is None) else None
     if (native.shape[2] == n_in and not BWD_OVERLAP) or not need_din:
         return igemm_bwd(features, out_bp, filters, table, mask, argsort, native, num, is_subm, plan,
-                         need_din, tile_plan=tp)
+                         need_din, tile_plan=tp, tile_order=tile_order)
     return _backward_pair(
-        lambda: igemm_dgrad(out_bp, filters, table, mask, argsort, n_in, is_subm),
+        lambda: igemm_dgrad(out_bp, filters, table, mask, argsort, n_in, is_subm, tile_order=tile_order),
         lambda: igemm_wgrad(features, out_bp, filters.shape, native, num, is_subm, plan),
         features)
 

@@ -134,6 +134,40 @@ def test_mask_sorted_order_gives_same_result(cuda, subm):
         torch.testing.assert_close(x, y, rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("subm", [True, False])
+def test_tile_order_tables_give_same_result(cuda, subm):
+    """Mask-sorted rows with the tables copied into tile order (ops.sort_rulebook / tables_of: what
+    the modules use for dense scenes) against the unsorted launch: bit-identical forward, dgrad,
+    fused backward."""
+    from spconv_amd.pytorch import ops
+    shape = [24, 40, 40]
+    stride = [1] * 3 if subm else [2] * 3
+    idx = dense_scene([36, 120, 120], 30000, 2, seed=9)
+    rb, _ = gpu_rulebook(idx, 2, shape, [3] * 3, stride, [1] * 3, [1] * 3, subm)
+    torch.manual_seed(0)
+    C, K = 32, 64
+    f = torch.randn(rb.n_in, C, device=cuda).half()
+    w = (torch.randn(K, 3, 3, 3, C, device=cuda) * 0.2).half()
+    d = (torch.randn(rb.n_out, K, device=cuda) * 0.2).half()
+    ident = 13 if subm else -1
+    bw = "fwd" if subm else "bwd"
+    t0 = (rb.pair_fwd, rb.mask_fwd) if subm else (rb.pair_bwd, rb.mask_bwd)
+    out0 = ops.igemm_fwd(f, w, rb.pair_fwd, rb.mask_fwd, None, rb.n_out, ident)
+    din0, dw0 = ops.igemm_bwd(f, d, w, t0[0], t0[1], None, rb.pair_native, rb.num_per_loc, subm, ops._plan_of(rb))
+    ops.sort_rulebook(rb)
+    pair, mask, order, to = ops.tables_of(rb, "fwd", K)
+    assert to and order is not None and pair is not rb.pair_fwd
+    assert torch.equal(pair, rb.pair_fwd[:, order.long()]) and torch.equal(mask, rb.mask_fwd[order.long()])
+    out1 = ops.igemm_fwd(f, w, pair, mask, order, rb.n_out, ident, tile_order=to)
+    assert torch.equal(out0, out1)
+    pair, mask, order, to = ops.tables_of(rb, bw, C)
+    din1, dw1 = ops.igemm_bwd(f, d, w, pair, mask, order, rb.pair_native, rb.num_per_loc, subm, ops._plan_of(rb),
+                              tile_order=to)
+    assert torch.equal(din0, din1) and torch.equal(dw0, dw1)
+    din2 = ops.igemm_dgrad(d, w, pair, mask, order, rb.n_in, subm, tile_order=to)
+    assert torch.equal(din0, din2)
+
+
 def test_transposed_and_inverse_conv(cuda):
     from spconv_amd.pytorch import ops
     shape = [10, 9, 9]
