@@ -65,7 +65,7 @@ struct GemmParams {
 // (results are wrong): 1 = weights staged once, 2 = also no per-step barrier, 3 = no MFMAs, 4 = no
 // gathered-row loads, 5 = no pair-word loads.  Compiles to nothing in the product build.
 #ifdef SPX_ABLATE
-#define SPX_ABL(p, v) ((p).dbg == (v))
+#define SPX_ABL(p, v) (SPX_ABLATE == (v))     // compile-time: one library per variant, no branch in the loop
 #else
 #define SPX_ABL(p, v) false
 #endif

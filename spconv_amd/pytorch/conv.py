@@ -247,17 +247,27 @@ class SparseConvolution(SparseModule):
                 "int8 must be called in static quantized module"
             assert bias is not None, "currently you must specify a bias"
             assert not training, "int8 is inference only"
-            assert not self.conv1x1 and not self.inverse, "int8 supports regular and subm convolutions"
+            assert not self.inverse, "int8 supports regular and subm convolutions"
         assert input.features.shape[1] == self.in_channels, "channel size mismatch"
         features = input.features
         indices = input.indices
         spatial_shape = input.spatial_shape
         batch_size = input.batch_size
-        bias_for_training = bias if training else None
-        bias_for_infer = bias if not training else None
+        # the differentiable path: training, and -- for ConvAlgo.Native layers, whose reference branch
+        # always goes through the autograd functions (conv.py:327-339) -- evaluation mode with
+        # gradients flowing (frozen-BN fine-tuning, saliency maps); a fused activation is then applied
+        # outside.  The implicit-GEMM algos follow `training`, like the reference (conv.py:404-452).
+        grad_path = training or (self.algo == ConvAlgo.Native and torch.is_grad_enabled() and not is_int8
+                                 and (input.features.requires_grad or weight.requires_grad))
+        bias_for_training = bias if grad_path else None
+        bias_for_infer = bias if not grad_path else None
         if training:
             assert self.act_type == Activation.None_, \
                 "act don't support backward, only used in inference"
+        if grad_path and int(np.prod(self.kernel_size)) > 128:
+            raise NotImplementedError(
+                f"kernel volume {int(np.prod(self.kernel_size))} > 128: this layer runs forward (inference) "
+                f"only -- the weight-gradient kernels cover kernel volumes up to 128")
         if self.subm:
             out_spatial_shape = spatial_shape
         elif self.transposed:
@@ -282,7 +292,7 @@ class SparseConvolution(SparseModule):
                                "transposed": self.transposed,
                                "input_channels": self.in_channels,
                                "out_channels": self.out_channels}}
-        if self.conv1x1:
+        if self.conv1x1 and not is_int8:      # (int8 1x1 layers take the kernel, like the reference: conv.py:225)
             # reference quirk kept on purpose (conv.py:232-234): the [K,1..,C] weight is
             # *viewed* as [C, K] without a transpose.
             features = torch.mm(input.features, weight.view(self.in_channels, self.out_channels))
@@ -340,7 +350,7 @@ class SparseConvolution(SparseModule):
             t = time.time()
 
         num_out = outids.shape[0]
-        if training:
+        if grad_path:
             # autograd path; bias is added outside the kernel like the reference
             pair_native = ops.attach_rulebook(rb.pair_native, rb)
             fn = (Fsp.indice_subm_conv if self.subm
@@ -365,6 +375,8 @@ class SparseConvolution(SparseModule):
                                          bias_for_infer, act_type, act_alpha, plan=tp, tile_order=tile_order)
         if bias_for_training is not None:
             out_features += bias_for_training
+        if grad_path and not training and add_input is None:
+            out_features = _apply_act(out_features, act_type, act_alpha, act_beta)
         if input.benchmark:
             torch.cuda.synchronize()
             out_tensor.benchmark_record[name]["time"].append(time.time() - t)

@@ -93,6 +93,20 @@ def _stream(t: torch.Tensor) -> int:
     return torch._C._cuda_getCurrentRawStream(t.device.index)
 
 
+def _on_device(fn):
+    """Runs a driver with the first tensor argument's device current (torch's DeviceGuard convention):
+    kernels, fills and scratch allocations of a call all belong to the device the data lives on, also
+    when the caller never called torch.cuda.set_device (model on cuda:1)."""
+    @functools.wraps(fn)
+    def guarded(*args, **kwargs):
+        t = next((a for a in args if isinstance(a, torch.Tensor)), None)
+        if t is not None and t.is_cuda and t.device.index != torch.cuda.current_device():
+            with torch.cuda.device(t.device):
+                return fn(*args, **kwargs)
+        return fn(*args, **kwargs)
+    return guarded
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -113,6 +127,7 @@ def _kv(ksize) -> int:
 
 
 # ---------------------------------------------------------------- rulebook
+@_on_device
 def build_rulebook(indices: torch.Tensor, batch_size: int, spatial_shape: List[int],
                    ksize: List[int], stride: List[int], padding: List[int],
                    dilation: List[int], out_padding: List[int], subm: bool = False,
@@ -188,12 +203,15 @@ def build_rulebook(indices: torch.Tensor, batch_size: int, spatial_shape: List[i
     return rb, out_shape
 
 
-# SPCONV_AMD_SORT: "auto" (default) = SubM rulebooks of >= 32 k rows with dense neighbourhoods (real
-# point clouds) get their rows sorted by mask on first use -- what the reference does for every
-# rulebook (SPCONV_DO_SORT, on by default there): tiles of equal-mask rows skip the offsets none of
-# their rows has (LiDAR fixture: 14 steps per 128-row tile instead of 27); "0" = only when asked
-# (do_sort / SPCONV_DO_SORT=1).
-_SORT_MODE = os.environ.get("SPCONV_AMD_SORT", "auto")
+# SPCONV_AMD_SORT: "0" (default) = rows are sorted by mask only when asked (do_sort / SPCONV_DO_SORT=1,
+# the reference's switch); "auto" = SubM rulebooks of >= 32 k rows with dense neighbourhoods get sorted
+# on first use.  Sorting is what the reference does for every rulebook (tiles of equal-mask rows skip the
+# offsets none of their rows has: 14 steps per 128-row tile instead of 27 on its LiDAR fixture), and with
+# the tables copied into tile order the sorted launch no longer pays scattered table reads (59 -> 43 us
+# forward on the fixture) -- but measured end to end it is a wash there (43.5 vs 40.0 us: the kernel is
+# bound by instruction issue and load latency, not by its step count), +19 % on the
+# synthetic LiDAR-like scene, and the sort + density read-back cost a single-scene training step 1 ms.
+_SORT_MODE = os.environ.get("SPCONV_AMD_SORT", "0")
 _SORT_MIN_ROWS = 32768
 
 
@@ -245,6 +263,7 @@ def tables_of(rb: Rulebook, which: str, cout: int = 64):
     return pair, mask, order, False
 
 
+@_on_device
 def mask_argsort(mask: torch.Tensor) -> torch.Tensor:
     """SpconvOps.sort_1d_by_key_allocator (all.py:935-991): argsort of the mask words."""
     L = _lib.load()
@@ -382,6 +401,7 @@ def _int_repr(t: torch.Tensor) -> torch.Tensor:
     return t.int_repr() if t.is_quantized else t
 
 
+@_on_device
 def igemm_fwd_int8(features: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
                    mask: Optional[torch.Tensor], argsort: Optional[torch.Tensor], n_out: int,
                    identity_k: int = -1, scale: Optional[torch.Tensor] = None,
@@ -441,6 +461,7 @@ def _pad_first(t: torch.Tensor, to: int) -> torch.Tensor:
     return torch.nn.functional.pad(t, pad)
 
 
+@_on_device
 def igemm_fwd(features: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
               mask: Optional[torch.Tensor], argsort: Optional[torch.Tensor], n_out: int,
               identity_k: int = -1, bias: Optional[torch.Tensor] = None,
@@ -489,6 +510,7 @@ def igemm_fwd(features: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
     return out if K == K0 else out[:, :K0].contiguous()
 
 
+@_on_device
 def igemm_dgrad(out_bp: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
                 mask: Optional[torch.Tensor], argsort: Optional[torch.Tensor], n_in: int,
                 subm: bool, plan: Optional[torch.Tensor] = None, tile_order: bool = False) -> torch.Tensor:
@@ -523,6 +545,7 @@ def igemm_dgrad(out_bp: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
     return din if C == C0 else din[:, :C0].contiguous()
 
 
+@_on_device
 def wgrad_plan(num_per_loc: torch.Tensor, n_in: int, kv: int, subm: bool) -> torch.Tensor:
     """Work plan of wgrad for one rulebook (built once, reused by every backward)."""
     L = _lib.load()
@@ -533,6 +556,7 @@ def wgrad_plan(num_per_loc: torch.Tensor, n_in: int, kv: int, subm: bool) -> tor
     return plan
 
 
+@_on_device
 def igemm_wgrad(features: torch.Tensor, out_bp: torch.Tensor, filters_shape, native: torch.Tensor,
                 num_per_loc: torch.Tensor, subm: bool,
                 plan: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -556,6 +580,7 @@ def igemm_wgrad(features: torch.Tensor, out_bp: torch.Tensor, filters_shape, nat
     return dw if (C == C0 and K == K0) else dw[:K0, ..., :C0].contiguous()
 
 
+@_on_device
 def igemm_bwd(features: torch.Tensor, out_bp: torch.Tensor, filters: torch.Tensor,
               table: torch.Tensor, mask: Optional[torch.Tensor], argsort: Optional[torch.Tensor],
               native: torch.Tensor, num_per_loc: torch.Tensor, subm: bool,
@@ -602,6 +627,7 @@ def _plan_of(rb: Optional[Rulebook]) -> Optional[torch.Tensor]:
     return rb.wgrad_plan
 
 
+@_on_device
 def bias_act_inplace(out: torch.Tensor, bias: Optional[torch.Tensor], act_type: int,
                      act_alpha: float = 0.0) -> torch.Tensor:
     """InferenceOps.bias_add_act_inplace & friends (csrc/sparse/inference.py:26-146)."""
@@ -817,6 +843,7 @@ def _mask_of(pair: torch.Tensor, fwd: bool) -> Optional[torch.Tensor]:
     return None if rb.subm else rb.mask_bwd
 
 
+@_on_device
 def indice_maxpool_implicit_gemm(features: torch.Tensor, indice_pairs: torch.Tensor,
                                  num_activate_out: int, init_zero: bool = False) -> torch.Tensor:
     """out[o] = max over the valid pairs of column o of pair_fwd [kv, n_out] (ops.py:1976-1997)."""
@@ -833,6 +860,7 @@ def indice_maxpool_implicit_gemm(features: torch.Tensor, indice_pairs: torch.Ten
     return out
 
 
+@_on_device
 def indice_maxpool_implicit_gemm_backward(features: torch.Tensor, out_features: torch.Tensor,
                                           out_bp: torch.Tensor, indice_pairs: torch.Tensor) -> torch.Tensor:
     """din from pair_bwd [kv, n_in] (ops.py:2000-2023)."""
@@ -847,6 +875,7 @@ def indice_maxpool_implicit_gemm_backward(features: torch.Tensor, out_features: 
     return din
 
 
+@_on_device
 def indice_avgpool_implicit_gemm(features: torch.Tensor, indice_pairs: torch.Tensor,
                                  num_activate_out: int, calc_count: bool):
     """(mean over the valid pairs, count [n_out] or empty) -- ops.py:2026-2056."""
@@ -862,6 +891,7 @@ def indice_avgpool_implicit_gemm(features: torch.Tensor, indice_pairs: torch.Ten
     return out, (count if count is not None else torch.Tensor())
 
 
+@_on_device
 def indice_avgpool_implicit_gemm_backward(out_bp: torch.Tensor, indice_pairs: torch.Tensor,
                                           count_out: torch.Tensor) -> torch.Tensor:
     """din[i] = sum_o dout[o] / count[o] over pair_bwd [kv, n_in] (cf. ops.py:2059-2084)."""
@@ -900,14 +930,20 @@ def indice_maxpool_backward(features, out_features, out_bp, indice_pairs, indice
 
 
 def global_pool_rearrange(indices: torch.Tensor, batch_size: int):
-    """Row ids of every batch item, padded to [batch, N], and the counts (ops.py:2087-2100)."""
-    b = indices[:, 0].long()
+    """Row ids of every batch item, padded to [batch, N], and the counts (ops.py:2087-2100).  One
+    stable sort by batch id + a scatter: no per-scene loop, no read-back."""
     n = indices.shape[0]
-    out = torch.zeros((batch_size, n), dtype=torch.int32, device=indices.device)
-    counts = torch.zeros((batch_size,), dtype=torch.int32, device=indices.device)
-    for i in range(batch_size):
-        rows = torch.nonzero(b == i, as_tuple=False).flatten().int()
-        out[i, :rows.numel()] = rows
-        counts[i] = rows.numel()
-    return out, counts
-
+    dev = indices.device
+    out = torch.zeros((batch_size, n), dtype=torch.int32, device=dev)
+    if n == 0:
+        return out, torch.zeros((batch_size,), dtype=torch.int32, device=dev)
+    b = indices[:, 0].long()
+    key = torch.where((b >= 0) & (b < batch_size), b, torch.full_like(b, batch_size))
+    order = torch.argsort(key, stable=True)
+    skey = key[order]
+    counts = torch.bincount(key, minlength=batch_size + 1)
+    starts = torch.cumsum(counts, 0) - counts
+    col = torch.arange(n, device=dev) - starts[skey]
+    keep = skey < batch_size
+    out[skey[keep], col[keep]] = order[keep].int()
+    return out, counts[:batch_size].int()

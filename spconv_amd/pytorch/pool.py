@@ -153,13 +153,22 @@ class SparseGlobalMaxOrAvgPool(SparseModule):
 
     def forward(self, input: SparseConvTensor):
         assert isinstance(input, SparseConvTensor) and not input.is_quantized, "not implemented"
-        out_indices, counts = ops.global_pool_rearrange(input.indices, input.batch_size)
-        counts_cpu = counts.cpu().numpy()
-        res = []
-        for i in range(input.batch_size):
-            real = input.features[out_indices[i, :counts_cpu[i]].long()]
-            res.append(torch.mean(real, dim=0) if self.is_mean else torch.max(real, dim=0)[0])
-        return torch.stack(res)
+        # one segmented reduction over the batch column (no per-scene loop, no read-back); rows whose
+        # batch index lies outside [0, batch_size) belong to no scene, as in global_pool_rearrange
+        bs, feats = input.batch_size, input.features
+        b = input.indices[:, 0].long()
+        keep = (b >= 0) & (b < bs)
+        b = torch.where(keep, b, torch.zeros_like(b))
+        idx = b.unsqueeze(1).expand(-1, feats.shape[1])
+        if self.is_mean:
+            w = keep.to(feats.dtype).unsqueeze(1)
+            total = torch.zeros((bs, feats.shape[1]), dtype=feats.dtype, device=feats.device).scatter_add(0, idx, feats * w)
+            count = torch.zeros((bs, 1), dtype=feats.dtype, device=feats.device).scatter_add(0, b.unsqueeze(1), w)
+            return total / count
+        lowest = torch.finfo(feats.dtype).min if feats.dtype.is_floating_point else torch.iinfo(feats.dtype).min
+        src = torch.where(keep.unsqueeze(1), feats, torch.full_like(feats, lowest))
+        return torch.full((bs, feats.shape[1]), lowest, dtype=feats.dtype, device=feats.device).scatter_reduce(
+            0, idx, src, "amax", include_self=True)
 
 
 class SparseGlobalAvgPool(SparseGlobalMaxOrAvgPool):

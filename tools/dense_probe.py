@@ -18,7 +18,8 @@ from spconv_amd.pytorch import ops  # noqa: E402
 def main():
     dev = torch.device("cuda:0")
     C = int(os.environ.get("PROBE_C", "64"))
-    idx, shape = bench.fixture_scene(0)
+    kind = os.environ.get("PROBE_SCENE", "fixture")
+    idx, shape = bench.make_scene(kind, 100_000, 0)
     ind = torch.from_numpy(idx).to(dev)
     rb = ops.build_rulebook(ind, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True)[0]
     ops._TILE_MODE = "1"
@@ -38,6 +39,11 @@ def main():
     span = 0 if os.environ.get("PROBE_EAGER") == "1" else 8
     res["v4_fwd_us"] = round(1e3 * bench.event_time_ms(
         lambda i: ops.igemm_fwd(f, w, rb.pair_fwd, rb.mask_fwd, None, n, 13), span=span), 2)
+    res["v4_dgrad_us"] = round(1e3 * bench.event_time_ms(
+        lambda i: ops.igemm_dgrad(f, w, rb.pair_fwd, rb.mask_fwd, None, n, True), span=span), 2)
+    if os.environ.get("PROBE_HALO", "0") != "1":
+        print(json.dumps(res))
+        return
     res["halo_fwd_us"] = round(1e3 * bench.event_time_ms(
         lambda i: ops.igemm_fwd(f, w, rb.pair_fwd, rb.mask_fwd, None, n, 13, plan=tp), span=span), 2)
     res["halo_dgrad_us"] = round(1e3 * bench.event_time_ms(
