@@ -326,6 +326,29 @@ int spx_hash_items(void *table_keys, void *table_vals, int capacity, int key_byt
                    void *keys_out, void *vals_out, int max_out, void *count_out, void *ws,
                    size_t ws_bytes, spx_stream_t stream);
 
+/* ---- batch normalisation (+ ReLU) over the features of a sparse tensor ---------------------------
+ * The reference hands `.features` of a SparseConvTensor to torch.nn.BatchNorm1d (SparseSequential,
+ * spconv/pytorch/modules.py:131-145; SparseBatchNorm / SparseReLU, :147-185).  These two calls do
+ * the same arithmetic (torch.nn.BatchNorm1d semantics: biased variance to normalise, unbiased for
+ * the running estimate, `momentum`, `eps`, optional affine) as three streaming launches per pass.
+ *   x, y, dy, dx      [n, C] row-major, dtype f16 / bf16 / f32, C a multiple of 8 (f32: 4), C <= 256
+ *   weight, bias      [C] fp32 or NULL;  running_mean / running_var [C] fp32 or NULL (updated in place
+ *                     when training, read when not)
+ *   save_mean / save_invstd [C] fp32: batch statistics for the backward pass (training)
+ *   relu              fuse max(0, .) into the output (and its mask into the backward pass)
+ *   ws                spx_batchnorm_ws_bytes(n, C) bytes */
+size_t spx_batchnorm_ws_bytes(int n, int C);
+int spx_batchnorm_fwd(const void *x, void *y, int n, int C, int dtype, const float *weight,
+                      const float *bias, float *running_mean, float *running_var, int training,
+                      float momentum, float eps, int relu, float *save_mean, float *save_invstd,
+                      void *ws, size_t ws_bytes, spx_stream_t stream);
+/* use_batch_stats = 1: `mean` / `invstd` are the saved batch statistics (training);
+ * 0: running_mean and 1 / sqrt(running_var + eps) (evaluation mode with gradients). */
+int spx_batchnorm_bwd(const void *x, const void *dy, void *dx, int n, int C, int dtype,
+                      const float *weight, const float *bias, const float *mean, const float *invstd,
+                      int use_batch_stats, int relu, float *dweight, float *dbias, void *ws,
+                      size_t ws_bytes, spx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

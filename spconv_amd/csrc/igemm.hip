@@ -1762,16 +1762,32 @@ wgrad_plan2_kernel(const int32_t *__restrict__ num, int n_in, int kv, int subm, 
     nseg_of[tid] = mine;
   }
   __syncthreads();
-  if (tid == 0) {
-    int run = 0;
-    for (int w = 0; w < G; ++w) {
-      const int c = nseg_of[w];
-      nseg_of[w] = run;
-      run += c;
+  {
+    // exclusive scan of the per-range segment counts over the whole block (1024 threads: wave scans
+    // + 16 wave totals) -- a single thread walking G entries was most of this launch's 15 us
+    __shared__ int wtot[kW2MaxG / 64];
+    const int lane = tid & 63, wv = tid >> 6;
+    const int c = tid < G ? mine : 0;
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int u = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += u;
     }
-    nseg_of[G] = run;
-    plan[0] = run;
-    plan[1] = per;
+    if (lane == 63) wtot[wv] = incl;
+    __syncthreads();
+    int prefix = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kW2MaxG / 64; ++w) {
+      if (w < wv) prefix += wtot[w];
+      total += wtot[w];
+    }
+    if (tid < G) nseg_of[tid] = prefix + incl - c;
+    if (tid == 0) {
+      nseg_of[G] = total;
+      plan[0] = total;
+      plan[1] = per;
+    }
   }
   __syncthreads();
   int32_t *seg = plan + plan2_seg(G, kv);

@@ -1,0 +1,481 @@
+// Batch normalisation (+ fused ReLU) over the [N, C] feature matrix of a sparse tensor.
+//
+// A voxel backbone interleaves every sparse convolution with BatchNorm1d + ReLU on the features
+// (the reference leaves them to torch: SparseSequential applies dense modules to `.features`,
+// modules.py:131-145).  On MI355X torch's channels-last kernels need 55-60 us for a 400 k x 16 fp16
+// matrix (13 MB: 0.23 TB/s) and were 35 % of the GPU time of BASELINE config 4; these are plain
+// HBM-bound streaming kernels instead (16 bytes per lane, rows interleaved over the lanes of a wave so
+// that every wave instruction covers whole 128-byte lines):
+//   forward (training)  bn_partial -> bn_finalize -> bn_apply
+//   forward (inference) bn_apply with the running statistics
+//   backward            bn_bwd_partial -> bn_bwd_finalize -> bn_bwd_apply
+// Statistics are accumulated in fp32 per block around a per-block shift (the block's first row) and
+// merged with Chan's parallel update, so cancellation is bounded by the spread inside ~400 rows.
+// Semantics are torch.nn.BatchNorm1d's: biased variance for normalisation, unbiased for the running
+// estimate, `momentum`, `eps`, affine weight / bias (may be NULL).
+#include "common.h"
+
+namespace spx {
+namespace {
+
+constexpr int kT = 256;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int DT> struct Vec;       // 16 bytes of input -> VPL floats
+template <> struct Vec<SPX_F32> {
+  static constexpr int VPL = 4;
+  static __device__ __forceinline__ void unpack(const u32x4 &v, float (&f)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = __builtin_bit_cast(float, v[i]);
+  }
+  static __device__ __forceinline__ u32x4 pack(const float (&f)[4]) {
+    return u32x4{__builtin_bit_cast(unsigned, f[0]), __builtin_bit_cast(unsigned, f[1]),
+                 __builtin_bit_cast(unsigned, f[2]), __builtin_bit_cast(unsigned, f[3])};
+  }
+};
+template <> struct Vec<SPX_F16> {
+  static constexpr int VPL = 8;
+  static __device__ __forceinline__ void unpack(const u32x4 &v, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(v[i] & 0xffffu)));
+      f[2 * i + 1] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(v[i] >> 16)));
+    }
+  }
+  static __device__ __forceinline__ u32x4 pack(const float (&f)[8]) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint16_t lo = __builtin_bit_cast(uint16_t, static_cast<_Float16>(f[2 * i]));
+      const uint16_t hi = __builtin_bit_cast(uint16_t, static_cast<_Float16>(f[2 * i + 1]));
+      v[i] = static_cast<unsigned>(lo) | (static_cast<unsigned>(hi) << 16);
+    }
+    return v;
+  }
+};
+template <> struct Vec<SPX_BF16> {
+  static constexpr int VPL = 8;
+  static __device__ __forceinline__ void unpack(const u32x4 &v, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = __builtin_bit_cast(float, v[i] << 16);
+      f[2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ unsigned rne(float x) {
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+  }
+  static __device__ __forceinline__ u32x4 pack(const float (&f)[8]) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = rne(f[2 * i]) | (rne(f[2 * i + 1]) << 16);
+    return v;
+  }
+};
+
+// A block owns rows [r0, r1); thread t reads the 16-byte piece (t % P) of rows r0 + t / P + i * (kT / P),
+// P = pieces per row = C / VPL (a power of two <= 64 is not required: kT / P rows per sweep, threads past
+// (kT / P) * P idle).
+struct RowSplit {
+  int r0, r1, piece, lane_row, rows_per_sweep;
+  bool active;
+};
+__device__ __forceinline__ RowSplit row_split(int n, int P, int nblocks) {
+  RowSplit s;
+  const long long per = (static_cast<long long>(n) + nblocks - 1) / nblocks;
+  s.r0 = static_cast<int>(min(static_cast<long long>(n), per * blockIdx.x));
+  s.r1 = static_cast<int>(min(static_cast<long long>(n), per * (blockIdx.x + 1)));
+  s.rows_per_sweep = kT / P;
+  s.piece = threadIdx.x % P;
+  s.lane_row = threadIdx.x / P;
+  s.active = s.lane_row < s.rows_per_sweep;
+  return s;
+}
+
+// Sums a[], b[] over the threads of the block that hold the same piece (threads piece + P * lane_row);
+// on return threads 0 .. C-1 hold the totals of channel threadIdx.x in (ra, rb).  P dividing 64: wave
+// butterflies + four wave totals through LDS; other P: a short serial loop.
+template <int VPL>
+__device__ __forceinline__ void piece_reduce(float (&a)[VPL], float (&b)[VPL], int P, int C, int rows_per_sweep,
+                                             float (*lds)[kT][VPL + 1], float &ra, float &rb) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  ra = rb = 0.f;
+  if (64 % P == 0) {
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      for (int d = P; d < 64; d <<= 1) {
+        a[i] += __shfl_xor(a[i], d, 64);
+        b[i] += __shfl_xor(b[i], d, 64);
+      }
+    }
+    if (lane < P) {
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) {
+        lds[0][wave * P + lane][i] = a[i];
+        lds[1][wave * P + lane][i] = b[i];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < C) {
+      const int piece = threadIdx.x / VPL, e = threadIdx.x % VPL;
+#pragma unroll
+      for (int w = 0; w < kT / 64; ++w) {
+        ra += lds[0][w * P + piece][e];
+        rb += lds[1][w * P + piece][e];
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    lds[0][threadIdx.x][i] = a[i];
+    lds[1][threadIdx.x][i] = b[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < C) {
+    const int piece = threadIdx.x / VPL, e = threadIdx.x % VPL;
+    for (int lr = 0; lr < rows_per_sweep; ++lr) {
+      ra += lds[0][lr * P + piece][e];
+      rb += lds[1][lr * P + piece][e];
+    }
+  }
+}
+
+// partial[b][0][c] = rows of block b, [1] = mean, [2] = M2 (sum of squared deviations)
+template <int DT>
+__global__ void __launch_bounds__(kT)
+bn_partial_kernel(const u32x4 *__restrict__ x, int n, int C, float *__restrict__ partial) {
+  constexpr int VPL = Vec<DT>::VPL;
+  __shared__ float lds[2][kT][VPL + 1];
+  const int P = C / VPL;
+  const RowSplit s = row_split(n, P, gridDim.x);
+  float shift[VPL], sum[VPL], sq[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) shift[i] = sum[i] = sq[i] = 0.f;
+  if (s.active && s.r0 < s.r1) Vec<DT>::unpack(x[static_cast<size_t>(s.r0) * P + s.piece], shift);
+  if (s.active) {
+    for (int r = s.r0 + s.lane_row; r < s.r1; r += s.rows_per_sweep) {
+      float f[VPL];
+      Vec<DT>::unpack(x[static_cast<size_t>(r) * P + s.piece], f);
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) {
+        const float d = f[i] - shift[i];
+        sum[i] += d;
+        sq[i] += d * d;
+      }
+    }
+  }
+  if (!s.active) {
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) sum[i] = sq[i] = 0.f;
+  }
+  float a, b;
+  piece_reduce<VPL>(sum, sq, P, C, s.rows_per_sweep, lds, a, b);
+  // threads 0 .. C-1: one channel each
+  if (threadIdx.x < C) {
+    const int piece = threadIdx.x / VPL, e = threadIdx.x % VPL;
+    const float cnt = static_cast<float>(s.r1 - s.r0);
+    // the shift of channel c is the block's first row, read again by this thread
+    float sh = 0.f;
+    if (s.r0 < s.r1) {
+      float f[VPL];
+      Vec<DT>::unpack(x[static_cast<size_t>(s.r0) * P + piece], f);
+      sh = f[e];
+    }
+    float *dst = partial + static_cast<size_t>(blockIdx.x) * 3 * C;
+    dst[threadIdx.x] = cnt;
+    dst[C + threadIdx.x] = cnt > 0.f ? sh + a / cnt : 0.f;
+    dst[2 * C + threadIdx.x] = cnt > 0.f ? b - a * a / cnt : 0.f;
+  }
+}
+
+// one block per channel: Chan merge of the G partials; mean / invstd out, running estimates updated
+__global__ void __launch_bounds__(kT)
+bn_finalize_kernel(const float *__restrict__ partial, int G, int C, float eps, float momentum,
+                   float *__restrict__ mean_out, float *__restrict__ invstd_out,
+                   float *__restrict__ running_mean, float *__restrict__ running_var) {
+  __shared__ float ln[kT], lm[kT], l2[kT];
+  const int c = blockIdx.x;
+  float n = 0.f, m = 0.f, M2 = 0.f;
+  for (int b = threadIdx.x; b < G; b += kT) {
+    const float nb = partial[static_cast<size_t>(b) * 3 * C + c];
+    const float mb = partial[static_cast<size_t>(b) * 3 * C + C + c];
+    const float Mb = partial[static_cast<size_t>(b) * 3 * C + 2 * C + c];
+    if (nb > 0.f) {
+      const float tot = n + nb, d = mb - m;
+      m += d * (nb / tot);
+      M2 += Mb + d * d * (n * nb / tot);
+      n = tot;
+    }
+  }
+  ln[threadIdx.x] = n;
+  lm[threadIdx.x] = m;
+  l2[threadIdx.x] = M2;
+  __syncthreads();
+  for (int stride = kT / 2; stride > 0; stride >>= 1) {
+    if (threadIdx.x < stride) {
+      const float na = ln[threadIdx.x], nb = ln[threadIdx.x + stride];
+      if (nb > 0.f) {
+        const float tot = na + nb, d = lm[threadIdx.x + stride] - lm[threadIdx.x];
+        lm[threadIdx.x] += d * (nb / tot);
+        l2[threadIdx.x] += l2[threadIdx.x + stride] + d * d * (na * nb / tot);
+        ln[threadIdx.x] = tot;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float cnt = ln[0], mean = lm[0];
+    const float var = cnt > 0.f ? l2[0] / cnt : 0.f;
+    mean_out[c] = mean;
+    invstd_out[c] = rsqrtf(var + eps);
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+    if (running_var) {
+      const float unbiased = cnt > 1.f ? l2[0] / (cnt - 1.f) : var;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+  }
+}
+
+// y = (x - mean) * invstd * w + b, optional ReLU.  stat_is_var: `invstd` holds a variance (inference
+// with the running estimate) and is turned into 1 / sqrt(var + eps) here.
+template <int DT>
+__global__ void __launch_bounds__(kT)
+bn_apply_kernel(const u32x4 *__restrict__ x, u32x4 *__restrict__ y, long long pieces, int C,
+                const float *__restrict__ mean, const float *__restrict__ invstd,
+                const float *__restrict__ weight, const float *__restrict__ bias, float eps,
+                int stat_is_var, int relu) {
+  constexpr int VPL = Vec<DT>::VPL;
+  const int P = C / VPL;
+  for (long long i = static_cast<long long>(blockIdx.x) * kT + threadIdx.x; i < pieces;
+       i += static_cast<long long>(gridDim.x) * kT) {
+    const int c0 = static_cast<int>(i % P) * VPL;
+    float f[VPL];
+    Vec<DT>::unpack(x[i], f);
+#pragma unroll
+    for (int e = 0; e < VPL; ++e) {
+      const float is = stat_is_var ? rsqrtf(invstd[c0 + e] + eps) : invstd[c0 + e];
+      const float sc = is * (weight ? weight[c0 + e] : 1.f);
+      float v = (f[e] - mean[c0 + e]) * sc + (bias ? bias[c0 + e] : 0.f);
+      if (relu) v = v > 0.f ? v : 0.f;
+      f[e] = v;
+    }
+    y[i] = Vec<DT>::pack(f);
+  }
+}
+
+// partial[b][0][c] = sum dy, [1][c] = sum dy * xhat over the block's rows (dy masked by y > 0 with ReLU)
+template <int DT>
+__global__ void __launch_bounds__(kT)
+bn_bwd_partial_kernel(const u32x4 *__restrict__ x, const u32x4 *__restrict__ dy, int n, int C,
+                      const float *__restrict__ mean, const float *__restrict__ invstd,
+                      const float *__restrict__ weight, const float *__restrict__ bias, int relu,
+                      float *__restrict__ partial) {
+  constexpr int VPL = Vec<DT>::VPL;
+  __shared__ float lds[2][kT][VPL + 1];
+  const int P = C / VPL;
+  const RowSplit s = row_split(n, P, gridDim.x);
+  float s1[VPL], s2[VPL], mu[VPL], is[VPL], w[VPL], bb[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    s1[i] = s2[i] = 0.f;
+    const int c = s.piece * VPL + i;
+    mu[i] = s.active ? mean[c] : 0.f;
+    is[i] = s.active ? invstd[c] : 0.f;
+    w[i] = (s.active && weight) ? weight[c] : 1.f;
+    bb[i] = (s.active && bias) ? bias[c] : 0.f;
+  }
+  if (s.active) {
+    for (int r = s.r0 + s.lane_row; r < s.r1; r += s.rows_per_sweep) {
+      float f[VPL], g[VPL];
+      Vec<DT>::unpack(x[static_cast<size_t>(r) * P + s.piece], f);
+      Vec<DT>::unpack(dy[static_cast<size_t>(r) * P + s.piece], g);
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) {
+        const float xh = (f[i] - mu[i]) * is[i];
+        const float gg = (relu && xh * w[i] + bb[i] <= 0.f) ? 0.f : g[i];
+        s1[i] += gg;
+        s2[i] += gg * xh;
+      }
+    }
+  }
+  float a, b;
+  piece_reduce<VPL>(s1, s2, P, C, s.rows_per_sweep, lds, a, b);
+  if (threadIdx.x < C) {
+    partial[static_cast<size_t>(blockIdx.x) * 2 * C + threadIdx.x] = a;
+    partial[static_cast<size_t>(blockIdx.x) * 2 * C + C + threadIdx.x] = b;
+  }
+}
+
+// sums[0][c] = sum dy (= dbias), sums[1][c] = sum dy * xhat (= dweight)
+__global__ void __launch_bounds__(kT)
+bn_bwd_finalize_kernel(const float *__restrict__ partial, int G, int C, float *__restrict__ sum_dy,
+                       float *__restrict__ sum_dy_xhat) {
+  __shared__ float la[kT], lb[kT];
+  const int c = blockIdx.x;
+  float a = 0.f, b = 0.f;
+  for (int g = threadIdx.x; g < G; g += kT) {
+    a += partial[static_cast<size_t>(g) * 2 * C + c];
+    b += partial[static_cast<size_t>(g) * 2 * C + C + c];
+  }
+  la[threadIdx.x] = a;
+  lb[threadIdx.x] = b;
+  __syncthreads();
+  for (int stride = kT / 2; stride > 0; stride >>= 1) {
+    if (threadIdx.x < stride) {
+      la[threadIdx.x] += la[threadIdx.x + stride];
+      lb[threadIdx.x] += lb[threadIdx.x + stride];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    sum_dy[c] = la[0];
+    sum_dy_xhat[c] = lb[0];
+  }
+}
+
+// training: dx = w * invstd * (dy - sum_dy / n - xhat * sum_dy_xhat / n);  inference statistics
+// (use_batch_stats == 0): dx = w * invstd * dy
+template <int DT>
+__global__ void __launch_bounds__(kT)
+bn_bwd_apply_kernel(const u32x4 *__restrict__ x, const u32x4 *__restrict__ dy, u32x4 *__restrict__ dx,
+                    long long pieces, int n, int C, const float *__restrict__ mean,
+                    const float *__restrict__ invstd, const float *__restrict__ weight,
+                    const float *__restrict__ bias, const float *__restrict__ sum_dy,
+                    const float *__restrict__ sum_dy_xhat, int relu, int use_batch_stats) {
+  constexpr int VPL = Vec<DT>::VPL;
+  const int P = C / VPL;
+  const float inv_n = n > 0 ? 1.f / static_cast<float>(n) : 0.f;
+  for (long long i = static_cast<long long>(blockIdx.x) * kT + threadIdx.x; i < pieces;
+       i += static_cast<long long>(gridDim.x) * kT) {
+    const int c0 = static_cast<int>(i % P) * VPL;
+    float f[VPL], g[VPL];
+    Vec<DT>::unpack(x[i], f);
+    Vec<DT>::unpack(dy[i], g);
+#pragma unroll
+    for (int e = 0; e < VPL; ++e) {
+      const int c = c0 + e;
+      const float w = weight ? weight[c] : 1.f;
+      const float xh = (f[e] - mean[c]) * invstd[c];
+      float gg = g[e];
+      if (relu && xh * w + (bias ? bias[c] : 0.f) <= 0.f) gg = 0.f;
+      const float corr = use_batch_stats ? (sum_dy[c] + xh * sum_dy_xhat[c]) * inv_n : 0.f;
+      f[e] = w * invstd[c] * (gg - corr);
+    }
+    dx[i] = Vec<DT>::pack(f);
+  }
+}
+
+int bn_blocks(int n) {
+  int g = div_up(n > 0 ? n : 1, 384);      // ~384 rows per block, at most 1024 blocks
+  return g < 1 ? 1 : (g > 1024 ? 1024 : g);
+}
+
+bool bn_shape_ok(int C, int dtype) {
+  const int vpl = dtype == SPX_F32 ? 4 : 8;
+  return (dtype == SPX_F32 || dtype == SPX_F16 || dtype == SPX_BF16) && C > 0 && C % vpl == 0 && C <= kT &&
+         C / vpl <= kT;
+}
+
+unsigned stream_grid(long long pieces) {
+  long long b = (pieces + kT - 1) / kT;
+  return static_cast<unsigned>(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace
+}  // namespace spx
+
+using namespace spx;
+
+#define SPX_BN_DISPATCH(dtype, CALL)                         \
+  do {                                                       \
+    if ((dtype) == SPX_F16) { CALL(SPX_F16); }               \
+    else if ((dtype) == SPX_BF16) { CALL(SPX_BF16); }        \
+    else { CALL(SPX_F32); }                                  \
+  } while (0)
+
+extern "C" {
+
+size_t spx_batchnorm_ws_bytes(int n, int C) {
+  return align_up(static_cast<size_t>(bn_blocks(n)) * 3 * (C > 0 ? C : 1) * sizeof(float), 256) + 256;
+}
+
+int spx_batchnorm_fwd(const void *x, void *y, int n, int C, int dtype, const float *weight,
+                      const float *bias, float *running_mean, float *running_var, int training,
+                      float momentum, float eps, int relu, float *save_mean, float *save_invstd,
+                      void *ws, size_t ws_bytes, spx_stream_t stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  SPX_CHECK(bn_shape_ok(C, dtype), "batchnorm: C = %d must be a multiple of %d (<= 256), dtype f16/bf16/f32", C,
+            dtype == SPX_F32 ? 4 : 8);
+  if (n == 0) return 0;
+  SPX_CHECK(x && y, "null tensor pointer");
+  const int vpl = dtype == SPX_F32 ? 4 : 8;
+  const long long pieces = static_cast<long long>(n) * (C / vpl);
+  const u32x4 *xv = static_cast<const u32x4 *>(x);
+  u32x4 *yv = static_cast<u32x4 *>(y);
+  if (training) {
+    SPX_CHECK(save_mean && save_invstd && ws && ws_bytes >= spx_batchnorm_ws_bytes(n, C),
+              "training needs save_mean / save_invstd and the workspace");
+    const int G = bn_blocks(n);
+    float *partial = static_cast<float *>(ws);
+#define SPX_BN_PARTIAL(D) hipLaunchKernelGGL(bn_partial_kernel<D>, dim3(G), dim3(kT), 0, s, xv, n, C, partial)
+    SPX_BN_DISPATCH(dtype, SPX_BN_PARTIAL);
+#undef SPX_BN_PARTIAL
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(kT), 0, s, partial, G, C, eps, momentum, save_mean,
+                       save_invstd, running_mean, running_var);
+#define SPX_BN_APPLY(D)                                                                                    \
+  hipLaunchKernelGGL(bn_apply_kernel<D>, dim3(stream_grid(pieces)), dim3(kT), 0, s, xv, yv, pieces, C,     \
+                     save_mean, save_invstd, weight, bias, eps, 0, relu)
+    SPX_BN_DISPATCH(dtype, SPX_BN_APPLY);
+#undef SPX_BN_APPLY
+  } else {
+    SPX_CHECK(running_mean && running_var, "inference needs the running statistics");
+#define SPX_BN_APPLY(D)                                                                                    \
+  hipLaunchKernelGGL(bn_apply_kernel<D>, dim3(stream_grid(pieces)), dim3(kT), 0, s, xv, yv, pieces, C,     \
+                     running_mean, running_var, weight, bias, eps, 1, relu)
+    SPX_BN_DISPATCH(dtype, SPX_BN_APPLY);
+#undef SPX_BN_APPLY
+  }
+  SPX_LAUNCH_CHECK();
+  return 0;
+}
+
+int spx_batchnorm_bwd(const void *x, const void *dy, void *dx, int n, int C, int dtype,
+                      const float *weight, const float *bias, const float *mean, const float *invstd,
+                      int use_batch_stats, int relu, float *dweight, float *dbias, void *ws,
+                      size_t ws_bytes, spx_stream_t stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  SPX_CHECK(bn_shape_ok(C, dtype), "batchnorm: unsupported C = %d / dtype", C);
+  SPX_CHECK(dweight && dbias && mean && invstd, "null pointer");
+  if (n == 0) {
+    SPX_HIP(hipMemsetAsync(dweight, 0, sizeof(float) * C, s));
+    SPX_HIP(hipMemsetAsync(dbias, 0, sizeof(float) * C, s));
+    return 0;
+  }
+  SPX_CHECK(x && dy && dx && ws && ws_bytes >= spx_batchnorm_ws_bytes(n, C), "null pointer / workspace too small");
+  const int vpl = dtype == SPX_F32 ? 4 : 8;
+  const long long pieces = static_cast<long long>(n) * (C / vpl);
+  const int G = bn_blocks(n);
+  float *partial = static_cast<float *>(ws);
+  const u32x4 *xv = static_cast<const u32x4 *>(x), *gv = static_cast<const u32x4 *>(dy);
+#define SPX_BN_BP(D)                                                                                        \
+  hipLaunchKernelGGL(bn_bwd_partial_kernel<D>, dim3(G), dim3(kT), 0, s, xv, gv, n, C, mean, invstd, weight, \
+                     bias, relu, partial)
+  SPX_BN_DISPATCH(dtype, SPX_BN_BP);
+#undef SPX_BN_BP
+  // sum dy = dbias, sum dy * xhat = dweight: finalised straight into the caller's gradient buffers
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(kT), 0, s, partial, G, C, dbias, dweight);
+#define SPX_BN_BA(D)                                                                                        \
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<D>, dim3(stream_grid(pieces)), dim3(kT), 0, s, xv, gv,             \
+                     static_cast<u32x4 *>(dx), pieces, n, C, mean, invstd, weight, bias, dbias, dweight,    \
+                     relu, use_batch_stats)
+  SPX_BN_DISPATCH(dtype, SPX_BN_BA);
+#undef SPX_BN_BA
+  SPX_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

@@ -620,13 +620,15 @@ subm_probe_all_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table 
 __global__ void __launch_bounds__(kBlock)
 subm_lists_kernel(const int32_t *__restrict__ pair_fwd, int kv, int n, int nblk256,
                   const int32_t *__restrict__ blockcount, int32_t *__restrict__ native,
-                  int32_t *__restrict__ num_per_loc, int num_len) {
+                  int32_t *__restrict__ num_per_loc, int num_len, int conv = 0) {
+  // conv != 0: regular / transposed convolution -- `pair_fwd` is then pair_bwd [kv, n_in], list k is
+  // read off its row k (indices.py:1767-1768), there is no mirror list and no identity list
   __shared__ int lds_wave[kBlock / 64];
   __shared__ int lds_red[2][kBlock / 64];
   const int list = blockIdx.y, blk = blockIdx.x;
   const int begin = blk * kItems;
   const size_t plane = static_cast<size_t>(kv) * n;
-  if (list == kv / 2) {                        // identity lists (indices.py:1678-1682)
+  if (!conv && list == kv / 2) {               // identity lists (indices.py:1678-1682)
     // counts exist for k < kv/2 only (indices.py:1685,1692); the rest of num_per_loc reads 0
     if (blk == 0)
       for (int i = kv / 2 + threadIdx.x; i < num_len; i += kBlock) num_per_loc[i] = 0;
@@ -667,7 +669,7 @@ subm_lists_kernel(const int32_t *__restrict__ pair_fwd, int kv, int n, int nblk2
   }
   if (blk == 0 && threadIdx.x == 0 && num_per_loc) num_per_loc[list] = all;
   if (!native) return;
-  const int32_t *row = pair_fwd + static_cast<size_t>(kv - 1 - list) * n;
+  const int32_t *row = pair_fwd + static_cast<size_t>(conv ? list : kv - 1 - list) * n;
   int32_t *in_k = native + static_cast<size_t>(list) * n;
   int32_t *out_k = native + plane + static_cast<size_t>(list) * n;
   int32_t *in_m = native + static_cast<size_t>(kv - 1 - list) * n;
@@ -682,15 +684,19 @@ subm_lists_kernel(const int32_t *__restrict__ pair_fwd, int kv, int n, int nblk2
       const int j = running + rank;
       in_k[j] = e;
       out_k[j] = v;
-      in_m[j] = v;
-      out_m[j] = e;
+      if (!conv) {
+        in_m[j] = v;
+        out_m[j] = e;
+      }
     }
     running += total;
     if (e < n && e >= all) {                   // tail of the list: this block's own position range
       in_k[e] = -1;
       out_k[e] = -1;
-      in_m[e] = -1;
-      out_m[e] = -1;
+      if (!conv) {
+        in_m[e] = -1;
+        out_m[e] = -1;
+      }
     }
   }
 }
@@ -802,18 +808,33 @@ conv_assign_kernel(const int32_t *__restrict__ indices, int n, Geom g, int trans
 __global__ void __launch_bounds__(kBlock)
 conv_stage2_kernel(const int32_t *__restrict__ slot_of, const int32_t *__restrict__ slot_out,
                    int n, int n_out, int32_t *__restrict__ pair_fwd,
-                   int32_t *__restrict__ pair_bwd) {
+                   int32_t *__restrict__ pair_bwd, int32_t *__restrict__ groupcount = nullptr) {
+  // groupcount[k][block]: pairs of offset k among this block's 256 input rows = the entries of
+  // ConvAlgo.Native list k that fall into the group (subm_lists_kernel turns them into offsets)
+  __shared__ int lds_wave[kBlock / 64];
   const int i = blockIdx.x * kBlock + threadIdx.x;
   const int k = blockIdx.y;
-  if (i >= n) return;
-  const size_t pos = static_cast<size_t>(k) * n + i;
-  const int slot = slot_of[pos];
   int oid = -1;
-  if (slot >= 0) {
-    oid = slot_out[slot];
-    pair_fwd[static_cast<size_t>(k) * n_out + oid] = i;
+  if (i < n) {
+    const size_t pos = static_cast<size_t>(k) * n + i;
+    const int slot = slot_of[pos];
+    if (slot >= 0) {
+      oid = slot_out[slot];
+      pair_fwd[static_cast<size_t>(k) * n_out + oid] = i;
+    }
+    pair_bwd[pos] = oid;
   }
-  pair_bwd[pos] = oid;
+  if (groupcount) {
+    const unsigned long long bal = __ballot(oid >= 0);
+    if ((threadIdx.x & 63) == 0) lds_wave[threadIdx.x >> 6] = __popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int sum = 0;
+#pragma unroll
+      for (int w = 0; w < kBlock / 64; ++w) sum += lds_wave[w];
+      groupcount[static_cast<size_t>(k) * gridDim.x + blockIdx.x] = sum;
+    }
+  }
 }
 
 // mask[row][w] bit k = (table[k][row] >= 0)  (indices.py:652-676)
@@ -1028,7 +1049,7 @@ size_t conv_max_out(int n_in, int ndim, const int *ksize, const int *stride, con
 
 struct ConvWs {
   Table t;
-  int32_t *slot_out, *slot_of, *blockcount, *blockoff, *d_nout;
+  int32_t *slot_out, *slot_of, *blockcount, *blockoff, *d_nout, *groupcount;
   int nblk;
   size_t bytes;
 };
@@ -1050,6 +1071,7 @@ ConvWs carve_conv_ws(void *ws, int n_in, int ndim, const int *ksize, const int *
   w.blockcount = cv.take<int32_t>(static_cast<size_t>(kv) * w.nblk);
   w.blockoff = cv.take<int32_t>(static_cast<size_t>(kv) * w.nblk);
   w.d_nout = cv.take<int32_t>(2);      // [0] number of outputs, [1] hash-table overflow flag
+  w.groupcount = cv.take<int32_t>(static_cast<size_t>(kv) * div_up(n_in > 0 ? n_in : 1, kBlock));
   w.bytes = cv.off;
   return w;
 }
@@ -1571,8 +1593,12 @@ int spx_conv_rulebook_count(const int32_t *indices, int n_in, int ndim, int batc
   if (n_in == 0) return 0;
   ConvWs w = carve_conv_ws(ws, n_in, ndim, ksize, stride, dilation, transposed,
                            keys_fit_u32(g.batch, g.out_dims, 4));
-  SPX_HIP(table_clear(w.t, s));
-  SPX_HIP(hipMemsetAsync(w.d_nout, 0, 2 * sizeof(int32_t), s));
+  {
+    FillList fills;                      // table and flags in one launch
+    table_fill(fills, w.t);
+    fills.add(w.d_nout, 2 * sizeof(int32_t), 0u);
+    SPX_HIP(fills.launch(s));
+  }
   const dim3 grid1(div_up(n_in, kBlock), g.kv);
   hipLaunchKernelGGL(conv_stage1_kernel, grid1, dim3(kBlock), 0, s, indices, n_in, g, transposed,
                      w.t, w.slot_of, w.d_nout + 1);
@@ -1606,12 +1632,20 @@ int spx_conv_rulebook_fill(const int32_t *indices, int n_in, int ndim, int batch
             "workspace too small");
   SPX_CHECK(pair_fwd && pair_bwd && out_indices, "out_indices, pair_fwd and pair_bwd are required");
   const int kv = g.kv, words = div_up(kv, 32);
+  const int ngroups = div_up(n_in > 0 ? n_in : 1, kBlock);
+  static const int version = env_int("SPX_CONV_V", 2);          // tuning knob (A/B runs)
+  // second form: the Native lists come from subm_lists_kernel (conv mode) over the 256-row pair counts
+  // stage 2 leaves behind -- no count / scan launches, no -1 pre-fill of the lists
+  const bool v2 = version >= 2 && (pair_native || num_per_loc) && ngroups <= 16384 && kv <= 128;
   FillList fills;                                           // every fill of this call: one launch
-  if (num_per_loc) fills.add(num_per_loc, sizeof(int32_t) * kv, 0u);
-  if (pair_native && n_in > 0)
-    fills.add(pair_native, sizeof(int32_t) * 2 * static_cast<size_t>(kv) * n_in, 0xFFFFFFFFu);
+  if (!v2) {
+    if (num_per_loc) fills.add(num_per_loc, sizeof(int32_t) * kv, 0u);
+    if (pair_native && n_in > 0)
+      fills.add(pair_native, sizeof(int32_t) * 2 * static_cast<size_t>(kv) * n_in, 0xFFFFFFFFu);
+  }
   if (n_in > 0 && n_out > 0)
     fills.add(pair_fwd, sizeof(int32_t) * static_cast<size_t>(kv) * n_out, 0xFFFFFFFFu);
+  if (v2 && n_in == 0 && num_per_loc) fills.add(num_per_loc, sizeof(int32_t) * kv, 0u);
   SPX_HIP(fills.launch(s));
   if (n_in == 0) return 0;
   ConvWs w = carve_conv_ws(ws, n_in, ndim, ksize, stride, dilation, transposed,
@@ -1621,7 +1655,7 @@ int spx_conv_rulebook_fill(const int32_t *indices, int n_in, int ndim, int batch
                      w.slot_of, w.t, w.nblk, w.blockoff, w.slot_out, out_indices);
   const dim3 grid1(div_up(n_in, kBlock), kv);
   hipLaunchKernelGGL(conv_stage2_kernel, grid1, dim3(kBlock), 0, s, w.slot_of, w.slot_out, n_in,
-                     n_out, pair_fwd, pair_bwd);
+                     n_out, pair_fwd, pair_bwd, v2 ? w.groupcount : nullptr);
   {
     const int na = mask_fwd ? n_out : 0, nb = mask_bwd ? n_in : 0;
     if (na + nb > 0)
@@ -1629,6 +1663,13 @@ int spx_conv_rulebook_fill(const int32_t *indices, int n_in, int ndim, int batch
                          na, mask_fwd, pair_bwd, nb, mask_bwd, kv, words);
   }
   SPX_LAUNCH_CHECK();
+  if (v2) {
+    SPX_CHECK(!pair_native || num_per_loc, "num_per_loc is required with pair_native");
+    hipLaunchKernelGGL(subm_lists_kernel, dim3(w.nblk, kv), dim3(kBlock), 0, s, pair_bwd, kv, n_in, ngroups,
+                       w.groupcount, pair_native, num_per_loc, 0, 1);
+    SPX_LAUNCH_CHECK();
+    return 0;
+  }
   if (pair_native) {
     SPX_CHECK(num_per_loc, "num_per_loc is required with pair_native");
     if (launch_native_lists(pair_bwd, 1, kv, n_in, kv, w.nblk, w.blockcount, w.blockoff,

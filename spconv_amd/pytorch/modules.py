@@ -72,13 +72,24 @@ class SparseSequential(SparseModule):
         self._register(str(len(self._modules)) if name is None else name, module)
 
     def forward(self, input):
-        for module in self._modules.values():
+        from spconv_amd.pytorch import norm
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            module = mods[i]
+            i += 1
             if is_spconv_module(module):
                 input = module(input)
             elif isinstance(input, SparseConvTensor):
                 # dense layers see the [N, C] feature matrix; skipped for empty tensors
                 if input.indices.shape[0] != 0:
-                    input = input.replace_feature(module(input.features))
+                    if norm.supported(input.features, module):
+                        # BatchNorm1d (+ the ReLU right behind it) in the streaming kernels of csrc/norm.hip
+                        fuse = i < len(mods) and type(mods[i]) is nn.ReLU
+                        input = input.replace_feature(norm.batch_norm(input.features, module, relu=fuse))
+                        i += 1 if fuse else 0
+                    else:
+                        input = input.replace_feature(module(input.features))
             else:
                 input = module(input)
         return input

@@ -1,0 +1,111 @@
+"""BatchNorm1d (+ ReLU) on the feature matrix of a SparseConvTensor through the HIP kernels of
+csrc/norm.hip.
+
+The reference leaves normalisation to torch: ``SparseSequential`` hands ``.features`` to whatever dense
+module comes next (spconv/pytorch/modules.py:131-145) and ``SparseBatchNorm`` is ``nn.BatchNorm1d`` on
+features (:147-160).  Same here -- any module still works -- but a plain ``nn.BatchNorm1d`` (and a
+``nn.ReLU`` right behind it) on CUDA features of a supported shape takes this path instead of torch's
+channels-last kernels, which are 4-5x slower on MI355X at backbone shapes.
+Semantics follow ``torch.nn.BatchNorm1d.forward``: batch statistics when training (or when the module
+keeps no running estimates), running estimates otherwise, ``momentum=None`` = cumulative average,
+``num_batches_tracked`` counted.  ``SPCONV_AMD_FUSED_BN=0`` switches the path off.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+from torch import nn
+
+from spconv_amd import _lib
+
+ENABLED = os.environ.get("SPCONV_AMD_FUSED_BN", "1") != "0"
+_DT = {torch.float16: _lib.DTYPE_F16, torch.bfloat16: _lib.DTYPE_BF16, torch.float32: _lib.DTYPE_F32}
+
+
+def supported(features: torch.Tensor, bn: nn.Module) -> bool:
+    """Plain BatchNorm1d (not a subclass with its own forward, e.g. SyncBatchNorm) on a contiguous
+    CUDA [N, C] matrix whose rows split into 16-byte pieces."""
+    if not ENABLED or type(bn) is not nn.BatchNorm1d or not features.is_cuda or features.dim() != 2:
+        return False
+    if features.dtype not in _DT or bn._forward_hooks or bn._forward_pre_hooks or bn._backward_hooks:
+        return False            # (user hooks fire on the module call: keep torch's path for them)
+    C = features.shape[1]
+    return C == bn.num_features and C % (4 if features.dtype == torch.float32 else 8) == 0 and C <= 256
+
+
+def _f32(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """Affine parameters as fp32 (a `.half()` model keeps them in fp16; the kernels read fp32)."""
+    if t is None:
+        return None
+    return t if t.dtype == torch.float32 else t.float()
+
+
+class _BatchNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu):
+        L = _lib.load()
+        x = x.contiguous()
+        n, C = x.shape
+        dev = x.device
+        y = torch.empty_like(x)
+        w32, b32 = _f32(weight), _f32(bias)
+        rm = running_mean if (running_mean is None or running_mean.dtype == torch.float32) else running_mean.float()
+        rv = running_var if (running_var is None or running_var.dtype == torch.float32) else running_var.float()
+        stats = torch.empty((2, C), dtype=torch.float32, device=dev)
+        ws = torch.empty((max(L.spx_batchnorm_ws_bytes(n, C), 16),), dtype=torch.uint8, device=dev)
+        stream = torch._C._cuda_getCurrentRawStream(dev.index)
+        p = lambda t: None if t is None else t.data_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(L.spx_batchnorm_fwd(x.data_ptr(), y.data_ptr(), n, C, _DT[x.dtype], p(w32), p(b32), p(rm),
+                                           p(rv), int(training), float(momentum), float(eps), int(relu),
+                                           stats[0].data_ptr(), stats[1].data_ptr(), ws.data_ptr(), ws.numel(),
+                                           stream))
+        if training:
+            if rm is not None and rm is not running_mean:
+                running_mean.copy_(rm)
+            if rv is not None and rv is not running_var:
+                running_var.copy_(rv)
+            mean, invstd = stats[0], stats[1]
+        else:
+            mean, invstd = rm, torch.rsqrt(rv + eps)
+        ctx.save_for_backward(x, w32, b32, mean, invstd)
+        ctx.training, ctx.relu = bool(training), bool(relu)
+        ctx.wdtype = None if weight is None else weight.dtype
+        ctx.bdtype = None if bias is None else bias.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.load()
+        x, w32, b32, mean, invstd = ctx.saved_tensors
+        n, C = x.shape
+        dev = x.device
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        grads = torch.empty((2, C), dtype=torch.float32, device=dev)
+        ws = torch.empty((max(L.spx_batchnorm_ws_bytes(n, C), 16),), dtype=torch.uint8, device=dev)
+        p = lambda t: None if t is None else t.data_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(L.spx_batchnorm_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), n, C, _DT[x.dtype], p(w32),
+                                           p(b32), mean.data_ptr(), invstd.data_ptr(), int(ctx.training),
+                                           int(ctx.relu), grads[0].data_ptr(), grads[1].data_ptr(), ws.data_ptr(),
+                                           ws.numel(), torch._C._cuda_getCurrentRawStream(dev.index)))
+        dw = None if ctx.wdtype is None else grads[0].to(ctx.wdtype)
+        db = None if ctx.bdtype is None else grads[1].to(ctx.bdtype)
+        return dx, dw, db, None, None, None, None, None, None
+
+
+def batch_norm(features: torch.Tensor, bn: nn.BatchNorm1d, relu: bool = False) -> torch.Tensor:
+    """``relu(bn(features))`` (relu optional) with torch.nn.BatchNorm1d's bookkeeping."""
+    momentum = 0.0 if bn.momentum is None else bn.momentum
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+        if bn.momentum is None:
+            momentum = 1.0 / float(bn.num_batches_tracked)
+    use_batch = bn.training or (bn.running_mean is None and bn.running_var is None)
+    update = bn.training and bn.track_running_stats
+    return _BatchNormFn.apply(features, bn.weight, bn.bias, bn.running_mean if (update or not use_batch) else None,
+                              bn.running_var if (update or not use_batch) else None, use_batch, momentum, bn.eps,
+                              relu)

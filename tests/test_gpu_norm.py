@@ -1,0 +1,107 @@
+"""BatchNorm1d (+ fused ReLU) over sparse-tensor features (csrc/norm.hip, spconv_amd/pytorch/norm.py)
+against torch.nn.BatchNorm1d evaluated in fp32 on the same (rounded) inputs: output, input gradient,
+affine gradients, running statistics, evaluation mode, and the SparseSequential hook."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(bn32, x32, dy32, relu):
+    x = x32.clone().requires_grad_(True)
+    y = bn32(x)
+    if relu:
+        y = torch.relu(y)
+    y.backward(dy32)
+    return y.detach(), x.grad, bn32.weight.grad, bn32.bias.grad
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+@pytest.mark.parametrize("n,C", [(100_003, 16), (40_000, 64), (7_777, 128), (5_000, 48), (300, 256), (1, 32)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_batchnorm_training_matches_torch(cuda, dtype, tol, n, C, relu):
+    from spconv_amd.pytorch import norm
+    if dtype == torch.float32 and C % 4:
+        pytest.skip("shape")
+    torch.manual_seed(n + C)
+    x = (torch.randn(n, C, device=cuda) * 1.7 + torch.linspace(-3, 3, C, device=cuda)).to(dtype)
+    dy = torch.randn(n, C, device=cuda).to(dtype)
+    bn = nn.BatchNorm1d(C, eps=1e-3, momentum=0.01).to(cuda)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    ref = copy.deepcopy(bn).float()
+    assert norm.supported(x, bn)
+    xg = x.clone().requires_grad_(True)
+    if n == 1:
+        with pytest.raises(ValueError):
+            ref(x.float())            # torch refuses one value per channel in training; so do we not: skip
+        return
+    y = norm.batch_norm(xg, bn, relu=relu)
+    y.backward(dy)
+    y_ref, dx_ref, dw_ref, db_ref = _ref(ref, x.float(), dy.float(), relu)
+    scale = lambda t: float(t.abs().max()) + 1e-12
+    assert float((y.float() - y_ref).abs().max()) <= tol * scale(y_ref)
+    assert float((xg.grad.float() - dx_ref).abs().max()) <= tol * scale(dx_ref)
+    assert float((bn.weight.grad - dw_ref).abs().max()) <= max(tol, 1e-4) * scale(dw_ref)
+    assert float((bn.bias.grad - db_ref).abs().max()) <= max(tol, 1e-4) * scale(db_ref)
+    assert torch.allclose(bn.running_mean, ref.running_mean, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(bn.running_var, ref.running_var, rtol=1e-4, atol=1e-5)
+    assert int(bn.num_batches_tracked) == 1
+
+
+def test_batchnorm_eval_mode_and_momentum_none(cuda):
+    from spconv_amd.pytorch import norm
+    torch.manual_seed(0)
+    C, n = 32, 9000
+    x = torch.randn(n, C, device=cuda).half()
+    bn = nn.BatchNorm1d(C, momentum=None).to(cuda)
+    ref = copy.deepcopy(bn)
+    for _ in range(3):                                   # cumulative moving average
+        norm.batch_norm(x, bn)
+        ref(x.float())
+    assert int(bn.num_batches_tracked) == 3
+    assert torch.allclose(bn.running_mean, ref.running_mean, atol=1e-4)
+    assert torch.allclose(bn.running_var, ref.running_var, rtol=1e-3, atol=1e-4)
+    bn.eval()
+    ref.eval()
+    xg = x.clone().requires_grad_(True)
+    y = norm.batch_norm(xg, bn, relu=True)
+    y.float().sum().backward()
+    xr = x.float().requires_grad_(True)
+    yr = torch.relu(ref(xr))
+    yr.sum().backward()
+    assert float((y.float() - yr).abs().max()) < 3e-3 * float(yr.abs().max())
+    assert float((xg.grad.float() - xr.grad).abs().max()) < 3e-3 * float(xr.grad.abs().max())
+
+
+def test_sparse_sequential_takes_the_fused_path(cuda, monkeypatch):
+    """Conv -> BatchNorm1d -> ReLU in a SparseSequential: same result with the streaming kernels and
+    with torch's BatchNorm (SPCONV_AMD_FUSED_BN=0), one launch set for BN + ReLU."""
+    import spconv_amd.pytorch as spconv
+    from spconv_amd.pytorch import norm
+    from spconv_amd.utils import synthetic
+    shape = [16, 40, 40]
+    idx = synthetic.lidar_like_scene(shape, 6000, 2, seed=1)
+    torch.manual_seed(1)
+    net = spconv.SparseSequential(spconv.SubMConv3d(8, 32, 3, bias=False, indice_key="a"), nn.BatchNorm1d(32),
+                                  nn.ReLU(), spconv.SparseConv3d(32, 64, 3, 2, 1, bias=False), nn.BatchNorm1d(64),
+                                  nn.ReLU()).to(cuda).half().train()
+    ref = copy.deepcopy(net)
+    f = torch.randn(idx.shape[0], 8, device=cuda).half()
+    calls = []
+    orig = norm.batch_norm
+    monkeypatch.setattr(norm, "batch_norm", lambda *a, **k: (calls.append(k.get("relu")), orig(*a, **k))[1])
+    y = net(spconv.SparseConvTensor(f, torch.from_numpy(idx).to(cuda), shape, 2))
+    y.features.float().square().sum().backward()
+    assert calls == [True, True]
+    monkeypatch.setattr(norm, "ENABLED", False)
+    yr = ref(spconv.SparseConvTensor(f, torch.from_numpy(idx).to(cuda), shape, 2))
+    yr.features.float().square().sum().backward()
+    assert float((y.features.float() - yr.features.float()).abs().max()) < 1e-2 * float(yr.features.float().abs().max())
+    for p, q in zip(net.parameters(), ref.parameters()):
+        assert float((p.grad.float() - q.grad.float()).abs().max()) <= 3e-2 * float(q.grad.float().abs().max()) + 1e-3

@@ -127,11 +127,13 @@ def test_spilled_tiles_read_through_the_pair_table(cuda):
     assert rel_err(b.float().cpu().numpy(), want.numpy()) < 2e-3
 
 
-def test_lidar_fixture_module_path_uses_the_plan_and_matches_the_oracle(cuda):
+def test_lidar_fixture_module_path_uses_the_plan_and_matches_the_oracle(cuda, monkeypatch):
     """Automatic mode on the reference's real-LiDAR fixture: the SubM rulebook is judged dense, the
     module's forward and the backward's dgrad run over the plan, results match the oracle."""
     import spconv_amd.pytorch as spconv
     from golden import lidar_scene
+    from spconv_amd.pytorch import ops
+    monkeypatch.setattr(ops, "_TILE_MODE", "auto")       # (off by default: the plain kernel is faster, DESIGN.md 6)
     idx, shape = lidar_scene()
     rng = np.random.default_rng(2)
     C = K = 64
