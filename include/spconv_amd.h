@@ -332,22 +332,25 @@ int spx_hash_items(void *table_keys, void *table_vals, int capacity, int key_byt
  * the same arithmetic (torch.nn.BatchNorm1d semantics: biased variance to normalise, unbiased for
  * the running estimate, `momentum`, `eps`, optional affine) as three streaming launches per pass.
  *   x, y, dy, dx      [n, C] row-major, dtype f16 / bf16 / f32, C a multiple of 8 (f32: 4), C <= 256
- *   weight, bias      [C] fp32 or NULL;  running_mean / running_var [C] fp32 or NULL (updated in place
- *                     when training, read when not)
+ *   weight, bias      [C] or NULL;  running_mean / running_var [C] or NULL (updated in place when
+ *                     training, read when not)
  *   save_mean / save_invstd [C] fp32: batch statistics for the backward pass (training)
  *   relu              fuse max(0, .) into the output (and its mask into the backward pass)
  *   ws                spx_batchnorm_ws_bytes(n, C) bytes */
 size_t spx_batchnorm_ws_bytes(int n, int C);
-int spx_batchnorm_fwd(const void *x, void *y, int n, int C, int dtype, const float *weight,
-                      const float *bias, float *running_mean, float *running_var, int training,
-                      float momentum, float eps, int relu, float *save_mean, float *save_invstd,
-                      void *ws, size_t ws_bytes, spx_stream_t stream);
-/* use_batch_stats = 1: `mean` / `invstd` are the saved batch statistics (training);
- * 0: running_mean and 1 / sqrt(running_var + eps) (evaluation mode with gradients). */
+/* weight / bias / running_mean / running_var: [C] vectors of dtype `param_dtype` (SPX_F32, or the
+ * 16-bit dtype of a model converted with .half() / .bfloat16()); any of them may be NULL. */
+int spx_batchnorm_fwd(const void *x, void *y, int n, int C, int dtype, const void *weight,
+                      const void *bias, void *running_mean, void *running_var, int param_dtype,
+                      int training, float momentum, float eps, int relu, float *save_mean,
+                      float *save_invstd, void *ws, size_t ws_bytes, spx_stream_t stream);
+/* use_batch_stats = 1: `mean` / `invstd` are the saved fp32 batch statistics (training);
+ * 0: fp32 copies of running_mean and 1 / sqrt(running_var + eps) (evaluation mode with gradients).
+ * dweight / dbias: [C] of `param_dtype`, or NULL. */
 int spx_batchnorm_bwd(const void *x, const void *dy, void *dx, int n, int C, int dtype,
-                      const float *weight, const float *bias, const float *mean, const float *invstd,
-                      int use_batch_stats, int relu, float *dweight, float *dbias, void *ws,
-                      size_t ws_bytes, spx_stream_t stream);
+                      const void *weight, const void *bias, int param_dtype, const float *mean,
+                      const float *invstd, int use_batch_stats, int relu, void *dweight, void *dbias,
+                      void *ws, size_t ws_bytes, spx_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -47,10 +47,10 @@ SIGNATURES = {
     "spx_igemm_dgrad_tiled": (ctypes.c_int, [vp, vp, vp, vp, vp] + [ctypes.c_int] * 7 + [vp]),
     "spx_batchnorm_ws_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "spx_batchnorm_fwd": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp,
-                                         ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int, vp, vp,
-                                         vp, ctypes.c_size_t, vp]),
-    "spx_batchnorm_bwd": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp,
-                                         ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_size_t, vp]),
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int,
+                                         vp, vp, vp, ctypes.c_size_t, vp]),
+    "spx_batchnorm_bwd": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int,
+                                         vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_size_t, vp]),
     "spx_mask_argsort_ws_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "spx_mask_argsort": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_size_t, vp]),
     "spx_native_to_table": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 5 + [vp, vp, vp]),

@@ -24,13 +24,16 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 template <int DT> struct Vec;       // 16 bytes of input -> VPL floats
 template <> struct Vec<SPX_F32> {
   static constexpr int VPL = 4;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
   static __device__ __forceinline__ void unpack(const u32x4 &v, float (&f)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) f[i] = __builtin_bit_cast(float, v[i]);
+    const f32x4 t = __builtin_bit_cast(f32x4, v);
+    f[0] = t.x;
+    f[1] = t.y;
+    f[2] = t.z;
+    f[3] = t.w;
   }
   static __device__ __forceinline__ u32x4 pack(const float (&f)[4]) {
-    return u32x4{__builtin_bit_cast(unsigned, f[0]), __builtin_bit_cast(unsigned, f[1]),
-                 __builtin_bit_cast(unsigned, f[2]), __builtin_bit_cast(unsigned, f[3])};
+    return __builtin_bit_cast(u32x4, f32x4{f[0], f[1], f[2], f[3]});
   }
 };
 template <> struct Vec<SPX_F16> {
@@ -75,6 +78,21 @@ template <> struct Vec<SPX_BF16> {
     return v;
   }
 };
+
+// Affine parameters and running estimates are [C] vectors in fp32 or in a 16-bit dtype (a model
+// converted with .half() / .bfloat16()): read / written through a runtime dtype code.  They are
+// touched once per block (staged into LDS) or once per channel, never per element.
+__device__ __forceinline__ float ldp(const void *p, int dt, int i) {
+  if (dt == SPX_F32) return static_cast<const float *>(p)[i];
+  const uint16_t h = static_cast<const uint16_t *>(p)[i];
+  if (dt == SPX_F16) return static_cast<float>(__builtin_bit_cast(_Float16, h));
+  return __builtin_bit_cast(float, static_cast<unsigned>(h) << 16);
+}
+__device__ __forceinline__ void stp(void *p, int dt, int i, float v) {
+  if (dt == SPX_F32) static_cast<float *>(p)[i] = v;
+  else if (dt == SPX_F16) static_cast<uint16_t *>(p)[i] = __builtin_bit_cast(uint16_t, static_cast<_Float16>(v));
+  else static_cast<uint16_t *>(p)[i] = static_cast<uint16_t>(Vec<SPX_BF16>::rne(v));
+}
 
 // A block owns rows [r0, r1); thread t reads the 16-byte piece (t % P) of rows r0 + t / P + i * (kT / P),
 // P = pieces per row = C / VPL (a power of two <= 64 is not required: kT / P rows per sweep, threads past
@@ -196,7 +214,7 @@ bn_partial_kernel(const u32x4 *__restrict__ x, int n, int C, float *__restrict__
 __global__ void __launch_bounds__(kT)
 bn_finalize_kernel(const float *__restrict__ partial, int G, int C, float eps, float momentum,
                    float *__restrict__ mean_out, float *__restrict__ invstd_out,
-                   float *__restrict__ running_mean, float *__restrict__ running_var) {
+                   void *__restrict__ running_mean, void *__restrict__ running_var, int pdt) {
   __shared__ float ln[kT], lm[kT], l2[kT];
   const int c = blockIdx.x;
   float n = 0.f, m = 0.f, M2 = 0.f;
@@ -232,23 +250,34 @@ bn_finalize_kernel(const float *__restrict__ partial, int G, int C, float eps, f
     const float var = cnt > 0.f ? l2[0] / cnt : 0.f;
     mean_out[c] = mean;
     invstd_out[c] = rsqrtf(var + eps);
-    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+    if (running_mean) stp(running_mean, pdt, c, (1.f - momentum) * ldp(running_mean, pdt, c) + momentum * mean);
     if (running_var) {
       const float unbiased = cnt > 1.f ? l2[0] / (cnt - 1.f) : var;
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+      stp(running_var, pdt, c, (1.f - momentum) * ldp(running_var, pdt, c) + momentum * unbiased);
     }
   }
 }
 
-// y = (x - mean) * invstd * w + b, optional ReLU.  stat_is_var: `invstd` holds a variance (inference
-// with the running estimate) and is turned into 1 / sqrt(var + eps) here.
+// y = x * scale[c] + shift[c] (scale = invstd * w, shift = b - mean * scale), optional ReLU.  The two
+// coefficient vectors are computed once per block into LDS.  stat_is_var: `stat2` holds a variance
+// (inference with the running estimate, dtype pdt like `stat1`) instead of the saved fp32 1 / std.
 template <int DT>
 __global__ void __launch_bounds__(kT)
 bn_apply_kernel(const u32x4 *__restrict__ x, u32x4 *__restrict__ y, long long pieces, int C,
-                const float *__restrict__ mean, const float *__restrict__ invstd,
-                const float *__restrict__ weight, const float *__restrict__ bias, float eps,
+                const void *__restrict__ stat1, const void *__restrict__ stat2,
+                const void *__restrict__ weight, const void *__restrict__ bias, int pdt, float eps,
                 int stat_is_var, int relu) {
   constexpr int VPL = Vec<DT>::VPL;
+  __shared__ __attribute__((aligned(16))) float l_sc[kT], l_sh[kT];
+  if (threadIdx.x < C) {
+    const int c = threadIdx.x;
+    const float mean = stat_is_var ? ldp(stat1, pdt, c) : static_cast<const float *>(stat1)[c];
+    const float is = stat_is_var ? rsqrtf(ldp(stat2, pdt, c) + eps) : static_cast<const float *>(stat2)[c];
+    const float sc = is * (weight ? ldp(weight, pdt, c) : 1.f);
+    l_sc[c] = sc;
+    l_sh[c] = (bias ? ldp(bias, pdt, c) : 0.f) - mean * sc;
+  }
+  __syncthreads();
   const int P = C / VPL;
   for (long long i = static_cast<long long>(blockIdx.x) * kT + threadIdx.x; i < pieces;
        i += static_cast<long long>(gridDim.x) * kT) {
@@ -257,9 +286,7 @@ bn_apply_kernel(const u32x4 *__restrict__ x, u32x4 *__restrict__ y, long long pi
     Vec<DT>::unpack(x[i], f);
 #pragma unroll
     for (int e = 0; e < VPL; ++e) {
-      const float is = stat_is_var ? rsqrtf(invstd[c0 + e] + eps) : invstd[c0 + e];
-      const float sc = is * (weight ? weight[c0 + e] : 1.f);
-      float v = (f[e] - mean[c0 + e]) * sc + (bias ? bias[c0 + e] : 0.f);
+      float v = f[e] * l_sc[c0 + e] + l_sh[c0 + e];
       if (relu) v = v > 0.f ? v : 0.f;
       f[e] = v;
     }
@@ -272,7 +299,7 @@ template <int DT>
 __global__ void __launch_bounds__(kT)
 bn_bwd_partial_kernel(const u32x4 *__restrict__ x, const u32x4 *__restrict__ dy, int n, int C,
                       const float *__restrict__ mean, const float *__restrict__ invstd,
-                      const float *__restrict__ weight, const float *__restrict__ bias, int relu,
+                      const void *__restrict__ weight, const void *__restrict__ bias, int pdt, int relu,
                       float *__restrict__ partial) {
   constexpr int VPL = Vec<DT>::VPL;
   __shared__ float lds[2][kT][VPL + 1];
@@ -285,8 +312,8 @@ bn_bwd_partial_kernel(const u32x4 *__restrict__ x, const u32x4 *__restrict__ dy,
     const int c = s.piece * VPL + i;
     mu[i] = s.active ? mean[c] : 0.f;
     is[i] = s.active ? invstd[c] : 0.f;
-    w[i] = (s.active && weight) ? weight[c] : 1.f;
-    bb[i] = (s.active && bias) ? bias[c] : 0.f;
+    w[i] = (s.active && weight) ? ldp(weight, pdt, c) : 1.f;
+    bb[i] = (s.active && bias) ? ldp(bias, pdt, c) : 0.f;
   }
   if (s.active) {
     for (int r = s.r0 + s.lane_row; r < s.r1; r += s.rows_per_sweep) {
@@ -312,8 +339,8 @@ bn_bwd_partial_kernel(const u32x4 *__restrict__ x, const u32x4 *__restrict__ dy,
 
 // sums[0][c] = sum dy (= dbias), sums[1][c] = sum dy * xhat (= dweight)
 __global__ void __launch_bounds__(kT)
-bn_bwd_finalize_kernel(const float *__restrict__ partial, int G, int C, float *__restrict__ sum_dy,
-                       float *__restrict__ sum_dy_xhat) {
+bn_bwd_finalize_kernel(const float *__restrict__ partial, int G, int C, float *__restrict__ sums,
+                       void *__restrict__ dweight, void *__restrict__ dbias, int pdt) {
   __shared__ float la[kT], lb[kT];
   const int c = blockIdx.x;
   float a = 0.f, b = 0.f;
@@ -332,23 +359,39 @@ bn_bwd_finalize_kernel(const float *__restrict__ partial, int G, int C, float *_
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    sum_dy[c] = la[0];
-    sum_dy_xhat[c] = lb[0];
+    sums[c] = la[0];                       // sum dy       (= dbias)
+    sums[C + c] = lb[0];                   // sum dy * xhat (= dweight)
+    if (dbias) stp(dbias, pdt, c, la[0]);
+    if (dweight) stp(dweight, pdt, c, lb[0]);
   }
 }
 
 // training: dx = w * invstd * (dy - sum_dy / n - xhat * sum_dy_xhat / n);  inference statistics
-// (use_batch_stats == 0): dx = w * invstd * dy
+// (use_batch_stats == 0): dx = w * invstd * dy.  Per-channel coefficients staged in LDS.
 template <int DT>
 __global__ void __launch_bounds__(kT)
 bn_bwd_apply_kernel(const u32x4 *__restrict__ x, const u32x4 *__restrict__ dy, u32x4 *__restrict__ dx,
                     long long pieces, int n, int C, const float *__restrict__ mean,
-                    const float *__restrict__ invstd, const float *__restrict__ weight,
-                    const float *__restrict__ bias, const float *__restrict__ sum_dy,
-                    const float *__restrict__ sum_dy_xhat, int relu, int use_batch_stats) {
+                    const float *__restrict__ invstd, const void *__restrict__ weight,
+                    const void *__restrict__ bias, int pdt, const float *__restrict__ sums, int relu,
+                    int use_batch_stats) {
   constexpr int VPL = Vec<DT>::VPL;
+  // xhat = x * l_a + l_b;  relu mask: xhat * l_w + l_bias <= 0;  dx = l_g * (dy' - l_c1 - xhat * l_c2)
+  __shared__ __attribute__((aligned(16))) float l_a[kT], l_b[kT], l_w[kT], l_bias[kT], l_g[kT], l_c1[kT], l_c2[kT];
+  if (threadIdx.x < C) {
+    const int c = threadIdx.x;
+    const float inv_n = (use_batch_stats && n > 0) ? 1.f / static_cast<float>(n) : 0.f;
+    const float w = weight ? ldp(weight, pdt, c) : 1.f;
+    l_a[c] = invstd[c];
+    l_b[c] = -mean[c] * invstd[c];
+    l_w[c] = w;
+    l_bias[c] = bias ? ldp(bias, pdt, c) : 0.f;
+    l_g[c] = w * invstd[c];
+    l_c1[c] = sums[c] * inv_n;
+    l_c2[c] = sums[C + c] * inv_n;
+  }
+  __syncthreads();
   const int P = C / VPL;
-  const float inv_n = n > 0 ? 1.f / static_cast<float>(n) : 0.f;
   for (long long i = static_cast<long long>(blockIdx.x) * kT + threadIdx.x; i < pieces;
        i += static_cast<long long>(gridDim.x) * kT) {
     const int c0 = static_cast<int>(i % P) * VPL;
@@ -358,12 +401,10 @@ bn_bwd_apply_kernel(const u32x4 *__restrict__ x, const u32x4 *__restrict__ dy, u
 #pragma unroll
     for (int e = 0; e < VPL; ++e) {
       const int c = c0 + e;
-      const float w = weight ? weight[c] : 1.f;
-      const float xh = (f[e] - mean[c]) * invstd[c];
+      const float xh = f[e] * l_a[c] + l_b[c];
       float gg = g[e];
-      if (relu && xh * w + (bias ? bias[c] : 0.f) <= 0.f) gg = 0.f;
-      const float corr = use_batch_stats ? (sum_dy[c] + xh * sum_dy_xhat[c]) * inv_n : 0.f;
-      f[e] = w * invstd[c] * (gg - corr);
+      if (relu && xh * l_w[c] + l_bias[c] <= 0.f) gg = 0.f;
+      f[e] = l_g[c] * (gg - l_c1[c] - xh * l_c2[c]);
     }
     dx[i] = Vec<DT>::pack(f);
   }
@@ -400,16 +441,18 @@ using namespace spx;
 extern "C" {
 
 size_t spx_batchnorm_ws_bytes(int n, int C) {
-  return align_up(static_cast<size_t>(bn_blocks(n)) * 3 * (C > 0 ? C : 1) * sizeof(float), 256) + 256;
+  // per-block partials (3 floats per channel) + the [2][C] sums of the backward pass
+  return align_up((static_cast<size_t>(bn_blocks(n)) * 3 + 2) * (C > 0 ? C : 1) * sizeof(float), 256) + 256;
 }
 
-int spx_batchnorm_fwd(const void *x, void *y, int n, int C, int dtype, const float *weight,
-                      const float *bias, float *running_mean, float *running_var, int training,
-                      float momentum, float eps, int relu, float *save_mean, float *save_invstd,
-                      void *ws, size_t ws_bytes, spx_stream_t stream) {
+int spx_batchnorm_fwd(const void *x, void *y, int n, int C, int dtype, const void *weight,
+                      const void *bias, void *running_mean, void *running_var, int param_dtype,
+                      int training, float momentum, float eps, int relu, float *save_mean,
+                      float *save_invstd, void *ws, size_t ws_bytes, spx_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   SPX_CHECK(bn_shape_ok(C, dtype), "batchnorm: C = %d must be a multiple of %d (<= 256), dtype f16/bf16/f32", C,
             dtype == SPX_F32 ? 4 : 8);
+  SPX_CHECK(param_dtype == SPX_F32 || param_dtype == SPX_F16 || param_dtype == SPX_BF16, "bad parameter dtype");
   if (n == 0) return 0;
   SPX_CHECK(x && y, "null tensor pointer");
   const int vpl = dtype == SPX_F32 ? 4 : 8;
@@ -425,17 +468,19 @@ int spx_batchnorm_fwd(const void *x, void *y, int n, int C, int dtype, const flo
     SPX_BN_DISPATCH(dtype, SPX_BN_PARTIAL);
 #undef SPX_BN_PARTIAL
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(kT), 0, s, partial, G, C, eps, momentum, save_mean,
-                       save_invstd, running_mean, running_var);
+                       save_invstd, running_mean, running_var, param_dtype);
 #define SPX_BN_APPLY(D)                                                                                    \
   hipLaunchKernelGGL(bn_apply_kernel<D>, dim3(stream_grid(pieces)), dim3(kT), 0, s, xv, yv, pieces, C,     \
-                     save_mean, save_invstd, weight, bias, eps, 0, relu)
+                     static_cast<const void *>(save_mean), static_cast<const void *>(save_invstd), weight,  \
+                     bias, param_dtype, eps, 0, relu)
     SPX_BN_DISPATCH(dtype, SPX_BN_APPLY);
 #undef SPX_BN_APPLY
   } else {
     SPX_CHECK(running_mean && running_var, "inference needs the running statistics");
 #define SPX_BN_APPLY(D)                                                                                    \
   hipLaunchKernelGGL(bn_apply_kernel<D>, dim3(stream_grid(pieces)), dim3(kT), 0, s, xv, yv, pieces, C,     \
-                     running_mean, running_var, weight, bias, eps, 1, relu)
+                     static_cast<const void *>(running_mean), static_cast<const void *>(running_var),      \
+                     weight, bias, param_dtype, eps, 1, relu)
     SPX_BN_DISPATCH(dtype, SPX_BN_APPLY);
 #undef SPX_BN_APPLY
   }
@@ -444,15 +489,17 @@ int spx_batchnorm_fwd(const void *x, void *y, int n, int C, int dtype, const flo
 }
 
 int spx_batchnorm_bwd(const void *x, const void *dy, void *dx, int n, int C, int dtype,
-                      const float *weight, const float *bias, const float *mean, const float *invstd,
-                      int use_batch_stats, int relu, float *dweight, float *dbias, void *ws,
-                      size_t ws_bytes, spx_stream_t stream) {
+                      const void *weight, const void *bias, int param_dtype, const float *mean,
+                      const float *invstd, int use_batch_stats, int relu, void *dweight, void *dbias,
+                      void *ws, size_t ws_bytes, spx_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   SPX_CHECK(bn_shape_ok(C, dtype), "batchnorm: unsupported C = %d / dtype", C);
-  SPX_CHECK(dweight && dbias && mean && invstd, "null pointer");
+  SPX_CHECK(param_dtype == SPX_F32 || param_dtype == SPX_F16 || param_dtype == SPX_BF16, "bad parameter dtype");
+  SPX_CHECK(mean && invstd, "null pointer");
+  const size_t pbytes = param_dtype == SPX_F32 ? 4 : 2;
   if (n == 0) {
-    SPX_HIP(hipMemsetAsync(dweight, 0, sizeof(float) * C, s));
-    SPX_HIP(hipMemsetAsync(dbias, 0, sizeof(float) * C, s));
+    if (dweight) SPX_HIP(hipMemsetAsync(dweight, 0, pbytes * C, s));
+    if (dbias) SPX_HIP(hipMemsetAsync(dbias, 0, pbytes * C, s));
     return 0;
   }
   SPX_CHECK(x && dy && dx && ws && ws_bytes >= spx_batchnorm_ws_bytes(n, C), "null pointer / workspace too small");
@@ -460,17 +507,18 @@ int spx_batchnorm_bwd(const void *x, const void *dy, void *dx, int n, int C, int
   const long long pieces = static_cast<long long>(n) * (C / vpl);
   const int G = bn_blocks(n);
   float *partial = static_cast<float *>(ws);
+  float *sums = partial + static_cast<size_t>(G) * 2 * C;      // [2][C] behind the partials
   const u32x4 *xv = static_cast<const u32x4 *>(x), *gv = static_cast<const u32x4 *>(dy);
 #define SPX_BN_BP(D)                                                                                        \
   hipLaunchKernelGGL(bn_bwd_partial_kernel<D>, dim3(G), dim3(kT), 0, s, xv, gv, n, C, mean, invstd, weight, \
-                     bias, relu, partial)
+                     bias, param_dtype, relu, partial)
   SPX_BN_DISPATCH(dtype, SPX_BN_BP);
 #undef SPX_BN_BP
-  // sum dy = dbias, sum dy * xhat = dweight: finalised straight into the caller's gradient buffers
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(kT), 0, s, partial, G, C, dbias, dweight);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(kT), 0, s, partial, G, C, sums, dweight, dbias,
+                     param_dtype);
 #define SPX_BN_BA(D)                                                                                        \
   hipLaunchKernelGGL(bn_bwd_apply_kernel<D>, dim3(stream_grid(pieces)), dim3(kT), 0, s, xv, gv,             \
-                     static_cast<u32x4 *>(dx), pieces, n, C, mean, invstd, weight, bias, dbias, dweight,    \
+                     static_cast<u32x4 *>(dx), pieces, n, C, mean, invstd, weight, bias, param_dtype, sums,  \
                      relu, use_batch_stats)
   SPX_BN_DISPATCH(dtype, SPX_BN_BA);
 #undef SPX_BN_BA

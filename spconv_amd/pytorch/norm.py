@@ -32,14 +32,17 @@ def supported(features: torch.Tensor, bn: nn.Module) -> bool:
     if features.dtype not in _DT or bn._forward_hooks or bn._forward_pre_hooks or bn._backward_hooks:
         return False            # (user hooks fire on the module call: keep torch's path for them)
     C = features.shape[1]
+    if _param_dtype(bn.weight, bn.bias, bn.running_mean, bn.running_var) not in _DT:
+        return False            # parameters and buffers of mixed dtypes: torch's path
     return C == bn.num_features and C % (4 if features.dtype == torch.float32 else 8) == 0 and C <= 256
 
 
-def _f32(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
-    """Affine parameters as fp32 (a `.half()` model keeps them in fp16; the kernels read fp32)."""
-    if t is None:
-        return None
-    return t if t.dtype == torch.float32 else t.float()
+def _param_dtype(*tensors) -> Optional[torch.dtype]:
+    """Common dtype of the module's parameter / buffer vectors (None when they disagree)."""
+    dts = {t.dtype for t in tensors if t is not None}
+    if not dts:
+        return torch.float32
+    return dts.pop() if len(dts) == 1 else None
 
 
 class _BatchNormFn(torch.autograd.Function):
@@ -50,50 +53,40 @@ class _BatchNormFn(torch.autograd.Function):
         n, C = x.shape
         dev = x.device
         y = torch.empty_like(x)
-        w32, b32 = _f32(weight), _f32(bias)
-        rm = running_mean if (running_mean is None or running_mean.dtype == torch.float32) else running_mean.float()
-        rv = running_var if (running_var is None or running_var.dtype == torch.float32) else running_var.float()
+        pdt = _param_dtype(weight, bias, running_mean, running_var)
         stats = torch.empty((2, C), dtype=torch.float32, device=dev)
         ws = torch.empty((max(L.spx_batchnorm_ws_bytes(n, C), 16),), dtype=torch.uint8, device=dev)
-        stream = torch._C._cuda_getCurrentRawStream(dev.index)
         p = lambda t: None if t is None else t.data_ptr()
         with torch.cuda.device(dev):
-            _lib.check(L.spx_batchnorm_fwd(x.data_ptr(), y.data_ptr(), n, C, _DT[x.dtype], p(w32), p(b32), p(rm),
-                                           p(rv), int(training), float(momentum), float(eps), int(relu),
-                                           stats[0].data_ptr(), stats[1].data_ptr(), ws.data_ptr(), ws.numel(),
-                                           stream))
+            _lib.check(L.spx_batchnorm_fwd(x.data_ptr(), y.data_ptr(), n, C, _DT[x.dtype], p(weight), p(bias),
+                                           p(running_mean), p(running_var), _DT[pdt], int(training), float(momentum),
+                                           float(eps), int(relu), stats[0].data_ptr(), stats[1].data_ptr(),
+                                           ws.data_ptr(), ws.numel(), torch._C._cuda_getCurrentRawStream(dev.index)))
         if training:
-            if rm is not None and rm is not running_mean:
-                running_mean.copy_(rm)
-            if rv is not None and rv is not running_var:
-                running_var.copy_(rv)
             mean, invstd = stats[0], stats[1]
         else:
-            mean, invstd = rm, torch.rsqrt(rv + eps)
-        ctx.save_for_backward(x, w32, b32, mean, invstd)
-        ctx.training, ctx.relu = bool(training), bool(relu)
-        ctx.wdtype = None if weight is None else weight.dtype
-        ctx.bdtype = None if bias is None else bias.dtype
+            mean, invstd = running_mean.float(), torch.rsqrt(running_var.float() + eps)
+        ctx.save_for_backward(x, weight, bias, mean, invstd)
+        ctx.training, ctx.relu, ctx.pdt = bool(training), bool(relu), pdt
         return y
 
     @staticmethod
     def backward(ctx, dy):
         L = _lib.load()
-        x, w32, b32, mean, invstd = ctx.saved_tensors
+        x, weight, bias, mean, invstd = ctx.saved_tensors
         n, C = x.shape
         dev = x.device
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        grads = torch.empty((2, C), dtype=torch.float32, device=dev)
+        dw = None if weight is None else torch.empty_like(weight)
+        db = None if bias is None else torch.empty_like(bias)
         ws = torch.empty((max(L.spx_batchnorm_ws_bytes(n, C), 16),), dtype=torch.uint8, device=dev)
         p = lambda t: None if t is None else t.data_ptr()
         with torch.cuda.device(dev):
-            _lib.check(L.spx_batchnorm_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), n, C, _DT[x.dtype], p(w32),
-                                           p(b32), mean.data_ptr(), invstd.data_ptr(), int(ctx.training),
-                                           int(ctx.relu), grads[0].data_ptr(), grads[1].data_ptr(), ws.data_ptr(),
-                                           ws.numel(), torch._C._cuda_getCurrentRawStream(dev.index)))
-        dw = None if ctx.wdtype is None else grads[0].to(ctx.wdtype)
-        db = None if ctx.bdtype is None else grads[1].to(ctx.bdtype)
+            _lib.check(L.spx_batchnorm_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), n, C, _DT[x.dtype], p(weight),
+                                           p(bias), _DT[ctx.pdt], mean.data_ptr(), invstd.data_ptr(),
+                                           int(ctx.training), int(ctx.relu), p(dw), p(db), ws.data_ptr(), ws.numel(),
+                                           torch._C._cuda_getCurrentRawStream(dev.index)))
         return dx, dw, db, None, None, None, None, None, None
 
 

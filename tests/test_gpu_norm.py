@@ -105,3 +105,31 @@ def test_sparse_sequential_takes_the_fused_path(cuda, monkeypatch):
     assert float((y.features.float() - yr.features.float()).abs().max()) < 1e-2 * float(yr.features.float().abs().max())
     for p, q in zip(net.parameters(), ref.parameters()):
         assert float((p.grad.float() - q.grad.float()).abs().max()) <= 3e-2 * float(q.grad.float().abs().max()) + 1e-3
+
+
+def test_half_model_parameters_are_read_in_place(cuda):
+    """`.half()` converts BatchNorm's parameters and buffers too: the kernels read / update them in that
+    dtype (no fp32 shadow copies), results match torch's fp16-parameter BatchNorm."""
+    from spconv_amd.pytorch import norm
+    torch.manual_seed(3)
+    n, C = 20_000, 64
+    x = torch.randn(n, C, device=cuda).half()
+    bn = nn.BatchNorm1d(C).to(cuda).half()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    ref = copy.deepcopy(bn)
+    dy = (torch.randn(n, C, device=cuda) * 0.01).half()       # (keeps the fp16 parameter gradients finite)
+    xg = x.clone().requires_grad_(True)
+    y = norm.batch_norm(xg, bn, relu=False)
+    y.backward(dy)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(dy)
+    assert bn.running_mean.dtype == torch.float16 and bn.weight.grad.dtype == torch.float16
+    assert float((y.float() - yr.float()).abs().max()) < 4e-3 * float(yr.float().abs().max())
+    assert float((xg.grad.float() - xr.grad.float()).abs().max()) < 6e-3 * float(xr.grad.float().abs().max())
+    assert torch.allclose(bn.running_mean.float(), ref.running_mean.float(), atol=2e-3)
+    assert torch.allclose(bn.running_var.float(), ref.running_var.float(), rtol=2e-3, atol=2e-3)
+    assert torch.allclose(bn.weight.grad.float(), ref.weight.grad.float(), rtol=2e-2, atol=2e-2)
+    assert torch.allclose(bn.bias.grad.float(), ref.bias.grad.float(), rtol=2e-2, atol=2e-2)
