@@ -136,6 +136,13 @@ int spx_table_to_native(const int32_t *table, int subm, int kv, int n, int32_t *
 
 /* -------------------------------------------------------------- convolution */
 
+/* Kernel volumes 33 .. 128 (the reference's multi-word masks, indices.py:1601-1618, ops.py:448,494-503)
+ * run as ceil(kv / 32) launches of the MFMA kernel whose partial sums travel through an fp32
+ * [n_dst, cout] scratch: pass spx_igemm_acc_bytes() bytes as `ws` to spx_igemm_fwd (n_dst = n_out,
+ * cout = K) / spx_igemm_dgrad (n_dst = n_in, cout = C).  0 for kv <= 32; without the scratch such
+ * layers take the generic (one thread per output) kernel. */
+size_t spx_igemm_acc_bytes(int n_dst, int cout, int kv);
+
 /* Output-stationary implicit GEMM (atomics-free):
  *   out[o,:] = sum_k [pair[k][o] >= 0] feat[pair[k][o],:] * W[:,k,:]^T  (+bias, act)
  * Replaces ConvGemmOps.implicit_gemm forward (csrc/sparse/convops.py:2073-2243,
@@ -148,7 +155,8 @@ int spx_table_to_native(const int32_t *table, int subm, int kv, int n, int32_t *
 int spx_igemm_fwd(const void *feat, const void *weight, void *out, const int32_t *pair,
                   const uint32_t *mask, const int32_t *argsort, int tile_order, int n_in, int n_out,
                   int C, int K, int kv, int dtype, int identity_k, const void *bias,
-                  int act, float act_alpha, spx_stream_t stream);
+                  int act, float act_alpha, void *ws, size_t ws_bytes,
+                  spx_stream_t stream);
 
 /* int8 inference forward.  Replaces the int8 branch of ConvGemmOps.implicit_gemm
  * (pytorch/ops.py:1540-1553,1631-1662, csrc/sparse/convops.py:2176-2205) as driven by the

@@ -57,8 +57,9 @@ SIGNATURES = {
     "spx_table_to_native_ws_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "spx_table_to_native": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp,
                                            ctypes.c_size_t, vp]),
-    "spx_igemm_fwd": (ctypes.c_int, [vp] * 6 + [ctypes.c_int] * 8 + [vp, ctypes.c_int,
-                                                                     ctypes.c_float, vp]),
+    "spx_igemm_acc_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "spx_igemm_fwd": (ctypes.c_int, [vp] * 6 + [ctypes.c_int] * 8 + [vp, ctypes.c_int, ctypes.c_float, vp,
+                                                                     ctypes.c_size_t, vp]),
     "spx_igemm_fwd_int8": (ctypes.c_int, [vp] * 6 + [ctypes.c_int] * 6 + [vp, vp, vp, ctypes.c_float,
                                                                        ctypes.c_int, ctypes.c_int,
                                                                        ctypes.c_float, vp]),

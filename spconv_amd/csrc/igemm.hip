@@ -51,6 +51,13 @@ struct GemmParams {
   int b_reverse;          // use weight slice kv-1-k for offset k (SubM dgrad)
   int tile_order;         // pair / mask are stored in tile order (row t of the tables belongs to
                           // destination row argsort[t]): rows sorted by mask keep coalesced table reads
+  // kernel volumes 33 .. 128 run as groups of <= 32 offsets (one mask word each): `pair` and `mask`
+  // point at the group's first table row / mask word, kbase is its first offset (weights are
+  // addressed with kbase + k, kv stays the whole kernel volume), mask_words the row stride of `mask`;
+  // partial sums travel between the launches of a layer in an fp32 [n_dst, COUT] scratch
+  int kbase, mask_words;
+  float *acc;             // fp32 scratch of a grouped layer, or null
+  int acc_mode;           // bit 0: add acc to the result, bit 1: store fp32 into acc instead of `out`
   int act;
   float act_alpha;
   // int8 inference epilogue (igemm_v4_kernel<.., DT = 2, ..>): bias is fp32 here
@@ -566,6 +573,8 @@ struct GemmRest {
   float add_scale;
   int out_dtype;
   int dbg;
+  float *acc;
+  int acc_mode;
 };
 
 template <int COUT, int MB, int DT, bool BT, int NKS = 2>
@@ -606,8 +615,13 @@ __device__ __forceinline__ void unpack_gemm_args(GemmParams &p, const void *argA
   p.CIN = CIN;
   p.kv = kv;
   p.identity_k = identity_k;
-  p.b_reverse = b_reverse & 1;          // the launch packs (reverse, tile order) into one preloaded SGPR
+  // the launch packs (reverse, tile order, mask stride, first offset of the group) into one preloaded SGPR
+  p.b_reverse = b_reverse & 1;
   p.tile_order = (b_reverse >> 1) & 1;
+  p.mask_words = ((b_reverse >> 2) & 3) + 1;
+  p.kbase = (b_reverse >> 4) & 127;
+  p.acc = rest.acc;
+  p.acc_mode = rest.acc_mode;
   p.out = rest.out;
   p.bias = rest.bias;
   p.strideK = rest.strideK;
@@ -752,7 +766,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   };
   auto load_b = [&](const StepIt &it) __attribute__((always_inline)) {
     const uint32_t tail = (!cfull && it.chunk == nchunk - 1) ? 0xffffffffu : 0u;
-    const int k = it.k < 0 ? 0 : it.k;
+    const int k = (it.k < 0 ? 0 : it.k) + p.kbase;
     const int kb = p.b_reverse ? p.kv - 1 - k : k;
     uint32_t so = static_cast<uint32_t>(kb) * static_cast<uint32_t>(p.strideK) * ES;
     if constexpr (!BT) so += static_cast<uint32_t>(it.chunk) * kRowBytes;
@@ -808,11 +822,11 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   it0.rest = 0;
   // the mask words head the longest dependency chain of the tile (mask -> pair words -> rows):
   // request them first, so they are not queued behind the 24 KB of identity-step loads
-  const __amdgpu_buffer_rsrc_t rM = make_rsrc(p.mask, p.mask ? pair_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rM = make_rsrc(p.mask, p.mask ? pair_bytes * p.mask_words : 0u);
   uint32_t mraw[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
-    mraw[mb] = __builtin_amdgcn_raw_buffer_load_b32(rM, goff[mb], 0, 0);
+    mraw[mb] = __builtin_amdgcn_raw_buffer_load_b32(rM, goff[mb] == kOob ? kOob : goff[mb] * p.mask_words, 0, 0);
   __builtin_amdgcn_sched_barrier(0);
   // identity step: start its loads before the mask words arrive.  Unconditional (a regular
   // conv has it0.k == -1 here and reads zero-sized resources) so that the wait for the mask
@@ -843,7 +857,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   SPX_STAMP(2);   // mask words arrived, tile mask exchanged
   uint32_t tilemask = lds_mask[0] | lds_mask[1] | lds_mask[2] | lds_mask[3];
   tilemask = __builtin_amdgcn_readfirstlane(tilemask);
-  if (p.kv < 32) tilemask &= (1u << p.kv) - 1u;
+  if (p.kv - p.kbase < 32) tilemask &= (1u << (p.kv - p.kbase)) - 1u;
   if (spec) {
     it0.rest = tilemask & ~(1u << p.identity_k);
   } else {
@@ -958,6 +972,26 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
         else bv[q] = to_float<BF16>(static_cast<const uint16_t *>(p.bias)[lgrp * CPL + q]);
       }
     }
+    if (p.acc_mode) {
+      // one group of a kernel volume > 32: partial sums come from / go to the fp32 scratch; bias and
+      // activation apply with the last group only (acc_mode bit 1 clear)
+      const __amdgpu_buffer_rsrc_t rS = make_rsrc(p.acc, static_cast<uint32_t>(p.n_dst) * (COUT * 4));
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const uint32_t so = grow[mb] < 0 ? kOob : static_cast<uint32_t>(grow[mb]) * (COUT * 4) + lgrp * (CPL * 4);
+        uint32_t prev[CPL];
+        if (p.acc_mode & 1) load_dwords<CPL>(prev, rS, so);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (p.acc_mode & 1) acc[nb][mb][e] += __builtin_bit_cast(float, prev[nb * 4 + e]);
+            prev[nb * 4 + e] = __builtin_bit_cast(uint32_t, static_cast<float>(acc[nb][mb][e]));
+          }
+        if (p.acc_mode & 2) store_dwords<CPL>(prev, rS, so);
+      }
+      if (p.acc_mode & 2) return;
+    }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
       uint32_t d[F32 ? CPL : CPL / 2];
@@ -1058,6 +1092,11 @@ constexpr size_t v4_smem_bytes() {
   return 2 * static_cast<size_t>(COUT) * kRowBytes + 64;   // two weight stages + 4 mask words
 }
 
+int v4_flags(const GemmParams &p) {
+  const int words = p.mask_words > 0 ? p.mask_words : 1;
+  return p.b_reverse | (p.tile_order << 1) | ((words - 1) << 2) | (p.kbase << 4);
+}
+
 bool v4_ok(const GemmParams &p, int es = 2, int out_es = 2) {
   const unsigned long long abytes = static_cast<unsigned long long>(p.n_src) * p.CIN * es;
   const unsigned long long pbytes = static_cast<unsigned long long>(p.n_dst) * 4ull;
@@ -1080,7 +1119,7 @@ int launch_v4(const GemmParams &p, hipStream_t s) {
 #define SPX_LAUNCH_V4(BTV, NKSV)                                                                     \
   hipLaunchKernelGGL((igemm_v4_kernel<COUT, MB, DT, BTV, NKSV>), dim3(ntiles), dim3(kThreads),          \
                      (v4_smem_bytes<COUT, MB>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,      \
-                     p.n_src, p.CIN, p.kv, p.identity_k, (p.b_reverse | (p.tile_order << 1)), r)
+                     p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(p), r)
   if (DT == 2 || p.strideD == 1) {
     if (half) SPX_LAUNCH_V4(false, 1);
     else SPX_LAUNCH_V4(false, 2);
@@ -2252,7 +2291,7 @@ int elem_bytes(int dtype) { return dtype == SPX_F32 ? 4 : (dtype == SPX_I8 ? 1 :
 bool mfma_ok(int dtype, int cin, int cout, int kv, const uint32_t *mask) {
   if (dtype != SPX_F16 && dtype != SPX_BF16 && dtype != SPX_F32) return false;
   if (cin % (dtype == SPX_F32 ? 4 : 8) != 0) return false;     // 16-byte lane pieces
-  if (kv > 32) return false;
+  if (kv > 128) return false;                                  // 33 .. 128: groups of 32 offsets
   (void)mask;
   return cout == 16 || cout == 32 || cout == 64 || cout == 128 || cout == 256;
 }
@@ -2303,12 +2342,45 @@ int dispatch_gather_gemm_f32(const GemmParams &p, hipStream_t s) {
   return -1;
 }
 
+int run_gather_gemm_single(const GemmParams &p, int dtype, hipStream_t s);
+
+// Kernel volumes 33 .. 128 (5x5x5, 4-d 3^4, ...): the reference covers them with multi-word masks
+// (indices.py:1601-1618, ops.py:448,494-503); here the layer runs as ceil(kv / 32) launches of the same
+// kernel, one mask word each, whose partial sums travel through an fp32 [n_dst, COUT] scratch -- the
+// result is rounded once, like a single launch.
 int run_gather_gemm(const GemmParams &p, int dtype, hipStream_t s) {
   if (p.n_dst == 0) return 0;
+  if (p.kv <= 32 || !mfma_ok(dtype, p.CIN, p.COUT, p.kv, p.mask) || !p.pair) return run_gather_gemm_single(p, dtype, s);
+  const int words = div_up(p.kv, 32);
+  const bool fits = static_cast<unsigned long long>(p.n_dst) * 4ull * words < 0x7fff0000ull &&
+                    static_cast<unsigned long long>(p.n_dst) * p.COUT * 4ull < 0x7fff0000ull &&
+                    v4_ok(p, dtype == SPX_F32 ? 4 : 2, dtype == SPX_F32 ? 4 : 2) && !p.argsort;
+  if (!fits || !p.acc) {
+    GemmParams q = p;                 // no scratch / beyond 32-bit offsets: the generic kernel
+    q.acc = nullptr;
+    return run_gather_gemm_single(q, dtype, s);
+  }
+  for (int g = 0; g < words; ++g) {
+    GemmParams q = p;
+    q.kbase = 32 * g;
+    q.pair = p.pair + static_cast<size_t>(32 * g) * p.n_dst;
+    q.mask = p.mask ? p.mask + g : nullptr;
+    q.mask_words = p.mask ? words : 1;
+    q.identity_k = (p.identity_k >= 32 * g && p.identity_k < 32 * g + 32) ? p.identity_k - 32 * g : -1;
+    q.acc_mode = (g > 0 ? 1 : 0) | (g < words - 1 ? 2 : 0);
+    if (int rc = run_gather_gemm_single(q, dtype, s)) return rc;
+  }
+  return 0;
+}
+
+int run_gather_gemm_single(const GemmParams &p, int dtype, hipStream_t s) {
+  if (p.n_dst == 0) return 0;
   static const int f32_mfma = env_int("SPX_F32_MFMA", 1);         // tuning knob (A/B runs)
-  if (dtype == SPX_F32 && f32_mfma && mfma_ok(dtype, p.CIN, p.COUT, p.kv, p.mask) && v4_ok(p, 4, 4))
+  const bool grouped = p.acc_mode != 0;
+  if (dtype == SPX_F32 && f32_mfma && mfma_ok(dtype, p.CIN, p.COUT, p.kv, p.mask) && v4_ok(p, 4, 4) &&
+      (p.kv <= 32 || grouped))
     return dispatch_gather_gemm_f32(p, s);
-  if (dtype != SPX_F32 && mfma_ok(dtype, p.CIN, p.COUT, p.kv, p.mask))
+  if (dtype != SPX_F32 && mfma_ok(dtype, p.CIN, p.COUT, p.kv, p.mask) && (p.kv <= 32 || grouped))
     return dtype == SPX_BF16 ? dispatch_gather_gemm<true>(p, s) : dispatch_gather_gemm<false>(p, s);
   if (p.tile_order) {
     set_error("tables in tile order are supported by the MFMA kernels only (channel counts / kernel volume)");
@@ -2433,6 +2505,8 @@ GemmRest rest_of(const GemmParams &p) {
   r.out_dtype = p.out_dtype;
   static const int dbg = env_int("SPX_V4_DBG", 0);
   r.dbg = dbg;
+  r.acc = p.acc;
+  r.acc_mode = p.acc_mode;
   return r;
 }
 
@@ -2450,12 +2524,12 @@ int launch_bwd(const GemmParams &p, const Wgrad2Params &q, int n_wgrad_blocks, h
   if (p.CIN * 2 <= 64)     // dgrad's reduction rows (dout channels) fit half a piece
     hipLaunchKernelGGL((igemm_bwd_kernel<COUT, MB, DT, 1>), dim3(n_dgrad + n_wgrad_blocks), dim3(kThreads),
                        (bwd_smem_bytes<COUT, MB>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,
-                       p.n_src, p.CIN, p.kv, p.identity_k, (p.b_reverse | (p.tile_order << 1)), rest_of(p),
+                       p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(p), rest_of(p),
                        wgrad_first ? ~n_wgrad_blocks : n_dgrad, q);
   else
     hipLaunchKernelGGL((igemm_bwd_kernel<COUT, MB, DT, 2>), dim3(n_dgrad + n_wgrad_blocks), dim3(kThreads),
                        (bwd_smem_bytes<COUT, MB>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,
-                       p.n_src, p.CIN, p.kv, p.identity_k, (p.b_reverse | (p.tile_order << 1)), rest_of(p),
+                       p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(p), rest_of(p),
                        wgrad_first ? ~n_wgrad_blocks : n_dgrad, q);
   SPX_LAUNCH_CHECK();
   return 0;
@@ -2479,10 +2553,14 @@ using namespace spx;
 
 extern "C" {
 
+size_t spx_igemm_acc_bytes(int n_dst, int cout, int kv) {
+  return kv > 32 ? align_up(static_cast<size_t>(n_dst > 0 ? n_dst : 1) * cout * sizeof(float), 256) : 0;
+}
+
 int spx_igemm_fwd(const void *feat, const void *weight, void *out, const int32_t *pair,
                   const uint32_t *mask, const int32_t *argsort, int tile_order, int n_in, int n_out, int C,
                   int K, int kv, int dtype, int identity_k, const void *bias, int act,
-                  float act_alpha, spx_stream_t stream) {
+                  float act_alpha, void *ws, size_t ws_bytes, spx_stream_t stream) {
   SPX_CHECK(C > 0 && K > 0 && kv > 0 && n_in >= 0 && n_out >= 0, "bad sizes");
   if (n_out == 0) return 0;                                   // empty scene: nothing to write
   SPX_CHECK((feat || n_in == 0) && weight && out, "null tensor pointer");
@@ -2508,6 +2586,7 @@ int spx_igemm_fwd(const void *feat, const void *weight, void *out, const int32_t
   p.tile_order = (tile_order && argsort) ? 1 : 0;
   p.act = act;
   p.act_alpha = act_alpha;
+  if (ws && ws_bytes >= spx_igemm_acc_bytes(n_out, K, kv) && kv > 32) p.acc = static_cast<float *>(ws);
   return run_gather_gemm(p, dtype, static_cast<hipStream_t>(stream));
 }
 
@@ -2603,19 +2682,19 @@ int spx_igemm_dgrad_tiled(const void *dout, const void *weight, void *din, const
 
 size_t spx_igemm_dgrad_ws_bytes(int C, int K, int kv, int dtype) {
   (void)C; (void)K; (void)kv; (void)dtype;
-  return 0;  // the weight transpose happens inside the kernel (LDS staging)
+  return 0;  // the weight transpose happens inside the kernel (LDS staging); kv > 32: spx_igemm_acc_bytes
 }
 
 int spx_igemm_dgrad(const void *dout, const void *weight, void *din, const int32_t *pair,
                     const uint32_t *mask, const int32_t *argsort, int tile_order, int n_out, int n_in, int C,
                     int K, int kv, int dtype, int subm, void *ws, size_t ws_bytes,
                     spx_stream_t stream) {
-  (void)ws; (void)ws_bytes;
   if (n_in == 0) return 0;                                    // empty input: no gradient rows
   SPX_CHECK((dout || n_out == 0) && weight && din, "null tensor pointer");
   SPX_CHECK(pair || kv == 1, "pair table required");
   GemmParams p = dgrad_params(dout, weight, din, pair, mask, argsort, n_out, n_in, C, K, kv, subm);
   p.tile_order = (tile_order && argsort) ? 1 : 0;
+  if (ws && ws_bytes >= spx_igemm_acc_bytes(n_in, C, kv) && kv > 32) p.acc = static_cast<float *>(ws);
   return run_gather_gemm(p, dtype, static_cast<hipStream_t>(stream));
 }
 
@@ -2809,7 +2888,7 @@ int spx_igemm_bwd(const void *feat, const void *dout, const void *weight, void *
                              static_cast<unsigned long long>(n_in) * C * 2ull < 0x7fff0000ull &&
                              static_cast<unsigned long long>(n_in) * 4ull < 0x7fff0000ull;
   const bool fusable = fuse && (dtype == SPX_F16 || dtype == SPX_BF16) && C % 8 == 0 && K % 8 == 0 &&
-                       mfma_ok(dtype, p.CIN, p.COUT, kv, mask) && p.COUT <= 128 && v4_ok(p) &&
+                       mfma_ok(dtype, p.CIN, p.COUT, kv, mask) && kv <= 32 && p.COUT <= 128 && v4_ok(p) &&
                        small_offsets && kv <= 128 && n_in > 0 && n_out > 0;
   if (!fusable) {
     if (spx_igemm_dgrad(dout, weight, din, pair, mask, argsort, tile_order, n_out, n_in, C, K, kv, dtype, subm,

@@ -490,7 +490,7 @@ def igemm_fwd(features: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
     # falling to the one-thread-per-output generic kernel (two orders of magnitude slower): the
     # extra columns cost a few bytes per row and contribute exact zeros.
     C = -(-C0 // _lane_mult(features.dtype)) * _lane_mult(features.dtype)
-    K = _round_cout(K0) if kv <= 32 else K0
+    K = _round_cout(K0) if kv <= 128 else K0
     if K and (C != C0 or K != K0):
         features = _pad_last(features, C)
         filters = _pad_first(_pad_last(filters, C), K)
@@ -503,10 +503,12 @@ def igemm_fwd(features: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
     out = torch.empty((n_out, K), dtype=features.dtype, device=features.device)
     if bias is not None:
         bias = bias.to(features.dtype).contiguous()
+    ws = _ws(L.spx_igemm_acc_bytes(n_out, K, kv), features.device) if kv > 32 else None   # fp32 partial sums
     _lib.check(L.spx_igemm_fwd(features.data_ptr(), filters.data_ptr(), out.data_ptr(),
                                _ptr(pair), _ptr(mask), _ptr(argsort), int(tile_order), features.shape[0], n_out,
                                C, K, kv, _dtype_code(features), identity_k, _ptr(bias),
-                               int(act_type), float(act_alpha), _stream(features)))
+                               int(act_type), float(act_alpha), _ptr(ws), 0 if ws is None else ws.numel(),
+                               _stream(features)))
     return out if K == K0 else out[:, :K0].contiguous()
 
 
@@ -528,7 +530,7 @@ def igemm_dgrad(out_bp: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
         return din
     # same padding rule as igemm_fwd: here K is the reduction length and C the output width
     K = -(-K0 // _lane_mult(out_bp.dtype)) * _lane_mult(out_bp.dtype)
-    C = _round_cout(C0) if kv <= 32 else C0
+    C = _round_cout(C0) if kv <= 128 else C0
     if C and (C != C0 or K != K0):
         out_bp = _pad_last(out_bp, K)
         filters = _pad_first(_pad_last(filters, C), K)
@@ -538,7 +540,7 @@ def igemm_dgrad(out_bp: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
     filters = filters.contiguous()
     din = torch.empty((n_in, C), dtype=out_bp.dtype, device=out_bp.device)
     code = _dtype_code(out_bp)
-    ws = _ws(L.spx_igemm_dgrad_ws_bytes(C, K, kv, code), out_bp.device)
+    ws = _ws(max(L.spx_igemm_dgrad_ws_bytes(C, K, kv, code), L.spx_igemm_acc_bytes(n_in, C, kv)), out_bp.device)
     _lib.check(L.spx_igemm_dgrad(out_bp.data_ptr(), filters.data_ptr(), din.data_ptr(), _ptr(pair),
                                  _ptr(mask), _ptr(argsort), int(tile_order), out_bp.shape[0], n_in, C, K, kv, code,
                                  int(subm), ws.data_ptr(), ws.numel(), _stream(out_bp)))
@@ -597,7 +599,7 @@ def igemm_bwd(features: torch.Tensor, out_bp: torch.Tensor, filters: torch.Tenso
     if tile_plan is not None and not tile_order and need_din and _halo_ok(out_bp.dtype, K0, C0, kvf):
         din = igemm_dgrad(out_bp, filters, table, mask, argsort, features.shape[0], subm, tile_plan)
         return din, igemm_wgrad(features, out_bp, filters.shape, native, num_per_loc, subm, plan)
-    if not need_din or K0 % m or C0 not in _MFMA_COUT:
+    if not need_din or K0 % m or C0 not in _MFMA_COUT or kvf > 32:      # (kv > 32: dgrad in groups of 32 offsets)
         din = igemm_dgrad(out_bp, filters, table, mask, argsort, features.shape[0], subm,
                           tile_order=tile_order) if need_din else None
         return din, igemm_wgrad(features, out_bp, filters.shape, native, num_per_loc, subm, plan)

@@ -118,6 +118,28 @@ def test_large_kernel_volume_two_mask_words(cuda):
     _check("dw", dw, dw_ref, 1e-3)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("ksize,stride,pad,subm,C,K", [
+    ([5, 5, 5], [1] * 3, [2] * 3, True, 32, 64),       # kv = 125: four mask words
+    ([5, 3, 3], [1] * 3, [2, 1, 1], True, 64, 64),     # kv = 45
+    ([4, 4, 4], [2] * 3, [1] * 3, False, 16, 32),      # kv = 64, regular conv
+    ([3, 5, 3], [2, 1, 2], [1, 2, 1], False, 48, 40),  # kv = 45, padded channel counts
+])
+def test_kernel_volumes_33_to_128_run_in_groups_of_32(cuda, dtype, ksize, stride, pad, subm, C, K):
+    """Kernel volumes beyond one mask word (the reference's multi-word masks): forward, dgrad and
+    wgrad on the MFMA kernels (ceil(kv / 32) launches through an fp32 scratch) against the oracle."""
+    shape = [18, 20, 22]
+    idx, ref, f, w, dout = _case(shape, 2500, 2, C, K, ksize, stride, pad, [1] * 3, subm, dtype)
+    out_ref = oracle.indice_conv(f, w, ref["pair"], ref["num"], ref["n_out"], subm=subm)
+    din_ref, dw_ref = oracle.indice_conv_backward(f, w, dout, ref["pair"], ref["num"], subm=subm)
+    rb, out, din, dw = _run_gpu(cuda, idx, 2, shape, ksize, stride, pad, [1] * 3, subm, False, f, w, dout, dtype)
+    assert rb.mask_fwd.shape[1] == (rb.kv + 31) // 32 > 1
+    tol = TOL[dtype]
+    _check("out", out, out_ref, tol)
+    _check("din", din, din_ref, tol)
+    _check("dw", dw, dw_ref, tol)
+
+
 @pytest.mark.parametrize("subm", [True, False])
 def test_mask_sorted_order_gives_same_result(cuda, subm):
     """mask_argsort only permutes which workgroup owns a row; results must not change."""
