@@ -2067,8 +2067,7 @@ wgrad_tr_kernel(Wgrad2Params p) {
 constexpr int kW3J = 64;          // pairs per chunk
 constexpr int kW3Stride = 80;     // floats per LDS row
 
-__global__ void __launch_bounds__(kThreads)
-wgrad_f32_kernel(Wgrad2Params p) {
+__device__ __forceinline__ void wgrad_f32_body(const Wgrad2Params &p, int block) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *sD = reinterpret_cast<float *>(smem);
   float *sF = sD + kW3J * kW3Stride;
@@ -2076,7 +2075,7 @@ wgrad_f32_kernel(Wgrad2Params p) {
   const int lrow = lane & 15, lgrp = lane >> 4;
   const int wk = wave >> 1, wc = wave & 1;
   const int ntile = p.tiles_k * p.tiles_c;
-  const int w = blockIdx.x / ntile, tile = blockIdx.x - w * ntile;
+  const int w = block / ntile, tile = block - w * ntile;
   const int kk0 = (tile / p.tiles_c) * kWT, c0 = (tile % p.tiles_c) * kWT;
   const int32_t *__restrict__ rec = p.plan2 + plan2_wg(w);
   const int32_t *__restrict__ segs = p.plan2 + plan2_seg(p.G, p.kv);
@@ -2167,6 +2166,11 @@ wgrad_f32_kernel(Wgrad2Params p) {
   }
 }
 
+__global__ void __launch_bounds__(kThreads)
+wgrad_f32_kernel(Wgrad2Params p) {
+  wgrad_f32_body(p, blockIdx.x);
+}
+
 // Backward of one layer in ONE launch: the wgrad ranges (the longer, streaming workgroups)
 // are dispatched first, the dgrad tiles after them.  The two halves only share read-only inputs; at ~100k voxels each of them
 // is latency-bound with idle issue slots and idle HBM bandwidth, so running them side by side
@@ -2188,7 +2192,8 @@ igemm_bwd_kernel(const void *argA, const void *argB, const uint32_t *arg_mask,
                      identity_k, b_reverse, rest);
     igemm_v4_body<COUT, MB, DT, true, NKS>(p, n_dgrad < 0 ? b - nw : b);
   } else {
-    wgrad_tr_body<DT == 1, 1>(wp, n_dgrad < 0 ? b : b - n_dgrad);
+    if constexpr (DT == 3) wgrad_f32_body(wp, n_dgrad < 0 ? b : b - n_dgrad);
+    else wgrad_tr_body<DT == 1, 1>(wp, n_dgrad < 0 ? b : b - n_dgrad);
   }
 }
 
@@ -2511,9 +2516,11 @@ GemmRest rest_of(const GemmParams &p) {
 }
 
 // LDS of the fused backward launch: the dgrad weight ring or one wgrad stage pair
-template <int COUT, int MB>
+template <int COUT, int MB, int DT = 0>
 constexpr size_t bwd_smem_bytes() {
-  const size_t a = v4_smem_bytes<COUT, MB>(), b = 2 * static_cast<size_t>(kW2J) * 128;
+  const size_t a = v4_smem_bytes<COUT, MB>();
+  const size_t b = DT == 3 ? 2 * static_cast<size_t>(kW3J) * kW3Stride * sizeof(float)
+                           : 2 * static_cast<size_t>(kW2J) * 128;
   return a > b ? a : b;
 }
 
@@ -2521,14 +2528,14 @@ template <int COUT, int MB, int DT>
 int launch_bwd(const GemmParams &p, const Wgrad2Params &q, int n_wgrad_blocks, hipStream_t s) {
   const int n_dgrad = div_up(p.n_dst, 64 * MB);
   static const int wgrad_first = env_int("SPX_BWD_WGRAD_FIRST", 1);   // tuning knob (A/B runs)
-  if (p.CIN * 2 <= 64)     // dgrad's reduction rows (dout channels) fit half a piece
+  if (p.CIN * (DT == 3 ? 4 : 2) <= 64)     // dgrad's reduction rows (dout channels) fit half a piece
     hipLaunchKernelGGL((igemm_bwd_kernel<COUT, MB, DT, 1>), dim3(n_dgrad + n_wgrad_blocks), dim3(kThreads),
-                       (bwd_smem_bytes<COUT, MB>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,
+                       (bwd_smem_bytes<COUT, MB, DT>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,
                        p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(p), rest_of(p),
                        wgrad_first ? ~n_wgrad_blocks : n_dgrad, q);
   else
     hipLaunchKernelGGL((igemm_bwd_kernel<COUT, MB, DT, 2>), dim3(n_dgrad + n_wgrad_blocks), dim3(kThreads),
-                       (bwd_smem_bytes<COUT, MB>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,
+                       (bwd_smem_bytes<COUT, MB, DT>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,
                        p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(p), rest_of(p),
                        wgrad_first ? ~n_wgrad_blocks : n_dgrad, q);
   SPX_LAUNCH_CHECK();
@@ -2887,9 +2894,13 @@ int spx_igemm_bwd(const void *feat, const void *dout, const void *weight, void *
   const bool small_offsets = static_cast<unsigned long long>(n_out) * K * 2ull < 0x7fff0000ull &&
                              static_cast<unsigned long long>(n_in) * C * 2ull < 0x7fff0000ull &&
                              static_cast<unsigned long long>(n_in) * 4ull < 0x7fff0000ull;
-  const bool fusable = fuse && (dtype == SPX_F16 || dtype == SPX_BF16) && C % 8 == 0 && K % 8 == 0 &&
-                       mfma_ok(dtype, p.CIN, p.COUT, kv, mask) && kv <= 32 && p.COUT <= 128 && v4_ok(p) &&
-                       small_offsets && kv <= 128 && n_in > 0 && n_out > 0;
+  const int es = dtype == SPX_F32 ? 4 : 2, lanes = 16 / es;
+  const bool offsets_fit = static_cast<unsigned long long>(n_out) * K * es < 0x7fff0000ull &&
+                           static_cast<unsigned long long>(n_in) * C * es < 0x7fff0000ull && small_offsets;
+  static const int f32_mfma = env_int("SPX_F32_MFMA", 1);
+  const bool fusable = fuse && (dtype == SPX_F16 || dtype == SPX_BF16 || (dtype == SPX_F32 && f32_mfma)) &&
+                       C % lanes == 0 && K % lanes == 0 && mfma_ok(dtype, p.CIN, p.COUT, kv, mask) && kv <= 32 &&
+                       p.COUT <= 128 && v4_ok(p, es, es) && offsets_fit && n_in > 0 && n_out > 0;
   if (!fusable) {
     if (spx_igemm_dgrad(dout, weight, din, pair, mask, argsort, tile_order, n_out, n_in, C, K, kv, dtype, subm,
                         nullptr, 0, stream))
@@ -2920,10 +2931,14 @@ int spx_igemm_bwd(const void *feat, const void *dout, const void *weight, void *
   q.tiles_k = div_up(K, kWT);
   q.G = wgrad_groups(n_in);
   const int ntile = q.tiles_c * q.tiles_k;
-  const int rc = dtype == SPX_BF16 ? dispatch_bwd<1>(p, q, q.G * ntile, s) : dispatch_bwd<0>(p, q, q.G * ntile, s);
+  const int rc = dtype == SPX_F32 ? dispatch_bwd<3>(p, q, q.G * ntile, s)
+                                  : (dtype == SPX_BF16 ? dispatch_bwd<1>(p, q, q.G * ntile, s)
+                                                       : dispatch_bwd<0>(p, q, q.G * ntile, s));
   if (rc) return rc;
   const dim3 rgrid2(kv * 256 < 512 ? kv * 256 : 512, ntile);   // block-stride over the work list
-  if (dtype == SPX_F16)
+  if (dtype == SPX_F32)
+    hipLaunchKernelGGL(wgrad_reduce2_kernel<float>, rgrid2, dim3(kRedThreads), 0, s, q, static_cast<float *>(dw));
+  else if (dtype == SPX_F16)
     hipLaunchKernelGGL(wgrad_reduce2_kernel<h16>, rgrid2, dim3(kRedThreads), 0, s, q, static_cast<h16 *>(dw));
   else
     hipLaunchKernelGGL(wgrad_reduce2_kernel<b16>, rgrid2, dim3(kRedThreads), 0, s, q, static_cast<b16 *>(dw));
