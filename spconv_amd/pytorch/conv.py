@@ -16,6 +16,8 @@ bookkeeping object (``IndiceData`` / ``ImplicitGemmIndiceData``) is stored.
 from __future__ import annotations
 
 import math
+import contextlib
+import sys
 import time
 from typing import List, Optional, Tuple, Union
 
@@ -27,6 +29,7 @@ from torch.nn.init import calculate_gain
 from torch.nn.parameter import Parameter
 
 from spconv_amd.constants import MODULE_DO_SORT, SAVED_WEIGHT_LAYOUT
+from spconv_amd.tools import save_debug_data
 from spconv_amd.pytorch import functional as Fsp
 from spconv_amd.pytorch import ops
 from spconv_amd.pytorch.core import (ConvAlgo, ImplicitGemmIndiceData, IndiceData, Rulebook,
@@ -331,11 +334,21 @@ class SparseConvolution(SparseModule):
             if input.benchmark:
                 torch.cuda.synchronize()
                 t = time.time()
-            rb, _ = ops.build_rulebook(indices, batch_size, spatial_shape, self.kernel_size,
-                                       self.stride, self.padding, self.dilation,
-                                       self.output_padding, self.subm, self.transposed,
-                                       do_sort=MODULE_DO_SORT,
-                                       need_native=torch.is_grad_enabled() or self.algo == ConvAlgo.Native)
+            try:
+                with _timed(input, sparse_unique_name or name, "gen_pairs"):
+                    rb, _ = ops.build_rulebook(indices, batch_size, spatial_shape, self.kernel_size,
+                                               self.stride, self.padding, self.dilation,
+                                               self.output_padding, self.subm, self.transposed,
+                                               do_sort=MODULE_DO_SORT,
+                                               need_native=torch.is_grad_enabled() or self.algo == ConvAlgo.Native)
+            except Exception:
+                # reference conv.py:289-297: say what was asked for and keep the inputs for a report
+                print(f"[Exception|rulebook] indices={tuple(indices.shape)},bs={batch_size},ss={spatial_shape},"
+                      f"algo={algo},ksize={self.kernel_size},stride={self.stride},padding={self.padding},"
+                      f"dilation={self.dilation},subm={self.subm},transpose={self.transposed}", file=sys.stderr)
+                save_debug_data((indices.detach().cpu().numpy(), batch_size, spatial_shape, self.kernel_size,
+                                 self.stride, self.padding, self.dilation, self.subm, self.transposed))
+                raise
             if input.benchmark:
                 torch.cuda.synchronize()
                 out_tensor.benchmark_record[name]["indice_gen_time"].append(time.time() - t)
@@ -350,6 +363,19 @@ class SparseConvolution(SparseModule):
             t = time.time()
 
         num_out = outids.shape[0]
+        with _timed(input, sparse_unique_name or name, "forward"):
+            out_features = self._run_kernels(grad_path, is_int8, input, features, weight, rb, num_out, algo,
+                                             bias_for_infer, act_type, act_alpha, act_beta, output_scale,
+                                             channel_scale, add_input)
+        if bias_for_training is not None:
+            out_features += bias_for_training
+        if grad_path and not training and add_input is None:
+            out_features = _apply_act(out_features, act_type, act_alpha, act_beta)
+        return self._finish(input, out_tensor, out_features, outids, indice_dict, out_spatial_shape, add_input,
+                            is_int8, name, features, t if input.benchmark else None)
+
+    def _run_kernels(self, grad_path, is_int8, input, features, weight, rb, num_out, algo, bias_for_infer,
+                     act_type, act_alpha, act_beta, output_scale, channel_scale, add_input):
         if grad_path:
             # autograd path; bias is added outside the kernel like the reference
             pair_native = ops.attach_rulebook(rb.pair_native, rb)
@@ -373,13 +399,13 @@ class SparseConvolution(SparseModule):
             tp = ops.tile_plan(rb, "fwd") if (not self.inverse and argsort is None) else None
             out_features = ops.igemm_fwd(features, w, table, mask, argsort, num_out, ident,
                                          bias_for_infer, act_type, act_alpha, plan=tp, tile_order=tile_order)
-        if bias_for_training is not None:
-            out_features += bias_for_training
-        if grad_path and not training and add_input is None:
-            out_features = _apply_act(out_features, act_type, act_alpha, act_beta)
-        if input.benchmark:
+        return out_features
+
+    def _finish(self, input, out_tensor, out_features, outids, indice_dict, out_spatial_shape, add_input,
+                is_int8, name, features, t0):
+        if t0 is not None:
             torch.cuda.synchronize()
-            out_tensor.benchmark_record[name]["time"].append(time.time() - t)
+            out_tensor.benchmark_record[name]["time"].append(time.time() - t0)
             out_tensor.benchmark_record[name]["num_points"].append(features.shape[0])
             out_tensor.benchmark_record[name]["num_out_points"].append(out_features.shape[0])
         if not self.subm and not self.inverse and self.record_voxel_count:
@@ -395,6 +421,17 @@ class SparseConvolution(SparseModule):
                 _apply_act(out_tensor.features + add_input.features, self.act_type,
                            self.act_alpha, self.act_beta))
         return out_tensor
+
+
+def _timed(input: SparseConvTensor, layer: Optional[str], what: str):
+    """Timer context of the tensor's CUDAKernelTimer ("<layer>.<what>"), or a no-op."""
+    timer = input._timer
+    if timer is None or not timer.enable:
+        return contextlib.nullcontext()
+    stack = contextlib.ExitStack()
+    stack.enter_context(timer.namespace(layer or "conv"))
+    stack.enter_context(timer.record(what))
+    return stack
 
 
 def _conv_cls(ndim: int, doc: str):

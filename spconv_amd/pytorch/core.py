@@ -177,7 +177,8 @@ class SparseConvTensor(metaclass=torch.fx.ProxyableClassMeta):
         batch index in column 0; spatial_shape: ndim ints; batch_size > 0.  The remaining
         arguments exist for signature compatibility (reference core.py:133-144):
         ``grid``/``voxel_num`` are carried along, ``benchmark`` records per-layer wall time,
-        ``permanent_thrust_allocator``/``enable_timer`` have no effect here.
+        ``permanent_thrust_allocator`` has no effect here; ``enable_timer`` attaches a
+        ``spconv_amd.tools.CUDAKernelTimer`` (HIP events) that every sparse layer records into.
         """
         if not _under_fx_trace(features, indices, batch_size):
             ndim = indices.shape[1] - 1
@@ -197,6 +198,9 @@ class SparseConvTensor(metaclass=torch.fx.ProxyableClassMeta):
         self.benchmark_record: Dict[str, Any] = {}
         self.thrust_allocator = None
         self._timer = None
+        if enable_timer:
+            from spconv_amd.tools import CUDAKernelTimer
+            self._timer = CUDAKernelTimer(True)
         self.force_algo = force_algo
         self.int8_scale: Optional[np.ndarray] = None
 

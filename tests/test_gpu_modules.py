@@ -231,3 +231,23 @@ def test_cfg4_second_style_backbone_batch_vs_oracle(cuda):
             a_idx[:, 0] = 0
             assert torch.equal(a_idx, one.indices.cpu())
             assert rel_err(one.features.float().cpu().numpy(), a_f.numpy()) < 2e-3
+
+
+def test_enable_timer_records_every_sparse_layer(cuda):
+    """SparseConvTensor(enable_timer=True): each sparse conv records its rulebook build and its
+    kernels under "<layer name>.gen_pairs" / "<layer name>.forward" (HIP events, ms)."""
+    import spconv_amd.pytorch as spconv
+    from spconv_amd.tools import CUDAKernelTimer
+    net = spconv.SparseSequential(spconv.SubMConv3d(8, 16, 3, indice_key="a"), nn.ReLU(),
+                                  spconv.SubMConv3d(16, 16, 3, indice_key="a"),
+                                  spconv.SparseConv3d(16, 32, 3, 2, 1)).to(cuda).half().eval()
+    spconv.assign_name_for_sparse_modules(net)
+    idx = scene([20, 20, 20], 1500, 1, 2)
+    x = spconv.SparseConvTensor(torch.randn(idx.shape[0], 8, device=cuda).half(), torch.from_numpy(idx).to(cuda),
+                                [20, 20, 20], 1, enable_timer=True)
+    with torch.no_grad():
+        y = net(x)
+    res = y._timer.get_all_pair_time()
+    assert set(res) == {"0.gen_pairs", "0.forward", "2.forward", "3.gen_pairs", "3.forward"}, res
+    assert all(v > 0 for v in res.values())
+    assert set(CUDAKernelTimer.collect_by_name("forward", res)) == {"0.forward", "2.forward", "3.forward"}

@@ -188,3 +188,23 @@ def test_bench_gpus_flag_becomes_a_launcher(tmp_path):
         bench.maybe_spawn(bench.parse(["--gpus", "4"]), ["--gpus", "4"])
     finally:
         del os.environ["WORLD_SIZE"]
+
+
+def test_kernel_timer_api_and_debug_dump(tmp_path, monkeypatch):
+    """spconv/tools.py:23-78 surface; on a box without a GPU the timer is inert like the reference's
+    CPU-only build.  SPCONV_DEBUG_SAVE_PATH pickles what a failing call was given."""
+    import pickle
+    from spconv_amd import tools
+    t = tools.CUDAKernelTimer(True)
+    with t.namespace("layer"), t.record("forward"):
+        pass
+    res = t.get_all_pair_time()
+    assert isinstance(res, dict) and (not t.enable) == (res == {})
+    assert tools.CUDAKernelTimer.collect_by_name("b", {"a.b.c": 1.0, "a.c": 2.0}) == {"a.b.c": 1.0}
+    x = spconv.SparseConvTensor(torch.zeros(2, 4), torch.zeros(2, 4, dtype=torch.int32), [4, 4, 4], 1,
+                                enable_timer=True)
+    assert x._timer is not None and x.replace_feature(x.features)._timer is x._timer
+    path = tmp_path / "dump.pkl"
+    monkeypatch.setattr(tools, "SPCONV_DEBUG_SAVE_PATH", str(path))
+    tools.save_debug_data(("indices", 3))
+    assert pickle.load(open(path, "rb")) == ("indices", 3)
