@@ -2312,6 +2312,8 @@ int dispatch_gather_gemm(const GemmParams &p, hipStream_t s) {
     // 56 vs 75 us at 200 k, equal on dense scenes)
     // (threshold: at 50 k rows 128-row tiles already win at every width, sparse and dense)
     const int mb = mb_forced ? mb_forced : ((p.n_dst <= 32 * 1024 || p.COUT == 128) ? 1 : 2);
+    if (mb == 4 && p.COUT == 64) return launch_v4<64, 4, BF16 ? 1 : 0>(p, s);     // experiment: 256-row tiles
+    if (mb == 4 && p.COUT == 32) return launch_v4<32, 4, BF16 ? 1 : 0>(p, s);
     switch (p.COUT) {
       case 16: return mb == 1 ? launch_v4<16, 1, BF16 ? 1 : 0>(p, s) : launch_v4<16, 2, BF16 ? 1 : 0>(p, s);
       case 32: return mb == 1 ? launch_v4<32, 1, BF16 ? 1 : 0>(p, s) : launch_v4<32, 2, BF16 ? 1 : 0>(p, s);
