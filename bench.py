@@ -455,6 +455,7 @@ def run_layer(args, D: Dist):
 
     launch = "eager"
     graphs = None         # one step per replay, one graph per scene
+    graph_grads = []      # the gradient tensor each per-scene graph writes
     graph_u = None        # U steps per replay over consecutive scenes (N = 1 only)
     graph_w = None        # U steps per replay, all on scene 0 (the Infinity-Cache-resident loop)
     U = max(1, args.graph_steps) if world == 1 else 1
@@ -474,6 +475,7 @@ def run_layer(args, D: Dist):
                 with torch.cuda.graph(g):
                     compute(sc)
                 graphs.append(g)
+                graph_grads.append(net.weight.grad)   # each graph writes dW into its own pool buffer
             if U > 1:
                 graph_u = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph_u):
@@ -488,6 +490,7 @@ def run_layer(args, D: Dist):
             print(f"[bench] graph capture failed ({type(e).__name__}: {e}); using eager launches",
                   file=sys.stderr)
             graphs = graph_u = graph_w = None
+            graph_grads = []
             torch.cuda.synchronize()
     if graph_u is None:
         U = 1
@@ -501,6 +504,7 @@ def run_layer(args, D: Dist):
         counter[0] += 1
         if graphs is not None:
             graphs[i].replay()
+            net.weight.grad = graph_grads[i]                       # the dW this replay produced
         else:
             compute(scenes[i])
         if bucket is not None:
@@ -810,7 +814,7 @@ def run_net(args, D: Dist):
                       "scenes_rotated": S, "launch": "eager", "parallelism": f"dp{world}", "ranks_seen": ranks_seen,
                       "dist_backend": D.backend if world > 1 else None},
            "roofline": roofline_obj("step", total, ms, "whole step: rulebook builders + igemm_v4 / igemm_bwd / "
-                                    "wgrad_reduce2 of every layer (+ torch BatchNorm / ReLU at config 4)", None,
+                                    "wgrad_reduce2 of every layer (+ the bn_* BatchNorm+ReLU kernels at config 4)", None,
                                     {"memory_level": "HBM (activations of a step exceed the Infinity Cache)",
                                      "note": "algorithmic bytes = conv layers only (SURVEY.md 8d formulas per layer); "
                                              "the time also holds rulebook builds, normalisation layers and host "
