@@ -1774,120 +1774,126 @@ __host__ __device__ inline int plan2_red(int G, int kv) {
   return (plan2_seg(G, kv) + 3 * (G + kv) + 3) & ~3;
 }
 
+// exclusive prefix sum of one int per thread over the whole kW2MaxG-thread block (wave scans + the
+// wave totals through LDS); returns the prefix, `total` = sum over the block.  One barrier.
+__device__ __forceinline__ int plan_scan(int v, int *wtot, int &total) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int u = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += u;
+  }
+  if (lane == 63) wtot[wv] = incl;
+  __syncthreads();
+  int prefix = 0;
+  total = 0;
+#pragma unroll
+  for (int w = 0; w < kW2MaxG / 64; ++w) {
+    const int t = wtot[w];
+    if (w < wv) prefix += t;
+    total += t;
+  }
+  return prefix + incl - v;
+}
+
+// One block.  Everything is a prefix sum or a closed form of the kv list lengths: the pairs of all
+// lists, laid end to end, are cut into G equal ranges (one per workgroup of the first stage); a
+// segment is the part of one list inside one range.  A range finds its first list by bisection
+// and walks on from there (1-2 lists at kv = 27), the number of ranges that touch list k is
+// floor((end-1)/per) - floor(start/per) + 1.
 __global__ void __launch_bounds__(kW2MaxG)
 wgrad_plan2_kernel(const int32_t *__restrict__ num, int n_in, int kv, int subm, int G,
                    int32_t *__restrict__ plan) {
-  __shared__ int start[130], cnt[129], nseg_of[kW2MaxG + 1], per_s, total_s;
+  __shared__ int start[130], kfirst[130], kcount[130], ritems[130];
+  __shared__ int wtot[4][kW2MaxG / 64];
   const int tid = threadIdx.x;
-  if (tid < kv) cnt[tid] = list_count(num, kv, subm, n_in, tid);
+  const int c = tid < kv ? list_count(num, kv, subm, n_in, tid) : 0;
+  int total;
+  const int st = plan_scan(c, wtot[0], total);
+  if (tid <= kv) start[tid] = st;               // start[kv] = total (threads >= kv add nothing)
+  const int per = total > 0 ? (total + G - 1) / G : 1;
   __syncthreads();
-  if (tid == 0) {
-    int run = 0;
-    for (int k = 0; k < kv; ++k) {
-      start[k] = run;
-      run += cnt[k];
-    }
-    start[kv] = run;
-    total_s = run;
-    per_s = run > 0 ? (run + G - 1) / G : 1;
-  }
-  __syncthreads();
-  const int per = per_s, total = total_s;
-  int lo = 0, hi = 0, mine = 0;
+
+  // ---- ranges: first list, number of segments
+  int lo = 0, hi = 0, mine = 0, k0 = 0;
   if (tid < G) {
     lo = min(total, tid * per);
     hi = min(total, lo + per);
-    for (int k = 0; k < kv; ++k) mine += (min(hi, start[k + 1]) > max(lo, start[k])) ? 1 : 0;
-    nseg_of[tid] = mine;
-  }
-  __syncthreads();
-  {
-    // exclusive scan of the per-range segment counts over the whole block (1024 threads: wave scans
-    // + 16 wave totals) -- a single thread walking G entries was most of this launch's 15 us
-    __shared__ int wtot[kW2MaxG / 64];
-    const int lane = tid & 63, wv = tid >> 6;
-    const int c = tid < G ? mine : 0;
-    int incl = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int u = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += u;
-    }
-    if (lane == 63) wtot[wv] = incl;
-    __syncthreads();
-    int prefix = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < kW2MaxG / 64; ++w) {
-      if (w < wv) prefix += wtot[w];
-      total += wtot[w];
-    }
-    if (tid < G) nseg_of[tid] = prefix + incl - c;
-    if (tid == 0) {
-      nseg_of[G] = total;
-      plan[0] = total;
-      plan[1] = per;
+    if (hi > lo) {
+      int a = 0, b = kv;                        // smallest k with start[k + 1] > lo
+      while (a < b) {
+        const int m = (a + b) >> 1;
+        if (start[m + 1] > lo) b = m;
+        else a = m + 1;
+      }
+      k0 = a;
+      for (int k = k0; k < kv && start[k] < hi; ++k)
+        mine += (min(hi, start[k + 1]) > max(lo, start[k])) ? 1 : 0;
     }
   }
-  __syncthreads();
+  int nseg_total;
+  const int seg0 = plan_scan(tid < G ? mine : 0, wtot[1], nseg_total);
+  if (tid == 0) {
+    plan[0] = nseg_total;
+    plan[1] = per;
+  }
   int32_t *seg = plan + plan2_seg(G, kv);
   if (tid < G) {
-    int s = nseg_of[tid];
+    int sg = seg0;
     int32_t *rec = plan + plan2_wg(tid);
-    rec[0] = s;
-    rec[1] = mine;
-    rec[2] = 0;
-    rec[3] = 0;
-    rec[4] = 0;
+    int r2 = 0, r3 = 0, r4 = 0;
     bool first = true;
-    for (int k = 0; k < kv; ++k) {
-      const int a = max(lo, start[k]), b = min(hi, start[k + 1]);
-      if (b > a) {
-        seg[3 * s] = k;
-        seg[3 * s + 1] = a - start[k];
-        seg[3 * s + 2] = b - start[k];
-        if (first) {
-          rec[2] = k;
-          rec[3] = a - start[k];
-          rec[4] = b - start[k];
-          first = false;
+    if (hi > lo) {
+      for (int k = k0; k < kv && start[k] < hi; ++k) {
+        const int a = max(lo, start[k]), b = min(hi, start[k + 1]);
+        if (b > a) {
+          seg[3 * sg] = k;
+          seg[3 * sg + 1] = a - start[k];
+          seg[3 * sg + 2] = b - start[k];
+          if (first) {
+            r2 = k;
+            r3 = a - start[k];
+            r4 = b - start[k];
+            first = false;
+          }
+          ++sg;
         }
-        ++s;
       }
     }
+    rec[0] = seg0;
+    rec[1] = mine;
+    rec[2] = r2;
+    rec[3] = r3;
+    rec[4] = r4;
   }
-  // first segment of offset k = number of segments of offsets < k (segments are ordered by k):
-  // count the segments per offset (LDS atomics), then a kv-long prefix sum
-  __shared__ int kcount[130], kfirst[130], ritems[130];
-  if (tid <= kv) kcount[tid] = 0;
-  __syncthreads();
-  if (tid < G) {
-    for (int k = 0; k < kv; ++k)
-      if (min(hi, start[k + 1]) > max(lo, start[k])) atomicAdd(&kcount[k], 1);
+
+  // ---- per offset: segments (= ranges touching the list), first segment, second-stage items
+  int kc = 0, nitems = 0, mode = 2;
+  if (tid < kv && c > 0) kc = (start[tid + 1] - 1) / per - start[tid] / per + 1;
+  if (tid < kv) {
+    // second-stage work list: block shape by segment count (see wgrad_reduce2_kernel)
+    mode = kc >= 48 ? 0 : (kc >= 6 ? 1 : 2);
+    nitems = (kWT * kWT) / (mode == 0 ? 16 : (mode == 1 ? 128 : 512));
   }
-  __syncthreads();
-  if (tid == 0) {
-    int run = 0, items = 0;
-    for (int k = 0; k < kv; ++k) {
-      kfirst[k] = run;
-      run += kcount[k];
-      // second-stage work list: block shape by segment count (see wgrad_reduce2_kernel)
-      const int mode = kcount[k] >= 48 ? 0 : (kcount[k] >= 6 ? 1 : 2);
-      ritems[k] = items;
-      items += (kWT * kWT) / (mode == 0 ? 16 : (mode == 1 ? 128 : 512));
-    }
-    kfirst[kv] = run;
-    ritems[kv] = items;
-    plan[plan2_red(G, kv)] = items;
+  int kc_total, items_total;
+  const int kf = plan_scan(kc, wtot[2], kc_total);
+  const int ri = plan_scan(nitems, wtot[3], items_total);
+  if (tid <= kv) {
+    kfirst[tid] = kf;
+    kcount[tid] = kc;
+    ritems[tid] = ri;
+    plan[plan2_kf(G) + tid] = kf;
   }
+  if (tid == 0) plan[plan2_red(G, kv)] = items_total;
   __syncthreads();
-  if (tid <= kv) plan[plan2_kf(G) + tid] = kfirst[tid];
   int32_t *rl = plan + plan2_red(G, kv);
   for (int k = 0; k < kv; ++k) {
-    const int mode = kcount[k] >= 48 ? 0 : (kcount[k] >= 6 ? 1 : 2);
-    const int E = mode == 0 ? 16 : (mode == 1 ? 128 : 512), cnt_items = (kWT * kWT) / E;
+    const int md = kcount[k] >= 48 ? 0 : (kcount[k] >= 6 ? 1 : 2);
+    const int E = md == 0 ? 16 : (md == 1 ? 128 : 512), cnt_items = (kWT * kWT) / E;
     for (int q = tid; q < cnt_items; q += kW2MaxG) {
       int32_t *item = rl + 4 + 4 * (ritems[k] + q);
-      item[0] = k | (mode << 8);
+      item[0] = k | (md << 8);
       item[1] = q * E;
       item[2] = kfirst[k];
       item[3] = kcount[k];
