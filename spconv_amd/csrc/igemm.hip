@@ -1928,11 +1928,16 @@ __device__ __forceinline__ uint4 wtr_frag(const char *stage, int row0, int lrow,
 
 // STAGES = 2: one barrier per chunk (64 KB of LDS); STAGES = 1: two barriers per chunk, 32 KB
 // (used when the kernel shares a launch with dgrad, see igemm_bwd_kernel)
-template <bool BF16, int STAGES>
+// SL: 16-byte slots of a row that are loaded at all (8 = 64 channels; 4 / 2 when both C and K fit
+// 32 / 16 channels: a thread then covers SL / 2 rows per operand instead of 4, with half / a quarter
+// of the load instructions per chunk; 7-9 % at 0.3 M - 1.2 M voxels, standalone launch only)
+template <bool BF16, int STAGES, int SL = 8>
 __device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, int block) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TILE_B = kW2J * 128;                // one operand tile: 128 pairs x 128 bytes
-  constexpr int RQ = kW2J / 32;                     // rows per thread and operand (4)
+  constexpr int RQ = SL / 2;                        // rows per thread and operand
+  constexpr int RSTEP = 2 * kW2J / SL;              // distance between a thread's rows
+  constexpr int RA = RQ < 2 ? 2 : RQ;               // (register arrays stay at >= 2 elements)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lrow = lane & 15, lgrp = lane >> 4;
   const int wk = wave >> 1, wc = wave & 1;          // wave quadrant: kk [32*wk,+32), c [32*wc,+32)
@@ -1951,12 +1956,18 @@ __device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, int block) 
   const uint32_t list_bytes = static_cast<uint32_t>(p.n_in) * 4u;
 
   // load role: 16-byte slot `slot` of rows r0 + 32 q (q = 0..3) of both operand tiles
-  const int slot = tid & 7, r0 = tid >> 3;
+  const int slot = tid & (SL - 1), r0 = tid / SL;
   const uint32_t dcol = kk0 + slot * 8 < p.K ? static_cast<uint32_t>(kk0 + slot * 8) * 2u : kOob;
   const uint32_t fcol = c0 + slot * 8 < p.C ? static_cast<uint32_t>(c0 + slot * 8) * 2u : kOob;
-  int lds_w[RQ];
+  int lds_w[RA];
 #pragma unroll
-  for (int q = 0; q < RQ; ++q) lds_w[q] = wtr_slot(r0 + 32 * q, slot);
+  for (int q = 0; q < RQ; ++q) lds_w[q] = wtr_slot(r0 + RSTEP * q, slot);
+  if constexpr (SL < 8) {
+    // slots nobody loads stay zero for the whole launch
+    for (int o = tid * 16; o < STAGES * 2 * TILE_B; o += kThreads * 16)
+      *reinterpret_cast<u32x4 *>(smem + o) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+  }
 
   for (int si = 0; si < nseg; ++si) {
     int k, begin, end;
@@ -1981,12 +1992,17 @@ __device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, int block) 
 #pragma unroll
       for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    uint32_t ii[RQ], oi[RQ];     // pair-list words of the chunk whose rows are fetched next
-    u32x4 dv[RQ], fv[RQ];        // rows in flight
+    // One chunk of rows in flight per workgroup, the pair-list words one chunk further ahead.  Deeper
+    // pipelines (two row sets, two word sets, a single LDS stage with three workgroups per CU, 768 or
+    // 1023 ranges) were all measured within 3 % of this on 0.3 M - 1.2 M voxel levels
+    // (profiles/r02_dense_regime_experiments.md): at that size the loop is bound by the 128-byte
+    // lines the gathers pull out of the Infinity Cache, once per offset, whatever the row width.
+    uint32_t ii[RA], oi[RA];
+    u32x4 dv[RA], fv[RA];
     auto load_words = [&](int base) __attribute__((always_inline)) {
 #pragma unroll
       for (int q = 0; q < RQ; ++q) {
-        const int j = base + r0 + 32 * q;
+        const int j = base + r0 + RSTEP * q;
         if (identity) {
           ii[q] = static_cast<uint32_t>(j);
           oi[q] = static_cast<uint32_t>(j);
@@ -2000,7 +2016,7 @@ __device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, int block) 
     auto load_rows = [&](int base) __attribute__((always_inline)) {
 #pragma unroll
       for (int q = 0; q < RQ; ++q) {
-        const bool ok = base + r0 + 32 * q < end;      // rows past the segment read as zero
+        const bool ok = base + r0 + RSTEP * q < end;      // rows past the segment read as zero
         dv[q] = __builtin_amdgcn_raw_buffer_load_b128(rD, ok ? (oi[q] * rowD + dcol) | (dcol & kOob) : kOob, 0, 0);
         fv[q] = __builtin_amdgcn_raw_buffer_load_b128(rF, ok ? (ii[q] * rowF + fcol) | (fcol & kOob) : kOob, 0, 0);
       }
@@ -2059,10 +2075,10 @@ __device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, int block) 
 #endif
 }
 
-template <bool BF16>
+template <bool BF16, int SL = 8>
 __global__ void __launch_bounds__(kThreads)
 wgrad_tr_kernel(Wgrad2Params p) {
-  wgrad_tr_body<BF16, 2>(p, blockIdx.x);
+  wgrad_tr_body<BF16, 2, SL>(p, blockIdx.x);
 }
 
 // fp32 wgrad on v_mfma_f32_16x16x4_f32 over the same balanced segments.  Each lane feeds ONE
@@ -2813,12 +2829,18 @@ int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t 
     q.G = wgrad_groups(n_in);
     const dim3 grid(static_cast<unsigned>(q.G) * ntile);
     const size_t lds = 2 * 2 * kW2J * 128;    // two stages x two operand tiles
+    const int sl = (C <= 16 && K <= 16) ? 2 : ((C <= 32 && K <= 32) ? 4 : 8);   // live 16-byte slots per row
     if (dtype == SPX_F32)
       hipLaunchKernelGGL(wgrad_f32_kernel, grid, dim3(kThreads), 2 * kW3J * kW3Stride * sizeof(float), s, q);
-    else if (dtype == SPX_F16)
-      hipLaunchKernelGGL(wgrad_tr_kernel<false>, grid, dim3(kThreads), lds, s, q);
-    else
-      hipLaunchKernelGGL(wgrad_tr_kernel<true>, grid, dim3(kThreads), lds, s, q);
+    else if (dtype == SPX_F16) {
+      if (sl == 2) hipLaunchKernelGGL((wgrad_tr_kernel<false, 2>), grid, dim3(kThreads), lds, s, q);
+      else if (sl == 4) hipLaunchKernelGGL((wgrad_tr_kernel<false, 4>), grid, dim3(kThreads), lds, s, q);
+      else hipLaunchKernelGGL((wgrad_tr_kernel<false, 8>), grid, dim3(kThreads), lds, s, q);
+    } else {
+      if (sl == 2) hipLaunchKernelGGL((wgrad_tr_kernel<true, 2>), grid, dim3(kThreads), lds, s, q);
+      else if (sl == 4) hipLaunchKernelGGL((wgrad_tr_kernel<true, 4>), grid, dim3(kThreads), lds, s, q);
+      else hipLaunchKernelGGL((wgrad_tr_kernel<true, 8>), grid, dim3(kThreads), lds, s, q);
+    }
     const dim3 rgrid2(kv * 256 < 512 ? kv * 256 : 512, ntile);   // block-stride over the work list
     if (dtype == SPX_F32)
       hipLaunchKernelGGL(wgrad_reduce2_kernel<float>, rgrid2, dim3(kRedThreads), 0, s, q,
