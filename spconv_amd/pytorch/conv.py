@@ -267,10 +267,6 @@ class SparseConvolution(SparseModule):
         if training:
             assert self.act_type == Activation.None_, \
                 "act don't support backward, only used in inference"
-        if grad_path and int(np.prod(self.kernel_size)) > 128:
-            raise NotImplementedError(
-                f"kernel volume {int(np.prod(self.kernel_size))} > 128: this layer runs forward (inference) "
-                f"only -- the weight-gradient kernels cover kernel volumes up to 128")
         if self.subm:
             out_spatial_shape = spatial_shape
         elif self.transposed:

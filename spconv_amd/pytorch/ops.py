@@ -558,6 +558,30 @@ def wgrad_plan(num_per_loc: torch.Tensor, n_in: int, kv: int, subm: bool) -> tor
     return plan
 
 
+_WGRAD_MAX_KV = 128     # offsets one spx_igemm_wgrad call / one plan covers
+
+
+def _wgrad_in_groups(features, out_bp, filters_shape, native, num_per_loc, subm: bool, kv: int):
+    """Kernel volumes beyond 128 (6x6x6, 7x7x7: the reference's Native path trains any volume,
+    ops.py:962-1015): the offsets go through spx_igemm_wgrad 128 at a time, each group with its own
+    slice of the lists and explicit per-list counts (SubM: the mirror rule of ops.py:962-968 resolved
+    here, on the device)."""
+    K0, C0 = filters_shape[0], filters_shape[-1]
+    n_in = native.shape[2]
+    counts = num_per_loc.to(torch.int32).clone()
+    if subm:
+        centre = kv // 2
+        counts[centre] = n_in
+        counts[centre + 1:] = num_per_loc[:kv - centre - 1].flip(0)
+    dw = torch.empty((K0, kv, C0), dtype=features.dtype, device=features.device)
+    for kbase in range(0, kv, _WGRAD_MAX_KV):
+        g = min(_WGRAD_MAX_KV, kv - kbase)
+        part = igemm_wgrad(features, out_bp, (K0, g, C0), native[:, kbase:kbase + g].contiguous(),
+                           counts[kbase:kbase + g].contiguous(), False, None)
+        dw[:, kbase:kbase + g] = part
+    return dw.view(tuple(filters_shape))
+
+
 @_on_device
 def igemm_wgrad(features: torch.Tensor, out_bp: torch.Tensor, filters_shape, native: torch.Tensor,
                 num_per_loc: torch.Tensor, subm: bool,
@@ -567,6 +591,8 @@ def igemm_wgrad(features: torch.Tensor, out_bp: torch.Tensor, filters_shape, nat
     L = _lib.load()
     K0, C0 = filters_shape[0], filters_shape[-1]
     kv = int(np.prod(filters_shape)) // (K0 * C0)
+    if kv > _WGRAD_MAX_KV:
+        return _wgrad_in_groups(features, out_bp, filters_shape, native, num_per_loc, subm, kv)
     m = _lane_mult(features.dtype)
     C, K = -(-C0 // m) * m, -(-K0 // m) * m          # the MFMA wgrad needs whole lane pieces
     features = _pad_last(features, C).contiguous()
@@ -622,7 +648,7 @@ def igemm_bwd(features: torch.Tensor, out_bp: torch.Tensor, filters: torch.Tenso
 
 
 def _plan_of(rb: Optional[Rulebook]) -> Optional[torch.Tensor]:
-    if rb is None or rb.pair_native is None:
+    if rb is None or rb.pair_native is None or rb.kv > _WGRAD_MAX_KV:
         return None
     if rb.wgrad_plan is None:
         rb.wgrad_plan = wgrad_plan(rb.num_per_loc, rb.n_in, rb.kv, rb.subm)

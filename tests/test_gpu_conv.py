@@ -140,6 +140,41 @@ def test_kernel_volumes_33_to_128_run_in_groups_of_32(cuda, dtype, ksize, stride
     _check("dw", dw, dw_ref, tol)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("ksize,stride,pad,subm,C,K", [
+    ([7, 7, 7], [1] * 3, [3] * 3, True, 16, 16),       # kv = 343 (odd: SubM mirror counts resolved on the host side)
+    ([6, 6, 6], [2] * 3, [2] * 3, False, 16, 32),      # kv = 216, regular conv
+])
+def test_kernel_volumes_beyond_128_train(cuda, dtype, ksize, stride, pad, subm, C, K):
+    """The reference's Native path trains any kernel volume (ops.py:962-1015): forward and dgrad on the
+    generic kernels, wgrad through spx_igemm_wgrad 128 offsets at a time -- all against the oracle."""
+    shape = [14, 16, 18]
+    idx, ref, f, w, dout = _case(shape, 600, 2, C, K, ksize, stride, pad, [1] * 3, subm, dtype)
+    out_ref = oracle.indice_conv(f, w, ref["pair"], ref["num"], ref["n_out"], subm=subm)
+    din_ref, dw_ref = oracle.indice_conv_backward(f, w, dout, ref["pair"], ref["num"], subm=subm)
+    rb, out, din, dw = _run_gpu(cuda, idx, 2, shape, ksize, stride, pad, [1] * 3, subm, False, f, w, dout, dtype)
+    assert rb.kv > 128
+    tol = TOL[dtype]
+    _check("out", out, out_ref, tol)
+    _check("din", din, din_ref, tol)
+    _check("dw", dw, dw_ref, tol)
+
+
+def test_module_with_kernel_volume_beyond_128_steps(cuda):
+    """A 7x7x7 SubMConv3d layer trains end to end (forward + backward through the autograd function)."""
+    import spconv_amd.pytorch as spconv
+    shape = [12, 12, 12]
+    idx = torch.from_numpy(scene(shape, 400, 1, seed=3)).to(cuda)
+    torch.manual_seed(0)
+    net = spconv.SubMConv3d(8, 8, 7, padding=3, bias=False, indice_key="k7").to(cuda)
+    assert int(np.prod(net.kernel_size)) == 343
+    f = torch.randn(idx.shape[0], 8, device=cuda, requires_grad=True)
+    y = net(spconv.SparseConvTensor(f, idx, shape, 1))
+    y.features.square().sum().backward()
+    assert net.weight.grad is not None and torch.isfinite(net.weight.grad).all()
+    assert f.grad is not None and float(f.grad.abs().sum()) > 0
+
+
 @pytest.mark.parametrize("subm", [True, False])
 def test_mask_sorted_order_gives_same_result(cuda, subm):
     """mask_argsort only permutes which workgroup owns a row; results must not change."""
