@@ -417,21 +417,30 @@ def igemm_fwd_int8(features: torch.Tensor, filters: torch.Tensor, pair: torch.Te
     filters = _int_repr(filters).contiguous()
     if features.dtype != torch.int8 or filters.dtype != torch.int8:
         raise TypeError("igemm_fwd_int8 needs int8 features and filters")
-    K, C = filters.shape[0], filters.shape[-1]
-    kv = filters.numel() // (K * C)
-    assert features.shape[1] == C, "channel size mismatch"
+    K0, C0 = filters.shape[0], filters.shape[-1]
+    kv = filters.numel() // (K0 * C0)
+    assert features.shape[1] == C0, "channel size mismatch"
+    # the int8 MFMA kernel takes reduction lengths in whole 16-byte lane pieces and the output widths it
+    # is instantiated for: zero-pad (a 4-channel first layer, 48 / 96-wide layers) and slice the result,
+    # as igemm_fwd does for the float types
+    C, K = -(-C0 // 16) * 16, (_round_cout(K0) or K0)
+    features, filters = _pad_last(features, C), _pad_first(_pad_last(filters, C), K)
     out = torch.empty((n_out, K), dtype=out_dtype, device=features.device)
     f32 = lambda t: None if t is None else t.to(device=features.device, dtype=torch.float32).contiguous()
     scale, bias = f32(scale), f32(bias)
+    if K != K0:
+        scale = None if scale is None else torch.nn.functional.pad(scale.reshape(-1), (0, K - K0), value=1.0)
+        bias = None if bias is None else torch.nn.functional.pad(bias.reshape(-1), (0, K - K0))
     if add is not None:
         add = _int_repr(add).contiguous()
-        assert add.dtype == torch.int8 and tuple(add.shape) == (n_out, K)
+        assert add.dtype == torch.int8 and tuple(add.shape) == (n_out, K0)
+        add = _pad_last(add, K)
     _lib.check(L.spx_igemm_fwd_int8(features.data_ptr(), filters.data_ptr(), out.data_ptr(), _ptr(pair),
                                     _ptr(mask), _ptr(argsort), features.shape[0], n_out, C, K, kv,
                                     identity_k, _ptr(scale), _ptr(bias), _ptr(add), float(add_scale),
                                     _OUT_CODES[out_dtype], int(act_type), float(act_alpha),
                                     _stream(features)))
-    return out
+    return out if K == K0 else out[:, :K0].contiguous()
 
 
 _MFMA_COUT = (16, 32, 64, 128, 256)

@@ -37,6 +37,11 @@ INT8_CASES = [
     ([24, 24, 24], 2000, 1, 32, 64, [3] * 3, [2] * 3, [1] * 3, [1] * 3, False),
     ([24, 24, 24], 2000, 1, 48, 32, [2] * 3, [2] * 3, [0] * 3, [1] * 3, False),   # C not multiple of 128 B
     ([24, 24, 24], 1200, 1, 144, 256, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True),  # two reduction pieces
+    # channel counts the kernel is not instantiated for: zero-padded by the host side (a 4-channel first
+    # layer, 48 / 96-wide layers)
+    ([24, 24, 24], 2500, 2, 4, 16, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True),
+    ([24, 24, 24], 2000, 1, 40, 48, [3] * 3, [2] * 3, [1] * 3, [1] * 3, False),
+    ([24, 24, 24], 2000, 1, 64, 96, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True),
 ]
 
 
