@@ -6,9 +6,26 @@ from __future__ import annotations
 
 from typing import Optional
 
+import contextlib
+import functools
+
 import torch
 
 from spconv_amd import _lib
+
+
+def _on_table_device(method):
+    """Runs a method with the table's device current (torch's DeviceGuard convention): the native calls
+    and their scratch allocations belong to the device the table lives on, also when the caller never
+    called torch.cuda.set_device."""
+    @functools.wraps(method)
+    def guarded(self, *args, **kwargs):
+        dev = self.keys_data.device
+        ctx = (torch.cuda.device(dev) if dev.type == "cuda" and dev.index != torch.cuda.current_device()
+               else contextlib.nullcontext())
+        with ctx:
+            return method(self, *args, **kwargs)
+    return guarded
 
 _ITEMSIZE = {torch.int32: 4, torch.int64: 8, torch.float32: 4, torch.float64: 8}
 
@@ -31,8 +48,9 @@ class HashTable:
         self.keys_data = torch.empty([max_size], dtype=key_dtype, device=device)
         self.values_data = torch.empty([max_size], dtype=value_dtype, device=device)
         self._L = _lib.load()
-        _lib.check(self._L.spx_hash_clear(self.keys_data.data_ptr(), max_size, self.key_itemsize,
-                                          self._stream()))
+        with torch.cuda.device(device):
+            _lib.check(self._L.spx_hash_clear(self.keys_data.data_ptr(), max_size, self.key_itemsize,
+                                              self._stream()))
 
     def _stream(self):
         return torch.cuda.current_stream(self.keys_data.device).cuda_stream
@@ -45,6 +63,7 @@ class HashTable:
         assert keys.dtype == self.key_dtype and keys.ndim == 1, "keys must be 1-d with the table's key dtype"
         return keys.contiguous()
 
+    @_on_table_device
     def insert(self, keys: torch.Tensor, values: Optional[torch.Tensor] = None):
         """insert keys (and values; without values the stored value is undefined)"""
         keys = self._check_keys(keys)
@@ -55,6 +74,7 @@ class HashTable:
                                            None if values is None else values.data_ptr(),
                                            keys.shape[0], self._stream()))
 
+    @_on_table_device
     def query(self, keys: torch.Tensor, values: Optional[torch.Tensor] = None):
         """-> (values, bool tensor that is True where the key was NOT found)"""
         keys = self._check_keys(keys)
@@ -65,6 +85,7 @@ class HashTable:
                                           is_empty.data_ptr(), keys.shape[0], self._stream()))
         return values, is_empty > 0
 
+    @_on_table_device
     def insert_exist_keys(self, keys: torch.Tensor, values: torch.Tensor):
         """overwrite the values of keys that exist; -> uint8 tensor, 1 where the key was missing"""
         keys = self._check_keys(keys)
@@ -79,6 +100,7 @@ class HashTable:
         return torch.empty((int(self._L.spx_hash_ws_bytes(self.keys_data.shape[0])),), dtype=torch.uint8,
                            device=self.keys_data.device)
 
+    @_on_table_device
     def assign_arange_(self):
         """every key gets a distinct value in [0, count); -> count (1-element tensor)"""
         assert self.value_dtype in (torch.int32, torch.int64)
@@ -88,6 +110,7 @@ class HashTable:
                                                   ws.numel(), self._stream()))
         return count
 
+    @_on_table_device
     def items(self, max_size: int = -1):
         """-> (keys, values, count): the first `count` entries are the table's content"""
         if max_size == -1:

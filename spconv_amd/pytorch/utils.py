@@ -69,6 +69,9 @@ class PointToVoxel(object):
         assert pc.device.type == self.device.type, "your pc device is wrong"
         assert pc.ndim == 2 and pc.shape[1] == self.num_point_features, \
             "your points num features doesn't equal to voxel."
+        if pc.is_cuda and pc.device.index != torch.cuda.current_device():
+            with torch.cuda.device(pc.device):         # DeviceGuard convention (ops._on_device)
+                return self.generate_voxel_with_id(pc, clear_voxels, empty_mean)
         L = _lib.load()
         with torch.no_grad():
             pc = pc.contiguous().float()
