@@ -34,29 +34,38 @@ struct Table {
   int32_t *vals;   // wide: vals[cap].  packed: the low halves of the slots (stride 2)
   uint32_t mask;   // capacity - 1 (capacity is a power of two)
   int packed;      // 1 when every key fits 32 bits
+  int gbits;       // low key bits that pick the slot inside a group of 2^gbits slots (see hash_key)
 };
 
 constexpr unsigned long long kEmptySlot = ~0ull;
 
-__device__ __forceinline__ uint32_t hash_key(hkey_t k) {
+// Home slot of a key: the murmur3 finaliser of key >> gbits picks a group of 2^gbits slots, the low key
+// bits the slot inside it (gbits = 3: 8 consecutive cells along the last spatial dimension share one
+// 64-byte line of the table).  Measured and left at gbits = 0 everywhere: on the half-full SubM tables
+// groups that are either empty or full turn every collision into a walk across a full group (fixture
+// rulebook 78 -> 139 us); on the 4-8 % full regular-conv tables the lookups get 5-12 % faster
+// (conv_count_first 8.5 -> 7.5, conv_assign 19.6 -> 18.0 us) but the inserts of neighbouring threads
+// now contend for the same lines (conv_stage1 22.6 -> 30.6 us).  Results never depend on the slot.
+__device__ __forceinline__ uint32_t hash_key(hkey_t k, int gbits) {
   // murmur3 fmix64
-  unsigned long long x = static_cast<unsigned long long>(k);
+  unsigned long long x = static_cast<unsigned long long>(k) >> gbits;
   x ^= x >> 33;
   x *= 0xff51afd7ed558ccdULL;
   x ^= x >> 33;
   x *= 0xc4ceb9fe1a85ec53ULL;
   x ^= x >> 33;
-  return static_cast<uint32_t>(x);
+  return (static_cast<uint32_t>(x) << gbits) | (static_cast<uint32_t>(k) & ((1u << gbits) - 1u));
 }
 
-__device__ __forceinline__ uint32_t hash_key32(uint32_t x) {
+__device__ __forceinline__ uint32_t hash_key32(uint32_t k, int gbits) {
   // murmur3 fmix32
+  uint32_t x = k >> gbits;
   x ^= x >> 16;
   x *= 0x85ebca6bu;
   x ^= x >> 13;
   x *= 0xc2b2ae35u;
   x ^= x >> 16;
-  return x;
+  return (x << gbits) | (k & ((1u << gbits) - 1u));
 }
 
 // Value stored in a slot returned by table_insert_min.
@@ -71,7 +80,7 @@ __device__ __forceinline__ int table_insert_min(const Table &t, hkey_t key, int3
     const uint32_t k32 = static_cast<uint32_t>(key);
     const unsigned long long want =
         (static_cast<unsigned long long>(k32) << 32) | static_cast<uint32_t>(val);
-    uint32_t slot = hash_key32(k32) & t.mask;
+    uint32_t slot = hash_key32(k32, t.gbits) & t.mask;
     for (uint32_t probe = 0; probe <= t.mask; ++probe) {  // bounded: the table is never full
       const unsigned long long prev = atomicCAS(&slots[slot], kEmptySlot, want);
       if (prev == kEmptySlot) return static_cast<int>(slot);
@@ -84,7 +93,7 @@ __device__ __forceinline__ int table_insert_min(const Table &t, hkey_t key, int3
     }
     return -1;
   }
-  uint32_t slot = hash_key(key) & t.mask;
+  uint32_t slot = hash_key(key, t.gbits) & t.mask;
   for (uint32_t probe = 0; probe <= t.mask; ++probe) {
     unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long *>(&t.keys[slot]),
                                         static_cast<unsigned long long>(-1LL),
@@ -105,7 +114,7 @@ __device__ __forceinline__ int32_t table_find(const Table &t, hkey_t key) {
   if (t.packed) {
     const unsigned long long *slots = reinterpret_cast<const unsigned long long *>(t.keys);
     const uint32_t k32 = static_cast<uint32_t>(key);
-    uint32_t slot = hash_key32(k32) & t.mask;
+    uint32_t slot = hash_key32(k32, t.gbits) & t.mask;
     for (uint32_t probe = 0; probe <= t.mask; ++probe) {
       const unsigned long long v = slots[slot];
       if (static_cast<uint32_t>(v >> 32) == k32 && v != kEmptySlot) return static_cast<int32_t>(v);
@@ -114,7 +123,7 @@ __device__ __forceinline__ int32_t table_find(const Table &t, hkey_t key) {
     }
     return -1;
   }
-  uint32_t slot = hash_key(key) & t.mask;
+  uint32_t slot = hash_key(key, t.gbits) & t.mask;
   for (uint32_t probe = 0; probe <= t.mask; ++probe) {
     const hkey_t k = t.keys[slot];
     if (k == key) return t.vals[slot];
@@ -535,7 +544,7 @@ subm_probe_all_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table 
   // the first row of this coordinate (duplicates: the smallest index won the slot); its first
   // slot word travels with the first chunk's loads
   const hkey_t own_key = layout_key(b, c, g.in_dims);
-  const uint32_t own_slot = hash_key32(static_cast<uint32_t>(own_key)) & t.mask;
+  const uint32_t own_slot = hash_key32(static_cast<uint32_t>(own_key), t.gbits) & t.mask;
   unsigned long long own_word = kEmptySlot;
   if (PACKED && hashed) own_word = slots[own_slot];
   bool first = false;
@@ -556,7 +565,7 @@ subm_probe_all_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table 
       const hkey_t wkey = layout_key(b, q, g.in_dims);
       if (!PACKED) wide[j] = wkey;
       key32[j] = static_cast<uint32_t>(wkey);
-      slot0[j] = hash_key32(key32[j]) & t.mask;
+      slot0[j] = hash_key32(key32[j], t.gbits) & t.mask;
       word[j] = kEmptySlot;
       if (PACKED && act[j]) word[j] = slots[slot0[j]];
       if (++r[3] >= g.ksize[3]) {             // ++r with carry, last dimension fastest
@@ -642,6 +651,14 @@ subm_lists_kernel(const int32_t *__restrict__ pair_fwd, int kv, int n, int nblk2
     }
     return;
   }
+  // the block's table entries are requested first, ahead of the count prefix (two independent latencies)
+  const int32_t *row = pair_fwd + static_cast<size_t>(conv ? list : kv - 1 - list) * n;
+  int vals[kItems / kBlock];
+#pragma unroll
+  for (int it = 0; it < kItems / kBlock; ++it) {
+    const int e = begin + it * kBlock + threadIdx.x;
+    vals[it] = (native && e < n) ? row[e] : -1;
+  }
   // prefix of the hit counts before this block's first 256-voxel group, and the list total
   const int32_t *cnt = blockcount + static_cast<size_t>(list) * nblk256;
   const int first_group = blk * (kItems / kBlock);
@@ -669,15 +686,15 @@ subm_lists_kernel(const int32_t *__restrict__ pair_fwd, int kv, int n, int nblk2
   }
   if (blk == 0 && threadIdx.x == 0 && num_per_loc) num_per_loc[list] = all;
   if (!native) return;
-  const int32_t *row = pair_fwd + static_cast<size_t>(conv ? list : kv - 1 - list) * n;
   int32_t *in_k = native + static_cast<size_t>(list) * n;
   int32_t *out_k = native + plane + static_cast<size_t>(list) * n;
   int32_t *in_m = native + static_cast<size_t>(kv - 1 - list) * n;
   int32_t *out_m = native + plane + static_cast<size_t>(kv - 1 - list) * n;
   int running = before;
+#pragma unroll
   for (int it = 0; it < kItems / kBlock; ++it) {
     const int e = begin + it * kBlock + threadIdx.x;
-    const int v = e < n ? row[e] : -1;
+    const int v = vals[it];
     int total;
     const int rank = block_rank(v >= 0, total, lds_wave);
     if (v >= 0) {
@@ -785,10 +802,26 @@ conv_assign_kernel(const int32_t *__restrict__ indices, int n, Geom g, int trans
   int r[4];
   decode_offset(k, g.ksize, r);
   const int lead = 4 - g.ndim;
+  // all of the block's loads first (8 independent slot -> table chains in flight): with the loads
+  // inside the ranking loop every iteration paid two dependent memory latencies between barriers
+  int slots[kItems / kBlock];
+  bool firsts[kItems / kBlock];
+#pragma unroll
   for (int it = 0; it < kItems / kBlock; ++it) {
     const int e = begin + it * kBlock + threadIdx.x;
-    int slot;
-    const bool first = is_first_seen(slot_of, t, static_cast<size_t>(k) * n + e, e < n, slot);
+    slots[it] = e < n ? slot_of[static_cast<size_t>(k) * n + e] : -1;
+  }
+#pragma unroll
+  for (int it = 0; it < kItems / kBlock; ++it) {
+    const int e = begin + it * kBlock + threadIdx.x;
+    firsts[it] = slots[it] >= 0 &&
+                 table_val(t, slots[it]) == static_cast<int32_t>(static_cast<size_t>(k) * n + e);
+  }
+#pragma unroll
+  for (int it = 0; it < kItems / kBlock; ++it) {
+    const int e = begin + it * kBlock + threadIdx.x;
+    const int slot = slots[it];
+    const bool first = firsts[it];
     int total;
     const int rank = block_rank(first, total, lds_wave);
     if (first) {
@@ -994,11 +1027,12 @@ bool keys_fit_u32(long long batch, const int *dims, int ndims) {
 }
 
 // Places a table of `cap` slots at `mem` (room for the wide form: 12 bytes per slot).
-void table_place(Table &t, hkey_t *keys, int32_t *vals, uint32_t cap, bool packed) {
+void table_place(Table &t, hkey_t *keys, int32_t *vals, uint32_t cap, bool packed, int gbits = 0) {
   t.keys = keys;
   t.vals = packed ? reinterpret_cast<int32_t *>(keys) : vals;
   t.mask = cap - 1;
   t.packed = packed ? 1 : 0;
+  t.gbits = gbits;
 }
 
 // The table's bytes as a 0xFF range of a FillList (see table_clear).
@@ -1304,7 +1338,7 @@ template <> struct UKey<unsigned long long> {
 
 template <typename K>
 __device__ __forceinline__ uint32_t user_hash(K k) {
-  return hash_key(static_cast<hkey_t>(k));
+  return hash_key(static_cast<hkey_t>(k), 0);
 }
 
 template <typename K>
