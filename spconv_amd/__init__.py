@@ -28,4 +28,5 @@ def install_as_spconv() -> None:
     for info in pkgutil.walk_packages(q.__path__, q.__name__ + "."):
         mod = importlib.import_module(info.name)
         sys.modules.setdefault(info.name.replace("spconv_amd.", "spconv.", 1), mod)
-    sys.modules.setdefault("spconv.constants", importlib.import_module("spconv_amd.constants"))
+    for name in ("constants", "core", "tools", "debug_utils", "pytorch.spatial", "pytorch.constants"):
+        sys.modules.setdefault(f"spconv.{name}", importlib.import_module(f"spconv_amd.{name}"))

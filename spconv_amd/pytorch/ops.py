@@ -677,6 +677,18 @@ def bias_act_inplace(out: torch.Tensor, bias: Optional[torch.Tensor], act_type: 
     return out
 
 
+def maximum_value_int_(ten: torch.Tensor, value: int) -> torch.Tensor:
+    """In-place ``ten = max(ten, value)`` for integer tensors (reference ops.py:2099-2105; used by the
+    voxeliser to clamp counts)."""
+    return ten.clamp_(min=int(value))
+
+
+def fused_indice_conv(features, filters, bias, indice_pairs, indice_pair_num, num_activate_out,
+                      inverse, subm):
+    """Present in the reference's namespace and unimplemented there as well (ops.py:1098-1100)."""
+    raise NotImplementedError
+
+
 # ----------------------------------------- layout conversion for bare tensors
 def _table_from_native(indice_pairs: torch.Tensor, indice_pair_num: torch.Tensor, n_dst: int,
                        subm: bool, inverse: bool):

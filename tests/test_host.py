@@ -208,3 +208,29 @@ def test_kernel_timer_api_and_debug_dump(tmp_path, monkeypatch):
     monkeypatch.setattr(tools, "SPCONV_DEBUG_SAVE_PATH", str(path))
     tools.save_debug_data(("indices", 3))
     assert pickle.load(open(path, "rb")) == ("indices", 3)
+
+
+def test_peripheral_modules_resolve_under_the_spconv_name():
+    """User code imports these by their reference names (spconv/core.py:22-36, debug_utils.py:21,
+    pytorch/constants.py:37, pytorch/spatial.py:28)."""
+    import spconv_amd
+    spconv_amd.install_as_spconv()
+    from spconv.core import AlgoHint, ConvAlgo
+    from spconv.debug_utils import spconv_save_debug_data
+    from spconv.pytorch.constants import PYTORCH_VERSION, is_amp_enabled
+    from spconv.pytorch.spatial import RemoveDuplicate
+    import spconv.pytorch as sp
+    assert ConvAlgo is sp.ConvAlgo and AlgoHint.BackwardWeight.value == 4
+    assert callable(spconv_save_debug_data) and is_amp_enabled() is False and len(PYTORCH_VERSION) == 3
+    assert issubclass(RemoveDuplicate, sp.SparseModule)
+
+
+def test_remove_duplicate_keeps_first_row_of_a_coordinate():
+    import torch
+    import spconv_amd.pytorch as sp
+    from spconv_amd.pytorch.spatial import RemoveDuplicate
+    idx = torch.tensor([[0, 1, 2, 3], [1, 1, 2, 3], [0, 1, 2, 3], [0, 0, 0, 0], [1, 1, 2, 3]], dtype=torch.int32)
+    feat = torch.arange(5, dtype=torch.float32).view(5, 1)
+    y = RemoveDuplicate()(sp.SparseConvTensor(feat, idx, [4, 4, 4], 2))
+    assert y.indices.tolist() == [[0, 1, 2, 3], [1, 1, 2, 3], [0, 0, 0, 0]]
+    assert y.features.view(-1).tolist() == [0.0, 1.0, 3.0]
