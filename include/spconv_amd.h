@@ -347,11 +347,14 @@ int spx_hash_items(void *table_keys, void *table_vals, int capacity, int key_byt
  *   ws                spx_batchnorm_ws_bytes(n, C) bytes */
 size_t spx_batchnorm_ws_bytes(int n, int C);
 /* weight / bias / running_mean / running_var: [C] vectors of dtype `param_dtype` (SPX_F32, or the
- * 16-bit dtype of a model converted with .half() / .bfloat16()); any of them may be NULL. */
+ * 16-bit dtype of a model converted with .half() / .bfloat16()); any of them may be NULL.
+ * num_batches_tracked: the module's int64 step counter (torch/nn/modules/batchnorm.py:160-175), incremented by
+ * the statistics kernel in training mode, or NULL. */
 int spx_batchnorm_fwd(const void *x, void *y, int n, int C, int dtype, const void *weight,
-                      const void *bias, void *running_mean, void *running_var, int param_dtype,
-                      int training, float momentum, float eps, int relu, float *save_mean,
-                      float *save_invstd, void *ws, size_t ws_bytes, spx_stream_t stream);
+                      const void *bias, void *running_mean, void *running_var,
+                      long long *num_batches_tracked, int param_dtype, int training, float momentum,
+                      float eps, int relu, float *save_mean, float *save_invstd, void *ws,
+                      size_t ws_bytes, spx_stream_t stream);
 /* use_batch_stats = 1: `mean` / `invstd` are the saved fp32 batch statistics (training);
  * 0: fp32 copies of running_mean and 1 / sqrt(running_var + eps) (evaluation mode with gradients).
  * dweight / dbias: [C] of `param_dtype`, or NULL. */

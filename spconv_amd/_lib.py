@@ -46,7 +46,7 @@ SIGNATURES = {
                             + [vp, ctypes.c_int, ctypes.c_float, vp]),
     "spx_igemm_dgrad_tiled": (ctypes.c_int, [vp, vp, vp, vp, vp] + [ctypes.c_int] * 7 + [vp]),
     "spx_batchnorm_ws_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
-    "spx_batchnorm_fwd": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp,
+    "spx_batchnorm_fwd": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int,
                                          vp, vp, vp, ctypes.c_size_t, vp]),
     "spx_batchnorm_bwd": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int,

@@ -214,9 +214,11 @@ bn_partial_kernel(const u32x4 *__restrict__ x, int n, int C, float *__restrict__
 __global__ void __launch_bounds__(kT)
 bn_finalize_kernel(const float *__restrict__ partial, int G, int C, float eps, float momentum,
                    float *__restrict__ mean_out, float *__restrict__ invstd_out,
-                   void *__restrict__ running_mean, void *__restrict__ running_var, int pdt) {
+                   void *__restrict__ running_mean, void *__restrict__ running_var, int pdt,
+                   long long *__restrict__ num_batches_tracked) {
   __shared__ float ln[kT], lm[kT], l2[kT];
   const int c = blockIdx.x;
+  if (num_batches_tracked && c == 0 && threadIdx.x == 0) *num_batches_tracked += 1;   // (no launch of its own)
   float n = 0.f, m = 0.f, M2 = 0.f;
   for (int b = threadIdx.x; b < G; b += kT) {
     const float nb = partial[static_cast<size_t>(b) * 3 * C + c];
@@ -446,9 +448,10 @@ size_t spx_batchnorm_ws_bytes(int n, int C) {
 }
 
 int spx_batchnorm_fwd(const void *x, void *y, int n, int C, int dtype, const void *weight,
-                      const void *bias, void *running_mean, void *running_var, int param_dtype,
-                      int training, float momentum, float eps, int relu, float *save_mean,
-                      float *save_invstd, void *ws, size_t ws_bytes, spx_stream_t stream) {
+                      const void *bias, void *running_mean, void *running_var,
+                      long long *num_batches_tracked, int param_dtype, int training, float momentum,
+                      float eps, int relu, float *save_mean, float *save_invstd, void *ws,
+                      size_t ws_bytes, spx_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   SPX_CHECK(bn_shape_ok(C, dtype), "batchnorm: C = %d must be a multiple of %d (<= 256), dtype f16/bf16/f32", C,
             dtype == SPX_F32 ? 4 : 8);
@@ -468,7 +471,7 @@ int spx_batchnorm_fwd(const void *x, void *y, int n, int C, int dtype, const voi
     SPX_BN_DISPATCH(dtype, SPX_BN_PARTIAL);
 #undef SPX_BN_PARTIAL
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(kT), 0, s, partial, G, C, eps, momentum, save_mean,
-                       save_invstd, running_mean, running_var, param_dtype);
+                       save_invstd, running_mean, running_var, param_dtype, num_batches_tracked);
 #define SPX_BN_APPLY(D)                                                                                    \
   hipLaunchKernelGGL(bn_apply_kernel<D>, dim3(stream_grid(pieces)), dim3(kT), 0, s, xv, yv, pieces, C,     \
                      static_cast<const void *>(save_mean), static_cast<const void *>(save_invstd), weight,  \

@@ -47,7 +47,7 @@ def _param_dtype(*tensors) -> Optional[torch.dtype]:
 
 class _BatchNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu, nbt=None):
         L = _lib.load()
         x = x.contiguous()
         n, C = x.shape
@@ -59,7 +59,7 @@ class _BatchNormFn(torch.autograd.Function):
         p = lambda t: None if t is None else t.data_ptr()
         with torch.cuda.device(dev):
             _lib.check(L.spx_batchnorm_fwd(x.data_ptr(), y.data_ptr(), n, C, _DT[x.dtype], p(weight), p(bias),
-                                           p(running_mean), p(running_var), _DT[pdt], int(training), float(momentum),
+                                           p(running_mean), p(running_var), p(nbt), _DT[pdt], int(training), float(momentum),
                                            float(eps), int(relu), stats[0].data_ptr(), stats[1].data_ptr(),
                                            ws.data_ptr(), ws.numel(), torch._C._cuda_getCurrentRawStream(dev.index)))
         if training:
@@ -87,18 +87,23 @@ class _BatchNormFn(torch.autograd.Function):
                                            p(bias), _DT[ctx.pdt], mean.data_ptr(), invstd.data_ptr(),
                                            int(ctx.training), int(ctx.relu), p(dw), p(db), ws.data_ptr(), ws.numel(),
                                            torch._C._cuda_getCurrentRawStream(dev.index)))
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 def batch_norm(features: torch.Tensor, bn: nn.BatchNorm1d, relu: bool = False) -> torch.Tensor:
     """``relu(bn(features))`` (relu optional) with torch.nn.BatchNorm1d's bookkeeping."""
     momentum = 0.0 if bn.momentum is None else bn.momentum
+    nbt = None
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-        if bn.momentum is None:
+        if bn.momentum is None:       # cumulative average: the factor is 1 / count, needed on the host
+            bn.num_batches_tracked.add_(1)
             momentum = 1.0 / float(bn.num_batches_tracked)
+        elif bn.num_batches_tracked.dtype == torch.int64 and bn.num_batches_tracked.is_cuda:
+            nbt = bn.num_batches_tracked          # incremented by the statistics kernel
+        else:
+            bn.num_batches_tracked.add_(1)
     use_batch = bn.training or (bn.running_mean is None and bn.running_var is None)
     update = bn.training and bn.track_running_stats
     return _BatchNormFn.apply(features, bn.weight, bn.bias, bn.running_mean if (update or not use_batch) else None,
                               bn.running_var if (update or not use_batch) else None, use_batch, momentum, bn.eps,
-                              relu)
+                              relu, nbt)
