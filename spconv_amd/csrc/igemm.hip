@@ -1747,6 +1747,7 @@ wgrad_reduce_kernel(WgradParams p, T *__restrict__ dw) {
 constexpr int kW2MaxG = 1024;
 constexpr int kW2J = 128;        // pairs per chunk
 constexpr int kW2Rec = 8;        // ints per workgroup record in the plan
+constexpr int kXcds = 8;         // MI355X: workgroup b of a launch runs on XCD b % 8
 
 struct Wgrad2Params {
   const void *feat;        // [n_in, C]
@@ -1756,6 +1757,7 @@ struct Wgrad2Params {
   const int32_t *num;      // [kv]
   const int32_t *plan2;    // see wgrad_plan2_kernel
   int n_in, n_out, C, K, kv, subm, tiles_c, tiles_k, G;
+  int xcd_order;           // ranges are handed out in the plan's XCD-aware order
 };
 
 // plan2 layout (int32):
@@ -1868,6 +1870,48 @@ wgrad_plan2_kernel(const int32_t *__restrict__ num, int n_in, int kv, int subm, 
     rec[4] = r4;
   }
 
+  // ---- which workgroup takes which range.  Workgroup b runs on XCD b % 8 (round-robin dispatch) and all
+  // ranges advance through their lists at about the same rate, so the ranges that start in the same
+  // eighth of their list -- the same eighth of the ROWS, every list being in row order -- go to the same
+  // XCD: its L2 then serves a row to the other offsets that use it, instead of 27 XCDs x offsets pulling
+  // it out of the Infinity Cache.  rec[5] of workgroup b = its range.
+  {
+    int x = 0;
+    if (tid < G && hi > lo) {
+      const int len = start[k0 + 1] - start[k0];
+      x = min(kXcds - 1, static_cast<int>(static_cast<long long>(lo - start[k0]) * kXcds / (len > 0 ? len : 1)));
+    }
+    // rank of the range among the ranges of its XCD (four scans of two 16-bit counters), and the XCD sizes
+    int rank = 0, before_x = 0;
+    int cnt_x[kXcds];
+#pragma unroll
+    for (int pr = 0; pr < kXcds / 2; ++pr) {
+      const int v = (tid < G) ? ((x == 2 * pr ? 1 : 0) | (x == 2 * pr + 1 ? 1 << 16 : 0)) : 0;
+      int tot;
+      const int ex = plan_scan(v, wtot[pr & 3], tot);
+      if (x == 2 * pr) rank = ex & 0xffff;
+      if (x == 2 * pr + 1) rank = ex >> 16;
+      cnt_x[2 * pr] = tot & 0xffff;
+      cnt_x[2 * pr + 1] = tot >> 16;
+      __syncthreads();                       // wtot[pr & 3] is reused by the next pair
+    }
+#pragma unroll
+    for (int y = 0; y < kXcds; ++y)
+      if (y < x) before_x += cnt_x[y];
+    if (tid < G) {
+      // position of this range in (XCD, rank) order -> the workgroup at the same position in
+      // (b % 8, b / 8) order; XCD y owns ceil((G - y) / 8) workgroups
+      int pos = before_x + rank, y = 0, base = 0;
+      for (; y < kXcds - 1; ++y) {
+        const int ny = (G - y + kXcds - 1) / kXcds;
+        if (pos < base + ny) break;
+        base += ny;
+      }
+      const int b = y + kXcds * (pos - base);
+      plan[plan2_wg(b < G ? b : tid) + 5] = tid;
+    }
+  }
+
   // ---- per offset: segments (= ranges touching the list), first segment, second-stage items
   int kc = 0, nitems = 0, mode = 2;
   if (tid < kv && c > 0) kc = (start[tid + 1] - 1) / per - start[tid] / per + 1;
@@ -1942,7 +1986,8 @@ __device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, int block) 
   const int lrow = lane & 15, lgrp = lane >> 4;
   const int wk = wave >> 1, wc = wave & 1;          // wave quadrant: kk [32*wk,+32), c [32*wc,+32)
   const int ntile = p.tiles_k * p.tiles_c;
-  const int w = block / ntile, tile = block - w * ntile;
+  const int wb = block / ntile, tile = block - wb * ntile;
+  const int w = p.xcd_order ? p.plan2[plan2_wg(wb) + 5] : wb;   // the range this workgroup takes (see the plan)
   const int kk0 = (tile / p.tiles_c) * kWT, c0 = (tile % p.tiles_c) * kWT;
   const int32_t *__restrict__ rec = p.plan2 + plan2_wg(w);     // uniform address: scalar loads
   const int32_t *__restrict__ segs = p.plan2 + plan2_seg(p.G, p.kv);
@@ -2487,6 +2532,11 @@ int wgrad_groups(int n_in) {
   return g < 1 ? 1 : g;
 }
 
+int wgrad_xcd_order() {
+  static const int v = env_int("SPX_WGRAD_XCD", 1);   // A/B switch
+  return v;
+}
+
 size_t wgrad_plan2_ints(int n_in, int kv) {
   const size_t G = wgrad_groups(n_in);
   return 8 + kW2Rec * G + kv + 1 + 3 * (G + kv) + 4 + 4 + 4 * static_cast<size_t>(kv) * 256 + 8;
@@ -2827,6 +2877,7 @@ int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t 
     q.tiles_c = p.tiles_c;
     q.tiles_k = p.tiles_k;
     q.G = wgrad_groups(n_in);
+    q.xcd_order = wgrad_xcd_order();
     const dim3 grid(static_cast<unsigned>(q.G) * ntile);
     const size_t lds = 2 * 2 * kW2J * 128;    // two stages x two operand tiles
     const int sl = (C <= 16 && K <= 16) ? 2 : ((C <= 32 && K <= 32) ? 4 : 8);   // live 16-byte slots per row
@@ -2960,6 +3011,7 @@ int spx_igemm_bwd(const void *feat, const void *dout, const void *weight, void *
   q.tiles_c = div_up(C, kWT);
   q.tiles_k = div_up(K, kWT);
   q.G = wgrad_groups(n_in);
+  q.xcd_order = wgrad_xcd_order();
   const int ntile = q.tiles_c * q.tiles_k;
   const int rc = dtype == SPX_F32 ? dispatch_bwd<3>(p, q, q.G * ntile, s)
                                   : (dtype == SPX_BF16 ? dispatch_bwd<1>(p, q, q.G * ntile, s)
