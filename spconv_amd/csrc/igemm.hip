@@ -1776,49 +1776,59 @@ __host__ __device__ inline int plan2_red(int G, int kv) {
   return (plan2_seg(G, kv) + 3 * (G + kv) + 3) & ~3;
 }
 
-// exclusive prefix sum of one int per thread over the whole kW2MaxG-thread block (wave scans + the
-// wave totals through LDS); returns the prefix, `total` = sum over the block.  One barrier.
-__device__ __forceinline__ int plan_scan(int v, int *wtot, int &total) {
+// exclusive prefix sum of one value per thread over the whole kW2MaxG-thread block (wave scans + the
+// wave totals through LDS); returns the prefix, `total` = sum over the block.  One barrier.  The plan
+// packs several small counters into one 64-bit value per scan.
+template <typename T>
+__device__ __forceinline__ T plan_scan(T v, T *wtot, T &total) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  int incl = v;
+  T incl = v;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
-    const int u = __shfl_up(incl, d, 64);
+    const T u = __shfl_up(incl, d, 64);
     if (lane >= d) incl += u;
   }
   if (lane == 63) wtot[wv] = incl;
   __syncthreads();
-  int prefix = 0;
+  T prefix = 0;
   total = 0;
 #pragma unroll
   for (int w = 0; w < kW2MaxG / 64; ++w) {
-    const int t = wtot[w];
+    const T t = wtot[w];
     if (w < wv) prefix += t;
     total += t;
   }
   return prefix + incl - v;
 }
 
-// One block.  Everything is a prefix sum or a closed form of the kv list lengths: the pairs of all
-// lists, laid end to end, are cut into G equal ranges (one per workgroup of the first stage); a
-// segment is the part of one list inside one range.  A range finds its first list by bisection
-// and walks on from there (1-2 lists at kv = 27), the number of ranges that touch list k is
-// floor((end-1)/per) - floor(start/per) + 1.
+// One block, three block-wide scans.  Everything is a prefix sum or a closed form of the kv list
+// lengths: the pairs of all lists, laid end to end, are cut into G equal ranges (one per workgroup
+// of the first stage); a segment is the part of one list inside one range.  A range finds its first
+// list by bisection and walks on from there (1-2 lists at kv = 27), the number of ranges that touch
+// list k is floor((end-1)/per) - floor(start/per) + 1.
+//
+// Which workgroup takes which range: workgroup b runs on XCD b % 8 (round-robin dispatch) and all
+// ranges advance through their lists at about the same rate, so the ranges that start in the same
+// eighth of their list -- the same eighth of the ROWS, every list being in row order -- go to the
+// same XCD: its L2 then serves a row to the other offsets that use it, instead of every XCD pulling
+// it out of the Infinity Cache once per offset.  rec[5] of workgroup b = its range.
 __global__ void __launch_bounds__(kW2MaxG)
 wgrad_plan2_kernel(const int32_t *__restrict__ num, int n_in, int kv, int subm, int G,
                    int32_t *__restrict__ plan) {
+  typedef unsigned long long u64;
   __shared__ int start[130], kfirst[130], kcount[130], ritems[130];
-  __shared__ int wtot[4][kW2MaxG / 64];
+  __shared__ int wtot_i[kW2MaxG / 64];
+  __shared__ u64 wtot_a[kW2MaxG / 64], wtot_b[kW2MaxG / 64];
   const int tid = threadIdx.x;
   const int c = tid < kv ? list_count(num, kv, subm, n_in, tid) : 0;
   int total;
-  const int st = plan_scan(c, wtot[0], total);
+  const int st = plan_scan<int>(c, wtot_i, total);
   if (tid <= kv) start[tid] = st;               // start[kv] = total (threads >= kv add nothing)
   const int per = total > 0 ? (total + G - 1) / G : 1;
   __syncthreads();
 
-  // ---- ranges: first list, number of segments
-  int lo = 0, hi = 0, mine = 0, k0 = 0;
+  // ---- ranges: first list, number of segments, XCD
+  int lo = 0, hi = 0, mine = 0, k0 = 0, x = 0;
   if (tid < G) {
     lo = min(total, tid * per);
     hi = min(total, lo + per);
@@ -1832,13 +1842,43 @@ wgrad_plan2_kernel(const int32_t *__restrict__ num, int n_in, int kv, int subm, 
       k0 = a;
       for (int k = k0; k < kv && start[k] < hi; ++k)
         mine += (min(hi, start[k + 1]) > max(lo, start[k])) ? 1 : 0;
+      const int len = start[k0 + 1] - start[k0];
+      x = min(kXcds - 1, static_cast<int>(static_cast<long long>(lo - start[k0]) * kXcds / (len > 0 ? len : 1)));
     }
   }
-  int nseg_total;
-  const int seg0 = plan_scan(tid < G ? mine : 0, wtot[1], nseg_total);
+  // ---- per offset: segments (= ranges touching the list), second-stage items
+  int kc = 0, nitems = 0;
+  if (tid < kv) {
+    if (c > 0) kc = (start[tid + 1] - 1) / per - start[tid] / per + 1;
+    // second-stage work list: block shape by segment count (see wgrad_reduce2_kernel)
+    const int mode = kc >= 48 ? 0 : (kc >= 6 ? 1 : 2);
+    nitems = (kWT * kWT) / (mode == 0 ? 16 : (mode == 1 ? 128 : 512));
+  }
+  // scan A: segments per range (11 bits: <= G + kv) | ranges of XCD 0..4 (10 bits each)
+  // scan B: ranges of XCD 5..7 (10 bits each) | segments per offset (11 bits, bit 30) | items (bit 41)
+  u64 va = 0, vb = 0;
+  if (tid < G) {
+    va = static_cast<u64>(mine);
+    if (x < 5) va |= 1ull << (11 + 10 * x);
+    else vb = 1ull << (10 * (x - 5));
+  }
+  vb |= (static_cast<u64>(kc) << 30) | (static_cast<u64>(nitems) << 41);
+  u64 ta, tb;
+  const u64 ea = plan_scan<u64>(va, wtot_a, ta);
+  const u64 eb = plan_scan<u64>(vb, wtot_b, tb);
+  const int seg0 = static_cast<int>(ea & 0x7ff), nseg_total = static_cast<int>(ta & 0x7ff);
+  const int kf = static_cast<int>((eb >> 30) & 0x7ff), ri = static_cast<int>(eb >> 41);
+  const int kc_total = static_cast<int>((tb >> 30) & 0x7ff), items_total = static_cast<int>(tb >> 41);
   if (tid == 0) {
     plan[0] = nseg_total;
     plan[1] = per;
+    plan[plan2_red(G, kv)] = items_total;
+  }
+  if (tid <= kv) {
+    kfirst[tid] = kf;
+    kcount[tid] = kc;
+    ritems[tid] = ri;
+    plan[plan2_kf(G) + tid] = tid == kv ? kc_total : kf;
   }
   int32_t *seg = plan + plan2_seg(G, kv);
   if (tid < G) {
@@ -1868,68 +1908,23 @@ wgrad_plan2_kernel(const int32_t *__restrict__ num, int n_in, int kv, int subm, 
     rec[2] = r2;
     rec[3] = r3;
     rec[4] = r4;
-  }
-
-  // ---- which workgroup takes which range.  Workgroup b runs on XCD b % 8 (round-robin dispatch) and all
-  // ranges advance through their lists at about the same rate, so the ranges that start in the same
-  // eighth of their list -- the same eighth of the ROWS, every list being in row order -- go to the same
-  // XCD: its L2 then serves a row to the other offsets that use it, instead of 27 XCDs x offsets pulling
-  // it out of the Infinity Cache.  rec[5] of workgroup b = its range.
-  {
-    int x = 0;
-    if (tid < G && hi > lo) {
-      const int len = start[k0 + 1] - start[k0];
-      x = min(kXcds - 1, static_cast<int>(static_cast<long long>(lo - start[k0]) * kXcds / (len > 0 ? len : 1)));
-    }
-    // rank of the range among the ranges of its XCD (four scans of two 16-bit counters), and the XCD sizes
-    int rank = 0, before_x = 0;
-    int cnt_x[kXcds];
+    // position of this range in (XCD, rank) order -> the workgroup at the same position in
+    // (b % 8, b / 8) order; XCD y owns ceil((G - y) / 8) workgroups
+    int pos = x < 5 ? static_cast<int>((ea >> (11 + 10 * x)) & 0x3ff) : static_cast<int>((eb >> (10 * (x - 5))) & 0x3ff);
 #pragma unroll
-    for (int pr = 0; pr < kXcds / 2; ++pr) {
-      const int v = (tid < G) ? ((x == 2 * pr ? 1 : 0) | (x == 2 * pr + 1 ? 1 << 16 : 0)) : 0;
-      int tot;
-      const int ex = plan_scan(v, wtot[pr & 3], tot);
-      if (x == 2 * pr) rank = ex & 0xffff;
-      if (x == 2 * pr + 1) rank = ex >> 16;
-      cnt_x[2 * pr] = tot & 0xffff;
-      cnt_x[2 * pr + 1] = tot >> 16;
-      __syncthreads();                       // wtot[pr & 3] is reused by the next pair
+    for (int y = 0; y < kXcds; ++y) {
+      const int cy = y < 5 ? static_cast<int>((ta >> (11 + 10 * y)) & 0x3ff) : static_cast<int>((tb >> (10 * (y - 5))) & 0x3ff);
+      if (y < x) pos += cy;
     }
-#pragma unroll
-    for (int y = 0; y < kXcds; ++y)
-      if (y < x) before_x += cnt_x[y];
-    if (tid < G) {
-      // position of this range in (XCD, rank) order -> the workgroup at the same position in
-      // (b % 8, b / 8) order; XCD y owns ceil((G - y) / 8) workgroups
-      int pos = before_x + rank, y = 0, base = 0;
-      for (; y < kXcds - 1; ++y) {
-        const int ny = (G - y + kXcds - 1) / kXcds;
-        if (pos < base + ny) break;
-        base += ny;
-      }
-      const int b = y + kXcds * (pos - base);
-      plan[plan2_wg(b < G ? b : tid) + 5] = tid;
+    int y = 0, base = 0;
+    for (; y < kXcds - 1; ++y) {
+      const int ny = (G - y + kXcds - 1) / kXcds;
+      if (pos < base + ny) break;
+      base += ny;
     }
+    const int b = y + kXcds * (pos - base);
+    plan[plan2_wg(b < G ? b : tid) + 5] = tid;
   }
-
-  // ---- per offset: segments (= ranges touching the list), first segment, second-stage items
-  int kc = 0, nitems = 0, mode = 2;
-  if (tid < kv && c > 0) kc = (start[tid + 1] - 1) / per - start[tid] / per + 1;
-  if (tid < kv) {
-    // second-stage work list: block shape by segment count (see wgrad_reduce2_kernel)
-    mode = kc >= 48 ? 0 : (kc >= 6 ? 1 : 2);
-    nitems = (kWT * kWT) / (mode == 0 ? 16 : (mode == 1 ? 128 : 512));
-  }
-  int kc_total, items_total;
-  const int kf = plan_scan(kc, wtot[2], kc_total);
-  const int ri = plan_scan(nitems, wtot[3], items_total);
-  if (tid <= kv) {
-    kfirst[tid] = kf;
-    kcount[tid] = kc;
-    ritems[tid] = ri;
-    plan[plan2_kf(G) + tid] = kf;
-  }
-  if (tid == 0) plan[plan2_red(G, kv)] = items_total;
   __syncthreads();
   int32_t *rl = plan + plan2_red(G, kv);
   for (int k = 0; k < kv; ++k) {
