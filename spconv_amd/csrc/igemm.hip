@@ -66,6 +66,7 @@ struct GemmParams {
   float add_scale;
   int out_dtype;          // SPX_I8 / SPX_F16 / SPX_BF16 / SPX_F32
   int dbg;                // ablation builds only (-DSPX_ABLATE, tools/dense_probe.py)
+  int xcd_rot;            // blocks of the launch ahead of this kernel body's first one, mod 8 (fused backward)
 };
 
 // Ablation switch of the measurement build (csrc/build_ablate.sh): which part of a step is left out
@@ -148,6 +149,22 @@ __device__ __forceinline__ int swz_off(int row, int slot, int row_bytes, int xma
 __device__ __forceinline__ int xcd_tile(int bid, int ntiles) {
   const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, j = bid >> 3;
   const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + j;
+}
+
+// The same for workgroups that are `rot` blocks into a launch (the dgrad tiles of the fused backward
+// come after the wgrad ranges): workgroup bid runs on XCD (bid + rot) % 8, and that XCD gets the
+// tile range at ITS position, so that it works on the same eighth of the rows as the wgrad ranges
+// the plan gave it (wgrad_plan2_kernel) and the two halves share the gradient rows in its L2.
+__device__ __forceinline__ int xcd_tile_rot(int bid, int ntiles, int rot) {
+  const int q = ntiles >> 3, r = ntiles & 7, cls = bid & 7, j = bid >> 3;   // class cls has q + (cls < r) tiles
+  const int phys = (cls + rot) & 7;
+  int base = 0;
+#pragma unroll
+  for (int y = 0; y < 8; ++y) {
+    const int c = (y - rot) & 7;                         // the class that runs on XCD y
+    if (y < phys) base += q + (c < r ? 1 : 0);
+  }
   return base + j;
 }
 
@@ -635,6 +652,7 @@ __device__ __forceinline__ void unpack_gemm_args(GemmParams &p, const void *argA
   p.add_scale = rest.add_scale;
   p.out_dtype = rest.out_dtype;
   p.dbg = rest.dbg;
+  p.xcd_rot = 0;
 }
 
 template <int COUT, int MB, int DT, bool BT, int NKS>
@@ -659,7 +677,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   SPX_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntiles = (p.n_dst + TM - 1) / TM;
-  const int tile = xcd_tile(block, ntiles);
+  const int tile = p.xcd_rot ? xcd_tile_rot(block, ntiles, p.xcd_rot) : xcd_tile(block, ntiles);
   const int lrow = lane & 15, lgrp = lane >> 4;
   const int slot = tid & 7, r0 = tid >> 3;
   // Output-channel permutation: MFMA row (g = i >> 2, e = i & 3) of channel block nb carries
@@ -2252,6 +2270,7 @@ igemm_bwd_kernel(const void *argA, const void *argB, const uint32_t *arg_mask,
     GemmParams p;
     unpack_gemm_args(p, argA, argB, arg_mask, arg_argsort, arg_pair, n_dst, n_src, CIN, kv,
                      identity_k, b_reverse, rest);
+    p.xcd_rot = (rest.dbg & 0x100) ? 0 : (nw & 7);      // (SPX_V4_DBG=256: A/B switch)
     igemm_v4_body<COUT, MB, DT, true, NKS>(p, n_dgrad < 0 ? b - nw : b);
   } else {
     if constexpr (DT == 3) wgrad_f32_body(wp, n_dgrad < 0 ? b : b - n_dgrad);
