@@ -25,6 +25,17 @@
 #include <type_traits>
 #include <utility>
 
+// cache policy of the loads that stream a table once per launch (pair words, mask words, pair lists):
+// 0 = default, 2 = non-temporal (A/B builds: -DSPX_AUX_TABLE=2)
+#ifndef SPX_AUX_TABLE
+#define SPX_AUX_TABLE 0
+#endif
+// the same for result rows / partial tiles that the launch itself never reads again: 2 = non-temporal
+// (igemm_v4 epilogue: cfg 2 step 37.4 -> 33.6 us), 0 in the A/B build
+#ifndef SPX_AUX_OUT
+#define SPX_AUX_OUT 2
+#endif
+
 namespace spx {
 namespace {
 
@@ -537,18 +548,19 @@ __device__ __forceinline__ ACC mfma_step(const uint4 &a, const uint4 &b, ACC c) 
 }
 
 // N consecutive dwords of one lane to / from a raw buffer, in the widest pieces
-template <int N>
+// AUX: cache policy bits of the store (gfx950: 1 = sc0, 2 = nt, 16 = sc1)
+template <int N, int AUX = 0>
 __device__ __forceinline__ void store_dwords(const uint32_t (&d)[N], __amdgpu_buffer_rsrc_t r,
                                              uint32_t vo) {
   if constexpr (N == 1) {
-    __builtin_amdgcn_raw_buffer_store_b32(d[0], r, vo, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(d[0], r, vo, 0, AUX);
   } else if constexpr (N == 2) {
-    __builtin_amdgcn_raw_buffer_store_b64(u32x2{d[0], d[1]}, r, vo, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{d[0], d[1]}, r, vo, 0, AUX);
   } else {
 #pragma unroll
     for (int q = 0; q < N / 4; ++q)
       __builtin_amdgcn_raw_buffer_store_b128(u32x4{d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]},
-                                             r, vo + q * 16, 0, 0);
+                                             r, vo + q * 16, 0, AUX);
   }
 }
 template <int N>
@@ -761,7 +773,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
     identr[S] = it.k == p.identity_k ? 0xffffffffu : 0u;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
-      idxr[S][mb] = SPX_ABL(p, 5) ? grow[mb] : static_cast<int>(__builtin_amdgcn_raw_buffer_load_b32(rP, goff[mb], 0, 0));
+      idxr[S][mb] = SPX_ABL(p, 5) ? grow[mb] : static_cast<int>(__builtin_amdgcn_raw_buffer_load_b32(rP, goff[mb], 0, SPX_AUX_TABLE));
   };
   auto load_a = [&](const StepIt &it, auto SET) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
@@ -844,7 +856,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   uint32_t mraw[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
-    mraw[mb] = __builtin_amdgcn_raw_buffer_load_b32(rM, goff[mb] == kOob ? kOob : goff[mb] * p.mask_words, 0, 0);
+    mraw[mb] = __builtin_amdgcn_raw_buffer_load_b32(rM, goff[mb] == kOob ? kOob : goff[mb] * p.mask_words, 0, SPX_AUX_TABLE);
   __builtin_amdgcn_sched_barrier(0);
   // identity step: start its loads before the mask words arrive.  Unconditional (a regular
   // conv has it0.k == -1 here and reads zero-sized resources) so that the wait for the mask
@@ -1032,7 +1044,11 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
       }
       const uint32_t vo = grow[mb] < 0 ? kOob
                                        : static_cast<uint32_t>(grow[mb]) * (COUT * ES) + lgrp * (CPL * ES);
-      store_dwords<(F32 ? CPL : CPL / 2)>(d, rO, vo);
+      // non-temporal stores: the rows are not read again by this launch, and lines left dirty in the L2 /
+      // Infinity Cache are written back at the kernel boundary and push the next scene's inputs out
+      // (cfg 2 step 37.4 -> 33.6 us; sc1 stores 41.9; neutral on the fixture and inside the backbone)
+      if (p.dbg & 0x400) store_dwords<(F32 ? CPL : CPL / 2)>(d, rO, vo);          // (SPX_V4_DBG=1024: plain, A/B)
+      else store_dwords<(F32 ? CPL : CPL / 2), 2>(d, rO, vo);
     }
   } else {
     // int8 inference epilogue (reference numerics: test/test_all_algo.py:272-287):
@@ -1082,20 +1098,20 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
           uint32_t d[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) d[e] = __builtin_bit_cast(uint32_t, v[e]);
-          store_dwords<4>(d, rO, rowoff[mb] == kOob ? kOob : (rowoff[mb] + nb * 4) * 4u);
+          store_dwords<4, SPX_AUX_OUT>(d, rO, rowoff[mb] == kOob ? kOob : (rowoff[mb] + nb * 4) * 4u);
         } else {
           uint32_t d[2];
 #pragma unroll
           for (int q = 0; q < 2; ++q)
             d[q] = p.out_dtype == SPX_BF16 ? pack2<true>(v[2 * q], v[2 * q + 1])
                                            : pack2<false>(v[2 * q], v[2 * q + 1]);
-          store_dwords<2>(d, rO, rowoff[mb] == kOob ? kOob : (rowoff[mb] + nb * 4) * 2u);
+          store_dwords<2, SPX_AUX_OUT>(d, rO, rowoff[mb] == kOob ? kOob : (rowoff[mb] + nb * 4) * 2u);
         }
       }
     }
     if (p.out_dtype == SPX_I8) {
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) store_dwords<CPL / 4>(addw[mb], rO, rowoff[mb]);
+      for (int mb = 0; mb < MB; ++mb) store_dwords<CPL / 4, SPX_AUX_OUT>(addw[mb], rO, rowoff[mb]);
     }
   }
   SPX_STAMP(6);   // stores issued
@@ -1666,7 +1682,8 @@ wgrad_mfma_kernel(WgradParams p) {
         for (int e = 0; e < 4; ++e) {
           const int kk = wk * 32 + a * 16 + (lane >> 4) * 4 + e;
           const int c = wc * 32 + b * 16 + (lane & 15);
-          dst[kk * kWT + c] = acc[a][b][e];
+          if (SPX_AUX_OUT) __builtin_nontemporal_store(acc[a][b][e], &dst[kk * kWT + c]);
+          else dst[kk * kWT + c] = acc[a][b][e];
         }
     __syncthreads();  // LDS is rewritten by the next work item
   }
@@ -2066,8 +2083,8 @@ __device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, int block) 
           oi[q] = static_cast<uint32_t>(j);
         } else {
           const uint32_t vo = j < end ? static_cast<uint32_t>(j) * 4u : kOob;
-          ii[q] = __builtin_amdgcn_raw_buffer_load_b32(rIn, vo, 0, 0);
-          oi[q] = __builtin_amdgcn_raw_buffer_load_b32(rOut, vo, 0, 0);
+          ii[q] = __builtin_amdgcn_raw_buffer_load_b32(rIn, vo, 0, SPX_AUX_TABLE);
+          oi[q] = __builtin_amdgcn_raw_buffer_load_b32(rOut, vo, 0, SPX_AUX_TABLE);
         }
       }
     };
@@ -2122,7 +2139,8 @@ __device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, int block) 
         for (int e = 0; e < 4; ++e) {
           const int kk = wk * 32 + a * 16 + lgrp * 4 + e;
           const int c = wc * 32 + b * 16 + lrow;
-          dst[kk * kWT + c] = acc[a][b][e];
+          if (SPX_AUX_OUT) __builtin_nontemporal_store(acc[a][b][e], &dst[kk * kWT + c]);
+          else dst[kk * kWT + c] = acc[a][b][e];
         }
     __syncthreads();  // both stages are rewritten by the next segment
   }
@@ -2240,7 +2258,8 @@ __device__ __forceinline__ void wgrad_f32_body(const Wgrad2Params &p, int block)
         for (int e = 0; e < 4; ++e) {
           const int kk = wk * 32 + a * 16 + lgrp * 4 + e;
           const int c = wc * 32 + b * 16 + lrow;
-          dst[kk * kWT + c] = acc[a][b][e];
+          if (SPX_AUX_OUT) __builtin_nontemporal_store(acc[a][b][e], &dst[kk * kWT + c]);
+          else dst[kk * kWT + c] = acc[a][b][e];
         }
     __syncthreads();
   }

@@ -292,7 +292,7 @@ bn_apply_kernel(const u32x4 *__restrict__ x, u32x4 *__restrict__ y, long long pi
       if (relu) v = v > 0.f ? v : 0.f;
       f[e] = v;
     }
-    y[i] = Vec<DT>::pack(f);
+    __builtin_nontemporal_store(Vec<DT>::pack(f), &y[i]);      // (not read again by this launch)
   }
 }
 
@@ -408,7 +408,7 @@ bn_bwd_apply_kernel(const u32x4 *__restrict__ x, const u32x4 *__restrict__ dy, u
       if (relu && xh * l_w[c] + l_bias[c] <= 0.f) gg = 0.f;
       f[e] = l_g[c] * (gg - l_c1[c] - xh * l_c2[c]);
     }
-    dx[i] = Vec<DT>::pack(f);
+    __builtin_nontemporal_store(Vec<DT>::pack(f), &dx[i]);
   }
 }
 
