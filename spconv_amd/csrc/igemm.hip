@@ -2565,6 +2565,12 @@ int wgrad_groups(int n_in) {
   return g < 1 ? 1 : g;
 }
 
+// blocks of the second stage (block-stride over at most kv * 256 items)
+int reduce2_blocks(int kv) {
+  static const int cap = env_int("SPX_REDUCE2_GRID", 512);   // tuning knob
+  return kv * 256 < cap ? kv * 256 : cap;
+}
+
 int wgrad_xcd_order() {
   static const int v = env_int("SPX_WGRAD_XCD", 1);   // A/B switch
   return v;
@@ -2925,7 +2931,7 @@ int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t 
       else if (sl == 4) hipLaunchKernelGGL((wgrad_tr_kernel<true, 4>), grid, dim3(kThreads), lds, s, q);
       else hipLaunchKernelGGL((wgrad_tr_kernel<true, 8>), grid, dim3(kThreads), lds, s, q);
     }
-    const dim3 rgrid2(kv * 256 < 512 ? kv * 256 : 512, ntile);   // block-stride over the work list
+    const dim3 rgrid2(reduce2_blocks(kv), ntile);   // block-stride over the work list
     if (dtype == SPX_F32)
       hipLaunchKernelGGL(wgrad_reduce2_kernel<float>, rgrid2, dim3(kRedThreads), 0, s, q,
                          static_cast<float *>(dw));
@@ -3050,7 +3056,7 @@ int spx_igemm_bwd(const void *feat, const void *dout, const void *weight, void *
                                   : (dtype == SPX_BF16 ? dispatch_bwd<1>(p, q, q.G * ntile, s)
                                                        : dispatch_bwd<0>(p, q, q.G * ntile, s));
   if (rc) return rc;
-  const dim3 rgrid2(kv * 256 < 512 ? kv * 256 : 512, ntile);   // block-stride over the work list
+  const dim3 rgrid2(reduce2_blocks(kv), ntile);   // block-stride over the work list
   if (dtype == SPX_F32)
     hipLaunchKernelGGL(wgrad_reduce2_kernel<float>, rgrid2, dim3(kRedThreads), 0, s, q, static_cast<float *>(dw));
   else if (dtype == SPX_F16)
