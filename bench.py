@@ -631,6 +631,9 @@ def run_layer(args, D: Dist):
                    "dist_backend": D.backend if world > 1 else None},
         "roofline": r_cold, "roofline_cold": r_cold, "roofline_warm": r_warm,
         "kernels": ktable(t_cold), "kernels_warm": ktable(t_warm),
+        "kernels_note": "each group is timed alone (its own hipGraph, rotating over the scenes); in a step the "
+                        "backward of scene i finds the rows and tables its forward has just read in the caches, "
+                        "so ms_per_step can be below fwd + bwd",
         "warm": None if warm_ms is None else {"ms_per_step": round(warm_ms, 5),
                                               "value": round(n / (warm_ms * 1e-3), 1),
                                               "note": "one scene replayed: Infinity-Cache-resident working set"},
