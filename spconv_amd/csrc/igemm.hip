@@ -2028,12 +2028,24 @@ __device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, int block) 
   const uint32_t rowD = static_cast<uint32_t>(p.K) * 2u, rowF = static_cast<uint32_t>(p.C) * 2u;
   const __amdgpu_buffer_rsrc_t rD = make_rsrc(p.dout, static_cast<uint32_t>(p.n_out) * rowD);
   const __amdgpu_buffer_rsrc_t rF = make_rsrc(p.feat, static_cast<uint32_t>(p.n_in) * rowF);
-  const uint32_t list_bytes = static_cast<uint32_t>(p.n_in) * 4u;
+  // both pair lists of an offset (in: native[0][k], out: native[1][k] = kv * n_in words further on) are
+  // read through ONE resource, so that one load per wave fetches the words of a whole chunk
+  const uint32_t list_bytes = (static_cast<uint32_t>(p.kv) + 1u) * static_cast<uint32_t>(p.n_in) * 4u;
+  const uint32_t out_list = static_cast<uint32_t>(p.kv) * static_cast<uint32_t>(p.n_in) * 4u;
 
-  // load role: 16-byte slot `slot` of rows r0 + 32 q (q = 0..3) of both operand tiles
+  // load role: 16-byte slot `slot` of rows r0 + RSTEP q (q < RQ) of both operand tiles
   const int slot = tid & (SL - 1), r0 = tid / SL;
   const uint32_t dcol = kk0 + slot * 8 < p.K ? static_cast<uint32_t>(kk0 + slot * 8) * 2u : kOob;
   const uint32_t fcol = c0 + slot * 8 < p.C ? static_cast<uint32_t>(c0 + slot * 8) * 2u : kOob;
+  // pair-list words: the 64 / SL rows of a wave x RQ steps are 32 pairs per chunk; lane L < 32 fetches the
+  // in-word of pair L of the wave, lane 32 + L its out-word (one buffer_load_dword per wave and chunk
+  // instead of 2 RQ with every word fetched SL times); the 2 RQ words a thread needs come back through
+  // ds_bpermute
+  constexpr int W_ROWS = 64 / SL;
+  const int wl_idx = lane & 31;
+  const int wl_row = (64 * wave) / SL + (wl_idx % W_ROWS) + RSTEP * (wl_idx / W_ROWS);
+  const uint32_t wl_list = (lane >> 5) ? out_list : 0u;
+  const int rsub = lane / SL;                       // this thread's row among the wave's W_ROWS rows
   int lds_w[RA];
 #pragma unroll
   for (int q = 0; q < RQ; ++q) lds_w[q] = wtr_slot(r0 + RSTEP * q, slot);
@@ -2056,10 +2068,7 @@ __device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, int block) 
       end = segs[3 * (seg_lo + si) + 2];
     }
     const bool identity = p.subm && k == p.kv / 2;
-    const __amdgpu_buffer_rsrc_t rIn =
-        make_rsrc(p.native + static_cast<size_t>(k) * p.n_in, list_bytes);
-    const __amdgpu_buffer_rsrc_t rOut =
-        make_rsrc(p.native + static_cast<size_t>(p.kv + k) * p.n_in, list_bytes);
+    const __amdgpu_buffer_rsrc_t rW = make_rsrc(p.native + static_cast<size_t>(k) * p.n_in, list_bytes);
 
     f32x4 acc[2][2];
 #pragma unroll
@@ -2072,28 +2081,27 @@ __device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, int block) 
     // 1023 ranges) were all measured within 3 % of this on 0.3 M - 1.2 M voxel levels
     // (profiles/r02_dense_regime_experiments.md): at that size the loop is bound by the 128-byte
     // lines the gathers pull out of the Infinity Cache, once per offset, whatever the row width.
-    uint32_t ii[RA], oi[RA];
+    uint32_t wd = 0;              // this lane's pair-list word of the chunk whose rows are fetched next
     u32x4 dv[RA], fv[RA];
     auto load_words = [&](int base) __attribute__((always_inline)) {
-#pragma unroll
-      for (int q = 0; q < RQ; ++q) {
-        const int j = base + r0 + RSTEP * q;
-        if (identity) {
-          ii[q] = static_cast<uint32_t>(j);
-          oi[q] = static_cast<uint32_t>(j);
-        } else {
-          const uint32_t vo = j < end ? static_cast<uint32_t>(j) * 4u : kOob;
-          ii[q] = __builtin_amdgcn_raw_buffer_load_b32(rIn, vo, 0, SPX_AUX_TABLE);
-          oi[q] = __builtin_amdgcn_raw_buffer_load_b32(rOut, vo, 0, SPX_AUX_TABLE);
-        }
+      const int j = base + wl_row;
+      if (identity) {
+        wd = static_cast<uint32_t>(j);
+      } else {
+        const uint32_t vo = j < end ? static_cast<uint32_t>(j) * 4u + wl_list : kOob;
+        wd = __builtin_amdgcn_raw_buffer_load_b32(rW, vo, 0, SPX_AUX_TABLE);
       }
     };
     auto load_rows = [&](int base) __attribute__((always_inline)) {
 #pragma unroll
       for (int q = 0; q < RQ; ++q) {
+        const uint32_t iq = static_cast<uint32_t>(
+            __builtin_amdgcn_ds_bpermute((q * W_ROWS + rsub) * 4, static_cast<int>(wd)));
+        const uint32_t oq = static_cast<uint32_t>(
+            __builtin_amdgcn_ds_bpermute((32 + q * W_ROWS + rsub) * 4, static_cast<int>(wd)));
         const bool ok = base + r0 + RSTEP * q < end;      // rows past the segment read as zero
-        dv[q] = __builtin_amdgcn_raw_buffer_load_b128(rD, ok ? (oi[q] * rowD + dcol) | (dcol & kOob) : kOob, 0, 0);
-        fv[q] = __builtin_amdgcn_raw_buffer_load_b128(rF, ok ? (ii[q] * rowF + fcol) | (fcol & kOob) : kOob, 0, 0);
+        dv[q] = __builtin_amdgcn_raw_buffer_load_b128(rD, ok ? (oq * rowD + dcol) | (dcol & kOob) : kOob, 0, 0);
+        fv[q] = __builtin_amdgcn_raw_buffer_load_b128(rF, ok ? (iq * rowF + fcol) | (fcol & kOob) : kOob, 0, 0);
       }
     };
     load_words(begin);
@@ -2893,7 +2901,7 @@ int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t 
   static const int wgrad_version = env_int("SPX_WGRAD_V", 2);    // tuning knob (A/B runs)
   const bool small_offsets = static_cast<unsigned long long>(n_out) * K * 2ull < 0x7fff0000ull &&
                              static_cast<unsigned long long>(n_in) * C * 2ull < 0x7fff0000ull &&
-                             static_cast<unsigned long long>(n_in) * 4ull < 0x7fff0000ull;
+                             static_cast<unsigned long long>(n_in) * 4ull * (kv + 1) < 0x7fff0000ull;   // both lists of an offset through one resource
   static const int f32_mfma = env_int("SPX_F32_MFMA", 1);         // tuning knob (A/B runs)
   const bool f32_path = dtype == SPX_F32 && f32_mfma && C % 4 == 0 && K % 4 == 0 &&
                         static_cast<unsigned long long>(n_out) * K * 4ull < 0x7fff0000ull &&
@@ -3013,7 +3021,7 @@ int spx_igemm_bwd(const void *feat, const void *dout, const void *weight, void *
   p.tile_order = (tile_order && argsort) ? 1 : 0;
   const bool small_offsets = static_cast<unsigned long long>(n_out) * K * 2ull < 0x7fff0000ull &&
                              static_cast<unsigned long long>(n_in) * C * 2ull < 0x7fff0000ull &&
-                             static_cast<unsigned long long>(n_in) * 4ull < 0x7fff0000ull;
+                             static_cast<unsigned long long>(n_in) * 4ull * (kv + 1) < 0x7fff0000ull;   // both lists of an offset through one resource
   const int es = dtype == SPX_F32 ? 4 : 2, lanes = 16 / es;
   const bool offsets_fit = static_cast<unsigned long long>(n_out) * K * es < 0x7fff0000ull &&
                            static_cast<unsigned long long>(n_in) * C * es < 0x7fff0000ull && small_offsets;
