@@ -234,3 +234,43 @@ def test_remove_duplicate_keeps_first_row_of_a_coordinate():
     y = RemoveDuplicate()(sp.SparseConvTensor(feat, idx, [4, 4, 4], 2))
     assert y.indices.tolist() == [[0, 1, 2, 3], [1, 1, 2, 3], [0, 0, 0, 0]]
     assert y.features.view(-1).tolist() == [0.0, 1.0, 3.0]
+
+
+def test_xcd_aware_mappings_are_bijective():
+    """The block -> tile map of the fused backward (csrc/igemm.hip: xcd_tile_rot) and the block -> range
+    hand-out of the wgrad plan (wgrad_plan2_kernel, rec[5]) restated in Python: every tile / range is
+    taken exactly once, and a workgroup that runs on XCD x gets work of row eighth x."""
+    def xcd_tile_rot(bid, ntiles, rot):
+        q, r, cls, j = ntiles >> 3, ntiles & 7, bid & 7, bid >> 3
+        phys = (cls + rot) & 7
+        base = sum(q + (1 if ((y - rot) & 7) < r else 0) for y in range(phys))
+        return base + j
+
+    for ntiles in (1, 7, 8, 9, 63, 782, 981, 1000):
+        for rot in range(8):
+            tiles = [xcd_tile_rot(b, ntiles, rot) for b in range(ntiles)]
+            assert sorted(tiles) == list(range(ntiles)), (ntiles, rot)
+            if ntiles >= 64:          # physical XCD of dgrad block b is (b + rot) % 8: its tiles lie in eighth x
+                for b in range(ntiles):
+                    x = (b + rot) & 7
+                    assert abs(tiles[b] / ntiles - (x + 0.5) / 8) <= 0.5 / 8 + 2 / ntiles
+
+    def hand_out(xcd_of_range):
+        """plan: ranges sorted by (xcd, rank) meet workgroups sorted by (b % 8, b // 8)."""
+        G = len(xcd_of_range)
+        order = sorted(range(G), key=lambda t: (xcd_of_range[t], t))
+        blocks = sorted(range(G), key=lambda b: (b % 8, b // 8))
+        take = [None] * G
+        for rng, b in zip(order, blocks):
+            take[b] = rng
+        return take
+
+    import random
+    rnd = random.Random(0)
+    for G in (1, 8, 242, 384, 1023):
+        xs = [min(7, (t * 8) // G) if rnd.random() < 0.9 else rnd.randrange(8) for t in range(G)]
+        take = hand_out(xs)
+        assert sorted(take) == list(range(G))
+        if G >= 64:
+            hits = sum(1 for b in range(G) if xs[take[b]] == b % 8)
+            assert hits >= 0.8 * G
