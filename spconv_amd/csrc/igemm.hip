@@ -2630,7 +2630,7 @@ GemmRest rest_of(const GemmParams &p) {
   r.add_scale = p.add_scale;
   r.out_dtype = p.out_dtype;
   static const int dbg = env_int("SPX_V4_DBG", 0);
-  r.dbg = dbg;
+  r.dbg = dbg | p.dbg;
   r.acc = p.acc;
   r.acc_mode = p.acc_mode;
   return r;
@@ -2712,7 +2712,8 @@ int spx_igemm_fwd(const void *feat, const void *weight, void *out, const int32_t
   p.identity_k = identity_k;
   p.b_reverse = 0;
   p.tile_order = (tile_order && argsort) ? 1 : 0;
-  p.act = act;
+  p.act = act & 0xff;
+  if (act & SPX_OUT_CACHED) p.dbg = 0x400;       // plain result stores: the next launch reads the rows
   p.act_alpha = act_alpha;
   if (ws && ws_bytes >= spx_igemm_acc_bytes(n_out, K, kv) && kv > 32) p.acc = static_cast<float *>(ws);
   return run_gather_gemm(p, dtype, static_cast<hipStream_t>(stream));

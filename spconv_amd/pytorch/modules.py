@@ -72,14 +72,19 @@ class SparseSequential(SparseModule):
         self._register(str(len(self._modules)) if name is None else name, module)
 
     def forward(self, input):
-        from spconv_amd.pytorch import norm
+        from spconv_amd.pytorch import norm, ops
         mods = list(self._modules.values())
         i = 0
         while i < len(mods):
             module = mods[i]
             i += 1
             if is_spconv_module(module):
-                input = module(input)
+                nxt = mods[i] if i < len(mods) else None
+                if isinstance(nxt, nn.modules.batchnorm._BatchNorm):
+                    with ops.output_stays_cached():     # the normalisation reads the rows next (ops._OUT_CACHED)
+                        input = module(input)
+                else:
+                    input = module(input)
             elif isinstance(input, SparseConvTensor):
                 # dense layers see the [N, C] feature matrix; skipped for empty tensors
                 if input.indices.shape[0] != 0:

@@ -16,9 +16,11 @@ this implementation has no CPU path.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import functools
 import os
+import threading
 import weakref
 from typing import List, Optional, Tuple
 
@@ -109,6 +111,22 @@ def _on_device(fn):
 
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
+
+
+# SPX_OUT_CACHED (include/spconv_amd.h): inside this context igemm_fwd asks for result rows that stay in
+# the caches -- SparseSequential opens it around a convolution whose output a BatchNorm reads next
+_OUT_CACHED = 0x100
+_out_policy = threading.local()
+
+
+@contextlib.contextmanager
+def output_stays_cached():
+    prev = getattr(_out_policy, "cached", False)
+    _out_policy.cached = True
+    try:
+        yield
+    finally:
+        _out_policy.cached = prev
 
 
 def _ws(nbytes: int, device) -> torch.Tensor:
@@ -516,7 +534,8 @@ def igemm_fwd(features: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
     _lib.check(L.spx_igemm_fwd(features.data_ptr(), filters.data_ptr(), out.data_ptr(),
                                _ptr(pair), _ptr(mask), _ptr(argsort), int(tile_order), features.shape[0], n_out,
                                C, K, kv, _dtype_code(features), identity_k, _ptr(bias),
-                               int(act_type), float(act_alpha), _ptr(ws), 0 if ws is None else ws.numel(),
+                               int(act_type) | (_OUT_CACHED if getattr(_out_policy, "cached", False) else 0),
+                               float(act_alpha), _ptr(ws), 0 if ws is None else ws.numel(),
                                _stream(features)))
     return out if K == K0 else out[:, :K0].contiguous()
 
