@@ -57,6 +57,12 @@ const char *spx_last_error(void);
 /* Library ABI version (major*1000 + minor). */
 int spx_version(void);
 
+/* Run-time override of a kernel-selection switch (same names as the SPX_* environment variables the
+ * library reads, e.g. "SPX_GEMM_V" = 4 | 5: generation of the gather-GEMM kernels).  Stands in for the
+ * per-process tuner state of the reference (ConvTunerSimple, csrc/sparse/convops.py:919-1466): tests and
+ * the benchmark use it to run two kernel generations against each other inside one process.  Host only. */
+int spx_set_option(const char *name_h, int value);
+
 /* ops.get_conv_output_size / get_deconv_output_size (pytorch/ops.py:73-96). Host only. */
 int spx_conv_out_shape(int ndim, const int *in_shape, const int *ksize, const int *stride,
                        const int *padding, const int *dilation, const int *out_padding,

@@ -26,6 +26,7 @@ vp = ctypes.c_void_p
 SIGNATURES = {
     "spx_last_error": (ctypes.c_char_p, []),
     "spx_version": (ctypes.c_int, []),
+    "spx_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     "spx_conv_out_shape": (ctypes.c_int, [ctypes.c_int] + [c_int_p] * 6 + [ctypes.c_int, c_int_p]),
     "spx_subm_rulebook_ws_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "spx_subm_rulebook": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_int_p,
@@ -105,7 +106,7 @@ def build(force: bool = False) -> str:
     """Compile the HIP sources for gfx950 (no GPU needed)."""
     script = os.path.join(_HERE, "csrc", "build.sh")
     if force:
-        for f in ("rulebook.o", "igemm.o", "pool.o", "common.o", "libspconv_amd.so"):
+        for f in ("rulebook.o", "igemm.o", "igemm5.o", "pool.o", "tileplan.o", "norm.o", "common.o", "libspconv_amd.so"):
             p = os.path.join(_HERE, "lib", f)
             if os.path.exists(p):
                 os.remove(p)

@@ -1,6 +1,9 @@
 // Host-only pieces of the C ABI: error channel, version, output-shape math.
 #include "common.h"
 
+#include <string.h>
+
+#include <mutex>
 #include <string>
 
 namespace spx {
@@ -16,9 +19,42 @@ void set_error(const char *fmt, ...) {
   va_end(ap);
   g_error = buf;
 }
+
+namespace {
+struct Option {
+  char name[48];
+  int value;
+};
+Option g_options[32];
+int g_noptions = 0;
+std::mutex g_option_mutex;
+}  // namespace
+
+int option_int(const char *name, int dflt) {
+  {
+    std::lock_guard<std::mutex> lock(g_option_mutex);
+    for (int i = 0; i < g_noptions; ++i)
+      if (strcmp(g_options[i].name, name) == 0) return g_options[i].value;
+  }
+  return env_int(name, dflt);
+}
 }  // namespace spx
 
 extern "C" {
+
+int spx_set_option(const char *name_h, int value) {
+  SPX_CHECK(name_h && strlen(name_h) < sizeof(spx::Option::name), "bad option name");
+  std::lock_guard<std::mutex> lock(spx::g_option_mutex);
+  for (int i = 0; i < spx::g_noptions; ++i)
+    if (strcmp(spx::g_options[i].name, name_h) == 0) {
+      spx::g_options[i].value = value;
+      return 0;
+    }
+  SPX_CHECK(spx::g_noptions < 32, "too many options");
+  strcpy(spx::g_options[spx::g_noptions].name, name_h);
+  spx::g_options[spx::g_noptions++].value = value;
+  return 0;
+}
 
 const char *spx_last_error(void) { return spx::g_error.c_str(); }
 

@@ -21,6 +21,10 @@ inline int env_int(const char *name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 
+// The same, read at every call and overridable at run time through spx_set_option (switches a test or a
+// benchmark flips inside one process; env_int values are usually cached in function-local statics).
+int option_int(const char *name, int dflt);
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
 

@@ -90,7 +90,11 @@ class SparseSequential(SparseModule):
                 if input.indices.shape[0] != 0:
                     if norm.supported(input.features, module):
                         # BatchNorm1d (+ the ReLU right behind it) in the streaming kernels of csrc/norm.hip
-                        fuse = i < len(mods) and type(mods[i]) is nn.ReLU
+                        # (a ReLU with user hooks -- feature extractors, CAM tools, observers -- is called as a
+                        # module so that they fire)
+                        fuse = (i < len(mods) and type(mods[i]) is nn.ReLU and not mods[i]._forward_hooks
+                                and not mods[i]._forward_pre_hooks and not mods[i]._backward_hooks
+                                and not getattr(mods[i], "_backward_pre_hooks", None))
                         input = input.replace_feature(norm.batch_norm(input.features, module, relu=fuse))
                         i += 1 if fuse else 0
                     else:

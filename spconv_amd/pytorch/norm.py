@@ -31,6 +31,8 @@ def supported(features: torch.Tensor, bn: nn.Module) -> bool:
         return False
     if features.dtype not in _DT or bn._forward_hooks or bn._forward_pre_hooks or bn._backward_hooks:
         return False            # (user hooks fire on the module call: keep torch's path for them)
+    if features.shape[0] <= 1 and (bn.training or bn.running_mean is None):
+        return False            # torch raises "Expected more than 1 value per channel": keep its error
     C = features.shape[1]
     if _param_dtype(bn.weight, bn.bias, bn.running_mean, bn.running_var) not in _DT:
         return False            # parameters and buffers of mixed dtypes: torch's path
@@ -71,6 +73,7 @@ class _BatchNormFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @torch.autograd.function.once_differentiable      # no double backward: an explicit error, not silent zeros
     def backward(ctx, dy):
         L = _lib.load()
         x, weight, bias, mean, invstd = ctx.saved_tensors

@@ -236,6 +236,10 @@ _SORT_MIN_ROWS = 32768
 def sort_rulebook(rb: Rulebook) -> None:
     """argsort of the mask words + copies of the tables in that order (both directions of a
     regular-conv rulebook).  The gather-GEMM then reads pair / mask by tile position."""
+    dev = rb.pair_fwd.device
+    if dev.type == "cuda" and dev.index != torch.cuda.current_device():
+        with torch.cuda.device(dev):                   # launches belong to the device the tables live on
+            return sort_rulebook(rb)
     L = _lib.load()
     rb.sort_decided = True
     for which in (("fwd",) if rb.subm else ("fwd", "bwd")):
@@ -338,9 +342,10 @@ def tile_plan(rb: Optional[Rulebook], direction: str) -> Optional[torch.Tensor]:
         plan = torch.empty((L.spx_tile_plan_bytes(n_dst, rb.kv) // 4,), dtype=torch.int32, device=table.device)
         ws = _ws(L.spx_tile_plan_ws_bytes(n_dst), table.device)
         inds = inds.contiguous()
-        _lib.check(L.spx_tile_plan_build(inds.data_ptr(), n_dst, inds.shape[1] - 1, int(rb.batch_size),
-                                         _lib.ints(shape), table.data_ptr(), rb.kv, plan.data_ptr(),
-                                         ws.data_ptr(), ws.numel(), _stream(table)))
+        with torch.cuda.device(table.device):          # (the launch belongs to the device the table lives on)
+            _lib.check(L.spx_tile_plan_build(inds.data_ptr(), n_dst, inds.shape[1] - 1, int(rb.batch_size),
+                                             _lib.ints(shape), table.data_ptr(), rb.kv, plan.data_ptr(),
+                                             ws.data_ptr(), ws.numel(), _stream(table)))
     rb.tile_plans[direction] = plan
     return plan
 

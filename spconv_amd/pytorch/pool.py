@@ -161,10 +161,15 @@ class SparseGlobalMaxOrAvgPool(SparseModule):
         b = torch.where(keep, b, torch.zeros_like(b))
         idx = b.unsqueeze(1).expand(-1, feats.shape[1])
         if self.is_mean:
-            w = keep.to(feats.dtype).unsqueeze(1)
-            total = torch.zeros((bs, feats.shape[1]), dtype=feats.dtype, device=feats.device).scatter_add(0, idx, feats * w)
-            count = torch.zeros((bs, 1), dtype=feats.dtype, device=feats.device).scatter_add(0, b.unsqueeze(1), w)
-            return total / count
+            # sums and row counts in fp32 whatever the feature dtype (torch.mean of the reference loop
+            # accumulates in fp32 too): an fp16 count saturates at 2048 rows, a bf16 one at 256, and a scene
+            # has tens of thousands.  A scene without rows gives NaN, like torch.mean over no rows.
+            acc_t = torch.float64 if feats.dtype == torch.float64 else torch.float32
+            w = keep.to(acc_t).unsqueeze(1)
+            total = torch.zeros((bs, feats.shape[1]), dtype=acc_t, device=feats.device).scatter_add(
+                0, idx, feats.to(acc_t) * w)
+            count = torch.zeros((bs, 1), dtype=acc_t, device=feats.device).scatter_add(0, b.unsqueeze(1), w)
+            return (total / count).to(feats.dtype)
         lowest = torch.finfo(feats.dtype).min if feats.dtype.is_floating_point else torch.iinfo(feats.dtype).min
         src = torch.where(keep.unsqueeze(1), feats, torch.full_like(feats, lowest))
         return torch.full((bs, feats.shape[1]), lowest, dtype=feats.dtype, device=feats.device).scatter_reduce(

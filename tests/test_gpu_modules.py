@@ -251,3 +251,26 @@ def test_enable_timer_records_every_sparse_layer(cuda):
     assert set(res) == {"0.gen_pairs", "0.forward", "2.forward", "3.gen_pairs", "3.forward"}, res
     assert all(v > 0 for v in res.values())
     assert set(CUDAKernelTimer.collect_by_name("forward", res)) == {"0.forward", "2.forward", "3.forward"}
+
+
+@pytest.mark.parametrize("act", ["None_", "ReLU", "LeakyReLU", "Sigmoid"])
+def test_eval_forward_is_the_same_with_and_without_grad(cuda, act):
+    """ConvAlgo.Native layers in eval mode: with gradients enabled the layer goes through the autograd
+    functions (bias and activation outside the kernel), without them through the fused inference
+    epilogue (round-2 ADVICE).  Both round the same fp32 sums to fp16, so they may differ by one
+    rounding of the bias add -- never by more."""
+    import spconv_amd.pytorch as spconv
+    from spconv_amd.pytorch.ops import Activation
+    shape, C, K = [16, 16, 16], 16, 32
+    idx = dense_scene(shape, 1200, 1, 4)
+    torch.manual_seed(1)
+    net = spconv.SubMConv3d(C, K, 3, bias=True, algo=spconv.ConvAlgo.Native,
+                            act_type=getattr(Activation, act), act_alpha=0.1).to(cuda).half().eval()
+    f = torch.randn(idx.shape[0], C, device=cuda).half()
+    ind = torch.from_numpy(idx).to(cuda)
+    with torch.no_grad():
+        y0 = net(spconv.SparseConvTensor(f, ind, shape, 1)).features
+    y1 = net(spconv.SparseConvTensor(f.clone().requires_grad_(True), ind, shape, 1)).features
+    assert y1.requires_grad and not y0.requires_grad
+    err = (y0.float() - y1.float().detach()).abs().max() / y0.float().abs().max().clamp_min(1e-6)
+    assert float(err) <= 2e-3, float(err)

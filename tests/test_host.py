@@ -274,3 +274,24 @@ def test_xcd_aware_mappings_are_bijective():
         if G >= 64:
             hits = sum(1 for b in range(G) if xs[take[b]] == b % 8)
             assert hits >= 0.8 * G
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_global_avg_pool_accumulates_in_fp32(dtype):
+    """6 000 rows per scene: an fp16 row count stops at 2048, a bf16 one at 256 (round-2 ADVICE);
+    the mean must match torch.mean over the scene's rows (which accumulates in fp32)."""
+    import spconv_amd.pytorch as spconv
+    g = torch.Generator().manual_seed(3)
+    bs, n, C = 3, 6000, 8
+    b = torch.arange(bs).repeat_interleave(n)
+    idx = torch.stack([b, torch.arange(bs * n) % 50, torch.arange(bs * n) % 37, torch.arange(bs * n) % 41], 1).int()
+    f = (torch.rand((bs * n, C), generator=g) + 0.5).to(dtype)          # all positive: the sum really grows
+    x = spconv.SparseConvTensor(f, idx, [50, 37, 41], bs)
+    got = spconv.SparseGlobalAvgPool()(x)
+    assert got.dtype == dtype and got.shape == (bs, C)
+    for i in range(bs):
+        want = f[b == i].float().mean(dim=0)
+        assert torch.allclose(got[i].float(), want, rtol=1e-2 if dtype == torch.bfloat16 else 2e-3, atol=0)
+    # a scene without rows: NaN for the mean (torch.mean over no rows), lowest value for the max
+    x2 = spconv.SparseConvTensor(f, idx, [50, 37, 41], bs + 1)
+    assert torch.isnan(spconv.SparseGlobalAvgPool()(x2)[bs]).all()
