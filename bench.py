@@ -73,6 +73,8 @@ def parse(argv=None):
     ap.add_argument("--cold", action="store_true", help="alias of the default (--scenes >= 4 enforced)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true",
+                    help="config 2 at N = 1 only: skip the compact block of the other configurations")
     ap.add_argument("--sort", action="store_true", help="mask_argsort the rulebook rows")
     ap.add_argument("--graph-steps", type=int, default=8,
                     help="steps captured per hipGraph at N = 1 (a replay boundary costs ~5 us; with N > 1 "
@@ -458,7 +460,9 @@ def run_layer(args, D: Dist):
     graph_grads = []      # the gradient tensor each per-scene graph writes
     graph_u = None        # U steps per replay over consecutive scenes (N = 1 only)
     graph_w = None        # U steps per replay, all on scene 0 (the Infinity-Cache-resident loop)
-    U = max(1, args.graph_steps) if world == 1 else 1
+    U = max(1, args.graph_steps)
+    graph_b = None        # N > 1: a second U-step graph with its own gradient buffers (the two alternate)
+    dws_a, dws_b = [], [] # the dW tensor each captured step of graph_u / graph_b writes
     if not args.no_graph:
         try:
             side = torch.cuda.Stream()
@@ -481,15 +485,23 @@ def run_layer(args, D: Dist):
                 with torch.cuda.graph(graph_u):
                     for u in range(U):
                         compute(scenes[u % S])
-                graph_w = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph_w):
-                    for u in range(U):
-                        compute(scenes[0])
+                        dws_a.append(net.weight.grad)
+                if world > 1:
+                    graph_b = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph_b):
+                        for u in range(U):
+                            compute(scenes[u % S])
+                            dws_b.append(net.weight.grad)
+                else:
+                    graph_w = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph_w):
+                        for u in range(U):
+                            compute(scenes[0])
             launch = "hipgraph"
         except Exception as e:  # capture unsupported -> eager launches, same work
             print(f"[bench] graph capture failed ({type(e).__name__}: {e}); using eager launches",
                   file=sys.stderr)
-            graphs = graph_u = graph_w = None
+            graphs = graph_u = graph_w = graph_b = None
             graph_grads = []
             torch.cuda.synchronize()
     if graph_u is None:
@@ -510,10 +522,62 @@ def run_layer(args, D: Dist):
         if bucket is not None:
             bucket.all_reduce(average=True)                        # one RCCL call per step
 
+    # N > 1: the gradient exchange leaves the critical path.  The U dW tensors of a replay are packed into one
+    # flat bucket and all-reduced (average) on a SIDE stream while the next replay -- the other graph, with its
+    # own gradient buffers -- runs; a graph is replayed again only after its bucket's all-reduce has finished.
+    # One RCCL call of U x 221 KB per U steps instead of a blocking small-message call behind every step.
+    overlap = None
+    if world > 1 and graph_b is not None:
+        import torch.distributed as dist
+        side_ar = torch.cuda.Stream()
+        numel = net.weight.numel()
+
+        class _Half:
+            pass
+        halves = []
+        for g, dws in ((graph_u, dws_a), (graph_b, dws_b)):
+            h = _Half()
+            h.graph, h.dws = g, dws
+            h.flat = torch.zeros((U, numel), dtype=dws[0].dtype, device=dev)
+            h.done, h.reduced = torch.cuda.Event(), torch.cuda.Event()
+            h.pending = False
+            halves.append(h)
+        overlap = {"halves": halves, "next": 0}
+
+        def replay_overlapped():
+            h = overlap["halves"][overlap["next"]]
+            overlap["next"] ^= 1
+            main = torch.cuda.current_stream()
+            if h.pending:
+                main.wait_event(h.reduced)           # its previous bucket has been reduced: buffers are free
+            h.graph.replay()
+            h.done.record(main)
+            with torch.cuda.stream(side_ar):
+                side_ar.wait_event(h.done)
+                torch._foreach_copy_(list(h.flat.unbind(0)), [d.reshape(-1) for d in h.dws])
+                if D.backend == "nccl":
+                    dist.all_reduce(h.flat, op=dist.ReduceOp.AVG)
+                else:
+                    dist.all_reduce(h.flat, op=dist.ReduceOp.SUM)
+                    h.flat.div_(world)
+                h.reduced.record(side_ar)
+            h.pending = True
+
+        def drain_overlapped():
+            for h in overlap["halves"]:
+                if h.pending:
+                    torch.cuda.current_stream().wait_event(h.reduced)
+                    h.pending = False
+
     def run_steps(k, warm=False):
         """Exactly k steps: whole U-step replays, then single steps."""
         gu = graph_w if warm else graph_u
-        if gu is not None:
+        if overlap is not None and not warm:
+            for _ in range(k // U):
+                replay_overlapped()
+            drain_overlapped()
+            k = k % U
+        elif gu is not None:
             for _ in range(k // U):
                 gu.replay()
             k = k % U
@@ -530,7 +594,7 @@ def run_layer(args, D: Dist):
         torch.cuda.synchronize()
         warm_ms = (time.perf_counter() - t1) / args.steps * 1e3
     single_replay_ms = None
-    if graph_u is not None:              # the rotating K steps with one step per replay, for reference
+    if graph_u is not None and world == 1:   # the rotating K steps with one step per replay, for reference
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(args.steps):
@@ -628,7 +692,11 @@ def run_layer(args, D: Dist):
                    "mask_sort": scenes[0].rb.argsort_fwd is not None, "tile_plan": tiled,
                    "parallelism": f"dp{world}",
                    "ranks_seen": ranks_seen,
-                   "dist_backend": D.backend if world > 1 else None},
+                   "dist_backend": D.backend if world > 1 else None,
+                   "gradient_exchange": None if world == 1 else (
+                       f"one flat-bucket all-reduce (average) of the {U} dW of a replay ({U} x {net.weight.numel() * s} B) "
+                       f"on a side stream, overlapped with the next replay (two graphs with their own gradient "
+                       f"buffers alternate)" if overlap is not None else "blocking all-reduce of dW after every step")},
         "roofline": r_cold, "roofline_cold": r_cold, "roofline_warm": r_warm,
         "kernels": ktable(t_cold), "kernels_warm": ktable(t_warm),
         "kernels_note": "each group is timed alone (its own hipGraph, rotating over the scenes); in a step the "
@@ -836,6 +904,45 @@ def run_net(args, D: Dist):
     return res
 
 
+def also_block(args, D: Dist):
+    """The other BASELINE configurations, a few seconds each, in the SAME process and JSON line as the
+    headline (N = 1 only): driver-observed numbers for the dense-neighbourhood layer (2b), the int8
+    layer (5), the stride-2 chain (3) and the backbone (4).  Compact: value, time per step, kernel-group
+    times, roofline fraction, PMC traffic where a committed pass exists."""
+    import copy
+    import gc
+    out = {}
+    for cfg in ("2b", "5", "3", "4"):
+        a = copy.copy(args)
+        a.config, a.no_cpu_baseline, a.voxels, a.channels, a.scene = cfg, True, None, None, None
+        a.scenes = min(args.scenes, 4)
+        a.steps = min(args.steps, 400 if cfg in ("2b", "5") else 40)
+        a.warmup = min(args.warmup, 40 if cfg in ("2b", "5") else 8)
+        t0 = time.perf_counter()
+        try:
+            r = run_layer(a, D) if cfg == "2b" else (run_int8(a, D) if cfg == "5" else run_net(a, D))
+        except Exception as e:                              # a failing side configuration must not cost the headline
+            out[cfg] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            continue
+        roof = r.get("roofline", {})
+        c = {"metric": r["metric"], "value": round(r["value"], 1), "unit": r["unit"],
+             "ms_per_step": round(r["ms_per_step"], 5), "steps": r["steps"], "dtype": r["dtype"],
+             "workload": r["config"]["workload"], "launch": r["config"].get("launch"),
+             "roofline": {k: roof.get(k) for k in ("group", "frac", "achieved", "algorithmic_bytes", "ms", "traffic")},
+             "wall_s": None}
+        if "kernels" in r:
+            c["kernels_ms"] = {k: v["ms"] for k, v in r["kernels"].items()}
+        for k in ("rulebook_device_ms", "eager_device_ms_per_step", "graph_ms_per_step"):
+            if k in r:
+                c[k] = r[k]
+        c["wall_s"] = round(time.perf_counter() - t0, 1)
+        out[cfg] = c
+        del r
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse(argv)
@@ -854,6 +961,8 @@ def main(argv=None):
         result = run_int8(args, D)
     else:
         result = run_net(args, D)
+    if D.rank == 0 and D.world == 1 and args.config == "2" and not args.no_also:
+        result["also"] = also_block(args, D)
     if D.rank == 0:
         print(json.dumps(result), flush=True)
     D.finish()

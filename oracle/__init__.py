@@ -183,13 +183,32 @@ def dense_tables(pair: np.ndarray, num_per_loc: np.ndarray, n_in: int, n_out: in
 # (ops.indice_conv ops.py:811-988, ops.indice_conv_backward ops.py:1103-1253;
 #  C++ twin convops.py:1540-1633,1775-1860 + cppcore.py:232-348)
 # --------------------------------------------------------------------------
+_REF_GATHER = False
+
+
+def use_reference_gather(on: bool) -> None:
+    """Route the row gather / scatter-add of the Native driver loops through the reference's OWN
+    GatherCPU code (oracle/_ref, rendered from spconv/csrc/sparse/gather.py:30-86) instead of the
+    restatement in oracle.cpp -- tests pin one against the other.  fp32 tensors, serial form only."""
+    global _REF_GATHER
+    _REF_GATHER = bool(on)
+
+
 def _gather(buf: torch.Tensor, src: torch.Tensor, inds: np.ndarray, omp: bool):
+    if _REF_GATHER and buf.dtype == torch.float32 and not omp:
+        from oracle import ref
+        ref.gather(buf.numpy(), src.numpy(), inds)
+        return
     fn = lib().orc_gather_omp if omp else lib().orc_gather
     fn(buf.data_ptr(), src.data_ptr(), _i32p(inds), len(inds), src.shape[1],
        src.element_size())
 
 
 def _scatter_add(dst: torch.Tensor, buf: torch.Tensor, inds: np.ndarray, omp: bool):
+    if _REF_GATHER and dst.dtype == torch.float32 and not omp:
+        from oracle import ref
+        ref.scatter_add(dst.numpy(), buf.numpy(), inds)
+        return
     if dst.dtype == torch.float32:
         fn = lib().orc_scatter_add_f32_omp if omp else lib().orc_scatter_add_f32
     elif dst.dtype == torch.float64:

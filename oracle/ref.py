@@ -55,7 +55,26 @@ def lib() -> ctypes.CDLL:
         _lib.ref_generate_inds.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                            ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                            ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + [ip] * 6
+        for fn in (_lib.ref_gather, _lib.ref_scatter_add):
+            fn.restype = ctypes.c_int
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                           ctypes.c_int]
     return _lib
+
+
+def gather(out: np.ndarray, src: np.ndarray, inds: np.ndarray) -> None:
+    """The reference's GatherCPU::gather (gather.py:30-53), executed: out[i] = src[inds[i]] (fp32 rows)."""
+    assert out.dtype == np.float32 and src.dtype == np.float32 and out.flags.c_contiguous and src.flags.c_contiguous
+    inds = np.ascontiguousarray(inds, dtype=np.int32)
+    lib().ref_gather(out.ctypes.data, src.ctypes.data, inds.ctypes.data, len(inds), src.shape[0], src.shape[1])
+
+
+def scatter_add(out: np.ndarray, buf: np.ndarray, inds: np.ndarray) -> None:
+    """The reference's GatherCPU::scatter_add (gather.py:55-86), executed: out[inds[i]] += buf[i]."""
+    assert out.dtype == np.float32 and buf.dtype == np.float32 and out.flags.c_contiguous and buf.flags.c_contiguous
+    inds = np.ascontiguousarray(inds, dtype=np.int32)
+    lib().ref_scatter_add(out.ctypes.data, buf.ctypes.data, inds.ctypes.data, len(inds), out.shape[0],
+                          out.shape[1])
 
 
 def _ints(v: Sequence[int]):

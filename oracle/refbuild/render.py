@@ -196,6 +196,11 @@ def _install():
     mods["cumm.gemm"].codeops = co
     mods["cumm.conv.params"].ConvProblem = ConvProblem
     mods["cumm.constants"].CUMM_CPU_ONLY_BUILD = True
+    # gather.py imports OMPLib from the reference's own package: a stand-in module keeps the package's
+    # __init__ (which loads the compiled extension) from being imported
+    for name in ("spconv", "spconv.csrc", "spconv.csrc.sparse", "spconv.csrc.sparse.cpu_core"):
+        mods[name] = types.ModuleType(name)
+    mods["spconv.csrc.sparse.cpu_core"].OMPLib = type("OMPLib", (Class,), {})
     sys.modules.update(mods)
 
 
@@ -206,6 +211,29 @@ def load_reference_indices():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod, path
+
+
+def load_reference_gather():
+    """spconv/csrc/sparse/gather.py (GatherCPU: the row gather / scatter-add of ConvAlgo.Native's CPU path)."""
+    _install()
+    path = os.path.join(REF, "spconv", "csrc", "sparse", "gather.py")
+    spec = importlib.util.spec_from_file_location("_reference_gather", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, path
+
+
+def emit_gather_class(obj):
+    out = ["namespace refgather {"]
+    for pyname, meta, fn in obj.functions():
+        if meta["kind"] != "static":
+            continue
+        code = fn(obj)
+        out.append(f"{code.ret_type} {_signature(pyname, code)} {{")
+        out += code.blocks
+        out.append("}")
+    out.append("}  // namespace refgather")
+    return "\n".join(out)
 
 
 # ----------------------------------------------------------------- emission
@@ -298,6 +326,20 @@ extern "C" int ref_generate_inds(int ndim, int subm, int transposed, int32_t *in
   }
   return -1;
 }
+
+// GatherCPU::gather / scatter_add (gather.py:30-86) on fp32 rows
+extern "C" int ref_gather(float *out, float *in, int32_t *inds, int nhot, int n_in, int channel) {
+  tv::Tensor o = tv::from_blob(out, {nhot, channel}), i = tv::from_blob(in, {n_in, channel});
+  tv::Tensor x = tv::from_blob(inds, {nhot});
+  refgather::gather(o, i, x);
+  return 0;
+}
+extern "C" int ref_scatter_add(float *out, float *in, int32_t *inds, int nhot, int n_out, int channel) {
+  tv::Tensor o = tv::from_blob(out, {n_out, channel}), i = tv::from_blob(in, {nhot, channel});
+  tv::Tensor x = tv::from_blob(inds, {nhot});
+  refgather::scatter_add(o, i, x);
+  return 0;
+}
 '''
 
 
@@ -312,6 +354,9 @@ def main():
         problem = ConvProblem(ndim)
         cpu = mod.SparseConvIndicesCPU(problem, dtypes.int32)
         parts.append(emit_cpu_class(cpu, ndim))
+    gmod, gpath = load_reference_gather()
+    parts.append("// ---- from " + gpath)
+    parts.append(emit_gather_class(gmod.GatherCPU()))
     parts.append(C_API)
     out = os.path.join(OUT_DIR, "ref_indices.cpp")
     with open(out, "w") as f:

@@ -17,6 +17,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <type_traits>
 #include <initializer_list>
 #include <limits>
 #include <sstream>
@@ -59,6 +61,8 @@ class Tensor {
   Tensor(void *p, std::vector<int64_t> shape) : ptr_(p), shape_(std::move(shape)) {}
   int64_t dim(int i) const { return shape_[i]; }
   int ndim() const { return static_cast<int>(shape_.size()); }
+  int dtype() const { return 0; }      // (fp32 views only, see tv::dispatch below)
+  int device() const { return -1; }
   template <typename T> T *data_ptr() { return static_cast<T *>(ptr_); }
   template <typename T> T *data_ptr() const { return static_cast<T *>(ptr_); }
 
@@ -71,6 +75,14 @@ inline Tensor from_blob(void *p, std::initializer_list<int64_t> shape) {
   return Tensor(p, std::vector<int64_t>(shape));
 }
 
+// gather.py's element-type dispatch and 1-d loop helper: the oracle drives the reference's gather /
+// scatter-add with fp32 rows only, so `dispatch` always takes the float branch; `kernel_1d` is the
+// serial form (the published CPU wheel has no OpenMP, README.md:133): one call over [0, n), step 1.
+struct half_t {};
+struct bfloat16_t {};
+template <typename... Ts, typename F> inline void dispatch(int /*dtype*/, F &&f) { f(float{}); }
+template <typename F> inline void kernel_1d(int /*device*/, int64_t n, F &&f) { f(0, static_cast<int>(n), 1); }
+
 template <typename... Ts> inline std::string ssprint(const Ts &...xs) {
   std::ostringstream ss;
   (void)std::initializer_list<int>{((ss << xs << ' '), 0)...};
@@ -79,6 +91,7 @@ template <typename... Ts> inline std::string ssprint(const Ts &...xs) {
 
 }  // namespace tv
 
+#define TV_DECLTYPE(x) std::decay_t<decltype(x)>
 #define TV_ASSERT_RT_ERR(cond, ...)                                                   \
   do {                                                                                \
     if (!(cond)) throw std::runtime_error(std::string(#cond " failed: ") + tv::ssprint(__VA_ARGS__)); \

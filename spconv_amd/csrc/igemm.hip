@@ -2140,8 +2140,10 @@ template <bool BF16>
 int dispatch_gather_gemm(const GemmParams &p, hipStream_t s) {
   const int version = option_int("SPX_GEMM_V", 4);          // kernel generation (spx_set_option / environment)
   static const int mb_forced = env_int("SPX_GEMM_MB", 0);
+  if (version == 6 && !mb_forced && v4_ok(p) && sp_ok(p, BF16 ? SPX_BF16 : SPX_F16))
+    return launch_sp(p, rest_of(p), BF16 ? SPX_BF16 : SPX_F16, s);
   // v5 (igemm5.hip): persistent loader / consumer workgroups; shapes it does not cover take v4
-  if (version >= 5 && !mb_forced && v4_ok(p) && v5_ok(p, BF16 ? SPX_BF16 : SPX_F16))
+  if (version == 5 && !mb_forced && v4_ok(p) && v5_ok(p, BF16 ? SPX_BF16 : SPX_F16))
     return launch_v5(p, rest_of(p), BF16 ? SPX_BF16 : SPX_F16, s);
   if (version >= 4 && v4_ok(p)) {
     // 64-row tiles while the grid would otherwise leave CUs idle, 128-row tiles beyond -- except

@@ -78,6 +78,9 @@ struct GemmRest {
 // igemm5.hip: persistent loader / consumer gather-GEMM (16-bit operands, <= 64 output channels)
 bool v5_ok(const GemmParams &p, int dtype);
 int launch_v5(const GemmParams &p, const GemmRest &r, int dtype, hipStream_t s);
+// igemm_sp.hip: one autonomous wave per 32 rows (sparse neighbourhoods; reduction index contiguous)
+bool sp_ok(const GemmParams &p, int dtype);
+int launch_sp(const GemmParams &p, const GemmRest &r, int dtype, hipStream_t s);
 
 namespace {
 

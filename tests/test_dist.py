@@ -75,3 +75,57 @@ def test_grad_bucket_all_reduce_gloo_world2():
         out = mgr.dict()
         mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
         assert dict(out) == {0: True, 1: True}
+
+
+def _conv_worker(rank, world, port, out):
+    """A 2-layer conv-only chain (SubM 3x3x3 -> stride-2 SparseConv) on this rank's scenes: the
+    averaged dW of the sharded run must equal the full-batch dW / world (scenes never interact)."""
+    import oracle
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(7)                         # same data on every rank
+    bs, shape, C, K1, K2 = 4, [10, 12, 14], 4, 6, 8
+    rows = []
+    for b in range(bs):
+        lin = rng.choice(int(np.prod(shape)), 150, replace=False)
+        zyx = np.stack(np.unravel_index(lin, shape), 1)
+        rows.append(np.concatenate([np.full((150, 1), b), zyx], 1))
+    idx = np.concatenate(rows).astype(np.int32)
+    feat = rng.uniform(-1, 1, (idx.shape[0], C)).astype(np.float32)
+    w1 = torch.from_numpy(rng.uniform(-1, 1, (K1, 3, 3, 3, C)).astype(np.float32))
+    w2 = torch.from_numpy(rng.uniform(-1, 1, (K2, 3, 3, 3, K1)).astype(np.float32))
+
+    def chain_grads(idx_np, feat_np, batch):
+        """forward through both layers, loss = sum(out * g) with g a fixed function of the OUTPUT
+        coordinates (so that sharding does not change it); returns (dW1, dW2)."""
+        f = torch.from_numpy(feat_np)
+        o1_inds, p1, n1, _ = oracle.get_indice_pairs(idx_np, batch, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, subm=True)
+        y1 = oracle.indice_conv(f, w1, p1, n1, idx_np.shape[0], subm=True)
+        o2_inds, p2, n2, oshape = oracle.get_indice_pairs(idx_np, batch, shape, [3] * 3, [2] * 3, [1] * 3, [1] * 3,
+                                                          subm=False)
+        y2 = oracle.indice_conv(y1, w2, p2, n2, o2_inds.shape[0], subm=False)
+        co = torch.from_numpy(o2_inds[:, 1:].astype(np.float32))
+        g = torch.sin(co.sum(1, keepdim=True) * 0.37 + torch.arange(K2).float() * 0.11)    # [n_out, K2]
+        assert g.shape == y2.shape
+        d1, dw2 = oracle.indice_conv_backward(y1, w2, g, p2, n2, subm=False)
+        _, dw1 = oracle.indice_conv_backward(f, w1, d1, p1, n1, subm=True)
+        return dw1, dw2
+    full1, full2 = chain_grads(idx, feat, bs)
+    li, lf, lb = shard_scenes(torch.from_numpy(idx), torch.from_numpy(feat), bs, rank, world)
+    m1, m2 = chain_grads(li.numpy(), lf.numpy(), lb)
+    p1, p2 = torch.nn.Parameter(w1.clone()), torch.nn.Parameter(w2.clone())
+    p1.grad, p2.grad = m1.clone(), m2.clone()
+    GradBucket([p1, p2]).all_reduce(average=True)
+    ok = bool(torch.allclose(p1.grad, full1 / world, rtol=1e-4, atol=1e-5)
+              and torch.allclose(p2.grad, full2 / world, rtol=1e-4, atol=1e-5))
+    out[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_conv_chain_gives_the_full_batch_gradient_gloo_world2():
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_conv_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        assert dict(out) == {0: True, 1: True}

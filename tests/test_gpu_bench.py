@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(args, extra_env=None, timeout=240):
+def _run(args, extra_env=None, timeout=420):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(extra_env or {})
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env,
@@ -28,12 +28,19 @@ def test_bench_single_gpu_contract(cuda):
     for key in ("roofline", "roofline_cold", "roofline_warm"):
         assert r[key]["bound"] == "hbm" and 0 < r[key]["frac"] < 1.0
     assert r["config"]["scenes_rotated"] == 4
+    # the other BASELINE configurations ride along in the same line (compact, N = 1 only)
+    assert set(r["also"]) == {"2b", "5", "3", "4"}
+    for cfg, c in r["also"].items():
+        assert "error" not in c, (cfg, c)
+        assert c["value"] > 0 and c["ms_per_step"] > 0 and 0 < c["roofline"]["frac"] < 1.0
 
 
 def test_bench_gpus_2_spawns_two_ranks(cuda):
-    r = _run(["--gpus", "2", "--steps", "6", "--warmup", "2", "--scenes", "2"],
+    r = _run(["--gpus", "2", "--steps", "20", "--warmup", "8", "--scenes", "2"],
              {"BENCH_DIST_BACKEND": "gloo", "BENCH_ONE_DEVICE": "1"})
     assert r["n_gpus"] == 2
+    # the gradient exchange is off the critical path: 8 steps per replay also at N > 1, one bucket per replay
+    assert r["config"]["steps_per_replay"] == 8 and "side stream" in r["config"]["gradient_exchange"]
     assert r["config"]["ranks_seen"] == 2 and r["config"]["parallelism"] == "dp2"
     assert r["config"]["dist_backend"] == "gloo"
 

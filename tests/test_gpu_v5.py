@@ -23,13 +23,13 @@ def _set_version(v):
 @pytest.fixture(autouse=True)
 def _restore_version():
     yield
-    _set_version(5)
+    _set_version(4)
 
 
-def _both(fn):
+def _both(fn, new=5):
     _set_version(4)
     a = fn()
-    _set_version(5)
+    _set_version(new)
     b = fn()
     torch.cuda.synchronize()
     return a, b
@@ -53,6 +53,34 @@ SUBM_CASES = [
     ([64, 64, 64], 70_000, False, 64, 64),        # more tiles than persistent workgroups
     ([10, 10, 10], 77, True, 64, 64),             # one partial tile
 ]
+
+
+@pytest.mark.parametrize("shape,n,dense,C,K", SUBM_CASES)
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_sparse_kernel_fwd_bit_identical_to_v4(cuda, shape, n, dense, C, K, dtype):
+    """SPX_GEMM_V = 6: one autonomous wave per 32 rows (csrc/igemm_sp.hip); forward-type GEMMs only."""
+    from spconv_amd.pytorch import ops
+    idx = dense_scene(shape, n, 1, 3) if dense else scene(shape, n, 1, 3)
+    rb, _ = gpu_rulebook(idx, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True)
+    rng = np.random.default_rng(1)
+    f, w, d = _tensors(rng, rb.n_in, rb.n_out, C, K, [3] * 3, dtype, cuda)
+    o4, o6 = _both(lambda: ops.igemm_fwd(f, w, rb.pair_fwd, rb.mask_fwd, None, rb.n_out, 13), new=6)
+    assert torch.equal(o4, o6), float((o4.float() - o6.float()).abs().max())
+
+
+def test_sparse_kernel_regular_conv_and_epilogue(cuda):
+    from spconv_amd.pytorch import ops
+    shape = [30, 30, 30]
+    idx = dense_scene(shape, 6000, 2, 7)
+    rb, _ = gpu_rulebook(idx, 2, shape, [3] * 3, [2] * 3, [1] * 3, [1] * 3, False)
+    rng = np.random.default_rng(3)
+    f, w, d = _tensors(rng, rb.n_in, rb.n_out, 32, 64, [3] * 3, torch.float16, cuda)
+    bias = torch.from_numpy(rng.uniform(-1, 1, 64).astype(np.float32)).to(cuda, torch.float16)
+    o4, o6 = _both(lambda: ops.igemm_fwd(f, w, rb.pair_fwd, rb.mask_fwd, None, rb.n_out, -1), new=6)
+    assert torch.equal(o4, o6)
+    o4, o6 = _both(lambda: ops.igemm_fwd(f, w, rb.pair_fwd, rb.mask_fwd, None, rb.n_out, -1, bias,
+                                         ops.Activation.ReLU, 0.0), new=6)
+    assert torch.equal(o4, o6)
 
 
 @pytest.mark.parametrize("shape,n,dense,C,K", SUBM_CASES)

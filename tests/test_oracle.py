@@ -305,3 +305,52 @@ def test_oracle_rulebook_equals_live_reference_library():
         got = oracle.get_indice_pairs(idx, bs, shape, ksize, stride, pad, dil, None, subm, transposed)
         for a, b in zip(got[:3], want[:3]):
             np.testing.assert_array_equal(a, b, err_msg=f"trial {trial}: {shape} k{ksize} s{stride} p{pad} d{dil}")
+
+
+def test_gather_scatter_add_equal_reference_executed_vectors():
+    """oracle.cpp's row gather / scatter-add against tests/golden/gather_ref.npz -- outputs of the
+    reference's own GatherCPU code (gather.py:30-86) executed through oracle/_ref
+    (tests/golden/make_ref_gather_golden.py): bit-exact, including the accumulation order of repeated
+    destination rows."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gather_ref.npz"))
+    src = torch.from_numpy(d["src"].copy())
+    buf = torch.full(tuple(d["gathered"].shape), float("nan"))
+    oracle._gather(buf, src, d["gather_inds"], False)
+    np.testing.assert_array_equal(buf.numpy(), d["gathered"])
+    acc = torch.from_numpy(d["acc_before"].copy())
+    oracle._scatter_add(acc, buf, d["scatter_inds"], False)
+    np.testing.assert_array_equal(acc.numpy(), d["acc_after"])
+    acc2 = torch.from_numpy(d["acc_before"].copy())               # the row-parallel variant: same sums, same order
+    oracle._scatter_add(acc2, buf, d["scatter_inds"], True)
+    np.testing.assert_allclose(acc2.numpy(), d["acc_after"], rtol=1e-6, atol=1e-6)
+
+
+def test_native_conv_loop_with_the_reference_gather_code():
+    """The per-offset driver loop (ops.py:962-986, 1225-1252 restated) run twice: with oracle.cpp's
+    gather / scatter-add and with the reference's own GatherCPU code switched in (oracle/_ref, when
+    present).  Forward, input gradient and weight gradient must be identical bit for bit."""
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("oracle/_ref not built here (needs /root/reference: make -C oracle ref)")
+    from spconv_amd.utils import synthetic
+    rng = np.random.default_rng(5)
+    for subm, stride in ((True, 1), (False, 2)):
+        shape, bs, C, K = [14, 15, 16], 2, 5, 7
+        idx = synthetic.uniform_scene(shape, 700, bs, seed=3)
+        out_inds, pair, num, _ = oracle.get_indice_pairs(idx, bs, shape, [3] * 3, [stride] * 3, [1] * 3, [1] * 3,
+                                                         None, subm, False)
+        f = torch.from_numpy(rng.uniform(-1, 1, (idx.shape[0], C)).astype(np.float32))
+        w = torch.from_numpy(rng.uniform(-1, 1, (K, 3, 3, 3, C)).astype(np.float32))
+        g = torch.from_numpy(rng.uniform(-1, 1, (out_inds.shape[0], K)).astype(np.float32))
+        res = []
+        for use_ref in (False, True):
+            oracle.use_reference_gather(use_ref)
+            try:
+                y = oracle.indice_conv(f, w, pair, num, out_inds.shape[0], subm=subm)
+                din, dw = oracle.indice_conv_backward(f, w, g, pair, num, subm=subm)
+            finally:
+                oracle.use_reference_gather(False)
+            res.append((y, din, dw))
+        for a, b in zip(*res):
+            assert torch.equal(a, b)

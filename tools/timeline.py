@@ -25,6 +25,7 @@ from spconv_amd.utils import synthetic  # noqa: E402
 def main():
     scene = sys.argv[1] if len(sys.argv) > 1 else "uniform"
     centre = len(sys.argv) > 2 and sys.argv[2] == "centre"
+    sp = len(sys.argv) > 2 and sys.argv[2] == "sp"          # igemm_sp_kernel (SPX_GEMM_V = 6): one wave per 32 rows
     dev = torch.device("cuda:0")
     n, C = 100000, 64
     gen = synthetic.uniform_scene if scene == "uniform" else synthetic.lidar_like_scene
@@ -34,16 +35,19 @@ def main():
     rb, _ = ops.build_rulebook(idx, 1, SHAPE, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True)
     mask = torch.full_like(rb.mask_fwd, 1 << 13) if centre else rb.mask_fwd
     L = _lib.load()
-    L.spx_debug_timeline.restype = ctypes.c_int
-    L.spx_debug_timeline.argtypes = [ctypes.c_void_p]
+    getter = L.spx_debug_timeline_sp if sp else L.spx_debug_timeline
+    getter.restype = ctypes.c_int
+    getter.argtypes = [ctypes.c_void_p]
+    if sp:
+        _lib.check(L.spx_set_option(b"SPX_GEMM_V", 6))
     for _ in range(20):
         ops.igemm_fwd(f, w, rb.pair_fwd, mask, None, n, 13)
     torch.cuda.synchronize()
     ops.igemm_fwd(f, w, rb.pair_fwd, mask, None, n, 13)
     buf = np.zeros((8192, 8), dtype=np.uint64)
-    _lib.check(L.spx_debug_timeline(buf.ctypes.data))
+    _lib.check(getter(buf.ctypes.data))
     mb = int(os.environ.get("SPX_GEMM_MB", "2"))
-    ntiles = (n + 64 * mb - 1) // (64 * mb)
+    ntiles = min(8192, (n + 31) // 32) if sp else (n + 64 * mb - 1) // (64 * mb)
     t = buf[:ntiles].astype(np.int64)
     t0 = t[:, 0].min()
     rel = (t - t0) / float(os.environ.get("SPX_TICK_MHZ", "100"))
