@@ -794,7 +794,7 @@ __global__ void __launch_bounds__(kBlock)
 conv_assign_kernel(const int32_t *__restrict__ indices, int n, Geom g, int transposed,
                    const int32_t *__restrict__ slot_of, Table t,
                    int nblk, const int32_t *__restrict__ blockoff,
-                   int32_t *__restrict__ slot_out, int32_t *__restrict__ out_indices) {
+                   int32_t *__restrict__ slot_out, int32_t *__restrict__ out_indices, int n_cap) {
   __shared__ int lds_wave[kBlock / 64];
   const int k = blockIdx.y, blk = blockIdx.x;
   const int begin = blk * kItems;
@@ -825,14 +825,18 @@ conv_assign_kernel(const int32_t *__restrict__ indices, int n, Geom g, int trans
     int total;
     const int rank = block_rank(first, total, lds_wave);
     if (first) {
+      // outputs beyond the caller's bound (num_out_act_bound, ops.py:263-266) are dropped: no
+      // coordinates, no pairs
       const int oid = running + rank;
-      slot_out[slot] = oid;
-      int b, c[4], q[4];
-      read_row(indices, e, g.ndim, b, c);
-      conv_out_coord(g, c, r, transposed, q);
-      int32_t *dst = out_indices + static_cast<size_t>(oid) * (g.ndim + 1);
-      dst[0] = b;
-      for (int d = lead; d < 4; ++d) dst[1 + d - lead] = q[d];
+      slot_out[slot] = oid < n_cap ? oid : -1;
+      if (oid < n_cap) {
+        int b, c[4], q[4];
+        read_row(indices, e, g.ndim, b, c);
+        conv_out_coord(g, c, r, transposed, q);
+        int32_t *dst = out_indices + static_cast<size_t>(oid) * (g.ndim + 1);
+        dst[0] = b;
+        for (int d = lead; d < 4; ++d) dst[1 + d - lead] = q[d];
+      }
     }
     running += total;
   }
@@ -852,8 +856,8 @@ conv_stage2_kernel(const int32_t *__restrict__ slot_of, const int32_t *__restric
     const size_t pos = static_cast<size_t>(k) * n + i;
     const int slot = slot_of[pos];
     if (slot >= 0) {
-      oid = slot_out[slot];
-      pair_fwd[static_cast<size_t>(k) * n_out + oid] = i;
+      oid = slot_out[slot];                          // -1: an output beyond the caller's bound
+      if (oid >= 0) pair_fwd[static_cast<size_t>(k) * n_out + oid] = i;
     }
     pair_bwd[pos] = oid;
   }
@@ -1092,7 +1096,10 @@ ConvWs carve_conv_ws(void *ws, int n_in, int ndim, const int *ksize, const int *
                      const int *dilation, int transposed, bool packed = false) {
   int kv = 1;
   for (int i = 0; i < ndim; ++i) kv *= ksize[i];
-  const uint32_t cap = table_capacity(conv_max_out(n_in, ndim, ksize, stride, dilation, transposed));
+  uint32_t cap = table_capacity(conv_max_out(n_in, ndim, ksize, stride, dilation, transposed));
+  // tests only (spx_set_option): a table smaller than the bound, to exercise the overflow report
+  const int test_cap = option_int("SPX_TEST_CONV_TABLE_CAP", 0);
+  if (test_cap > 0 && static_cast<uint32_t>(test_cap) < cap) cap = table_capacity(static_cast<size_t>(test_cap) / 2);
   ConvWs w;
   w.nblk = div_up(n_in > 0 ? n_in : 1, kItems);
   Carver cv(ws);
@@ -1686,7 +1693,7 @@ int spx_conv_rulebook_fill(const int32_t *indices, int n_in, int ndim, int batch
                            keys_fit_u32(g.batch, g.out_dims, 4));   // as spx_conv_rulebook_count
   const dim3 grid2(w.nblk, kv);
   hipLaunchKernelGGL(conv_assign_kernel, grid2, dim3(kBlock), 0, s, indices, n_in, g, transposed,
-                     w.slot_of, w.t, w.nblk, w.blockoff, w.slot_out, out_indices);
+                     w.slot_of, w.t, w.nblk, w.blockoff, w.slot_out, out_indices, n_out);
   const dim3 grid1(div_up(n_in, kBlock), kv);
   hipLaunchKernelGGL(conv_stage2_kernel, grid1, dim3(kBlock), 0, s, w.slot_of, w.slot_out, n_in,
                      n_out, pair_fwd, pair_bwd, v2 ? w.groupcount : nullptr);

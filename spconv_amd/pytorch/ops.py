@@ -150,7 +150,8 @@ def build_rulebook(indices: torch.Tensor, batch_size: int, spatial_shape: List[i
                    ksize: List[int], stride: List[int], padding: List[int],
                    dilation: List[int], out_padding: List[int], subm: bool = False,
                    transpose: bool = False, need_bwd_table: bool = False,
-                   do_sort: bool = False, need_native: bool = True) -> Tuple[Rulebook, List[int]]:
+                   do_sort: bool = False, need_native: bool = True,
+                   num_out_act_bound: int = -1) -> Tuple[Rulebook, List[int]]:
     """One call builds every artefact (dense tables, masks, Native lists).  need_native=False
     (inference) leaves the ConvAlgo.Native lists out -- three launches and two thirds of the
     fill traffic -- and the Rulebook derives them from the tables if they are asked for later."""
@@ -201,6 +202,11 @@ def build_rulebook(indices: torch.Tensor, batch_size: int, spatial_shape: List[i
         n_out = int(n_out_c.value)
         if n_out == 0:
             raise ValueError(_POINT_VANISH_MSG.format(spatial_shape, ksize, stride, padding, dilation))
+        if 0 < num_out_act_bound < n_out:
+            # the reference's bounded mode (ops.py:263-266, indices.py:460-499): at most `bound` outputs
+            # exist; here the FIRST `bound` in the canonical (first-seen) order survive, pairs into the
+            # others are dropped
+            n_out = int(num_out_act_bound)
         out_indices = torch.empty((n_out, ndim + 1), **i32)
         pair_fwd = torch.empty((kv, n_out), **i32)
         pair_bwd = torch.empty((kv, n_in), **i32)
@@ -371,7 +377,7 @@ def get_indice_pairs(indices: torch.Tensor, batch_size: int, spatial_shape: List
                      transpose: bool = False, num_out_act_bound: int = -1):
     """Returns (out_inds, pair [2, kv, N_in], indice_num_per_loc [kv]) -- ConvAlgo.Native layout."""
     rb, _ = build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation,
-                           out_padding, subm, transpose)
+                           out_padding, subm, transpose, num_out_act_bound=num_out_act_bound)
     return rb.out_indices, _attach(rb.pair_native, rb), rb.num_per_loc
 
 
@@ -391,7 +397,7 @@ def get_indice_pairs_implicit_gemm(indices: torch.Tensor, batch_size: int,
     kv = _kv(ksize)
     rb, _ = build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation,
                            out_padding, subm, transpose, need_bwd_table=subm and is_train,
-                           do_sort=do_sort and kv <= 32)
+                           do_sort=do_sort and kv <= 32, num_out_act_bound=num_out_act_bound)
     masks = [np.array([0xffffffff], dtype=np.uint32)]
     arg_fwd = rb.argsort_fwd if rb.argsort_fwd is not None else torch.arange(
         rb.n_out, dtype=torch.int32, device=indices.device)

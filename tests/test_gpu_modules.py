@@ -264,7 +264,8 @@ def test_eval_forward_is_the_same_with_and_without_grad(cuda, act):
     shape, C, K = [16, 16, 16], 16, 32
     idx = dense_scene(shape, 1200, 1, 4)
     torch.manual_seed(1)
-    net = spconv.SubMConv3d(C, K, 3, bias=True, algo=spconv.ConvAlgo.Native,
+    from spconv_amd.pytorch.conv import SparseConvolution
+    net = SparseConvolution(3, C, K, 3, padding=1, bias=True, subm=True, algo=spconv.ConvAlgo.Native,
                             act_type=getattr(Activation, act), act_alpha=0.1).to(cuda).half().eval()
     f = torch.randn(idx.shape[0], C, device=cuda).half()
     ind = torch.from_numpy(idx).to(cuda)

@@ -254,3 +254,49 @@ def test_gpu_rulebook_equals_reference_digests_at_baseline_sizes(cuda):
         got = (digest(to_np(rb.out_indices)), digest(to_np(rb.pair_native)), digest(to_np(rb.num_per_loc)))
         assert got == (w["out_inds"], w["pair"], w["num"]), f"chain level {level}"
         cur, cur_shape = to_np(rb.out_indices), list(out_shape)
+
+
+def test_output_table_overflow_is_reported(cuda):
+    """The regular-conv builder sizes its output hash table for the worst case; an insert that finds
+    the table full must surface as an error of the count call, not as a silently truncated rulebook.
+    The test shrinks the table through the test-only option SPX_TEST_CONV_TABLE_CAP (512 slots) and
+    builds a rulebook with thousands of distinct outputs."""
+    from spconv_amd import _lib
+    L = _lib.load()
+    shape = [30, 30, 30]
+    idx = scene(shape, 4000, 1, 21)
+    _lib.check(L.spx_set_option(b"SPX_TEST_CONV_TABLE_CAP", 512))
+    try:
+        with pytest.raises(RuntimeError, match="overflow"):
+            gpu_rulebook(idx, 1, shape, [3] * 3, [2] * 3, [1] * 3, [1] * 3, False)
+    finally:
+        _lib.check(L.spx_set_option(b"SPX_TEST_CONV_TABLE_CAP", 0))
+    rb, _ = gpu_rulebook(idx, 1, shape, [3] * 3, [2] * 3, [1] * 3, [1] * 3, False)   # and the full-size table works
+    assert rb.n_out > 512
+
+
+def test_num_out_act_bound_caps_the_outputs(cuda):
+    """ops.get_indice_pairs(..., num_out_act_bound=B) (reference ops.py:263-266): at most B outputs; the
+    first B of the unbounded rulebook (canonical first-seen order) survive with exactly their pairs."""
+    from spconv_amd.pytorch import ops
+    shape = [24, 24, 24]
+    idx = scene(shape, 3000, 2, 5)
+    t = torch.from_numpy(idx).to(cuda)
+    args = (t, 2, shape, [3] * 3, [2] * 3, [1] * 3, [1] * 3, [0] * 3)
+    full, _ = ops.build_rulebook(*args, False)
+    B = full.n_out // 2
+    rb, _ = ops.build_rulebook(*args, False, num_out_act_bound=B)
+    assert rb.n_out == B and rb.out_indices.shape[0] == B
+    np.testing.assert_array_equal(to_np(rb.out_indices), to_np(full.out_indices)[:B])
+    np.testing.assert_array_equal(to_np(rb.pair_fwd), to_np(full.pair_fwd)[:, :B])
+    fb = to_np(full.pair_bwd)
+    np.testing.assert_array_equal(to_np(rb.pair_bwd), np.where(fb < B, fb, -1))
+    # the Native lists hold exactly the surviving pairs, in the unbounded order
+    nat, num = to_np(rb.pair_native), to_np(rb.num_per_loc)
+    fnat, fnum = to_np(full.pair_native), to_np(full.num_per_loc)
+    for k in range(27):
+        keep = fnat[1, k, :fnum[k]] < B
+        np.testing.assert_array_equal(nat[:, k, :num[k]], fnat[:, k, :fnum[k]][:, keep])
+    # a bound above the real count changes nothing
+    same, _ = ops.build_rulebook(*args, False, num_out_act_bound=full.n_out + 10)
+    assert same.n_out == full.n_out
