@@ -75,7 +75,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true",
                     help="config 2 at N = 1 only: skip the compact block of the other configurations")
-    ap.add_argument("--sort", action="store_true", help="mask_argsort the rulebook rows")
+    ap.add_argument("--sort", choices=["auto", "on", "off"], default="auto",
+                    help="row order of the rulebook tables: auto = density-aware (ops.build_rulebook(do_sort='auto'): "
+                         "sparse SubM rulebooks are mask-sorted, dense ones stay in row order), on / off = forced")
     ap.add_argument("--graph-steps", type=int, default=8,
                     help="steps captured per hipGraph at N = 1 (a replay boundary costs ~5 us; with N > 1 "
                          "the gradient all-reduce follows every step, so one step per replay)")
@@ -428,7 +430,7 @@ def run_layer(args, D: Dist):
 
         def build(sc=sc):
             return ops.build_rulebook(sc.indices, 1, sc.shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3,
-                                      True, do_sort=args.sort)[0]
+                                      True, do_sort={"auto": "auto", "on": True, "off": False}[args.sort])[0]
         sc.rb = build()
         torch.cuda.synchronize()
         if si == 0:                      # rulebook build: timed separately (wall, incl. enqueue)
@@ -638,7 +640,7 @@ def run_layer(args, D: Dist):
                 "dgrad": event_time_ms(dgrad, span=sp), "wgrad": event_time_ms(wgrad, span=sp)}
     t_cold = groups_for(lambda i: i % S)
     t_warm = groups_for(lambda i: 0) if S > 1 else t_cold
-    t_eager = event_time_ms(lambda i: compute(scenes[i % S]), iters=20, warm=5)
+    t_eager = event_time_ms(lambda i: compute(scenes[i % S]), iters=200, warm=30)
     t_sort_dev = None
     if scenes[0].rb.argsort_fwd is not None:      # mask sort + tile-order table copies: once per rulebook
         t_sort_dev = round(event_time_ms(lambda i: ops.sort_rulebook(scenes[0].rb), iters=10, warm=2), 4)

@@ -1563,6 +1563,17 @@ __device__ __forceinline__ T plan_scan(T v, T *wtot, T &total) {
   return prefix + incl - v;
 }
 
+// Segment cost padding of the plan (see wgrad_plan2_kernel): on unless switched off for an A/B run.
+__device__ __forceinline__ bool subm_cost_pad(int n_in, int kv) {
+  (void)n_in;
+  (void)kv;
+#ifdef SPX_WGRAD_NO_PAD
+  return false;
+#else
+  return true;
+#endif
+}
+
 // One block, three block-wide scans.  Everything is a prefix sum or a closed form of the kv list
 // lengths: the pairs of all lists, laid end to end, are cut into G equal ranges (one per workgroup
 // of the first stage); a segment is the part of one list inside one range.  A range finds its first
@@ -1578,16 +1589,29 @@ __global__ void __launch_bounds__(kW2MaxG)
 wgrad_plan2_kernel(const int32_t *__restrict__ num, int n_in, int kv, int subm, int G,
                    int32_t *__restrict__ plan) {
   typedef unsigned long long u64;
-  __shared__ int start[130], kfirst[130], kcount[130], ritems[130];
+  __shared__ int start[130], lpad[130], kfirst[130], kcount[130], ritems[130];
   __shared__ int wtot_i[kW2MaxG / 64];
   __shared__ u64 wtot_a[kW2MaxG / 64], wtot_b[kW2MaxG / 64];
   const int tid = threadIdx.x;
   const int c = tid < kv ? list_count(num, kv, subm, n_in, tid) : 0;
+  // The lists are laid end to end in COST units: a list of c pairs takes c + ov of them, the first ov being
+  // the fixed price of a segment (pair words -> rows -> first MFMAs before anything overlaps, the partial
+  // tile it writes).  Cutting by pairs alone put the 26 short lists of a sparse SubM rulebook (~120 pairs
+  // each at BASELINE config 2) into a handful of ranges of 3-4 segments -- 3-4 dependent chains in a row,
+  // the slowest workgroups of the launch; with the padding a short list fills most of a range by itself.
+  const int ov = (c > 0 && subm_cost_pad(n_in, kv)) ? kW2J + kW2J / 2 : 0;
   int total;
-  const int st = plan_scan<int>(c, wtot_i, total);
+  const int st = plan_scan<int>(c + ov, wtot_i, total);
   if (tid <= kv) start[tid] = st;               // start[kv] = total (threads >= kv add nothing)
+  if (tid < kv) lpad[tid] = ov;
   const int per = total > 0 ? (total + G - 1) / G : 1;
   __syncthreads();
+  // pairs of list k inside the cost interval [a, b): list positions [pa, pb)
+  auto pairs_in = [&](int k, int a, int b, int &pa, int &pb) {
+    const int p0 = start[k] + lpad[k], len = start[k + 1] - p0;
+    pa = min(max(a - p0, 0), len);
+    pb = min(max(b - p0, 0), len);
+  };
 
   // ---- ranges: first list, number of segments, XCD
   int lo = 0, hi = 0, mine = 0, k0 = 0, x = 0;
@@ -1602,16 +1626,21 @@ wgrad_plan2_kernel(const int32_t *__restrict__ num, int n_in, int kv, int subm, 
         else a = m + 1;
       }
       k0 = a;
-      for (int k = k0; k < kv && start[k] < hi; ++k)
-        mine += (min(hi, start[k + 1]) > max(lo, start[k])) ? 1 : 0;
-      const int len = start[k0 + 1] - start[k0];
-      x = min(kXcds - 1, static_cast<int>(static_cast<long long>(lo - start[k0]) * kXcds / (len > 0 ? len : 1)));
+      for (int k = k0; k < kv && start[k] < hi; ++k) {
+        int pa, pb;
+        pairs_in(k, lo, hi, pa, pb);
+        mine += pb > pa ? 1 : 0;
+      }
+      int pa, pb;
+      pairs_in(k0, lo, hi, pa, pb);
+      const int len = start[k0 + 1] - start[k0] - lpad[k0];
+      x = min(kXcds - 1, static_cast<int>(static_cast<long long>(pa) * kXcds / (len > 0 ? len : 1)));
     }
   }
   // ---- per offset: segments (= ranges touching the list), second-stage items
   int kc = 0, nitems = 0;
   if (tid < kv) {
-    if (c > 0) kc = (start[tid + 1] - 1) / per - start[tid] / per + 1;
+    if (c > 0) kc = (start[tid + 1] - 1) / per - (start[tid] + ov) / per + 1;   // ranges touching the PAIRS of the list
     // second-stage work list: block shape by segment count (see wgrad_reduce2_kernel)
     const int mode = kc >= 48 ? 0 : (kc >= 6 ? 1 : 2);
     nitems = (kWT * kWT) / (mode == 0 ? 16 : (mode == 1 ? 128 : 512));
@@ -1650,15 +1679,16 @@ wgrad_plan2_kernel(const int32_t *__restrict__ num, int n_in, int kv, int subm, 
     bool first = true;
     if (hi > lo) {
       for (int k = k0; k < kv && start[k] < hi; ++k) {
-        const int a = max(lo, start[k]), b = min(hi, start[k + 1]);
+        int a, b;
+        pairs_in(k, lo, hi, a, b);
         if (b > a) {
           seg[3 * sg] = k;
-          seg[3 * sg + 1] = a - start[k];
-          seg[3 * sg + 2] = b - start[k];
+          seg[3 * sg + 1] = a;
+          seg[3 * sg + 2] = b;
           if (first) {
             r2 = k;
-            r3 = a - start[k];
-            r4 = b - start[k];
+            r3 = a;
+            r4 = b;
             first = false;
           }
           ++sg;

@@ -66,6 +66,8 @@ class Rulebook:
         # direction, None while unsorted; sort_decided: the automatic mode looked at this rulebook
         self.sorted_tables = {}
         self.sort_decided = False
+        # density class (ops.sparse_neighbourhoods): None = not measured yet
+        self.sparse_class = None
 
     def _ensure_native(self) -> None:
         """Inference builds only the dense tables; the ConvAlgo.Native lists (consumed by wgrad

@@ -295,3 +295,49 @@ def test_global_avg_pool_accumulates_in_fp32(dtype):
     # a scene without rows: NaN for the mean (torch.mean over no rows), lowest value for the max
     x2 = spconv.SparseConvTensor(f, idx, [50, 37, 41], bs + 1)
     assert torch.isnan(spconv.SparseGlobalAvgPool()(x2)[bs]).all()
+
+
+def test_wgrad_plan_cost_space_cut_covers_every_pair_once():
+    """wgrad_plan2_kernel (csrc/igemm.hip) restated: the pair lists are laid end to end in COST units
+    (pairs + a fixed pad per non-empty list) and cut into G equal ranges; a segment is the part of a
+    list's PAIRS inside a range.  Every pair belongs to exactly one segment, the closed form the second
+    stage uses for the segments of a list equals their enumerated count, and the short lists of a sparse
+    SubM rulebook no longer pile up in a few ranges."""
+    def cut(lens, G, ov):
+        pad = [ov if c > 0 else 0 for c in lens]
+        start = [0]
+        for c, p in zip(lens, pad):
+            start.append(start[-1] + c + p)
+        total = start[-1]
+        per = max(1, -(-total // G))
+        segs = []
+        for t in range(G):
+            lo = min(total, t * per)
+            hi = min(total, lo + per)
+            for k, c in enumerate(lens):
+                p0 = start[k] + pad[k]
+                pa = min(max(lo - p0, 0), c)
+                pb = min(max(hi - p0, 0), c)
+                if pb > pa:
+                    segs.append((t, k, pa, pb))
+        kc = [((start[k + 1] - 1) // per - (start[k] + pad[k]) // per + 1) if c > 0 else 0 for k, c in enumerate(lens)]
+        return segs, kc
+
+    cases = [([121] * 13 + [100000] + [121] * 13, 242),            # BASELINE config 2 (SubM, uniform scene)
+             ([30000 + 997 * k for k in range(27)], 384),          # dense scene
+             ([0, 5, 0, 1, 0, 0, 700, 0, 3], 7), ([1], 1), ([0, 0, 4096], 64)]
+    for lens, G in cases:
+        for ov in (0, 192):
+            segs, kc = cut(lens, G, ov)
+            for k, c in enumerate(lens):
+                mine = sorted((a, b) for _, kk, a, b in segs if kk == k)
+                assert len(mine) == kc[k], (lens, G, ov, k)
+                pos = 0
+                for a, b in mine:
+                    assert a == pos and b > a
+                    pos = b
+                assert pos == c
+            assert [s[:2] for s in segs] == sorted(s[:2] for s in segs)       # (range, list) order = (list, range) order
+    # the point of the pad: segments per range at config 2
+    worst = lambda ov: max(sum(1 for s in cut(cases[0][0], 242, ov)[0] if s[0] == t) for t in range(242))
+    assert worst(0) >= 4 and worst(192) <= 2
