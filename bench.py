@@ -275,7 +275,10 @@ def fixture_scene(seed):
     if seed & 4:
         y, x = x.copy(), y.copy()
     lin = np.ravel_multi_index((z, y, x), shape)
-    np.random.default_rng(seed).shuffle(lin)
+    if os.environ.get("BENCH_FIXTURE_ORDER", "shuffled") == "raster":
+        lin = np.sort(lin)            # A/B: rows in raster order (what the row order alone is worth)
+    else:
+        np.random.default_rng(seed).shuffle(lin)
     coords = np.stack(np.unravel_index(lin, shape), axis=-1).astype(np.int32)
     idx = np.concatenate([np.zeros((coords.shape[0], 1), dtype=np.int32), coords], axis=1)
     return np.ascontiguousarray(idx), shape
@@ -782,7 +785,8 @@ def run_int8(args, D: Dist):
     t_cold = event_time_ms(fwd, span=0 if args.no_graph else max(S, 8))
     t_warm = event_time_ms(lambda i: fwd(0), span=0 if args.no_graph else 8)
     ab = algorithmic_bytes(n, n, C, K, 27, 1)["fwd"]
-    r = roofline_obj("fwd", ab, t_cold, f"igemm_v4_kernel<{K},2,int8,fwd> (v_mfma_i32_16x16x64_i8)", None,
+    r = roofline_obj("fwd", ab, t_cold, f"igemm_v4_kernel<{K},1,int8,fwd> (v_mfma_i32_16x16x64_i8)",
+                     pmc_traffic(f"uniform-i8-c{C}-n{voxels}", "fwd"),
                      {"memory_level": f"HBM: {S} scenes rotated" if S >= 4 else "Infinity Cache (single scene)"})
     res = {"metric": "active-voxels/sec forward, int8 3x3x3 SubMConv3d C=128 (BASELINE config 5)",
            "value": n_total * args.steps / elapsed, "unit": "voxels/s", "n_gpus": D.world, "steps": args.steps,

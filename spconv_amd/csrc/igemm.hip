@@ -485,7 +485,12 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   int idxr[2][MB];
   uint32_t identr[2] = {0u, 0u};   // wave-uniform: idxr[S] stands for the identity offset
   u32x4 areg[2][MB][AK];
-  u32x4 breg[BA];
+  // WD = 2: two weight register sets -- a slice is requested THREE steps before its MFMAs (two before it
+  // is written to the LDS stage) instead of two (one): on dense scenes a step was as long as the L2
+  // round trip of its successor's weights.  16-bit operands up to 64 output channels (8 more
+  // registers keep 4 waves per SIMD there); the wider and the int8 / fp32 variants keep one set.
+  constexpr int WD = (!I8 && !F32 && COUT <= 64) ? SPX_WD : 1;
+  u32x4 breg[2][BA];
 
   // Straight-line on purpose (no branch around a load): the compiler's s_waitcnt counts stay
   // exact only when every path issues the same loads.  A step that does not exist (k < 0)
@@ -521,7 +526,8 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
       }
     }
   };
-  auto load_b = [&](const StepIt &it) __attribute__((always_inline)) {
+  auto load_b = [&](const StepIt &it, auto WSET) __attribute__((always_inline)) {
+    constexpr int WS = decltype(WSET)::value;
     const uint32_t tail = (!cfull && it.chunk == nchunk - 1) ? 0xffffffffu : 0u;
     const int k = (it.k < 0 ? 0 : it.k) + p.kbase;
     const int kb = p.b_reverse ? p.kv - 1 - k : k;
@@ -531,15 +537,16 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
     const __amdgpu_buffer_rsrc_t r = make_rsrc(p.B, it.k >= 0 ? w_bytes : 0u);
 #pragma unroll
     for (int j = 0; j < BROWS; ++j)
-      breg[j] = __builtin_amdgcn_raw_buffer_load_b128(r, boff[j] | (boff_tail[j] & tail), so, 0);
+      breg[WS][j] = __builtin_amdgcn_raw_buffer_load_b128(r, boff[j] | (boff_tail[j] & tail), so, 0);
   };
-  auto store_b = [&](char *ldsB) __attribute__((always_inline)) {
+  auto store_b = [&](char *ldsB, auto WSET) __attribute__((always_inline)) {
+    constexpr int WS = decltype(WSET)::value;
     if constexpr (!BT) {
 #pragma unroll
       for (int j = 0; j < BROWS; ++j) {
         const int n = r0 + 32 * j;
         if (COUT >= 32 * (j + 1) || n < COUT)    // compile-time true except for COUT == 16
-          *reinterpret_cast<u32x4 *>(ldsB + swzB(n, slot)) = breg[j];
+          *reinterpret_cast<u32x4 *>(ldsB + swzB(n, slot)) = breg[WS][j];
       }
     } else if constexpr (F32) {
       // transpose: element (reduction row r0, channel n) lands in row n, byte column 4 * r0
@@ -549,7 +556,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
         for (int e = 0; e < 4; ++e) {
           const int n = j * 32 + slot * 4 + e;
           if (COUT >= 32 * (j + 1) || n < COUT)
-            *reinterpret_cast<uint32_t *>(ldsB + swzB(n, r0 >> 2) + (r0 & 3) * 4) = breg[j][e];
+            *reinterpret_cast<uint32_t *>(ldsB + swzB(n, r0 >> 2) + (r0 & 3) * 4) = breg[WS][j][e];
         }
       }
     } else {
@@ -559,7 +566,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int n = jj * 64 + slot * 8 + e;
-          const uint32_t ev = breg[2 * jj][e >> 1], od = breg[2 * jj + 1][e >> 1];
+          const uint32_t ev = breg[WS][2 * jj][e >> 1], od = breg[WS][2 * jj + 1][e >> 1];
           const uint32_t v = (e & 1) ? __builtin_amdgcn_perm(od, ev, 0x07060302u)
                                      : __builtin_amdgcn_perm(od, ev, 0x05040100u);
           if (COUT >= 64 * (jj + 1) || n < COUT)
@@ -588,7 +595,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   // identity step: start its loads before the mask words arrive.  Unconditional (a regular
   // conv has it0.k == -1 here and reads zero-sized resources) so that the wait for the mask
   // words below stays a counted one.
-  load_b(it0);
+  load_b(it0, Set0{});
   identr[0] = 0xffffffffu;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) idxr[0][mb] = 0;
@@ -609,7 +616,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   // SubM: the identity step's weights go into stage 0 BEFORE the barrier that publishes the
   // wave masks, so that one barrier serves both and the identity MFMAs can start as soon as
   // their rows have arrived (they do not depend on the mask exchange at all)
-  if (spec) store_b(smem);
+  if (spec) store_b(smem, Set0{});
   __syncthreads();
   SPX_STAMP(2);   // mask words arrived, tile mask exchanged
   uint32_t tilemask = lds_mask[0] | lds_mask[1] | lds_mask[2] | lds_mask[3];
@@ -619,10 +626,10 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
     it0.rest = tilemask & ~(1u << p.identity_k);
   } else {
     it0 = step_begin(tilemask);
-    load_b(it0);
+    load_b(it0, Set0{});
     load_idx(it0, Set0{});
     load_a(it0, Set0{});
-    store_b(smem);
+    store_b(smem, Set0{});
     __syncthreads();          // regular conv: the first step's weights could not be staged earlier
   }
   StepIt it1 = step_next(it0, nchunk);
@@ -666,17 +673,19 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   // steady-state ones.
   load_idx(it1, Set1{});
   __builtin_amdgcn_sched_barrier(0);
-  load_b(it1);
+  using WSetA = std::integral_constant<int, (WD == 2 ? 1 : 0)>;   // set of the odd steps' weights
+  load_b(it1, WSetA{});
   __builtin_amdgcn_sched_barrier(0);
   load_idx(it2, Set0{});        // idxr[0] was consumed by load_a(it0): reuse it for step 2
   __builtin_amdgcn_sched_barrier(0);
   compute(it0, Set0{});
   __builtin_amdgcn_sched_barrier(0);
   load_a(it1, Set1{});
-  store_b(smem + B_BYTES);      // weights of step 1 -> stage 1 (published by step 1's barrier)
+  store_b(smem + B_BYTES, WSetA{});      // weights of step 1 -> stage 1 (published by step 1's barrier)
   {
     const StepIt it3 = step_next(it2, nchunk);
-    load_b(it2);
+    load_b(it2, Set0{});
+    if constexpr (WD == 2) load_b(it3, Set1{});   // step 3's weights: in flight two steps before their LDS write
     __builtin_amdgcn_sched_barrier(0);
     load_idx(it3, Set1{});
     __builtin_amdgcn_sched_barrier(0);
@@ -693,10 +702,16 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   auto step = [&](auto SET) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
     if (!SPX_ABL(p, 2)) __syncthreads();   // stage 1-S is free (read at step t-1), stage S is complete
-    if (!SPX_ABL(p, 1) && !SPX_ABL(p, 2)) store_b(smem + (1 - S) * B_BYTES);
+    // WD = 1: breg[0] holds step t+1's weights, reloaded with step t+2's.  WD = 2: set (t+1) & 1 = 1 - S
+    // holds step t+1's (requested at step t-2) and is reloaded with step t+3's; set S holds step t+2's.
+    using WSetN = std::integral_constant<int, (WD == 2 ? 1 - S : 0)>;
+    if (!SPX_ABL(p, 1) && !SPX_ABL(p, 2)) store_b(smem + (1 - S) * B_BYTES, WSetN{});
     compute(it0, SET);
     const StepIt it3 = step_next(it2, nchunk);
-    if (!SPX_ABL(p, 1) && !SPX_ABL(p, 2)) load_b(it2);
+    if (!SPX_ABL(p, 1) && !SPX_ABL(p, 2)) {
+      if constexpr (WD == 2) load_b(it3, WSetN{});
+      else load_b(it2, WSetN{});
+    }
     __builtin_amdgcn_sched_barrier(0);   // weights first: they are the first thing step t+1 waits for
     load_idx(it3, std::integral_constant<int, 1 - S>{});
     __builtin_amdgcn_sched_barrier(0);

@@ -14,6 +14,10 @@
 #endif
 // the same for result rows / partial tiles that the launch itself never reads again: 2 = non-temporal
 // (igemm_v4 epilogue: cfg 2 step 37.4 -> 33.6 us), 0 in the A/B build
+// weight register sets of igemm_v4_kernel's step pipeline (A/B builds: -DSPX_WD=1)
+#ifndef SPX_WD
+#define SPX_WD 2
+#endif
 #ifndef SPX_AUX_OUT
 #define SPX_AUX_OUT 2
 #endif

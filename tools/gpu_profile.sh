@@ -6,7 +6,7 @@ TAG=${1:-r01}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
-CMD="python $R/bench.py --steps 50 --warmup 10 --no-graph --no-cpu-baseline"
+CMD="python $R/bench.py --steps 50 --warmup 10 --no-graph --no-cpu-baseline --no-also"
 echo "== bench default"; timeout 300 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; echo "rc=$?"; cat gpurun_out/bench_$TAG.json
 echo "== rocprof stats"; (cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_stats -o bench -- $CMD > $R/gpurun_out/rocprof_stats.log 2>&1); echo "rc=$?"
 echo "== rocprof pmc SQ"; (cd /tmp && timeout 150 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES -d $R/gpurun_out/prof_${TAG}_sq -o bench -- $CMD > $R/gpurun_out/rocprof_sq.log 2>&1); echo "rc=$?"
