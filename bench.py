@@ -739,15 +739,16 @@ def run_int8(args, D: Dist):
         idx_np, shape = make_scene(args.scene or "uniform", voxels, seed=D.rank * S + si)
         ind = torch.from_numpy(idx_np).to(dev)
         rb = ops.build_rulebook(ind, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True,
-                                need_native=False)[0]
+                                need_native=False, do_sort={"auto": "auto", "on": True, "off": False}[args.sort])[0]
         f = torch.from_numpy(rng.integers(-127, 128, (idx_np.shape[0], C), dtype=np.int8)).to(dev)
         scenes.append((idx_np, shape, rb, f))
     n = scenes[0][0].shape[0]
 
     def fwd(i):
         _, _, rb, f = scenes[i % S]
-        return ops.igemm_fwd_int8(f, w, rb.pair_fwd, rb.mask_fwd, None, n, 13, scale, bias, None, 0.0,
-                                  torch.int8, ops.Activation.ReLU, 0.0)
+        pair, mask, order, to = ops.tables_of(rb, "fwd", K)
+        return ops.igemm_fwd_int8(f, w, pair, mask, order, n, 13, scale, bias, None, 0.0,
+                                  torch.int8, ops.Activation.ReLU, 0.0, tile_order=to)
     graphs = None
     if not args.no_graph:
         try:
@@ -795,6 +796,7 @@ def run_int8(args, D: Dist):
            "config": {"workload": f"int8 SubMConv3d 3x3x3 C={C}->{K}, {n} uniform voxels/scene, per-channel scale + "
                                   f"bias + ReLU, int8 out, inference forward only (BASELINE config 5)",
                       "scenes_rotated": S, "launch": "hipgraph" if graphs is not None else "eager",
+                      "mask_sort": scenes[0][2].argsort_fwd is not None,
                       "parallelism": f"dp{D.world}", "ranks_seen": ranks_seen},
            "roofline": r, "roofline_cold": r,
            "roofline_warm": roofline_obj("fwd", ab, t_warm, r["kernel"], None, {"memory_level": "Infinity Cache"})}

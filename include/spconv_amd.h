@@ -50,6 +50,10 @@ enum spx_act { SPX_ACT_NONE = 0, SPX_ACT_RELU = 1, SPX_ACT_SIGMOID = 2, SPX_ACT_
  * step).  Without it the rows leave the L2 as they are written, which is what a layer measured alone
  * wants (config 2: 37.4 -> 33.6 us per step). */
 #define SPX_OUT_CACHED 0x100
+/* OR-ed into the `act` argument of spx_igemm_fwd_int8 (which has no tile_order argument of its own):
+ * `pair` and `mask` are stored in tile order, i.e. row t of the tables belongs to output row
+ * argsort[t] (spx_permute_tables), as for tile_order = 1 of spx_igemm_fwd. */
+#define SPX_TILE_ORDER 0x200
 
 /* Error text of the last failing call on this thread ("" if none). */
 const char *spx_last_error(void);

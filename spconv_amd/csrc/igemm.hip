@@ -2530,7 +2530,8 @@ int spx_igemm_fwd_int8(const void *feat, const void *weight, void *out, const in
   p.kv = kv;
   p.identity_k = identity_k;
   p.b_reverse = 0;
-  p.act = act;
+  p.tile_order = ((act & SPX_TILE_ORDER) && argsort) ? 1 : 0;
+  p.act = act & 0xff;
   p.act_alpha = act_alpha;
   p.scale = scale;
   p.add = add;

@@ -116,6 +116,7 @@ def _ptr(t: Optional[torch.Tensor]):
 # SPX_OUT_CACHED (include/spconv_amd.h): inside this context igemm_fwd asks for result rows that stay in
 # the caches -- SparseSequential opens it around a convolution whose output a BatchNorm reads next
 _OUT_CACHED = 0x100
+_TILE_ORDER = 0x200           # SPX_TILE_ORDER: tables of the int8 forward are stored in tile order
 _out_policy = threading.local()
 
 
@@ -465,7 +466,8 @@ def igemm_fwd_int8(features: torch.Tensor, filters: torch.Tensor, pair: torch.Te
                    identity_k: int = -1, scale: Optional[torch.Tensor] = None,
                    bias: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None,
                    add_scale: float = 0.0, out_dtype: torch.dtype = torch.int8,
-                   act_type: int = Activation.None_, act_alpha: float = 0.0) -> torch.Tensor:
+                   act_type: int = Activation.None_, act_alpha: float = 0.0,
+                   tile_order: bool = False) -> torch.Tensor:
     """int8 inference forward (i32 accumulate on v_mfma_i32_16x16x64_i8):
     ``v = acc * scale[k] + bias[k] + add * add_scale; v = act(v)``; int8 output =
     ``clip(round_half_even(v), -128, 127)`` (reference numerics test/test_all_algo.py:272-287)."""
@@ -496,8 +498,9 @@ def igemm_fwd_int8(features: torch.Tensor, filters: torch.Tensor, pair: torch.Te
     _lib.check(L.spx_igemm_fwd_int8(features.data_ptr(), filters.data_ptr(), out.data_ptr(), _ptr(pair),
                                     _ptr(mask), _ptr(argsort), features.shape[0], n_out, C, K, kv,
                                     identity_k, _ptr(scale), _ptr(bias), _ptr(add), float(add_scale),
-                                    _OUT_CODES[out_dtype], int(act_type), float(act_alpha),
-                                    _stream(features)))
+                                    _OUT_CODES[out_dtype],
+                                    int(act_type) | (_TILE_ORDER if (tile_order and argsort is not None) else 0),
+                                    float(act_alpha), _stream(features)))
     return out if K == K0 else out[:, :K0].contiguous()
 
 
@@ -867,7 +870,7 @@ def implicit_gemm(features: torch.Tensor, filters: torch.Tensor, pair_fwd: torch
     rb: Optional[Rulebook] = rulebook_of(pair_fwd)
     argsort, tile_order = (rb.argsort_fwd if rb is not None else None), False
     kv = pair_fwd.shape[0]
-    if rb is not None and pair_fwd is rb.pair_fwd and features.dtype not in (torch.int8, torch.qint8):
+    if rb is not None and pair_fwd is rb.pair_fwd:
         pair_fwd, mask, argsort, tile_order = tables_of(rb, "fwd", filters.shape[0])
     if features.dtype in (torch.int8, torch.qint8):
         # int8 inference (ops.py:1540-1553,1631-1662): scale = per-channel multiplier, bias is
@@ -877,7 +880,7 @@ def implicit_gemm(features: torch.Tensor, filters: torch.Tensor, pair_fwd: torch
         beta = output_add_scale / output_scale if output_add is not None else 0.0
         out = igemm_fwd_int8(features, filters, pair_fwd, mask, argsort, num_activate_out,
                              kv // 2 if is_subm else -1, scale, bias, output_add, beta, out_dt,
-                             act_type, act_alpha)
+                             act_type, act_alpha, tile_order=tile_order)
         if out_dt == torch.int8 and features.is_quantized:
             out = torch._make_per_tensor_quantized_tensor(out, float(output_scale), 0)
         return out, None, -1

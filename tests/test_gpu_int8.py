@@ -95,6 +95,14 @@ def test_int8_mask_sorted_rows_and_argsort(cuda):
                              rb.mask_fwd, rb.argsort_fwd, rb.n_out, rb.kv // 2,
                              torch.from_numpy(scale), torch.from_numpy(bias))
     np.testing.assert_array_equal(to_np(got), want)
+    # the same through the tables in tile order (SPX_TILE_ORDER: row t of pair / mask belongs to output
+    # row argsort[t]), as ops.tables_of hands them out for a sorted rulebook
+    pair_t, mask_t, order, to = ops.tables_of(rb, "fwd", K)
+    assert to and order is rb.argsort_fwd and pair_t is not rb.pair_fwd
+    got_t = ops.igemm_fwd_int8(torch.from_numpy(f).to(cuda), torch.from_numpy(w).to(cuda), pair_t, mask_t, order,
+                               rb.n_out, rb.kv // 2, torch.from_numpy(scale), torch.from_numpy(bias),
+                               tile_order=True)
+    np.testing.assert_array_equal(to_np(got_t), want)
 
 
 def test_quantized_module_matches_formula(cuda):

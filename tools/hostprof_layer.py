@@ -76,32 +76,3 @@ for name, fn in (("forward", fwd), ("step", step)):
     print(f"---- cProfile of 200 x {name} (tottime, us per call = tottime * 5000)")
     print("\n".join(l[:150] for l in sio.getvalue().splitlines()[4:40]))
 
-# does a captured hipGraph in the same process change the eager host cost?  (bench.py measures its
-# `eager_device_ms_per_step` after its graph captures)
-side = torch.cuda.Stream()
-side.wait_stream(torch.cuda.current_stream())
-with torch.cuda.stream(side):
-    for _ in range(3):
-        step()
-torch.cuda.current_stream().wait_stream(side)
-torch.cuda.synchronize()
-g = torch.cuda.CUDAGraph()
-with torch.cuda.graph(g):
-    step()
-g.replay()
-torch.cuda.synchronize()
-for _ in range(30):
-    step()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(N):
-    step()
-torch.cuda.synchronize()
-print("eager step after a graph capture in this process: %.1f us" % ((time.perf_counter() - t0) / N * 1e6))
-a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-a.record()
-for _ in range(N):
-    step()
-b.record()
-torch.cuda.synchronize()
-print("the same between HIP events: %.1f us" % (a.elapsed_time(b) / N * 1e3))
