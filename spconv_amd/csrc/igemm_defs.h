@@ -79,6 +79,8 @@ struct GemmRest {
   int acc_mode;
 };
 
+// igemm_gen1.hip: first-generation gather-GEMM (tensors beyond 32-bit buffer offsets)
+int launch_gather_gemm_gen1(const GemmParams &p, bool bf16, hipStream_t s);
 // igemm5.hip: persistent loader / consumer gather-GEMM (16-bit operands, <= 64 output channels)
 bool v5_ok(const GemmParams &p, int dtype);
 int launch_v5(const GemmParams &p, const GemmRest &r, int dtype, hipStream_t s);
