@@ -643,7 +643,26 @@ def run_layer(args, D: Dist):
                 "dgrad": event_time_ms(dgrad, span=sp), "wgrad": event_time_ms(wgrad, span=sp)}
     t_cold = groups_for(lambda i: i % S)
     t_warm = groups_for(lambda i: 0) if S > 1 else t_cold
-    t_eager = event_time_ms(lambda i: compute(scenes[i % S]), iters=200, warm=30)
+    # eager launches of the same step.  Fresh leaf tensors: the benchmark's own leaves were first used on the
+    # capture side stream, and autograd ties a leaf's AccumulateGrad node to that stream -- every eager backward
+    # on the main stream would then pay cross-stream event traffic (166 us per step instead of ~75) that a
+    # training loop, which stays on one stream, never sees.
+    import copy
+    net_e = copy.deepcopy(net)
+    eager = []
+    for sc in scenes:
+        fe = sc.feats.detach().clone().requires_grad_(True)
+        xe = spconv.SparseConvTensor(fe, sc.indices, sc.shape, 1)
+        xe.indice_dict["bench"] = sc.x.indice_dict["bench"]
+        eager.append((fe, xe, sc.dout))
+
+    def compute_eager(i):
+        fe, xe, do = eager[i % S]
+        net_e.weight.grad = None
+        fe.grad = None
+        net_e(xe).features.backward(do)
+    t_eager = event_time_ms(compute_eager, iters=200, warm=30)
+    del net_e, eager
     t_sort_dev = None
     if scenes[0].rb.argsort_fwd is not None:      # mask sort + tile-order table copies: once per rulebook
         t_sort_dev = round(event_time_ms(lambda i: ops.sort_rulebook(scenes[0].rb), iters=10, warm=2), 4)

@@ -341,3 +341,51 @@ def test_wgrad_plan_cost_space_cut_covers_every_pair_once():
     # the point of the pad: segments per range at config 2
     worst = lambda ov: max(sum(1 for s in cut(cases[0][0], 242, ov)[0] if s[0] == t) for t in range(242))
     assert worst(0) >= 4 and worst(192) <= 2
+
+
+def test_device_guard_switches_to_the_tensor_device(monkeypatch):
+    """ops._on_device (torch's DeviceGuard convention) with a faked second device: a driver called with a
+    tensor on cuda:1 while cuda:0 is current must run inside torch.cuda.device(cuda:1); with the tensor's
+    device already current, or a CPU tensor, it must not touch the guard.  (A 1-GPU box cannot exercise
+    this for real: round-2 verdict.)"""
+    from spconv_amd.pytorch import ops
+
+    class FakeDev:
+        def __init__(self, index):
+            self.index, self.type = index, "cuda"
+
+    class FakeTensor(torch.Tensor):
+        pass
+
+    entered = []
+
+    class Guard:
+        def __init__(self, dev):
+            self.dev = dev
+
+        def __enter__(self):
+            entered.append(self.dev.index)
+
+        def __exit__(self, *a):
+            entered.append(-self.dev.index)
+            return False
+
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    monkeypatch.setattr(torch.cuda, "device", Guard)
+    seen = []
+
+    @ops._on_device
+    def driver(t, extra=None):
+        seen.append(list(entered))
+        return "ok"
+
+    def fake(index):
+        t = FakeTensor(torch.zeros(1))
+        t.__class__ = type("T", (FakeTensor,), {"is_cuda": True, "device": FakeDev(index)})
+        return t
+
+    assert driver(fake(1)) == "ok" and seen[-1] == [1] and entered == [1, -1]     # guarded: entered, then left
+    entered.clear()
+    assert driver(fake(0)) == "ok" and entered == []                               # already current: no guard
+    assert driver(torch.zeros(2)) == "ok" and entered == []                        # CPU tensor: no guard
+    assert driver(None, extra=fake(1)) == "ok" and entered == []                   # only positional tensors decide
