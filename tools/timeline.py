@@ -26,14 +26,18 @@ def main():
     scene = sys.argv[1] if len(sys.argv) > 1 else "uniform"
     centre = len(sys.argv) > 2 and sys.argv[2] == "centre"
     sp = len(sys.argv) > 2 and sys.argv[2] == "sp"          # igemm_sp_kernel (SPX_GEMM_V = 6): one wave per 32 rows
+    srt = len(sys.argv) > 2 and sys.argv[2] == "sort"       # mask-sorted rows, tables in tile order
     dev = torch.device("cuda:0")
     n, C = 100000, 64
     gen = synthetic.uniform_scene if scene == "uniform" else synthetic.lidar_like_scene
     idx = torch.from_numpy(gen(SHAPE, n, 1, seed=0)).to(dev)
     f = (torch.rand(n, C, device=dev) * 2 - 1).half()
     w = (torch.rand(C, 3, 3, 3, C, device=dev) * 2 - 1).half()
-    rb, _ = ops.build_rulebook(idx, 1, SHAPE, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True)
+    rb, _ = ops.build_rulebook(idx, 1, SHAPE, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True, do_sort=srt)
     mask = torch.full_like(rb.mask_fwd, 1 << 13) if centre else rb.mask_fwd
+    pair, order, to = rb.pair_fwd, None, False
+    if srt:
+        pair, mask, order, to = ops.tables_of(rb, "fwd", C)
     L = _lib.load()
     getter = L.spx_debug_timeline_sp if sp else L.spx_debug_timeline
     getter.restype = ctypes.c_int
@@ -41,16 +45,16 @@ def main():
     if sp:
         _lib.check(L.spx_set_option(b"SPX_GEMM_V", 6))
     for _ in range(20):
-        ops.igemm_fwd(f, w, rb.pair_fwd, mask, None, n, 13)
+        ops.igemm_fwd(f, w, pair, mask, order, n, 13, tile_order=to)
     torch.cuda.synchronize()
-    ops.igemm_fwd(f, w, rb.pair_fwd, mask, None, n, 13)
+    ops.igemm_fwd(f, w, pair, mask, order, n, 13, tile_order=to)
     buf = np.zeros((8192, 8), dtype=np.uint64)
     _lib.check(getter(buf.ctypes.data))
     mb = int(os.environ.get("SPX_GEMM_MB", "2"))
     ntiles = min(8192, (n + 31) // 32) if sp else (n + 64 * mb - 1) // (64 * mb)
     t = buf[:ntiles].astype(np.int64)
     t0 = t[:, 0].min()
-    rel = (t - t0) / float(os.environ.get("SPX_TICK_MHZ", "100"))
+    rel = (t - t0) / float(os.environ.get("SPX_TICK_MHZ", "2200"))       # s_memtime: shader clock under load
     names = ["entry", "ident_issued", "mask_known", "prologue_done", "loop_done", "staged",
              "stores_issued", "stores_retired"]
     out = {"scene": scene, "centre_only": centre, "tiles": int(ntiles), "stamps_us": {}, "phases_us": {}}
@@ -63,7 +67,7 @@ def main():
         out["phases_us"][f"{names[i - 1]}->{names[i]}"] = [round(float(v), 2) for v in q]
     # s_memtime is per XCD (not synchronised across dies): spans are taken inside each XCD
     # (workgroup b runs on XCD b % 8) and the stamps above are only meaningful as differences
-    tick = 1.0 / float(os.environ.get("SPX_TICK_MHZ", "100"))
+    tick = 1.0 / float(os.environ.get("SPX_TICK_MHZ", "2200"))
     spans, ramps = [], []
     for x in range(8):
         g = t[x::8]
