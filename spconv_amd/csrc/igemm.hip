@@ -141,11 +141,21 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   constexpr int CPL = NB * 4;                           // consecutive output channels per lane
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint32_t *lds_mask = reinterpret_cast<uint32_t *>(smem + 2 * B_BYTES);  // [4]
+  // int8: per-channel scale and bias of the quantised epilogue, staged once per workgroup ([2][COUT] fp32
+  // behind the mask words) -- read per lane from memory they were 64 dependent dword loads at the end of
+  // every tile
+  float *lds_sb = reinterpret_cast<float *>(smem + 2 * B_BYTES + 64);
 
   SPX_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntiles = (p.n_dst + TM - 1) / TM;
-  const int tile = p.xcd_rot ? xcd_tile_rot(block, ntiles, p.xcd_rot) : xcd_tile(block, ntiles);
+  // Tables in tile order = rows sorted by mask word: the tiles at the END hold the rows with the most
+  // offsets (the identity-only rows sort first), and a launch lasts as long as its slowest workgroup.
+  // Those tiles are handed to the FIRST blocks (longest work first), one after the other to different
+  // XCDs; contiguous per-XCD ranges buy nothing here -- a sorted tile gathers mostly its own rows.
+  // (int8 config 5, two dispatch rounds: the 26 us tail tiles no longer start in the second round.)
+  const int tile = p.tile_order ? ntiles - 1 - block
+                                : (p.xcd_rot ? xcd_tile_rot(block, ntiles, p.xcd_rot) : xcd_tile(block, ntiles));
   const int lrow = lane & 15, lgrp = lane >> 4;
   const int slot = tid & 7, r0 = tid >> 3;
   // Output-channel permutation: MFMA row (g = i >> 2, e = i & 3) of channel block nb carries
@@ -346,6 +356,11 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   // wave masks, so that one barrier serves both and the identity MFMAs can start as soon as
   // their rows have arrived (they do not depend on the mask exchange at all)
   if (spec) store_b(smem, Set0{});
+  if constexpr (I8) {
+    const float *bias_f = static_cast<const float *>(p.bias);
+    for (int c = tid; c < 2 * COUT; c += kThreads)
+      lds_sb[c] = c < COUT ? (p.scale ? p.scale[c] : 1.f) : (bias_f ? bias_f[c - COUT] : 0.f);
+  }
   __syncthreads();
   SPX_STAMP(2);   // mask words arrived, tile mask exchanged
   uint32_t tilemask = lds_mask[0] | lds_mask[1] | lds_mask[2] | lds_mask[3];
@@ -530,7 +545,6 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
         make_rsrc(p.out, static_cast<uint32_t>(p.n_dst) * static_cast<uint32_t>(COUT * oes));
     const __amdgpu_buffer_rsrc_t rAdd =
         make_rsrc(p.add, p.add ? static_cast<uint32_t>(p.n_dst) * COUT : 0u);
-    const float *bias = static_cast<const float *>(p.bias);
     uint32_t rowoff[MB];
     uint32_t addw[MB][CPL / 4];
 #pragma unroll
@@ -541,29 +555,50 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
     // four channels (one output dword of an int8 row) at a time keeps the live set small
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-      float sc[4], bv[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        sc[e] = p.scale ? p.scale[lgrp * CPL + nb * 4 + e] : 1.f;
-        bv[e] = bias ? bias[lgrp * CPL + nb * 4 + e] : 0.f;
-      }
+      const float4 sc4 = *reinterpret_cast<const float4 *>(lds_sb + lgrp * CPL + nb * 4);
+      const float4 bv4 = *reinterpret_cast<const float4 *>(lds_sb + COUT + lgrp * CPL + nb * 4);
+      const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, bv[4] = {bv4.x, bv4.y, bv4.z, bv4.w};
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
+        // (uniform conditions hoisted out of the per-value work: at 64 values per lane the epilogue of a
+        // tile was ~5.5 us of vector ALU time, more than an identity-only tile's loads and MFMAs)
         float v[4];
 #pragma unroll
+        // every product and sum rounded on its own: the reference formula is numpy arithmetic,
+        // ((acc * scale) + bias) + (add * add_scale), and a fused multiply-add lands on the other side of a
+        // rounding tie for ~4 values in 10 million.  (HIP's __fmul_rn is a plain `*` that the compiler is
+        // free to contract; the empty asm pins the rounded product in a register.)
         for (int e = 0; e < 4; ++e) {
-          const int a8 = static_cast<int>(static_cast<int8_t>((addw[mb][nb] >> (e * 8)) & 0xff));
-          float t = static_cast<float>(acc[nb][mb][e]) * sc[e] + bv[e];
-          t += static_cast<float>(a8) * p.add_scale;
-          v[e] = apply_act(t, p.act, p.act_alpha);
+          float prod = static_cast<float>(acc[nb][mb][e]) * sc[e];
+          asm volatile("" : "+v"(prod));
+          v[e] = prod + bv[e];
         }
-        if (p.out_dtype == SPX_I8) {
-          uint32_t word = 0;
+        if (p.add) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float r = fminf(fmaxf(__builtin_rintf(v[e]), -128.f), 127.f);
-            word |= (static_cast<uint32_t>(static_cast<int>(r)) & 0xffu) << (8 * e);
+            const int a8 = static_cast<int>(static_cast<int8_t>((addw[mb][nb] >> (e * 8)) & 0xff));
+            float prod = static_cast<float>(a8) * p.add_scale;
+            asm volatile("" : "+v"(prod));
+            v[e] += prod;
           }
+        }
+        if (p.act == SPX_ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        } else if (p.act != SPX_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act, p.act_alpha);
+        }
+        if (p.out_dtype == SPX_I8) {
+          // round half to even, clamp, and pack the four low bytes: two v_cvt_pk_i16_i32 + one v_perm_b32
+          int q[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            q[e] = static_cast<int>(__builtin_amdgcn_fmed3f(__builtin_rintf(v[e]), -128.f, 127.f));
+          typedef short s16x2 __attribute__((ext_vector_type(2)));
+          const uint32_t p01 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(q[0], q[1]));
+          const uint32_t p23 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(q[2], q[3]));
+          const uint32_t word = __builtin_amdgcn_perm(p23, p01, 0x06040200u);
           addw[mb][nb] = word;                            // reuse: the residual word is consumed
         } else if (p.out_dtype == SPX_F32) {
           uint32_t d[4];
@@ -592,9 +627,10 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
 #endif
 }
 
-template <int COUT, int MB>
+template <int COUT, int MB, int DT = 0>
 constexpr size_t v4_smem_bytes() {
-  return 2 * static_cast<size_t>(COUT) * kRowBytes + 64;   // two weight stages + 4 mask words
+  // two weight stages + 4 mask words (+ int8: scale and bias of the epilogue)
+  return 2 * static_cast<size_t>(COUT) * kRowBytes + 64 + (DT == 2 ? 2 * static_cast<size_t>(COUT) * 4 : 0);
 }
 
 int v4_flags(const GemmParams &p) {
@@ -623,7 +659,7 @@ int launch_v4(const GemmParams &p, hipStream_t s) {
   const bool half = p.CIN * es <= 64;        // narrow rows: only the first 64 bytes of a piece exist
 #define SPX_LAUNCH_V4(BTV, NKSV)                                                                     \
   hipLaunchKernelGGL((igemm_v4_kernel<COUT, MB, DT, BTV, NKSV>), dim3(ntiles), dim3(kThreads),          \
-                     (v4_smem_bytes<COUT, MB>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,      \
+                     (v4_smem_bytes<COUT, MB, DT>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,  \
                      p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(p), r)
   if (DT == 2 || p.strideD == 1) {
     if (half) SPX_LAUNCH_V4(false, 1);

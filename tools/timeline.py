@@ -26,9 +26,10 @@ def main():
     scene = sys.argv[1] if len(sys.argv) > 1 else "uniform"
     centre = len(sys.argv) > 2 and sys.argv[2] == "centre"
     sp = len(sys.argv) > 2 and sys.argv[2] == "sp"          # igemm_sp_kernel (SPX_GEMM_V = 6): one wave per 32 rows
-    srt = len(sys.argv) > 2 and sys.argv[2] == "sort"       # mask-sorted rows, tables in tile order
+    srt = len(sys.argv) > 2 and sys.argv[2] in ("sort", "i8sort")   # mask-sorted rows, tables in tile order
+    i8 = len(sys.argv) > 2 and sys.argv[2] in ("i8", "i8sort")      # BASELINE config 5: int8, C = K = 128, 200 k voxels
     dev = torch.device("cuda:0")
-    n, C = 100000, 64
+    n, C = (200000, 128) if (len(sys.argv) > 2 and sys.argv[2] in ("i8", "i8sort")) else (100000, 64)
     gen = synthetic.uniform_scene if scene == "uniform" else synthetic.lidar_like_scene
     idx = torch.from_numpy(gen(SHAPE, n, 1, seed=0)).to(dev)
     f = (torch.rand(n, C, device=dev) * 2 - 1).half()
@@ -38,6 +39,11 @@ def main():
     pair, order, to = rb.pair_fwd, None, False
     if srt:
         pair, mask, order, to = ops.tables_of(rb, "fwd", C)
+    if i8:
+        f = torch.randint(-127, 128, (n, C), dtype=torch.int8, device=dev)
+        w = torch.randint(-127, 128, (C, 3, 3, 3, C), dtype=torch.int8, device=dev)
+        sc = torch.rand(C, device=dev) * 1e-2
+        bi = torch.rand(C, device=dev)
     L = _lib.load()
     getter = L.spx_debug_timeline_sp if sp else L.spx_debug_timeline
     getter.restype = ctypes.c_int
@@ -45,13 +51,17 @@ def main():
     if sp:
         _lib.check(L.spx_set_option(b"SPX_GEMM_V", 6))
     for _ in range(20):
-        ops.igemm_fwd(f, w, pair, mask, order, n, 13, tile_order=to)
+        (ops.igemm_fwd_int8(f, w, pair, mask, order, n, 13, sc, bi, None, 0.0, torch.int8, ops.Activation.ReLU, 0.0,
+                            tile_order=to) if i8 else ops.igemm_fwd(f, w, pair, mask, order, n, 13, tile_order=to))
     torch.cuda.synchronize()
-    ops.igemm_fwd(f, w, pair, mask, order, n, 13, tile_order=to)
+    (ops.igemm_fwd_int8(f, w, pair, mask, order, n, 13, sc, bi, None, 0.0, torch.int8, ops.Activation.ReLU, 0.0,
+                            tile_order=to) if i8 else ops.igemm_fwd(f, w, pair, mask, order, n, 13, tile_order=to))
     buf = np.zeros((8192, 8), dtype=np.uint64)
     _lib.check(getter(buf.ctypes.data))
     mb = int(os.environ.get("SPX_GEMM_MB", "2"))
     ntiles = min(8192, (n + 31) // 32) if sp else (n + 64 * mb - 1) // (64 * mb)
+    if i8:
+        ntiles = (n + 127) // 128
     t = buf[:ntiles].astype(np.int64)
     t0 = t[:, 0].min()
     rel = (t - t0) / float(os.environ.get("SPX_TICK_MHZ", "2200"))       # s_memtime: shader clock under load
