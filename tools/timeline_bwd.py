@@ -36,15 +36,17 @@ def main():
     f = (torch.rand(n, C, device=dev) * 2 - 1).half()
     dout = ((torch.rand(n, C, device=dev) * 2 - 1) * 0.2).half()
     w = (torch.rand(C, 3, 3, 3, C, device=dev) * 2 - 1).half()
-    rb, _ = ops.build_rulebook(idx, 1, SHAPE, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True)
+    srt = len(sys.argv) > 2 and sys.argv[2] == "sort"
+    rb, _ = ops.build_rulebook(idx, 1, SHAPE, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True, do_sort=srt)
     plan = ops._plan_of(rb)
+    pair, mask, order_, to = ops.tables_of(rb, "fwd", C)
     L = _lib.load()
     L.spx_debug_timeline.restype = ctypes.c_int
     L.spx_debug_timeline.argtypes = [ctypes.c_void_p]
 
     def run():
-        return ops.igemm_bwd(f, dout, w, rb.pair_fwd, rb.mask_fwd, rb.argsort_fwd, rb.pair_native,
-                             rb.num_per_loc, True, plan)
+        return ops.igemm_bwd(f, dout, w, pair, mask, order_, rb.pair_native,
+                             rb.num_per_loc, True, plan, tile_order=to)
     for _ in range(20):
         run()
     torch.cuda.synchronize()
@@ -62,7 +64,7 @@ def main():
     ntiles = (n + 127) // 128
     # wgrad groups = blocks before the dgrad tiles (the library's sizing rule; TL_NW overrides)
     nw = int(os.environ.get("TL_NW", "0")) or (1024 - ntiles if 128 <= 1024 - ntiles < 384 else 384)
-    tick = 1.0 / float(os.environ.get("SPX_TICK_MHZ", "1000"))   # observed: ~1 ns per tick
+    tick = 1.0 / float(os.environ.get("SPX_TICK_MHZ", "2200"))   # s_memtime: shader clock under load (~2.2 GHz)
     t = buf[:nw + ntiles].astype(np.int64)
     # s_memtime is per XCD and the counters are not aligned: group the workgroups by clock domain
     # (entries of one launch lie within a few thousand ticks, the domains are millions apart) and
