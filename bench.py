@@ -559,7 +559,8 @@ def run_layer(args, D: Dist):
             h.done.record(main)
             with torch.cuda.stream(side_ar):
                 side_ar.wait_event(h.done)
-                torch._foreach_copy_(list(h.flat.unbind(0)), [d.reshape(-1) for d in h.dws])
+                for row, d in zip(h.flat.unbind(0), h.dws):      # U small device-to-device copies into the bucket
+                    row.copy_(d.reshape(-1))
                 if D.backend == "nccl":
                     dist.all_reduce(h.flat, op=dist.ReduceOp.AVG)
                 else:

@@ -30,6 +30,8 @@ def main():
     i8 = len(sys.argv) > 2 and sys.argv[2] in ("i8", "i8sort")      # BASELINE config 5: int8, C = K = 128, 200 k voxels
     dev = torch.device("cuda:0")
     n, C = (200000, 128) if (len(sys.argv) > 2 and sys.argv[2] in ("i8", "i8sort")) else (100000, 64)
+    n = int(os.environ.get("TL_N", n))                     # voxels (the stamp table holds 8192 workgroups)
+    C = int(os.environ.get("TL_C", C))
     gen = synthetic.uniform_scene if scene == "uniform" else synthetic.lidar_like_scene
     idx = torch.from_numpy(gen(SHAPE, n, 1, seed=0)).to(dev)
     f = (torch.rand(n, C, device=dev) * 2 - 1).half()
@@ -86,6 +88,13 @@ def main():
     out["xcd_span_us"] = [round(float(v), 2) for v in spans]
     out["xcd_entry_ramp_us"] = [round(float(v), 2) for v in ramps]
     out["wg_lifetime_us"] = [round(float(v), 2) for v in np.percentile((t[:, 7] - t[:, 0]) * tick, [10, 50, 90, 100])]
+    # how well the launch packs: busy time of all workgroups / (slots x the longest per-XCD span); the rest is
+    # ramp, dispatch rounds that end with a heavy tile, and the tail
+    slots = int(os.environ.get("TL_SLOTS", "1024"))
+    busy = float(((t[:, 7] - t[:, 0]) * tick).sum())
+    out["packing"] = {"slots": slots, "busy_us_total": round(busy, 1),
+                      "span_us": round(float(np.median(spans)), 2),
+                      "efficiency": round(busy / (min(slots, ntiles) * float(np.median(spans))), 3)}
     print(json.dumps(out))
 
 
