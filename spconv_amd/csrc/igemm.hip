@@ -105,6 +105,7 @@ __device__ __forceinline__ void unpack_gemm_args(GemmParams &p, const void *argA
   p.tile_order = (b_reverse >> 1) & 1;
   p.mask_words = ((b_reverse >> 2) & 3) + 1;
   p.kbase = (b_reverse >> 4) & 127;
+  p.lpt = (b_reverse >> 11) & 1;
   p.acc = rest.acc;
   p.acc_mode = rest.acc_mode;
   p.out = rest.out;
@@ -154,7 +155,10 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   // Those tiles are handed to the FIRST blocks (longest work first), one after the other to different
   // XCDs; contiguous per-XCD ranges buy nothing here -- a sorted tile gathers mostly its own rows.
   // (int8 config 5, two dispatch rounds: the 26 us tail tiles no longer start in the second round.)
-  const int tile = p.tile_order ? ntiles - 1 - block
+  // Only when the launch has more tiles than resident workgroups (the host sets `lpt`): a single-round
+  // launch keeps the XCD mapping, which lets the dgrad tiles and the wgrad ranges of one row eighth share
+  // the gradient rows in one L2 (config 2 backward: 57 vs 67 MB of HBM traffic).
+  const int tile = (p.tile_order && p.lpt) ? ntiles - 1 - block
                                 : (p.xcd_rot ? xcd_tile_rot(block, ntiles, p.xcd_rot) : xcd_tile(block, ntiles));
   const int lrow = lane & 15, lgrp = lane >> 4;
   const int slot = tid & 7, r0 = tid >> 3;
@@ -635,7 +639,7 @@ constexpr size_t v4_smem_bytes() {
 
 int v4_flags(const GemmParams &p) {
   const int words = p.mask_words > 0 ? p.mask_words : 1;
-  return p.b_reverse | (p.tile_order << 1) | ((words - 1) << 2) | (p.kbase << 4);
+  return p.b_reverse | (p.tile_order << 1) | ((words - 1) << 2) | (p.kbase << 4) | ((p.lpt ? 1 : 0) << 11);
 }
 
 bool v4_ok(const GemmParams &p, int es = 2, int out_es = 2) {
@@ -654,13 +658,16 @@ GemmRest rest_of(const GemmParams &p);
 template <int COUT, int MB, int DT>
 int launch_v4(const GemmParams &p, hipStream_t s) {
   const int ntiles = div_up(p.n_dst, 64 * MB);
+  GemmParams q = p;
+  // more tiles than workgroups the chip holds at once (4 per CU up to 64 output channels, fewer beyond)
+  q.lpt = p.tile_order && ntiles > ((DT == 2 || COUT > 64) ? 512 : 1024);
   const GemmRest r = rest_of(p);
   constexpr int es = DT == 2 ? 1 : (DT == 3 ? 4 : 2);
   const bool half = p.CIN * es <= 64;        // narrow rows: only the first 64 bytes of a piece exist
 #define SPX_LAUNCH_V4(BTV, NKSV)                                                                     \
   hipLaunchKernelGGL((igemm_v4_kernel<COUT, MB, DT, BTV, NKSV>), dim3(ntiles), dim3(kThreads),          \
                      (v4_smem_bytes<COUT, MB, DT>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,  \
-                     p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(p), r)
+                     p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(q), r)
   if (DT == 2 || p.strideD == 1) {
     if (half) SPX_LAUNCH_V4(false, 1);
     else SPX_LAUNCH_V4(false, 2);
@@ -2183,15 +2190,17 @@ template <int COUT, int MB, int DT>
 int launch_bwd(const GemmParams &p, const Wgrad2Params &q, int n_wgrad_blocks, hipStream_t s) {
   const int n_dgrad = div_up(p.n_dst, 64 * MB);
   static const int wgrad_first = env_int("SPX_BWD_WGRAD_FIRST", 1);   // tuning knob (A/B runs)
+  GemmParams pl = p;
+  pl.lpt = p.tile_order && n_dgrad + n_wgrad_blocks > 1024;           // (see launch_v4)
   if (p.CIN * (DT == 3 ? 4 : 2) <= 64)     // dgrad's reduction rows (dout channels) fit half a piece
     hipLaunchKernelGGL((igemm_bwd_kernel<COUT, MB, DT, 1>), dim3(n_dgrad + n_wgrad_blocks), dim3(kThreads),
                        (bwd_smem_bytes<COUT, MB, DT>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,
-                       p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(p), rest_of(p),
+                       p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(pl), rest_of(p),
                        wgrad_first ? ~n_wgrad_blocks : n_dgrad, q);
   else
     hipLaunchKernelGGL((igemm_bwd_kernel<COUT, MB, DT, 2>), dim3(n_dgrad + n_wgrad_blocks), dim3(kThreads),
                        (bwd_smem_bytes<COUT, MB, DT>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,
-                       p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(p), rest_of(p),
+                       p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(pl), rest_of(p),
                        wgrad_first ? ~n_wgrad_blocks : n_dgrad, q);
   SPX_LAUNCH_CHECK();
   return 0;

@@ -54,6 +54,7 @@ struct GemmParams {
   int out_dtype;          // SPX_I8 / SPX_F16 / SPX_BF16 / SPX_F32
   int dbg;                // ablation builds only (-DSPX_ABLATE, tools/dense_probe.py)
   int xcd_rot;            // blocks of the launch ahead of this kernel body's first one, mod 8 (fused backward)
+  int lpt;                // tables in tile order AND more tiles than resident workgroups: longest tiles first
 };
 
 // DT: 0 = f16, 1 = bf16, 2 = int8 (i32 accumulate, quantised epilogue; forward only), 3 = fp32
