@@ -61,7 +61,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--config", choices=["2", "2b", "3", "4", "5"], default="2")
+    ap.add_argument("--config", choices=["2", "2b", "3", "4", "4i", "5"], default="2")
     ap.add_argument("--voxels", type=int, default=None, help="voxels per scene (config default if unset)")
     ap.add_argument("--channels", type=int, default=None)
     ap.add_argument("--scene", choices=["uniform", "lidar", "fixture"], default=None,
@@ -932,6 +932,88 @@ def run_net(args, D: Dist):
     return res
 
 
+def run_infer(args, D: Dist):
+    """Configuration 4 as INFERENCE (eval mode, no autograd), two ways on the same scenes: the eager
+    forward pass (one device -> host read of the output count per strided layer, ~90 launches enqueued
+    from Python) and the static-shape form (spconv_amd/pytorch/static.py: input padded with dead rows,
+    every strided layer bounded, rulebook builds and gather-GEMMs of the whole pass in ONE captured
+    graph; a step = copy the scene into the static buffers + replay).  Live rows of both are compared
+    bit for bit on every scene before anything is timed."""
+    import spconv_amd.pytorch as spconv
+    from spconv_amd.pytorch.static import StaticInference, strided_layers
+    from spconv_amd.utils import nets
+    dev, world, rank = D.dev, D.world, D.rank
+    S = max(1, min(args.scenes, 4))
+    voxels = args.voxels or 100_000
+    torch.manual_seed(0)
+    net = nets.second_backbone(4).to(dev).half().eval()
+    bs, kind = 4, args.scene or "lidar"
+    data = []
+    for si in range(S):
+        idx_np, shape = make_scene(kind, voxels, seed=rank * S + si, batch=bs, shape=nets.SECOND_SHAPE)
+        data.append((torch.from_numpy(idx_np).to(dev), torch.randn(idx_np.shape[0], 4, device=dev).half(), shape))
+    shape = data[0][2]
+    D.init()
+    # bounds: the largest output count of each strided layer over the scenes + 10 %
+    seen = {}
+    hooks = [m.register_forward_hook(lambda mod, a, out, k=k: seen.__setitem__(k, max(seen.get(k, 0), out.features.shape[0])))
+             for k, m in strided_layers(net).items()]
+    want = []
+    with torch.no_grad():
+        for ind, f, _ in data:
+            y = net(spconv.SparseConvTensor(f, ind, shape, bs))
+            want.append((y.indices.clone(), y.features.clone()))
+    for h in hooks:
+        h.remove()
+    cnt = [0]
+
+    def eager_steps(k):
+        with torch.no_grad():
+            for _ in range(k):
+                ind, f, _ = data[cnt[0] % S]
+                cnt[0] += 1
+                net(spconv.SparseConvTensor(f, ind, shape, bs))
+    warm, steps = min(args.warmup, 20), min(args.steps, 200)
+    t_eager = timed_region(D, eager_steps, warm, steps)
+    bounds = {k: int(v * 1.1) + 1 for k, v in seen.items()}
+    n_max = max(d[0].shape[0] for d in data)
+    runner = StaticInference(net, int(n_max * 1.05) + 1, 4, shape, bs, torch.float16, bounds=bounds)
+    identical = True
+    for (ind, f, _), (wi, wf) in zip(data, want):
+        got = runner(f, ind)
+        n_live = wi.shape[0]
+        identical &= bool(torch.equal(got.indices[:n_live], wi) and torch.equal(got.features[:n_live], wf)
+                          and bool((got.indices[n_live:, 0] < 0).all()))
+    identical &= runner.overflowed() == {}
+
+    def graph_steps(k):
+        for _ in range(k):
+            ind, f, _ = data[cnt[0] % S]
+            cnt[0] += 1
+            runner(f, ind)
+    elapsed = timed_region(D, graph_steps, warm, steps)
+    n_mean = sum(d[0].shape[0] for d in data) / S
+    elapsed, n_total, ranks_seen = D.reduce_max_sum(elapsed, n_mean)
+    if rank != 0:
+        return None
+    for m in strided_layers(net).values():
+        m.static_num_out = 0
+    ms = elapsed / steps * 1e3
+    return {"metric": "active-voxels/sec, inference forward through the SECOND-style VoxelBackBone8x, static-shape "
+                      "graph replay (BASELINE config 4 network)",
+            "value": n_total * steps / elapsed, "unit": "voxels/s", "n_gpus": world, "steps": steps, "warmup": warm,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+            "data": "synthetic",
+            "eager_ms_per_step": t_eager / steps * 1e3, "graph_ms_per_step": ms,
+            "live_rows_identical_to_eager": identical,
+            "config": {"workload": f"12 sparse convs + BatchNorm1d + ReLU, eval mode, fp16, {bs} {kind} scenes of "
+                                   f"~{voxels} voxels per step ({int(n_mean)} input voxels), fresh rulebooks every "
+                                   f"step INSIDE the graph, input padded to {runner.max_voxels} rows",
+                       "bounds": bounds, "input_voxels_per_gpu": int(n_mean), "scenes_rotated": S,
+                       "launch": "hipGraph replay (rulebooks + convolutions), one graph for every scene",
+                       "parallelism": f"dp{world}", "ranks_seen": ranks_seen}}
+
+
 def also_block(args, D: Dist):
     """The other BASELINE configurations, a few seconds each, in the SAME process and JSON line as the
     headline (N = 1 only): driver-observed numbers for the dense-neighbourhood layer (2b), the int8
@@ -940,7 +1022,7 @@ def also_block(args, D: Dist):
     import copy
     import gc
     out = {}
-    for cfg in ("2b", "5", "3", "4"):
+    for cfg in ("2b", "5", "3", "4", "4i"):
         a = copy.copy(args)
         a.config, a.no_cpu_baseline, a.voxels, a.channels, a.scene = cfg, True, None, None, None
         a.scenes = min(args.scenes, 4)
@@ -948,7 +1030,8 @@ def also_block(args, D: Dist):
         a.warmup = min(args.warmup, 40 if cfg in ("2b", "5") else 8)
         t0 = time.perf_counter()
         try:
-            r = run_layer(a, D) if cfg == "2b" else (run_int8(a, D) if cfg == "5" else run_net(a, D))
+            r = (run_layer(a, D) if cfg == "2b" else run_int8(a, D) if cfg == "5"
+                 else run_infer(a, D) if cfg == "4i" else run_net(a, D))
         except Exception as e:                              # a failing side configuration must not cost the headline
             out[cfg] = {"error": f"{type(e).__name__}: {e}"[:300]}
             continue
@@ -960,7 +1043,8 @@ def also_block(args, D: Dist):
              "wall_s": None}
         if "kernels" in r:
             c["kernels_ms"] = {k: v["ms"] for k, v in r["kernels"].items()}
-        for k in ("rulebook_device_ms", "eager_device_ms_per_step", "graph_ms_per_step"):
+        for k in ("rulebook_device_ms", "eager_device_ms_per_step", "graph_ms_per_step", "eager_ms_per_step",
+                  "live_rows_identical_to_eager"):
             if k in r:
                 c[k] = r[k]
         c["wall_s"] = round(time.perf_counter() - t0, 1)
@@ -987,6 +1071,8 @@ def main(argv=None):
         result = run_layer(args, D)
     elif args.config == "5":
         result = run_int8(args, D)
+    elif args.config == "4i":
+        result = run_infer(args, D)
     else:
         result = run_net(args, D)
     if D.rank == 0 and D.world == 1 and args.config == "2" and not args.no_also:

@@ -106,7 +106,8 @@ size_t spx_conv_rulebook_ws_bytes(int n_in, int ndim, const int *ksize, const in
 /* Regular / transposed conv rulebook, phase 1: hash the candidate output
  * coordinates and count the distinct ones.  Replaces stage1 + unique
  * (indices.py:501-597,997-1016,1118-1455; pytorch/ops.py:566-642).
- * Writes the count to *n_out_h after synchronising `stream` (the one D->H read).
+ * Writes the count to *n_out_h after synchronising `stream` (the one D->H read); with
+ * n_out_h == NULL nothing is read and the count stays in the workspace (spx_conv_rulebook_static).
  * `ws` must be passed unchanged to spx_conv_rulebook_fill. */
 int spx_conv_rulebook_count(const int32_t *indices, int n_in, int ndim, int batch_size,
                             const int *in_shape, const int *out_shape, const int *ksize,
@@ -129,6 +130,27 @@ int spx_conv_rulebook_fill(const int32_t *indices, int n_in, int ndim, int batch
                            int32_t *pair_fwd, int32_t *pair_bwd, uint32_t *mask_fwd,
                            uint32_t *mask_bwd, int32_t *pair_native, int32_t *num_per_loc,
                            void *ws, size_t ws_bytes, spx_stream_t stream);
+
+/* Static-shape form of the two phases above: room for n_out_cap outputs, NOTHING read back, every
+ * launch stream-ordered -- the call can be captured in a hipGraph and replayed on new coordinates of
+ * the same n_in.  It is the GPU side of the reference's bounded inference mode (num_out_act_bound,
+ * ops.py:263-266,644-645; the pre-sized workspace of csrc/sparse/all.py:2030-2185).
+ *   - input rows with batch index < 0 are dead rows (padding up to the static n_in): they create no
+ *     output and no pair
+ *   - outputs are numbered in the CPU path's first-seen order; the first n_out_cap survive, pairs
+ *     into later ones are dropped (as with spx_conv_rulebook_fill and n_out < the count)
+ *   - out_indices rows past the number of outputs are -1 (dead rows for the next layer), their
+ *     pair_fwd column is -1 and their mask 0
+ *   - n_out_dev [2] (device): {distinct outputs found -- may exceed n_out_cap --, hash-table
+ *     overflow flag}; the caller reads it whenever it next synchronises
+ * spx_conv_rulebook_count with n_out_h == NULL is the same count without the read. */
+int spx_conv_rulebook_static(const int32_t *indices, int n_in, int ndim, int batch_size,
+                             const int *in_shape, const int *out_shape, const int *ksize,
+                             const int *stride, const int *padding, const int *dilation,
+                             int transposed, int n_out_cap, int32_t *out_indices,
+                             int32_t *pair_fwd, int32_t *pair_bwd, uint32_t *mask_fwd,
+                             uint32_t *mask_bwd, int32_t *n_out_dev, void *ws, size_t ws_bytes,
+                             spx_stream_t stream);
 
 /* mask_argsort: permutation that groups rows with equal masks (stable, ascending
  * mask value).  Replaces SpconvOps.sort_1d_by_key_allocator (all.py:935-991). */

@@ -1630,7 +1630,7 @@ int spx_conv_rulebook_count(const int32_t *indices, int n_in, int ndim, int batc
     SPX_CHECK(out_shape[i] > 0 && stride[i] > 0, "bad output shape / stride at dim %d", i);
   SPX_CHECK(ws_bytes >= spx_conv_rulebook_ws_bytes(n_in, ndim, ksize, stride, dilation, transposed),
             "workspace too small");
-  *n_out_h = 0;
+  if (n_out_h) *n_out_h = 0;
   if (n_in == 0) return 0;
   ConvWs w = carve_conv_ws(ws, n_in, ndim, ksize, stride, dilation, transposed,
                            keys_fit_u32(g.batch, g.out_dims, 4));
@@ -1649,6 +1649,7 @@ int spx_conv_rulebook_count(const int32_t *indices, int n_in, int ndim, int batc
   hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kBlock), 0, s, w.blockcount, w.blockoff,
                      g.kv * w.nblk, w.d_nout);
   SPX_LAUNCH_CHECK();
+  if (!n_out_h) return 0;                // static-shape form: the count stays on the device
   int32_t host_n[2] = {0, 0};
   SPX_HIP(hipMemcpyAsync(host_n, w.d_nout, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   SPX_HIP(hipStreamSynchronize(s));
@@ -1723,6 +1724,34 @@ int spx_conv_rulebook_fill(const int32_t *indices, int n_in, int ndim, int batch
                        num_per_loc);
     SPX_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+int spx_conv_rulebook_static(const int32_t *indices, int n_in, int ndim, int batch_size,
+                             const int *in_shape, const int *out_shape, const int *ksize,
+                             const int *stride, const int *padding, const int *dilation,
+                             int transposed, int n_out_cap, int32_t *out_indices, int32_t *pair_fwd,
+                             int32_t *pair_bwd, uint32_t *mask_fwd, uint32_t *mask_bwd,
+                             int32_t *n_out_dev, void *ws, size_t ws_bytes, spx_stream_t stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  SPX_CHECK(n_out_cap > 0 && n_out_dev && out_indices, "n_out_cap > 0, n_out_dev and out_indices are required");
+  SPX_CHECK(n_in > 0, "static-shape rulebook needs n_in > 0 (pad the input with batch = -1 rows)");
+  // every launch below is stream-ordered and nothing is read back: the whole call can sit in a
+  // hipGraph.  Rows past the number of distinct outputs keep out_indices = -1 (a dead row for the
+  // next layer: subm_insert_kernel / conv_stage1_kernel skip batch < 0), pair_fwd = -1, mask = 0.
+  SPX_HIP(hipMemsetAsync(out_indices, 0xFF, sizeof(int32_t) * static_cast<size_t>(n_out_cap) * (ndim + 1), s));
+  int rc = spx_conv_rulebook_count(indices, n_in, ndim, batch_size, in_shape, out_shape, ksize, stride,
+                                   padding, dilation, transposed, ws, ws_bytes, nullptr, stream);
+  if (rc) return rc;
+  rc = spx_conv_rulebook_fill(indices, n_in, ndim, batch_size, in_shape, out_shape, ksize, stride,
+                              padding, dilation, transposed, n_out_cap, out_indices, pair_fwd, pair_bwd,
+                              mask_fwd, mask_bwd, nullptr, nullptr, ws, ws_bytes, stream);
+  if (rc) return rc;
+  const Geom g = make_geom(ndim, batch_size, in_shape, out_shape, ksize, stride, padding, dilation);
+  ConvWs w = carve_conv_ws(ws, n_in, ndim, ksize, stride, dilation, transposed,
+                           keys_fit_u32(g.batch, g.out_dims, 4));
+  // {distinct outputs found (may exceed the cap: the first n_out_cap survive), hash-table overflow flag}
+  SPX_HIP(hipMemcpyAsync(n_out_dev, w.d_nout, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
   return 0;
 }
 

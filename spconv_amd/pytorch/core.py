@@ -68,6 +68,9 @@ class Rulebook:
         self.sort_decided = False
         # density class (ops.sparse_neighbourhoods): None = not measured yet
         self.sparse_class = None
+        # static-shape build (ops.build_rulebook(static_num_out=...)): device int32 [2] =
+        # {distinct outputs found, hash-table overflow}; rows >= the count are dead.  None otherwise.
+        self.n_out_dev = None
 
     def _ensure_native(self) -> None:
         """Inference builds only the dense tables; the ConvAlgo.Native lists (consumed by wgrad

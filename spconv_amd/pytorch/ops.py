@@ -152,10 +152,16 @@ def build_rulebook(indices: torch.Tensor, batch_size: int, spatial_shape: List[i
                    dilation: List[int], out_padding: List[int], subm: bool = False,
                    transpose: bool = False, need_bwd_table: bool = False,
                    do_sort: bool = False, need_native: bool = True,
-                   num_out_act_bound: int = -1) -> Tuple[Rulebook, List[int]]:
+                   num_out_act_bound: int = -1, static_num_out: int = 0) -> Tuple[Rulebook, List[int]]:
     """One call builds every artefact (dense tables, masks, Native lists).  need_native=False
     (inference) leaves the ConvAlgo.Native lists out -- three launches and two thirds of the
-    fill traffic -- and the Rulebook derives them from the tables if they are asked for later."""
+    fill traffic -- and the Rulebook derives them from the tables if they are asked for later.
+
+    static_num_out > 0 (regular / transposed convolution, inference): the STATIC-SHAPE form -- every
+    output tensor has static_num_out rows, nothing is read back from the device (the whole build can
+    be captured in a graph), rows past the real output count are dead (out_indices -1, no pairs) and
+    `rb.n_out_dev` holds {outputs found, table overflow} on the device.  Input rows with a negative
+    batch index are dead rows in every mode."""
     _require_gpu(indices, "indices")
     assert indices.dtype == torch.int32 and indices.ndim == 2
     L = _lib.load()
@@ -196,6 +202,25 @@ def build_rulebook(indices: torch.Tensor, batch_size: int, spatial_shape: List[i
                 _lib.ints(padding), _lib.ints(dilation), int(transpose))
         ws = _ws(L.spx_conv_rulebook_ws_bytes(n_in, ndim, _lib.ints(ksize), _lib.ints(stride),
                                               _lib.ints(dilation), int(transpose)), dev)
+        if static_num_out > 0:
+            n_out = int(static_num_out)
+            out_indices = torch.empty((n_out, ndim + 1), **i32)
+            pair_fwd = torch.empty((kv, n_out), **i32)
+            pair_bwd = torch.empty((kv, n_in), **i32)
+            mask_fwd = torch.empty((n_out, words), **i32)
+            mask_bwd = torch.empty((n_in, words), **i32)
+            n_out_dev = torch.empty((2,), **i32)
+            _lib.check(L.spx_conv_rulebook_static(indices.data_ptr(), n_in, ndim, batch_size, *args, n_out,
+                                                  out_indices.data_ptr(), pair_fwd.data_ptr(),
+                                                  pair_bwd.data_ptr(), mask_fwd.data_ptr(),
+                                                  mask_bwd.data_ptr(), n_out_dev.data_ptr(),
+                                                  ws.data_ptr(), ws.numel(), stream))
+            rb = Rulebook(out_indices, pair_fwd, pair_bwd, mask_fwd, mask_bwd, None, None, n_in, n_out,
+                          kv, False)
+            rb.n_out_dev = n_out_dev
+            rb.in_indices, rb.in_shape, rb.out_shape, rb.batch_size = (indices, list(spatial_shape),
+                                                                       list(out_shape), batch_size)
+            return rb, out_shape
         n_out_c = ctypes.c_int(0)
         _lib.check(L.spx_conv_rulebook_count(indices.data_ptr(), n_in, ndim, batch_size, *args,
                                              ws.data_ptr(), ws.numel(), ctypes.byref(n_out_c),

@@ -86,9 +86,13 @@ class _SparsePoolBase(SparseModule):
             t = time.time()
         if self.indice_key is not None and input.find_indice_pair(self.indice_key) is not None:
             raise ValueError(f"indice key {self.indice_key} exists")
+        # static-shape inference (spconv_amd.pytorch.static): frozen output bound, no read-back
+        static = 0 if (self.training or self.subm or self.algo == ConvAlgo.Native
+                       or torch.is_grad_enabled()) else int(getattr(self, "static_num_out", 0) or 0)
         rb, _ = ops.build_rulebook(indices, batch_size, spatial_shape, self.kernel_size, self.stride,
                                    self.padding, self.dilation, [0] * self.ndim, self.subm, False,
-                                   need_bwd_table=True)
+                                   need_bwd_table=True, need_native=not static, static_num_out=static)
+        self._static_n_out_dev = rb.n_out_dev
         outids = rb.out_indices
         if input.benchmark:
             torch.cuda.synchronize()

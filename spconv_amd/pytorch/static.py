@@ -1,0 +1,161 @@
+"""Static-shape inference: one hipGraph for a whole sparse backbone, rulebook builds included.
+
+The reference's deployment path sizes every buffer before the first layer runs and bounds the number
+of outputs of each strided layer (num_out_act_bound: spconv/pytorch/ops.py:263-266,644-645; the
+pre-sized workspace of csrc/sparse/all.py:2030-2185; the per-layer maxima a trained model carries
+in `max_num_voxels_during_training`, pytorch/conv.py:44,131-138).  With those bounds every tensor of
+a forward pass has a static shape, so on this backend the WHOLE pass -- hash-table builds, pair
+tables, gather-GEMMs -- can be recorded once and replayed per scene:
+
+  * the input is padded to `max_voxels` rows; padding rows carry batch index -1 (dead rows: the
+    rulebook kernels neither hash them nor pair them, csrc/rulebook.hip subm_insert_kernel /
+    conv_stage1_kernel)
+  * a strided layer builds its rulebook with spx_conv_rulebook_static (include/spconv_amd.h): room
+    for `static_num_out` outputs, nothing read back; the rows past the real count come out dead
+  * SubM layers need nothing special: n_out == n_in
+  * the count each strided layer found stays on the device; `overflowed()` reads all of them in one
+    synchronisation whenever the caller wants to know (a scene with more outputs than a bound keeps
+    the first `bound` in the canonical order, like the reference's bounded mode)
+
+Live rows of the result are bit-identical to the eager, unbounded forward pass of the same scene
+(tests/test_gpu_static.py).  Inference only (eval mode, no autograd): batch statistics or a
+backward pass over dead rows would not be the reference's.
+"""
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from spconv_amd.pytorch.conv import SparseConvolution
+from spconv_amd.pytorch.core import SparseConvTensor
+from spconv_amd.pytorch.pool import SparseMaxPool
+
+__all__ = ["StaticInference", "strided_layers", "freeze_bounds", "dense_static"]
+
+
+def strided_layers(net: torch.nn.Module) -> Dict[str, torch.nn.Module]:
+    """The layers that create a new set of voxels (their output count depends on the scene)."""
+    out = {}
+    for name, m in net.named_modules():
+        if isinstance(m, SparseConvolution) and not m.subm and not m.inverse and not m.conv1x1:
+            out[name] = m
+        elif isinstance(m, SparseMaxPool) and not m.subm:
+            out[name] = m
+    return out
+
+
+def freeze_bounds(net: torch.nn.Module, bounds: Optional[Dict[str, int]] = None,
+                  margin: float = 1.25) -> Dict[str, int]:
+    """Sets `static_num_out` on every strided layer: from `bounds` (layer name -> rows), else from the
+    layer's recorded maximum (`record_voxel_count=True`: max_num_voxels_during_training) * margin.
+    Returns the bounds used.  `freeze_bounds(net, {})` with margin 0 clears them."""
+    used = {}
+    for name, m in strided_layers(net).items():
+        if bounds is not None and name in bounds:
+            b = int(bounds[name])
+        elif bounds is not None and margin == 0:
+            b = 0
+        else:
+            rec = m.get_max_num_voxels()
+            if rec is None or int(rec.item()) <= 0:
+                raise ValueError(f"layer {name!r}: no bound given and no recorded voxel count (construct it with "
+                                 f"record_voxel_count=True and run representative scenes first)")
+            b = int(int(rec.item()) * margin) + 1
+        m.static_num_out = b
+        used[name] = b
+    return used
+
+
+def dense_static(t: SparseConvTensor, channels_first: bool = True) -> torch.Tensor:
+    """SparseConvTensor.dense() for a tensor with dead rows (batch index -1): they land in a scratch
+    batch slot that is cut off.  No data-dependent shape: can sit inside the captured graph."""
+    idx = t.indices.long()
+    B, nd = t.batch_size, len(t.spatial_shape)
+    dead = idx[:, 0] < 0
+    b = torch.where(dead, torch.full_like(idx[:, 0], B), idx[:, 0])
+    buf = t.features.new_zeros((B + 1, *t.spatial_shape, t.features.shape[1]))
+    buf[(b,) + tuple(idx[:, 1 + d].clamp(min=0) for d in range(nd))] = t.features
+    res = buf[:B]
+    if not channels_first:
+        return res
+    return res.permute(0, nd + 1, *range(1, nd + 1)).contiguous()
+
+
+class StaticInference:
+    """`net` (eval mode, SparseConvTensor -> SparseConvTensor or tensor) captured for scenes of at
+    most `max_voxels` voxels.
+
+        runner = StaticInference(net, max_voxels=120_000, in_channels=4, spatial_shape=[41, 1600, 1408],
+                                 batch_size=1, dtype=torch.float16, bounds={"conv2": 60_000, ...})
+        out = runner(features, indices)         # replay; `out` lives in static buffers
+        live = out.indices[:, 0] >= 0           # rows of this scene
+        runner.overflowed()                     # one synchronisation: {layer: outputs found} over a bound
+    """
+
+    def __init__(self, net: torch.nn.Module, max_voxels: int, in_channels: int,
+                 spatial_shape: Sequence[int], batch_size: int, dtype: torch.dtype = torch.float16,
+                 bounds: Optional[Dict[str, int]] = None, margin: float = 1.25,
+                 device: Optional[torch.device] = None, warmup: int = 2):
+        if not torch.cuda.is_available():
+            raise RuntimeError("StaticInference needs the GPU (there is no CPU path)")
+        self.net = net.eval()
+        self.device = torch.device(device if device is not None else "cuda")
+        self.max_voxels = int(max_voxels)
+        self.spatial_shape = list(spatial_shape)
+        self.batch_size = int(batch_size)
+        self.bounds = freeze_bounds(net, bounds, margin)
+        self._layers = strided_layers(net)
+        nd = len(self.spatial_shape)
+        self.features = torch.zeros((self.max_voxels, in_channels), dtype=dtype, device=self.device)
+        self.indices = torch.full((self.max_voxels, nd + 1), -1, dtype=torch.int32, device=self.device)
+        self._live = 0
+        self.graph = None
+        self.out = None
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(max(warmup, 1)):        # allocator / option caches warm, nothing captured yet
+                self._forward()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(g):
+            self.out = self._forward()
+        self.graph = g
+        # the device-side counters of the captured pass (static tensors of the graph's pool)
+        self._counters = {name: m._static_n_out_dev for name, m in self._layers.items()
+                          if getattr(m, "_static_n_out_dev", None) is not None}
+
+    def _forward(self):
+        x = SparseConvTensor(self.features, self.indices, self.spatial_shape, self.batch_size)
+        return self.net(x)
+
+    def load(self, features: torch.Tensor, indices: torch.Tensor) -> None:
+        """Copies one scene into the static input buffers (stream-ordered, no synchronisation)."""
+        n = features.shape[0]
+        if n > self.max_voxels:
+            raise ValueError(f"scene has {n} voxels, the graph was captured for at most {self.max_voxels}")
+        assert indices.shape[0] == n and indices.dtype == torch.int32
+        self.features[:n].copy_(features)
+        self.indices[:n].copy_(indices)
+        if n < self._live:                          # rows the previous scene used and this one does not
+            self.features[n:self._live].zero_()
+            self.indices[n:self._live].fill_(-1)
+        self._live = n
+
+    def __call__(self, features: torch.Tensor, indices: torch.Tensor):
+        self.load(features, indices)
+        self.graph.replay()
+        return self.out
+
+    def counts(self) -> Dict[str, List[int]]:
+        """{layer: [outputs found, hash-table overflow flag]} of the last replay (synchronises)."""
+        if not self._counters:
+            return {}
+        names = list(self._counters)
+        host = torch.stack([self._counters[k] for k in names]).cpu().tolist()
+        return dict(zip(names, host))
+
+    def overflowed(self) -> Dict[str, int]:
+        """Layers whose last replay found more outputs than their bound (or filled their hash table):
+        {layer: outputs found}.  Empty = every live row is exact."""
+        return {k: c for k, (c, ovf) in self.counts().items() if c > self.bounds[k] or ovf}

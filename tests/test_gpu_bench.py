@@ -29,7 +29,8 @@ def test_bench_single_gpu_contract(cuda):
         assert r[key]["bound"] == "hbm" and 0 < r[key]["frac"] < 1.0
     assert r["config"]["scenes_rotated"] == 4
     # the other BASELINE configurations ride along in the same line (compact, N = 1 only)
-    assert set(r["also"]) == {"2b", "5", "3", "4"}
+    assert set(r["also"]) == {"2b", "5", "3", "4", "4i"}
+    assert r["also"]["4i"]["live_rows_identical_to_eager"] is True
     for cfg, c in r["also"].items():
         assert "error" not in c, (cfg, c)
         assert c["value"] > 0 and c["ms_per_step"] > 0 and 0 < c["roofline"]["frac"] < 1.0

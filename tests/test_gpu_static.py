@@ -1,0 +1,177 @@
+"""GPU: static-shape inference -- the bounded rulebook build that reads nothing back
+(spx_conv_rulebook_static, include/spconv_amd.h; the reference's num_out_act_bound mode,
+spconv/pytorch/ops.py:263-266,644-645 and csrc/sparse/all.py:2030-2185) and a whole backbone, rulebook
+builds included, captured in one graph (spconv_amd/pytorch/static.py).  Bar: the live rows are
+BIT-identical to the eager, unbounded path on the same scene; dead rows never leak into live ones."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from util import dense_scene, gpu_rulebook, oracle_rulebook, scene, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+def _padded(idx, n_static):
+    pad = np.full((n_static - idx.shape[0], idx.shape[1]), -1, np.int32)
+    return np.concatenate([idx, pad], 0)
+
+
+@pytest.mark.parametrize("ksize,stride,padding,transpose", [([3] * 3, [2] * 3, [1] * 3, False),
+                                                           ([2] * 3, [2] * 3, [0] * 3, False),
+                                                           ([3, 1, 3], [2, 1, 2], [1, 0, 1], False),
+                                                           ([3] * 3, [2] * 3, [1] * 3, True)])
+def test_static_rulebook_equals_dynamic_and_oracle(cuda, ksize, stride, padding, transpose):
+    shape, bs, n, n_static = [20, 22, 24], 2, 1500, 4096
+    idx = scene(shape, n, bs, 3)
+    n = idx.shape[0]
+    ref = oracle_rulebook(idx, bs, shape, ksize, stride, padding, [1] * 3, False, transpose)
+    n_out = ref["n_out"]
+    cap = n_out + 777
+    rb, _ = gpu_rulebook(_padded(idx, n_static), bs, shape, ksize, stride, padding, [1] * 3, False, transpose,
+                         static_num_out=cap, need_native=False)
+    assert rb.n_out == cap and rb.n_in == n_static
+    assert to_np(rb.n_out_dev).tolist() == [n_out, 0]
+    oi, pf, pb = to_np(rb.out_indices), to_np(rb.pair_fwd), to_np(rb.pair_bwd)
+    np.testing.assert_array_equal(oi[:n_out], ref["out_inds"])
+    assert (oi[n_out:] == -1).all()
+    np.testing.assert_array_equal(pf[:, :n_out], ref["fwd"])
+    assert (pf[:, n_out:] == -1).all()
+    np.testing.assert_array_equal(pb[:, :n], ref["bwd"])
+    assert (pb[:, n:] == -1).all()
+    mf, mb = to_np(rb.mask_fwd).view(np.uint32), to_np(rb.mask_bwd).view(np.uint32)
+    np.testing.assert_array_equal(mf[:n_out], ref["mfwd"])
+    assert (mf[n_out:] == 0).all() and (mb[n:] == 0).all()
+
+
+def test_static_rulebook_cap_below_count_keeps_first_rows(cuda):
+    shape, bs = [24, 24, 24], 1
+    idx = scene(shape, 4000, bs, 5)
+    ref = oracle_rulebook(idx, bs, shape, [3] * 3, [2] * 3, [1] * 3, [1] * 3, False)
+    n_out = ref["n_out"]
+    cap = n_out // 2
+    rb, _ = gpu_rulebook(idx, bs, shape, [3] * 3, [2] * 3, [1] * 3, [1] * 3, False, static_num_out=cap,
+                         need_native=False)
+    assert to_np(rb.n_out_dev).tolist() == [n_out, 0]          # the count found, not the cap
+    np.testing.assert_array_equal(to_np(rb.out_indices), ref["out_inds"][:cap])
+    np.testing.assert_array_equal(to_np(rb.pair_fwd), ref["fwd"][:, :cap])
+    pb = to_np(rb.pair_bwd)
+    np.testing.assert_array_equal(pb, np.where(ref["bwd"] < cap, ref["bwd"], -1))
+
+
+def test_subm_rulebook_ignores_dead_rows(cuda):
+    shape, bs, n, n_static = [30, 30, 30], 1, 5000, 6001
+    idx = scene(shape, n, bs, 7)
+    n = idx.shape[0]
+    ref = oracle_rulebook(idx, bs, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True)
+    rb, _ = gpu_rulebook(_padded(idx, n_static), bs, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True,
+                         need_native=False)
+    pf = to_np(rb.pair_fwd)
+    np.testing.assert_array_equal(pf[:, :n], ref["fwd"])
+    dead = pf[:, n:]
+    centre = 13
+    assert (np.delete(dead, centre, 0) == -1).all()            # a dead row has no neighbour ...
+    assert (pf[:, :n] < n).all()                               # ... and no live row points at one
+
+
+def _backbone(spconv, C, dev, dtype, pool=False):
+    from torch import nn
+    torch.manual_seed(7)
+    down2 = (spconv.SparseMaxPool3d(2, 2) if pool
+             else spconv.SparseConv3d(32, 64, 3, 2, 1, bias=False, indice_key="d2"))
+    net = spconv.SparseSequential(
+        spconv.SubMConv3d(C, 16, 3, bias=False, indice_key="s0"), nn.BatchNorm1d(16), nn.ReLU(),
+        spconv.SubMConv3d(16, 16, 3, bias=False, indice_key="s0"), nn.BatchNorm1d(16), nn.ReLU(),
+        spconv.SparseConv3d(16, 32, 3, 2, 1, bias=False, indice_key="d1"), nn.BatchNorm1d(32), nn.ReLU(),
+        spconv.SubMConv3d(32, 32, 3, bias=True, indice_key="s1"), nn.ReLU(),
+        down2,
+        spconv.SubMConv3d(32 if pool else 64, 64, 3, bias=False, indice_key="s2"), nn.BatchNorm1d(64), nn.ReLU(),
+    ).to(dev)
+    with torch.no_grad():                                      # non-trivial running statistics
+        for m in net.modules():
+            if isinstance(m, nn.BatchNorm1d):
+                m.running_mean.uniform_(-0.2, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.2, 0.2)
+    return net.to(dtype).eval()
+
+
+def _scene_tensors(shape, n, bs, C, seed, dev, dtype):
+    idx = scene(shape, n, bs, seed)
+    rng = np.random.default_rng(seed)
+    f = torch.from_numpy(rng.uniform(-1, 1, (idx.shape[0], C)).astype(np.float32)).to(dev, dtype)
+    return f, torch.from_numpy(idx).to(dev)
+
+
+@pytest.mark.parametrize("pool", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_captured_backbone_is_bit_identical_to_eager(cuda, pool, dtype):
+    import spconv_amd.pytorch as spconv
+    from spconv_amd.pytorch.static import StaticInference, dense_static, strided_layers
+    shape, bs, C = [32, 40, 40], 2, 4
+    net = _backbone(spconv, C, cuda, dtype, pool)
+    assert len(strided_layers(net)) == 2
+    names = list(strided_layers(net))
+    eager = copy.deepcopy(net)                                  # (the runner freezes bounds on `net`)
+    runner = StaticInference(net, max_voxels=12_000, in_channels=C, spatial_shape=shape, batch_size=bs,
+                             dtype=dtype, bounds={names[0]: 13_000, names[1]: 1_700})
+    for n, seed in ((4500, 1), (2001, 2), (5999, 3), (388, 4)):        # voxels per batch item: growing and shrinking scenes
+        f, idx = _scene_tensors(shape, n, bs, C, seed, cuda, dtype)
+        with torch.no_grad():
+            want = eager(spconv.SparseConvTensor(f, idx, shape, bs))
+        got = runner(f, idx)
+        assert runner.overflowed() == {}, runner.counts()
+        live = got.indices[:, 0] >= 0
+        n_live = int(live.sum())
+        assert n_live == want.indices.shape[0]
+        assert bool(live[:n_live].all())                        # live rows first, in the canonical order
+        assert torch.equal(got.indices[:n_live], want.indices)
+        assert torch.equal(got.features[:n_live], want.features)
+        if not pool:                                            # (a max pool leaves `lowest` in its dead rows)
+            assert torch.isfinite(got.features.float()).all()
+        assert torch.equal(dense_static(got), want.dense())
+        counts = runner.counts()
+        assert counts[names[1]][0] == n_live
+
+
+def test_overflow_is_reported_and_first_rows_survive(cuda):
+    import spconv_amd.pytorch as spconv
+    from spconv_amd.pytorch.static import StaticInference
+    shape, bs, C = [24, 24, 24], 1, 4
+    net = spconv.SparseSequential(spconv.SparseConv3d(C, 16, 3, 2, 1, bias=False)).to(cuda).half().eval()
+    f, idx = _scene_tensors(shape, 5000, bs, C, 9, cuda, torch.float16)
+    with torch.no_grad():
+        want = net(spconv.SparseConvTensor(f, idx, shape, bs))
+    n_out = want.indices.shape[0]
+    cap = n_out - 100
+    runner = StaticInference(net, 6000, C, shape, bs, torch.float16, bounds={"0": cap})
+    got = runner(f, idx)
+    assert runner.overflowed() == {"0": n_out}
+    assert torch.equal(got.indices, want.indices[:cap])
+    assert torch.equal(got.features, want.features[:cap])      # a surviving output keeps ALL its pairs
+
+
+def test_bounds_from_recorded_voxel_counts(cuda):
+    import spconv_amd.pytorch as spconv
+    from spconv_amd.pytorch.static import freeze_bounds, strided_layers
+    shape, bs, C = [24, 24, 24], 1, 4
+    net = spconv.SparseSequential(
+        spconv.SparseConv3d(C, 16, 3, 2, 1, bias=False, record_voxel_count=True)).to(cuda).half()
+    with pytest.raises(ValueError, match="no recorded voxel count"):
+        freeze_bounds(net)
+    sizes = []
+    net.train()
+    for seed in (1, 2, 3):
+        f, idx = _scene_tensors(shape, 3000 + 500 * seed, bs, C, seed, cuda, torch.float16)
+        sizes.append(net(spconv.SparseConvTensor(f, idx, shape, bs)).indices.shape[0])
+    used = freeze_bounds(net, margin=1.5)
+    assert used == {"0": int(max(sizes) * 1.5) + 1}
+    assert list(strided_layers(net).values())[0].static_num_out == used["0"]
+    # a training-mode forward ignores the bound
+    list(strided_layers(net).values())[0].static_num_out = 10
+    f, idx = _scene_tensors(shape, 3500, bs, C, 1, cuda, torch.float16)
+    assert net(spconv.SparseConvTensor(f, idx, shape, bs)).indices.shape[0] == sizes[0]
+    assert freeze_bounds(net, {}, margin=0) == {"0": 0}
