@@ -958,6 +958,11 @@ def run_infer(args, D: Dist):
     seen = {}
     hooks = [m.register_forward_hook(lambda mod, a, out, k=k: seen.__setitem__(k, max(seen.get(k, 0), out.features.shape[0])))
              for k, m in strided_layers(net).items()]
+    # algorithmic bytes of every conv layer's forward (SURVEY.md 8d formula per layer), summed over the scenes
+    ab = [0]
+    hooks += [m.register_forward_hook(lambda mod, a, out: ab.__setitem__(0, ab[0] + algorithmic_bytes(
+        a[0].features.shape[0], out.features.shape[0], max(mod.in_channels, 8), mod.out_channels,
+        int(np.prod(mod.kernel_size)), 2)["fwd"])) for m in nets.conv_layers(net)]
     want = []
     with torch.no_grad():
         for ind, f, _ in data:
@@ -1006,6 +1011,11 @@ def run_infer(args, D: Dist):
             "data": "synthetic",
             "eager_ms_per_step": t_eager / steps * 1e3, "graph_ms_per_step": ms,
             "live_rows_identical_to_eager": identical,
+            "roofline": roofline_obj("step", ab[0] / S, ms, "whole inference pass: rulebook builders + igemm_v4 of every "
+                                     "layer + eval BatchNorm / ReLU", None,
+                                     {"note": "algorithmic bytes = conv layers' forward only (SURVEY.md 8d formulas per "
+                                              "layer); the time also holds the rulebook builds (about half of it) and the "
+                                              "normalisation layers: an end-to-end fraction, not a kernel's"}),
             "config": {"workload": f"12 sparse convs + BatchNorm1d + ReLU, eval mode, fp16, {bs} {kind} scenes of "
                                    f"~{voxels} voxels per step ({int(n_mean)} input voxels), fresh rulebooks every "
                                    f"step INSIDE the graph, input padded to {runner.max_voxels} rows",

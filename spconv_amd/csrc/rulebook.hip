@@ -20,6 +20,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <mutex>
 #include <utility>
 
 namespace spx {
@@ -74,6 +75,7 @@ __device__ __forceinline__ int32_t table_val(const Table &t, int slot) {
 }
 
 // Inserts key (if absent) and lowers its value to min(value, val). Returns the slot.
+template <bool LOOK = false>
 __device__ __forceinline__ int table_insert_min(const Table &t, hkey_t key, int32_t val) {
   if (t.packed) {
     unsigned long long *slots = reinterpret_cast<unsigned long long *>(t.keys);
@@ -82,11 +84,17 @@ __device__ __forceinline__ int table_insert_min(const Table &t, hkey_t key, int3
         (static_cast<unsigned long long>(k32) << 32) | static_cast<uint32_t>(val);
     uint32_t slot = hash_key32(k32, t.gbits) & t.mask;
     for (uint32_t probe = 0; probe <= t.mask; ++probe) {  // bounded: the table is never full
-      const unsigned long long prev = atomicCAS(&slots[slot], kEmptySlot, want);
-      if (prev == kEmptySlot) return static_cast<int>(slot);
-      if (static_cast<uint32_t>(prev >> 32) == k32) {
-        // same key: the word only ever decreases, so a value already <= ours stays
-        if (static_cast<uint32_t>(prev) > static_cast<uint32_t>(val)) atomicMin(&slots[slot], want);
+      // look before the atomic: a slot only ever goes empty -> key, and its value only decreases, so a
+      // (possibly stale) plain read that shows our key with a value <= ours, or another key, is final --
+      // several inputs reach the same output on dense scenes, and all but the winner leave here
+      // (LOOK: regular-conv builders; SubM keys are distinct, there the read would only add latency)
+      unsigned long long cur = LOOK ? slots[slot] : kEmptySlot;
+      if (cur == kEmptySlot) {
+        cur = atomicCAS(&slots[slot], kEmptySlot, want);
+        if (cur == kEmptySlot) return static_cast<int>(slot);
+      }
+      if (static_cast<uint32_t>(cur >> 32) == k32) {
+        if (static_cast<uint32_t>(cur) > static_cast<uint32_t>(val)) atomicMin(&slots[slot], want);
         return static_cast<int>(slot);
       }
       slot = (slot + 1) & t.mask;
@@ -95,13 +103,16 @@ __device__ __forceinline__ int table_insert_min(const Table &t, hkey_t key, int3
   }
   uint32_t slot = hash_key(key, t.gbits) & t.mask;
   for (uint32_t probe = 0; probe <= t.mask; ++probe) {
-    unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long *>(&t.keys[slot]),
-                                        static_cast<unsigned long long>(-1LL),
-                                        static_cast<unsigned long long>(key));
+    unsigned long long prev = LOOK ? static_cast<unsigned long long>(t.keys[slot])     // (as above)
+                                   : static_cast<unsigned long long>(-1LL);
+    if (prev == static_cast<unsigned long long>(-1LL))
+      prev = atomicCAS(reinterpret_cast<unsigned long long *>(&t.keys[slot]),
+                       static_cast<unsigned long long>(-1LL), static_cast<unsigned long long>(key));
     if (prev == static_cast<unsigned long long>(-1LL) ||
         prev == static_cast<unsigned long long>(key)) {
       // values start as 0xFFFFFFFF (one memset with the keys): unsigned min
-      atomicMin(reinterpret_cast<unsigned int *>(&t.vals[slot]), static_cast<unsigned int>(val));
+      if (!LOOK || static_cast<unsigned int>(t.vals[slot]) > static_cast<unsigned int>(val))
+        atomicMin(reinterpret_cast<unsigned int *>(&t.vals[slot]), static_cast<unsigned int>(val));
       return static_cast<int>(slot);
     }
     slot = (slot + 1) & t.mask;
@@ -392,6 +403,7 @@ __device__ __forceinline__ int block_rank(bool pred, int &total, int *lds_wave /
 
 // seq-wise exclusive scan of `cnt` (length len per sequence), one block per
 // sequence; totals[seq] receives the sequence sum.
+constexpr int kScanPer = 32;          // items per thread of the one-pass form
 __global__ void __launch_bounds__(kBlock)
 scan_kernel(const int32_t *__restrict__ cnt, int32_t *__restrict__ off, int len,
             int32_t *__restrict__ totals) {
@@ -400,6 +412,41 @@ scan_kernel(const int32_t *__restrict__ cnt, int32_t *__restrict__ off, int len,
   const int32_t *c = cnt + static_cast<size_t>(seq) * len;
   int32_t *o = off + static_cast<size_t>(seq) * len;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (len <= kBlock * kScanPer) {
+    // one pass: every thread owns `per` consecutive items (all loads in flight together), one block
+    // scan of the thread sums -- the loop below pays a load -> barrier -> store round per 256 items
+    const int per = (len + kBlock - 1) / kBlock, base = threadIdx.x * per;
+    int v[kScanPer];
+    int sum = 0;
+#pragma unroll
+    for (int e = 0; e < kScanPer; ++e) {
+      v[e] = (e < per && base + e < len) ? c[base + e] : 0;
+      sum += v[e];
+    }
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int u = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += u;
+    }
+    if (lane == 63) lds_wave[wave] = incl;
+    __syncthreads();
+    int prefix = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) {
+      const int x = lds_wave[w];
+      if (w < wave) prefix += x;
+      total += x;
+    }
+    int run = prefix + incl - sum;
+#pragma unroll
+    for (int e = 0; e < kScanPer; ++e) {
+      if (e < per && base + e < len) o[base + e] = run;
+      run += v[e];
+    }
+    if (threadIdx.x == 0 && totals) totals[seq] = total;
+    return;
+  }
   int carry = 0;
   for (int base = 0; base < len; base += kBlock) {
     const int idx = base + threadIdx.x;
@@ -754,7 +801,7 @@ conv_stage1_kernel(const int32_t *__restrict__ indices, int n, Geom g, int trans
   const size_t pos = static_cast<size_t>(k) * n + i;
   int slot = -1;
   if (b >= 0 && b < g.batch && conv_out_coord(g, c, r, transposed, q)) {
-    slot = table_insert_min(t, layout_key(b, q, g.out_dims), static_cast<int32_t>(pos));
+    slot = table_insert_min<true>(t, layout_key(b, q, g.out_dims), static_cast<int32_t>(pos));
     if (slot < 0) *overflow = 1;          // table full: reported by spx_conv_rulebook_count
   }
   slot_of[pos] = slot;
@@ -871,6 +918,280 @@ conv_stage2_kernel(const int32_t *__restrict__ slot_of, const int32_t *__restric
       for (int w = 0; w < kBlock / 64; ++w) sum += lds_wave[w];
       groupcount[static_cast<size_t>(k) * gridDim.x + blockIdx.x] = sum;
     }
+  }
+}
+
+
+// ------------------------------------------ regular conv, third generation: compact candidates
+// A strided convolution pairs an input with FEW of the kv offsets: along one axis only the r with
+// (c + p - r d) % s == 0 reach an output, at most ceil(k gcd(d, s) / s) of them (conv_max_out), so
+// k = 3 / s = 2 in 3-d has <= 8 candidates per input out of 27 (3.4 on average), k = 2 / s = 2 exactly
+// one.  The second-generation passes above launch a thread per (offset, input) and stream kv x N
+// arrays five times; 85 % of those threads divide, find no pair and write a -1.  Here one thread owns
+// an input row: it derives the valid offsets of each axis as a bit set (no integer division: h / s by
+// a float multiply, exact below 2^21), walks their product in ascending k -- the candidate index j --
+// and every per-candidate array is [MJ, N] with MJ <= 8.  The first-seen numbering (k-major, then
+// input-major, indices.py:1742-1771) comes from a BIT MAP of the first-seen candidates, one row per
+// offset: the count of an (offset, 2048-input block) is a popcount, the rank of an entry a prefix
+// popcount -- in input order by construction, no ballots, no barriers, every pass elementwise.
+constexpr int kMaxCand = 8;       // candidates per input the compact passes are instantiated for
+constexpr int kMaxKv3 = 64;       // offsets (bit-map rows held in LDS)
+
+struct CandIter {
+  uint32_t vm[4], v[4];
+  bool live;
+  // valid offsets per axis of input coordinate c (regular conv): bit r of vm[d]
+  __device__ __forceinline__ void init(const Geom &g, const int (&c)[4], bool row_ok) {
+    live = row_ok;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const float inv = 1.0f / static_cast<float>(g.stride[d]);
+      uint32_t m = 0;
+      for (int r = 0; r < g.ksize[d]; ++r) {
+        const int h = c[d] + g.padding[d] - r * g.dilation[d];
+        const int q = __float2int_rn(static_cast<float>(h) * inv);
+        if (q * g.stride[d] == h && q >= 0 && q < g.out_dims[d]) m |= 1u << r;
+      }
+      vm[d] = v[d] = m;
+      live = live && m != 0;
+    }
+  }
+  // current candidate: offset index k and output coordinate q
+  __device__ __forceinline__ int offset(const Geom &g, const int (&c)[4], int (&q)[4]) const {
+    int k = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const int r = __builtin_ctz(v[d]);
+      k = k * g.ksize[d] + r;
+      const int h = c[d] + g.padding[d] - r * g.dilation[d];
+      q[d] = __float2int_rn(static_cast<float>(h) * (1.0f / static_cast<float>(g.stride[d])));
+    }
+    return k;
+  }
+  __device__ __forceinline__ int offset(const Geom &g) const {
+    int k = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) k = k * g.ksize[d] + __builtin_ctz(v[d]);
+    return k;
+  }
+  __device__ __forceinline__ void next() {     // odometer over the bit sets, last axis fastest
+#pragma unroll
+    for (int d = 3; d >= 0; --d) {
+      v[d] &= v[d] - 1;
+      if (v[d]) return;
+      v[d] = vm[d];
+    }
+    live = false;
+  }
+};
+
+// pass 1: insert every candidate output key with value = min first-seen position (k * n + i);
+// slot_c[j][i] = its slot (entries past an input's candidate count are never read)
+template <int MJ>
+__global__ void __launch_bounds__(kBlock)
+conv3_insert_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table t,
+                    int32_t *__restrict__ slot_c, int32_t *__restrict__ overflow) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  int b, c[4];
+  read_row(indices, i, g.ndim, b, c);
+  CandIter it;
+  it.init(g, c, b >= 0 && b < g.batch);
+  // blockIdx.y: the thread's share of the row's candidates (j = y mod gridDim.y) -- a small scene
+  // does not have enough rows to hide eight dependent atomic round trips per thread
+  const int share = blockIdx.y, shares = gridDim.y - 1;
+#pragma unroll
+  for (int j = 0; j < MJ; ++j) {
+    if (!it.live) break;
+    if ((j & shares) == share) {
+      int q[4];
+      const int k = it.offset(g, c, q);
+      const int slot = table_insert_min<true>(t, layout_key(b, q, g.out_dims), k * n + i);
+      if (slot < 0) *overflow = 1;             // table full: reported by spx_conv_rulebook_count
+      slot_c[static_cast<size_t>(j) * n + i] = slot;
+    }
+    it.next();
+  }
+}
+
+// pass 2: bit map of the first-seen candidates, one row of nblk * 64 words per offset (bit i of row k:
+// input i is the first to reach its output through k).  A workgroup collects the bits of its 256 rows
+// in LDS -- 32 neighbouring inputs share a word, global atomics on it would serialise inside the wave --
+// and ORs its non-zero words (8 per offset) into the map; also the per-input byte of first-seen
+// candidate indices that lets pass 3 skip everything else
+template <int MJ>
+__global__ void __launch_bounds__(kBlock)
+conv3_first_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table t,
+                   const int32_t *__restrict__ slot_c, int nblk, uint32_t *__restrict__ firstbits,
+                   uint8_t *__restrict__ firstflags) {
+  __shared__ uint32_t bm[kMaxKv3][kBlock / 32];
+  const int i = blockIdx.x * kBlock + threadIdx.x, kv = g.kv;
+  for (int w = threadIdx.x; w < kv * (kBlock / 32); w += kBlock) (&bm[0][0])[w] = 0;
+  __syncthreads();
+  const int share = blockIdx.y, shares = gridDim.y - 1;      // (as conv3_insert_kernel)
+  if (i < n) {
+    int b, c[4];
+    read_row(indices, i, g.ndim, b, c);
+    CandIter it;
+    it.init(g, c, b >= 0 && b < g.batch);
+    int kk[MJ], slot[MJ];
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) {             // every load of the row first
+      kk[j] = -1;
+      slot[j] = -1;
+      if (it.live) {
+        if ((j & shares) == share) {
+          kk[j] = it.offset(g);
+          slot[j] = slot_c[static_cast<size_t>(j) * n + i];
+        }
+        it.next();
+      }
+    }
+    int val[MJ];
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) val[j] = slot[j] >= 0 ? table_val(t, slot[j]) : -1;
+    uint32_t flags = 0;
+#pragma unroll
+    for (int j = 0; j < MJ; ++j)
+      if (slot[j] >= 0 && val[j] == kk[j] * n + i) {
+        atomicOr(&bm[kk[j]][threadIdx.x >> 5], 1u << (threadIdx.x & 31));
+        flags |= 1u << j;
+      }
+    firstflags[static_cast<size_t>(share) * n + i] = static_cast<uint8_t>(flags);   // one plane per share
+  }
+  __syncthreads();
+  const size_t rowwords = static_cast<size_t>(nblk) * (kItems / 32);
+  for (int w = threadIdx.x; w < kv * (kBlock / 32); w += kBlock) {
+    const uint32_t word = (&bm[0][0])[w];
+    if (word) {
+      uint32_t *dst = &firstbits[(w / (kBlock / 32)) * rowwords + blockIdx.x * (kBlock / 32) + (w % (kBlock / 32))];
+      if (shares) atomicOr(dst, word); else *dst = word;       // one share: this workgroup owns the word
+    }
+  }
+}
+
+// pass 2b: one wave per (offset, 2048-input block): popcount of the block's 64 bit-map words
+// (-> blockcount, for the scan) and their exclusive prefix inside the block (-> wordpre)
+__global__ void __launch_bounds__(kBlock)
+conv3_count_kernel(const uint32_t *__restrict__ firstbits, int rows, int32_t *__restrict__ wordpre,
+                   int32_t *__restrict__ blockcount) {
+  const int row = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const size_t at = static_cast<size_t>(row) * (kItems / 32) + lane;
+  const int cnt = __popc(firstbits[at]);
+  int incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int u = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += u;
+  }
+  wordpre[at] = incl - cnt;
+  if (lane == 63) blockcount[row] = incl;
+}
+
+// pass 3: number the first-seen candidates -- blockoff of (offset, block) + first-seen entries of the
+// block before this word + set bits below this input's -- and write their coordinates;
+// slot_out[slot] = output row (or -1 beyond the caller's bound)
+template <int MJ>
+__global__ void __launch_bounds__(kBlock)
+conv3_assign_kernel(const int32_t *__restrict__ indices, int n, Geom g,
+                    const int32_t *__restrict__ slot_c, int nblk,
+                    const uint32_t *__restrict__ firstbits, const uint8_t *__restrict__ firstflags,
+                    const int32_t *__restrict__ wordpre, const int32_t *__restrict__ blockoff,
+                    int32_t *__restrict__ slot_out, int32_t *__restrict__ out_indices, int n_cap) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t flags = firstflags[static_cast<size_t>(blockIdx.y) * n + i];     // (shares as in pass 2)
+  if (!flags) return;                          // (most inputs are first for no offset)
+  int b, c[4];
+  read_row(indices, i, g.ndim, b, c);
+  CandIter it;
+  it.init(g, c, b >= 0 && b < g.batch);
+  const int lead = 4 - g.ndim;
+  const size_t rowwords = static_cast<size_t>(nblk) * (kItems / 32);
+#pragma unroll
+  for (int j = 0; j < MJ; ++j) {
+    if (!it.live) break;
+    if ((flags >> j) & 1u) {
+      int q[4];
+      const int k = it.offset(g, c, q);
+      const size_t at = k * rowwords + (i >> 5);
+      const int oid = blockoff[static_cast<size_t>(k) * nblk + i / kItems] + wordpre[at] +
+                      __popc(firstbits[at] & ((1u << (i & 31)) - 1u));
+      const int slot = slot_c[static_cast<size_t>(j) * n + i];
+      // outputs beyond the caller's bound (num_out_act_bound, ops.py:263-266) are dropped
+      slot_out[slot] = oid < n_cap ? oid : -1;
+      if (oid < n_cap) {
+        int32_t *dst = out_indices + static_cast<size_t>(oid) * (g.ndim + 1);
+        dst[0] = b;
+        for (int d = lead; d < 4; ++d) dst[1 + d - lead] = q[d];
+      }
+    }
+    it.next();
+  }
+}
+
+// pass 4: both tables, the input-side mask and the per-(offset, 256 rows) pair counts of the Native
+// lists.  pair_bwd and mask_bwd are written whole (no -1 pre-fill, no second pass over pair_bwd).
+template <int MJ>
+__global__ void __launch_bounds__(kBlock)
+conv3_pairs_kernel(const int32_t *__restrict__ indices, int n, Geom g,
+                   const int32_t *__restrict__ slot_c, const int32_t *__restrict__ slot_out, int n_out,
+                   int32_t *__restrict__ pair_fwd, int32_t *__restrict__ pair_bwd,
+                   uint32_t *__restrict__ mask_bwd, int words, int32_t *__restrict__ groupcount) {
+  __shared__ int lds_cnt[kMaxKv3];
+  const int i = blockIdx.x * kBlock + threadIdx.x, kv = g.kv;
+  if (groupcount) {
+    if (threadIdx.x < kMaxKv3) lds_cnt[threadIdx.x] = 0;
+    __syncthreads();
+  }
+  int kk[MJ], oid[MJ];
+#pragma unroll
+  for (int j = 0; j < MJ; ++j) {
+    kk[j] = -1;
+    oid[j] = -1;
+  }
+  if (i < n) {
+    int b, c[4];
+    read_row(indices, i, g.ndim, b, c);
+    CandIter it;
+    it.init(g, c, b >= 0 && b < g.batch);
+    int slot[MJ];
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) {
+      slot[j] = -1;
+      if (it.live) {
+        kk[j] = it.offset(g);
+        slot[j] = slot_c[static_cast<size_t>(j) * n + i];
+        it.next();
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < MJ; ++j)
+      if (slot[j] >= 0) oid[j] = slot_out[slot[j]];    // -1: an output beyond the caller's bound
+#pragma unroll
+    for (int j = 0; j < MJ; ++j)
+      if (oid[j] >= 0) pair_fwd[static_cast<size_t>(kk[j]) * n_out + oid[j]] = i;
+  }
+  uint32_t mword = 0;
+  for (int k = 0; k < kv; ++k) {
+    int val = -1;
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) val = kk[j] == k ? oid[j] : val;
+    if (i < n) pair_bwd[static_cast<size_t>(k) * n + i] = val;
+    if (val >= 0) mword |= 1u << (k & 31);
+    if (mask_bwd && i < n && ((k & 31) == 31 || k == kv - 1)) {
+      mask_bwd[static_cast<size_t>(i) * words + (k >> 5)] = mword;
+      mword = 0;
+    }
+    if (groupcount) {
+      const unsigned long long bal = __ballot(val >= 0);
+      if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&lds_cnt[k], __popcll(bal));
+    }
+  }
+  if (groupcount) {
+    __syncthreads();
+    if (threadIdx.x < kv) groupcount[static_cast<size_t>(threadIdx.x) * gridDim.x + blockIdx.x] = lds_cnt[threadIdx.x];
   }
 }
 
@@ -1039,6 +1360,12 @@ void table_place(Table &t, hkey_t *keys, int32_t *vals, uint32_t cap, bool packe
   t.gbits = gbits;
 }
 
+// The same storage as a smaller table (capacity a power of two below the placed one).
+void table_shrink(Table &t, uint32_t cap) {
+  if (!t.packed) t.vals = reinterpret_cast<int32_t *>(t.keys + cap);
+  t.mask = cap - 1;
+}
+
 // The table's bytes as a 0xFF range of a FillList (see table_clear).
 void table_fill(FillList &f, const Table &t) {
   const size_t cap = static_cast<size_t>(t.mask) + 1;
@@ -1088,9 +1415,45 @@ size_t conv_max_out(int n_in, int ndim, const int *ksize, const int *stride, con
 struct ConvWs {
   Table t;
   int32_t *slot_out, *slot_of, *blockcount, *blockoff, *d_nout, *groupcount;
+  uint32_t *firstbits;                 // compact passes: [kv, nblk, 64] first-seen bit map ...
+  int32_t *wordpre;                    // ... first-seen entries of the block before each of its words
+  uint8_t *firstflags;                 // ... and per input the candidate indices that are first-seen
   int nblk;
   size_t bytes;
 };
+
+// Candidates per input the compact passes (conv3_*) run with -- 1, 2, 4 or 8 -- or 0 when the
+// problem takes the thread-per-(offset, input) passes: transposed convolution, stride 1 (every offset
+// is a candidate), more than 8 candidates, kv > 64, coordinates beyond the float-exact range.
+int conv3_cands(int ndim, const int *in_shape, const int *ksize, const int *stride, const int *padding,
+                const int *dilation, int transposed) {
+  if (option_int("SPX_CONV_V", 3) < 3 || transposed) return 0;       // (2: the passes above, for A/B runs)
+  int kv = 1;
+  for (int i = 0; i < ndim; ++i) {
+    kv *= ksize[i];
+    const long long reach = static_cast<long long>(ksize[i]) * (dilation ? dilation[i] : 1);
+    if (ksize[i] > 32 || in_shape[i] + static_cast<long long>(padding[i]) >= (1 << 21) || reach >= (1 << 21)) return 0;
+  }
+  const size_t m = conv_max_out(1, ndim, ksize, stride, dilation, 0);
+  if (kv > kMaxKv3 || m > kMaxCand || 2 * m > static_cast<size_t>(kv)) return 0;
+  return m <= 1 ? 1 : (m <= 2 ? 2 : (m <= 4 ? 4 : 8));
+}
+
+// Shares per input row of the compact passes that are bound by dependent memory round trips (grid.y): a
+// power of two <= the candidate count, enough for ~1.5 M threads.
+int conv3_shares(int n_in, int mj) {
+  int s = 1;
+  while (s < mj && static_cast<long long>(n_in) * s < 1500000) s <<= 1;
+  return s;
+}
+
+#define SPX_CONV3_LAUNCH(kernel, mj, ...)                                     \
+  do {                                                                        \
+    if ((mj) == 1) hipLaunchKernelGGL(kernel<1>, __VA_ARGS__);                \
+    else if ((mj) == 2) hipLaunchKernelGGL(kernel<2>, __VA_ARGS__);           \
+    else if ((mj) == 4) hipLaunchKernelGGL(kernel<4>, __VA_ARGS__);           \
+    else hipLaunchKernelGGL(kernel<8>, __VA_ARGS__);                          \
+  } while (0)
 
 ConvWs carve_conv_ws(void *ws, int n_in, int ndim, const int *ksize, const int *stride,
                      const int *dilation, int transposed, bool packed = false) {
@@ -1113,6 +1476,9 @@ ConvWs carve_conv_ws(void *ws, int n_in, int ndim, const int *ksize, const int *
   w.blockoff = cv.take<int32_t>(static_cast<size_t>(kv) * w.nblk);
   w.d_nout = cv.take<int32_t>(2);      // [0] number of outputs, [1] hash-table overflow flag
   w.groupcount = cv.take<int32_t>(static_cast<size_t>(kv) * div_up(n_in > 0 ? n_in : 1, kBlock));
+  w.firstbits = cv.take<uint32_t>(static_cast<size_t>(kv <= kMaxKv3 ? kv : 0) * w.nblk * (kItems / 32));
+  w.wordpre = cv.take<int32_t>(static_cast<size_t>(kv <= kMaxKv3 ? kv : 0) * w.nblk * (kItems / 32));
+  w.firstflags = cv.take<uint8_t>(static_cast<size_t>(kMaxCand) * (n_in > 0 ? n_in : 1));
   w.bytes = cv.off;
   return w;
 }
@@ -1617,11 +1983,59 @@ size_t spx_conv_rulebook_ws_bytes(int n_in, int ndim, const int *ksize, const in
   return carve_conv_ws(nullptr, n_in, ndim, ksize, stride, dilation, transposed).bytes + 256;
 }
 
-int spx_conv_rulebook_count(const int32_t *indices, int n_in, int ndim, int batch_size,
-                            const int *in_shape, const int *out_shape, const int *ksize,
-                            const int *stride, const int *padding, const int *dilation,
-                            int transposed, void *ws, size_t ws_bytes, int *n_out_h,
-                            spx_stream_t stream) {
+}  // extern "C"
+
+namespace spx {
+namespace {
+// Table sizing of the compact passes.  The guaranteed bound (conv_max_out: 8 N for k = 3 / s = 2) gives
+// a table that is 4 % full on a LiDAR scene -- 67 MB of slots for 313 k outputs at 400 k inputs, every
+// probe its own HBM line, 20 us of fill.  The builder therefore sizes the table for the outputs it
+// EXPECTS and keeps the bound as the fallback:
+//   * static-shape form: the caller's output bound (more distinct candidates than 2x that: the
+//     overflow flag the caller reads back with the count)
+//   * two-call form: the outputs-per-input ratio the same geometry produced last time (+25 %), kept in
+//     a small direct-mapped cache -- the role of the reference's per-problem tuner cache
+//     (convops.py:1150,1283-1297); a table that overflows is seen in the count's read-back and the
+//     pass is run again at the guaranteed size.  Results never depend on the size.
+struct RatioEntry {
+  unsigned long long key;
+  int ratio_x64;                     // ceil(64 * n_out / n_in) of the last build, 0 = none yet
+};
+RatioEntry g_ratio[64];
+std::mutex g_ratio_mutex;
+
+unsigned long long geometry_key(int ndim, const int *in_shape, const int *ksize, const int *stride,
+                                const int *padding, const int *dilation) {
+  unsigned long long h = 1469598103934665603ull ^ static_cast<unsigned>(ndim);
+  for (int i = 0; i < ndim; ++i)
+    for (const int v : {in_shape[i], ksize[i], stride[i], padding[i], dilation ? dilation[i] : 1}) {
+      h ^= static_cast<unsigned>(v);
+      h *= 1099511628211ull;
+    }
+  return h | 1ull;
+}
+
+size_t expected_outputs(unsigned long long key, int n_in) {
+  std::lock_guard<std::mutex> lock(g_ratio_mutex);
+  const RatioEntry &e = g_ratio[key % 64];
+  if (e.key != key || e.ratio_x64 <= 0) return 0;                       // unknown: the bound
+  return static_cast<size_t>(n_in) * e.ratio_x64 / 64 * 5 / 4 + 4096;
+}
+
+void remember_outputs(unsigned long long key, int n_in, int n_out) {
+  std::lock_guard<std::mutex> lock(g_ratio_mutex);
+  RatioEntry &e = g_ratio[key % 64];
+  e.key = key;
+  e.ratio_x64 = static_cast<int>((static_cast<long long>(n_out) * 64 + n_in - 1) / (n_in > 0 ? n_in : 1)) + 1;
+}
+
+// expect_out: distinct outputs to size the hash table for (0 = the guaranteed bound).  *overflow_h (with
+// n_out_h): the table filled up -- the caller decides whether a larger table exists.
+int conv_count_impl(const int32_t *indices, int n_in, int ndim, int batch_size,
+                    const int *in_shape, const int *out_shape, const int *ksize,
+                    const int *stride, const int *padding, const int *dilation,
+                    int transposed, void *ws, size_t ws_bytes, int *n_out_h, int *overflow_h,
+                    size_t expect_out, spx_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   SPX_CHECK(ndim >= 1 && ndim <= kMaxNdim, "ndim must be in [1,4], got %d", ndim);
   const Geom g = make_geom(ndim, batch_size, in_shape, out_shape, ksize, stride, padding, dilation);
@@ -1634,18 +2048,34 @@ int spx_conv_rulebook_count(const int32_t *indices, int n_in, int ndim, int batc
   if (n_in == 0) return 0;
   ConvWs w = carve_conv_ws(ws, n_in, ndim, ksize, stride, dilation, transposed,
                            keys_fit_u32(g.batch, g.out_dims, 4));
+  const int mj = conv3_cands(ndim, in_shape, ksize, stride, padding, dilation, transposed);
+  if (mj && expect_out > 0) {            // (the later passes of this form never touch the table)
+    const uint32_t cap = table_capacity(expect_out);
+    if (cap < w.t.mask + 1u) table_shrink(w.t, cap);
+  }
   {
     FillList fills;                      // table and flags in one launch
     table_fill(fills, w.t);
     fills.add(w.d_nout, 2 * sizeof(int32_t), 0u);
+    if (mj) fills.add(w.firstbits, sizeof(uint32_t) * static_cast<size_t>(g.kv) * w.nblk * (kItems / 32), 0u);
     SPX_HIP(fills.launch(s));
   }
-  const dim3 grid1(div_up(n_in, kBlock), g.kv);
-  hipLaunchKernelGGL(conv_stage1_kernel, grid1, dim3(kBlock), 0, s, indices, n_in, g, transposed,
+  if (mj) {
+    const int shares = conv3_shares(n_in, mj);
+    SPX_CONV3_LAUNCH(conv3_insert_kernel, mj, dim3(div_up(n_in, kBlock), shares), dim3(kBlock), 0, s, indices, n_in, g,
                      w.t, w.slot_of, w.d_nout + 1);
-  const dim3 grid2(w.nblk, g.kv);
-  hipLaunchKernelGGL(conv_count_first_kernel, grid2, dim3(kBlock), 0, s, w.slot_of, w.t, n_in,
-                     w.nblk, w.blockcount);
+    SPX_CONV3_LAUNCH(conv3_first_kernel, mj, dim3(div_up(n_in, kBlock), shares), dim3(kBlock), 0, s, indices, n_in, g, w.t,
+                     static_cast<const int32_t *>(w.slot_of), w.nblk, w.firstbits, w.firstflags);
+    hipLaunchKernelGGL(conv3_count_kernel, dim3(div_up(g.kv * w.nblk, kBlock / 64)), dim3(kBlock), 0, s,
+                       static_cast<const uint32_t *>(w.firstbits), g.kv * w.nblk, w.wordpre, w.blockcount);
+  } else {
+    const dim3 grid1(div_up(n_in, kBlock), g.kv);
+    hipLaunchKernelGGL(conv_stage1_kernel, grid1, dim3(kBlock), 0, s, indices, n_in, g, transposed,
+                       w.t, w.slot_of, w.d_nout + 1);
+    const dim3 grid2(w.nblk, g.kv);
+    hipLaunchKernelGGL(conv_count_first_kernel, grid2, dim3(kBlock), 0, s, w.slot_of, w.t, n_in,
+                       w.nblk, w.blockcount);
+  }
   hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kBlock), 0, s, w.blockcount, w.blockoff,
                      g.kv * w.nblk, w.d_nout);
   SPX_LAUNCH_CHECK();
@@ -1653,11 +2083,42 @@ int spx_conv_rulebook_count(const int32_t *indices, int n_in, int ndim, int batc
   int32_t host_n[2] = {0, 0};
   SPX_HIP(hipMemcpyAsync(host_n, w.d_nout, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   SPX_HIP(hipStreamSynchronize(s));
-  SPX_CHECK(host_n[1] == 0, "output hash table overflow: more distinct outputs than the bound %zu",
-            conv_max_out(n_in, ndim, ksize, stride, dilation, transposed));
   *n_out_h = host_n[0];
+  *overflow_h = host_n[1];
   return 0;
 }
+}  // namespace
+}  // namespace spx
+
+extern "C" {
+
+int spx_conv_rulebook_count(const int32_t *indices, int n_in, int ndim, int batch_size,
+                            const int *in_shape, const int *out_shape, const int *ksize,
+                            const int *stride, const int *padding, const int *dilation,
+                            int transposed, void *ws, size_t ws_bytes, int *n_out_h,
+                            spx_stream_t stream) {
+  using namespace spx;
+  SPX_CHECK(ndim >= 1 && ndim <= kMaxNdim, "ndim must be in [1,4], got %d", ndim);
+  int overflow = 0;
+  if (!n_out_h)      // nothing read back: the guaranteed size
+    return conv_count_impl(indices, n_in, ndim, batch_size, in_shape, out_shape, ksize, stride, padding,
+                           dilation, transposed, ws, ws_bytes, nullptr, &overflow, 0, stream);
+  const unsigned long long key = geometry_key(ndim, in_shape, ksize, stride, padding, dilation);
+  const size_t expect = option_int("SPX_CONV_TABLE_ADAPT", 1) ? expected_outputs(key, n_in) : 0;
+  int rc = conv_count_impl(indices, n_in, ndim, batch_size, in_shape, out_shape, ksize, stride, padding,
+                           dilation, transposed, ws, ws_bytes, n_out_h, &overflow, expect, stream);
+  if (rc) return rc;
+  if (overflow && expect > 0) {          // the expectation was too small: once more, at the bound
+    rc = conv_count_impl(indices, n_in, ndim, batch_size, in_shape, out_shape, ksize, stride, padding,
+                         dilation, transposed, ws, ws_bytes, n_out_h, &overflow, 0, stream);
+    if (rc) return rc;
+  }
+  SPX_CHECK(overflow == 0, "output hash table overflow: more distinct outputs than the bound %zu",
+            conv_max_out(n_in, ndim, ksize, stride, dilation, transposed));
+  if (n_in > 0) remember_outputs(key, n_in, *n_out_h);
+  return 0;
+}
+
 
 int spx_conv_rulebook_fill(const int32_t *indices, int n_in, int ndim, int batch_size,
                            const int *in_shape, const int *out_shape, const int *ksize,
@@ -1693,13 +2154,24 @@ int spx_conv_rulebook_fill(const int32_t *indices, int n_in, int ndim, int batch
   ConvWs w = carve_conv_ws(ws, n_in, ndim, ksize, stride, dilation, transposed,
                            keys_fit_u32(g.batch, g.out_dims, 4));   // as spx_conv_rulebook_count
   const dim3 grid2(w.nblk, kv);
-  hipLaunchKernelGGL(conv_assign_kernel, grid2, dim3(kBlock), 0, s, indices, n_in, g, transposed,
-                     w.slot_of, w.t, w.nblk, w.blockoff, w.slot_out, out_indices, n_out);
-  const dim3 grid1(div_up(n_in, kBlock), kv);
-  hipLaunchKernelGGL(conv_stage2_kernel, grid1, dim3(kBlock), 0, s, w.slot_of, w.slot_out, n_in,
-                     n_out, pair_fwd, pair_bwd, v2 ? w.groupcount : nullptr);
+  const int mj = conv3_cands(ndim, in_shape, ksize, stride, padding, dilation, transposed);
+  if (mj) {
+    SPX_CONV3_LAUNCH(conv3_assign_kernel, mj, dim3(div_up(n_in, kBlock), conv3_shares(n_in, mj)), dim3(kBlock), 0, s, indices, n_in, g,
+                     static_cast<const int32_t *>(w.slot_of), w.nblk, static_cast<const uint32_t *>(w.firstbits),
+                     static_cast<const uint8_t *>(w.firstflags), static_cast<const int32_t *>(w.wordpre),
+                     static_cast<const int32_t *>(w.blockoff), w.slot_out, out_indices, n_out);
+    SPX_CONV3_LAUNCH(conv3_pairs_kernel, mj, dim3(div_up(n_in, kBlock)), dim3(kBlock), 0, s, indices, n_in, g,
+                     static_cast<const int32_t *>(w.slot_of), static_cast<const int32_t *>(w.slot_out), n_out,
+                     pair_fwd, pair_bwd, mask_bwd, words, v2 ? w.groupcount : nullptr);
+  } else {
+    hipLaunchKernelGGL(conv_assign_kernel, grid2, dim3(kBlock), 0, s, indices, n_in, g, transposed,
+                       w.slot_of, w.t, w.nblk, w.blockoff, w.slot_out, out_indices, n_out);
+    const dim3 grid1(div_up(n_in, kBlock), kv);
+    hipLaunchKernelGGL(conv_stage2_kernel, grid1, dim3(kBlock), 0, s, w.slot_of, w.slot_out, n_in,
+                       n_out, pair_fwd, pair_bwd, v2 ? w.groupcount : nullptr);
+  }
   {
-    const int na = mask_fwd ? n_out : 0, nb = mask_bwd ? n_in : 0;
+    const int na = mask_fwd ? n_out : 0, nb = (mask_bwd && !mj) ? n_in : 0;
     if (na + nb > 0)
       hipLaunchKernelGGL(mask_from_tables_kernel, dim3(div_up(na + nb, kBlock)), dim3(kBlock), 0, s, pair_fwd,
                          na, mask_fwd, pair_bwd, nb, mask_bwd, kv, words);
@@ -1740,8 +2212,10 @@ int spx_conv_rulebook_static(const int32_t *indices, int n_in, int ndim, int bat
   // hipGraph.  Rows past the number of distinct outputs keep out_indices = -1 (a dead row for the
   // next layer: subm_insert_kernel / conv_stage1_kernel skip batch < 0), pair_fwd = -1, mask = 0.
   SPX_HIP(hipMemsetAsync(out_indices, 0xFF, sizeof(int32_t) * static_cast<size_t>(n_out_cap) * (ndim + 1), s));
-  int rc = spx_conv_rulebook_count(indices, n_in, ndim, batch_size, in_shape, out_shape, ksize, stride,
-                                   padding, dilation, transposed, ws, ws_bytes, nullptr, stream);
+  int unused = 0;
+  int rc = spx::conv_count_impl(indices, n_in, ndim, batch_size, in_shape, out_shape, ksize, stride, padding,
+                                dilation, transposed, ws, ws_bytes, nullptr, &unused,
+                                static_cast<size_t>(n_out_cap), stream);
   if (rc) return rc;
   rc = spx_conv_rulebook_fill(indices, n_in, ndim, batch_size, in_shape, out_shape, ksize, stride,
                               padding, dilation, transposed, n_out_cap, out_indices, pair_fwd, pair_bwd,

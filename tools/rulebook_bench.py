@@ -1,0 +1,67 @@
+#!/usr/bin/env python
+"""Device time of the rulebook builders (graph replay between HIP events: no host time in the figure).
+
+    SubM k3 (inference tables only / with the Native lists), SparseConv k3 s2 p1 and k2 s2 in the
+    static-shape form (spx_conv_rulebook_static: the same passes as the two-call form, nothing read
+    back, so it can sit in a graph), second- vs third-generation passes (SPX_CONV_V = 2 / 3).
+
+Scenes: uniform 100 k (BASELINE config 2), LiDAR-like 100 k and 4 x 100 k (config 4 level 1), the
+reference fixture.  One JSON line.   python tools/rulebook_bench.py"""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from spconv_amd import _lib  # noqa: E402
+from spconv_amd.pytorch import ops  # noqa: E402
+from spconv_amd.utils import nets  # noqa: E402
+
+
+def set_option(name, v):
+    _lib.check(_lib.load().spx_set_option(name.encode(), int(v)))
+
+
+def main():
+    dev = torch.device("cuda:0")
+    rows = []
+    scenes = [("uniform", 100_000, 1, None), ("lidar", 100_000, 1, None), ("lidar", 100_000, 4, nets.SECOND_SHAPE),
+              ("fixture", 0, 1, None)]
+    for kind, n, bs, shape in scenes:
+        idx, shape = bench.make_scene(kind, n, 0, batch=bs, shape=shape)
+        ind = torch.from_numpy(idx).to(dev)
+        N = ind.shape[0]
+        row = dict(scene=kind, batch=bs, voxels=N)
+
+        def subm(native):
+            return lambda i: ops.build_rulebook(ind, bs, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True,
+                                                need_native=native)
+        row["subm_tables_us"] = round(bench.event_time_ms(subm(False), iters=40, span=4) * 1e3, 1)
+        row["subm_with_lists_us"] = round(bench.event_time_ms(subm(True), iters=40, span=4) * 1e3, 1)
+        for name, k, s, p in (("conv_k3s2", 3, 2, 1), ("conv_k2s2", 2, 2, 0)):
+            rb, _ = ops.build_rulebook(ind, bs, shape, [k] * 3, [s] * 3, [p] * 3, [1] * 3, [0] * 3, False)
+            cap = rb.n_out + 1024
+            row[name + "_n_out"] = rb.n_out
+            ref = None
+            for v in (2, 3):
+                set_option("SPX_CONV_V", v)
+                fn = lambda i: ops.build_rulebook(ind, bs, shape, [k] * 3, [s] * 3, [p] * 3, [1] * 3, [0] * 3, False,
+                                                  need_native=False, static_num_out=cap)
+                row[f"{name}_v{v}_us"] = round(bench.event_time_ms(fn, iters=40, span=4) * 1e3, 1)
+                got = fn(0)[0]
+                torch.cuda.synchronize()
+                t = (got.out_indices, got.pair_fwd, got.pair_bwd, got.mask_fwd, got.mask_bwd)
+                if ref is None:
+                    ref = t
+                else:
+                    row[name + "_v3_equals_v2"] = all(torch.equal(a, b) for a, b in zip(ref, t))
+            set_option("SPX_CONV_V", 3)
+        rows.append(row)
+    print(json.dumps({"rulebook_device_us": rows}))
+
+
+if __name__ == "__main__":
+    main()
