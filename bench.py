@@ -877,6 +877,19 @@ def run_net(args, D: Dist):
     warm = min(args.warmup, 20)
     steps = min(args.steps, 200)
     elapsed = timed_region(D, run_steps, warm, steps)
+    eager_ms, static_info = None, None
+    if args.config == "3" and not args.no_graph:
+        # the same step with static shapes, captured (rulebooks included); `value` is from this loop when it
+        # ran clean, the eager loop's time rides along
+        try:
+            t_static, static_info = static_training_steps(net, data, bs, cin, data[0][2], steps, warm, D)
+            if not static_info["overflowed"] and static_info["dw_rel_diff_vs_eager"] < 2e-3:
+                eager_ms, elapsed = elapsed / steps * 1e3, t_static
+            else:
+                static_info["rejected"] = True
+        except Exception as e:
+            static_info = {"error": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.synchronize()
     n_mean = sum(b[0].shape[0] for b in batches) / S
     elapsed, n_total, ranks_seen = D.reduce_max_sum(elapsed, n_mean)
     if rank != 0:
@@ -910,7 +923,10 @@ def run_net(args, D: Dist):
                                   f"({int(n_mean)} input voxels), fresh rulebooks every step, forward + backward"
                                   + (" + flat-bucket RCCL gradient all-reduce" if world > 1 else ""),
                       "input_voxels_per_gpu": int(n_mean), "layer_voxels": [[r["n_in"], r["n_out"]] for r in recs],
-                      "scenes_rotated": S, "launch": "eager", "parallelism": f"dp{world}", "ranks_seen": ranks_seen,
+                      "scenes_rotated": S,
+                      "launch": "eager" if eager_ms is None else "hipGraph replay of the whole step (static shapes: "
+                                "rulebook builds + forward + backward captured once, one graph for every scene)",
+                      "static_shapes": static_info, "parallelism": f"dp{world}", "ranks_seen": ranks_seen,
                       "dist_backend": D.backend if world > 1 else None},
            "roofline": roofline_obj("step", total, ms, "whole step: rulebook builders + igemm_v4 / igemm_bwd / "
                                     "wgrad_reduce2 of every layer (+ the bn_* BatchNorm+ReLU kernels at config 4)", None,
@@ -919,6 +935,8 @@ def run_net(args, D: Dist):
                                              "the time also holds rulebook builds, normalisation layers and host "
                                              "enqueue gaps, so this is the end-to-end fraction, not a kernel's"})}
     res["roofline_cold"] = res["roofline"]
+    if eager_ms is not None:
+        res["eager_ms_per_step"] = eager_ms
     if world == 1 and not args.no_cpu_baseline:
         t, done = cpu_baseline_net(recs)
         frac_layers = done / len(recs)
@@ -930,6 +948,94 @@ def run_net(args, D: Dist):
                                          + ("" if done == len(recs) else
                                             "; value extrapolated by layer count (bounded sample)")}
     return res
+
+
+def static_training_steps(net, data, bs, cin, shape, steps, warm, D: Dist):
+    """The training step of a network of strided convolutions (BASELINE config 3) with static shapes: input
+    padded with dead rows, every layer's output bounded at 1.1 x the largest count over the scenes, rulebook
+    builds + forward + backward of the whole step in ONE captured graph that serves every scene
+    (spx_conv_rulebook_static: nothing is read back).  Returns (seconds for `steps` steps, info dict); the
+    weight gradients of scene 0 are compared with the eager, unbounded step before anything is timed."""
+    import copy
+    import spconv_amd.pytorch as spconv
+    from spconv_amd.pytorch.static import strided_layers
+    dev = D.dev
+    S = len(data)
+    net_e = copy.deepcopy(net)                       # eager, unbounded reference
+    seen = {}
+    hooks = [m.register_forward_hook(lambda mod, a, out, k=k: seen.__setitem__(k, max(seen.get(k, 0), out.features.shape[0])))
+             for k, m in strided_layers(net_e).items()]
+    with torch.no_grad():
+        for ind, f, _ in data:
+            net_e(spconv.SparseConvTensor(f, ind, shape, bs))
+    for h in hooks:
+        h.remove()
+    bounds = {k: int(v * 1.1) + 1 for k, v in seen.items()}
+    layers = strided_layers(net)
+    for k, m in layers.items():
+        m.static_num_out = bounds[k]
+    n_max = int(max(d[0].shape[0] for d in data) * 1.05) + 1
+    fbuf = torch.zeros((n_max, cin), dtype=torch.float16, device=dev).requires_grad_(True)
+    ibuf = torch.full((n_max, len(shape) + 1), -1, dtype=torch.int32, device=dev)
+    k_last = list(layers.values())[-1].out_channels
+    gstat = ((torch.rand((bounds[list(layers)[-1]], k_last), device=dev) - 0.5) * 0.2).half()
+    live = [0]
+
+    def load(si):
+        ind, f, _ = data[si]
+        n = ind.shape[0]
+        with torch.no_grad():
+            fbuf[:n].copy_(f)
+            ibuf[:n].copy_(ind)
+            if n < live[0]:
+                fbuf[n:live[0]].zero_()
+                ibuf[n:live[0]].fill_(-1)
+        live[0] = n
+
+    def compute():
+        net.zero_grad(set_to_none=True)
+        fbuf.grad = None
+        y = net(spconv.SparseConvTensor(fbuf, ibuf, shape, bs))
+        y.features.backward(gstat)
+    load(0)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            compute()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        compute()
+    counters = {k: m._static_n_out_dev for k, m in layers.items()}
+    # parity of the captured step against the eager, unbounded one (scene 0)
+    load(0)
+    g.replay()
+    ind, f, _ = data[0]
+    fe = f.clone().requires_grad_(True)
+    ye = net_e(spconv.SparseConvTensor(fe, ind, shape, bs))
+    ye.features.backward(gstat[:ye.features.shape[0]])
+    torch.cuda.synchronize()
+    worst = 0.0
+    for pa, pb in zip(net.parameters(), net_e.parameters()):
+        d = (pa.grad.float() - pb.grad.float()).norm() / pb.grad.float().norm().clamp_min(1e-20)
+        worst = max(worst, float(d))
+    din = float((fbuf.grad[:ind.shape[0]].float() - fe.grad.float()).norm() / fe.grad.float().norm().clamp_min(1e-20))
+    cnt = [0]
+
+    def run_steps(k):
+        for _ in range(k):
+            load(cnt[0] % S)
+            cnt[0] += 1
+            g.replay()
+    elapsed = timed_region(D, run_steps, warm, steps)
+    found = {k: v.cpu().tolist() for k, v in counters.items()}
+    over = {k: c for k, (c, o) in found.items() if c > bounds[k] or o}
+    for m in layers.values():
+        m.static_num_out = 0
+    return elapsed, {"bounds": bounds, "padded_input_rows": n_max, "dw_rel_diff_vs_eager": worst,
+                     "din_rel_diff_vs_eager": din, "overflowed": over}
 
 
 def run_infer(args, D: Dist):

@@ -141,16 +141,19 @@ int spx_conv_rulebook_fill(const int32_t *indices, int n_in, int ndim, int batch
  *     into later ones are dropped (as with spx_conv_rulebook_fill and n_out < the count)
  *   - out_indices rows past the number of outputs are -1 (dead rows for the next layer), their
  *     pair_fwd column is -1 and their mask 0
+ *   - pair_native / num_per_loc (or NULL): the ConvAlgo.Native lists as spx_conv_rulebook_fill writes
+ *     them (training: the weight-gradient kernels read them); dead rows are in no list
  *   - n_out_dev [2] (device): {distinct outputs found -- may exceed n_out_cap --, hash-table
- *     overflow flag}; the caller reads it whenever it next synchronises
+ *     overflow flag: more distinct candidates than the table sized for 2 x n_out_cap holds};
+ *     the caller reads it whenever it next synchronises
  * spx_conv_rulebook_count with n_out_h == NULL is the same count without the read. */
 int spx_conv_rulebook_static(const int32_t *indices, int n_in, int ndim, int batch_size,
                              const int *in_shape, const int *out_shape, const int *ksize,
                              const int *stride, const int *padding, const int *dilation,
                              int transposed, int n_out_cap, int32_t *out_indices,
                              int32_t *pair_fwd, int32_t *pair_bwd, uint32_t *mask_fwd,
-                             uint32_t *mask_bwd, int32_t *n_out_dev, void *ws, size_t ws_bytes,
-                             spx_stream_t stream);
+                             uint32_t *mask_bwd, int32_t *pair_native, int32_t *num_per_loc,
+                             int32_t *n_out_dev, void *ws, size_t ws_bytes, spx_stream_t stream);
 
 /* mask_argsort: permutation that groups rows with equal masks (stable, ascending
  * mask value).  Replaces SpconvOps.sort_1d_by_key_allocator (all.py:935-991). */

@@ -40,7 +40,7 @@ SIGNATURES = {
                                + [c_int_p] * 6 + [ctypes.c_int, ctypes.c_int] + [vp] * 7
                                + [vp, ctypes.c_size_t, vp]),
     "spx_conv_rulebook_static": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
-                                 + [c_int_p] * 6 + [ctypes.c_int, ctypes.c_int] + [vp] * 6
+                                 + [c_int_p] * 6 + [ctypes.c_int, ctypes.c_int] + [vp] * 8
                                  + [vp, ctypes.c_size_t, vp]),
     "spx_tile_plan_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "spx_tile_plan_ws_bytes": (ctypes.c_size_t, [ctypes.c_int]),

@@ -2035,7 +2035,10 @@ int conv_count_impl(const int32_t *indices, int n_in, int ndim, int batch_size,
                     const int *in_shape, const int *out_shape, const int *ksize,
                     const int *stride, const int *padding, const int *dilation,
                     int transposed, void *ws, size_t ws_bytes, int *n_out_h, int *overflow_h,
-                    size_t expect_out, spx_stream_t stream) {
+                    size_t expect_out, spx_stream_t stream, const FillList *more = nullptr,
+                    int32_t *nout_dev = nullptr) {
+  // more: fills of the caller that ride in this pass's fill launch; nout_dev: where {count, overflow}
+  // go instead of the workspace (static-shape form: no copy afterwards)
   hipStream_t s = static_cast<hipStream_t>(stream);
   SPX_CHECK(ndim >= 1 && ndim <= kMaxNdim, "ndim must be in [1,4], got %d", ndim);
   const Geom g = make_geom(ndim, batch_size, in_shape, out_shape, ksize, stride, padding, dilation);
@@ -2056,7 +2059,11 @@ int conv_count_impl(const int32_t *indices, int n_in, int ndim, int batch_size,
   {
     FillList fills;                      // table and flags in one launch
     table_fill(fills, w.t);
+    if (nout_dev) w.d_nout = nout_dev;
     fills.add(w.d_nout, 2 * sizeof(int32_t), 0u);
+    if (more)
+      for (int j = 0; j < more->jobs.n; ++j)
+        fills.add(more->jobs.ptr[j], more->jobs.words[j] * 4, more->jobs.value[j]);
     if (mj) fills.add(w.firstbits, sizeof(uint32_t) * static_cast<size_t>(g.kv) * w.nblk * (kItems / 32), 0u);
     SPX_HIP(fills.launch(s));
   }
@@ -2120,13 +2127,18 @@ int spx_conv_rulebook_count(const int32_t *indices, int n_in, int ndim, int batc
 }
 
 
-int spx_conv_rulebook_fill(const int32_t *indices, int n_in, int ndim, int batch_size,
-                           const int *in_shape, const int *out_shape, const int *ksize,
-                           const int *stride, const int *padding, const int *dilation,
-                           int transposed, int n_out, int32_t *out_indices, int32_t *pair_fwd,
-                           int32_t *pair_bwd, uint32_t *mask_fwd, uint32_t *mask_bwd,
-                           int32_t *pair_native, int32_t *num_per_loc, void *ws,
-                           size_t ws_bytes, spx_stream_t stream) {
+}  // extern "C"
+
+namespace spx {
+namespace {
+// prefilled: pair_fwd already holds -1 (the static-shape form puts that fill into the first launch)
+int conv_fill_impl(const int32_t *indices, int n_in, int ndim, int batch_size,
+                   const int *in_shape, const int *out_shape, const int *ksize,
+                   const int *stride, const int *padding, const int *dilation,
+                   int transposed, int n_out, int32_t *out_indices, int32_t *pair_fwd,
+                   int32_t *pair_bwd, uint32_t *mask_fwd, uint32_t *mask_bwd,
+                   int32_t *pair_native, int32_t *num_per_loc, void *ws,
+                   size_t ws_bytes, spx_stream_t stream, bool prefilled) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   SPX_CHECK(ndim >= 1 && ndim <= kMaxNdim, "ndim must be in [1,4], got %d", ndim);
   const Geom g = make_geom(ndim, batch_size, in_shape, out_shape, ksize, stride, padding, dilation);
@@ -2146,7 +2158,7 @@ int spx_conv_rulebook_fill(const int32_t *indices, int n_in, int ndim, int batch
     if (pair_native && n_in > 0)
       fills.add(pair_native, sizeof(int32_t) * 2 * static_cast<size_t>(kv) * n_in, 0xFFFFFFFFu);
   }
-  if (n_in > 0 && n_out > 0)
+  if (n_in > 0 && n_out > 0 && !prefilled)
     fills.add(pair_fwd, sizeof(int32_t) * static_cast<size_t>(kv) * n_out, 0xFFFFFFFFu);
   if (v2 && n_in == 0 && num_per_loc) fills.add(num_per_loc, sizeof(int32_t) * kv, 0u);
   SPX_HIP(fills.launch(s));
@@ -2198,35 +2210,54 @@ int spx_conv_rulebook_fill(const int32_t *indices, int n_in, int ndim, int batch
   }
   return 0;
 }
+}  // namespace
+}  // namespace spx
+
+extern "C" {
+
+int spx_conv_rulebook_fill(const int32_t *indices, int n_in, int ndim, int batch_size,
+                           const int *in_shape, const int *out_shape, const int *ksize,
+                           const int *stride, const int *padding, const int *dilation,
+                           int transposed, int n_out, int32_t *out_indices, int32_t *pair_fwd,
+                           int32_t *pair_bwd, uint32_t *mask_fwd, uint32_t *mask_bwd,
+                           int32_t *pair_native, int32_t *num_per_loc, void *ws,
+                           size_t ws_bytes, spx_stream_t stream) {
+  return spx::conv_fill_impl(indices, n_in, ndim, batch_size, in_shape, out_shape, ksize, stride, padding,
+                             dilation, transposed, n_out, out_indices, pair_fwd, pair_bwd, mask_fwd, mask_bwd,
+                             pair_native, num_per_loc, ws, ws_bytes, stream, false);
+}
 
 int spx_conv_rulebook_static(const int32_t *indices, int n_in, int ndim, int batch_size,
                              const int *in_shape, const int *out_shape, const int *ksize,
                              const int *stride, const int *padding, const int *dilation,
                              int transposed, int n_out_cap, int32_t *out_indices, int32_t *pair_fwd,
                              int32_t *pair_bwd, uint32_t *mask_fwd, uint32_t *mask_bwd,
-                             int32_t *n_out_dev, void *ws, size_t ws_bytes, spx_stream_t stream) {
+                             int32_t *pair_native, int32_t *num_per_loc, int32_t *n_out_dev, void *ws,
+                             size_t ws_bytes, spx_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   SPX_CHECK(n_out_cap > 0 && n_out_dev && out_indices, "n_out_cap > 0, n_out_dev and out_indices are required");
   SPX_CHECK(n_in > 0, "static-shape rulebook needs n_in > 0 (pad the input with batch = -1 rows)");
   // every launch below is stream-ordered and nothing is read back: the whole call can sit in a
   // hipGraph.  Rows past the number of distinct outputs keep out_indices = -1 (a dead row for the
   // next layer: subm_insert_kernel / conv_stage1_kernel skip batch < 0), pair_fwd = -1, mask = 0.
-  SPX_HIP(hipMemsetAsync(out_indices, 0xFF, sizeof(int32_t) * static_cast<size_t>(n_out_cap) * (ndim + 1), s));
+  // Both sizes are known up front, so the -1 fills of the outputs ride in the first pass's fill launch
+  // and {distinct outputs found (may exceed the cap: the first n_out_cap survive), hash-table overflow
+  // flag} are written straight into n_out_dev: two launches and a copy fewer than the two-call form.
+  SPX_CHECK(pair_fwd && pair_bwd, "pair_fwd and pair_bwd are required");
+  (void)s;
+  int kv = 1;
+  for (int i = 0; i < ndim; ++i) kv *= ksize[i];
+  spx::FillList pre;
+  pre.add(out_indices, sizeof(int32_t) * static_cast<size_t>(n_out_cap) * (ndim + 1), 0xFFFFFFFFu);
+  pre.add(pair_fwd, sizeof(int32_t) * static_cast<size_t>(kv) * n_out_cap, 0xFFFFFFFFu);
   int unused = 0;
   int rc = spx::conv_count_impl(indices, n_in, ndim, batch_size, in_shape, out_shape, ksize, stride, padding,
                                 dilation, transposed, ws, ws_bytes, nullptr, &unused,
-                                static_cast<size_t>(n_out_cap), stream);
+                                static_cast<size_t>(n_out_cap), stream, &pre, n_out_dev);
   if (rc) return rc;
-  rc = spx_conv_rulebook_fill(indices, n_in, ndim, batch_size, in_shape, out_shape, ksize, stride,
-                              padding, dilation, transposed, n_out_cap, out_indices, pair_fwd, pair_bwd,
-                              mask_fwd, mask_bwd, nullptr, nullptr, ws, ws_bytes, stream);
-  if (rc) return rc;
-  const Geom g = make_geom(ndim, batch_size, in_shape, out_shape, ksize, stride, padding, dilation);
-  ConvWs w = carve_conv_ws(ws, n_in, ndim, ksize, stride, dilation, transposed,
-                           keys_fit_u32(g.batch, g.out_dims, 4));
-  // {distinct outputs found (may exceed the cap: the first n_out_cap survive), hash-table overflow flag}
-  SPX_HIP(hipMemcpyAsync(n_out_dev, w.d_nout, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-  return 0;
+  return spx::conv_fill_impl(indices, n_in, ndim, batch_size, in_shape, out_shape, ksize, stride, padding,
+                             dilation, transposed, n_out_cap, out_indices, pair_fwd, pair_bwd, mask_fwd, mask_bwd,
+                             pair_native, num_per_loc, ws, ws_bytes, stream, true);
 }
 
 size_t spx_mask_argsort_ws_bytes(int n) { return radix_argsort_ws_bytes(n) + 256; }

@@ -331,16 +331,16 @@ class SparseConvolution(SparseModule):
                 torch.cuda.synchronize()
                 t = time.time()
             try:
-                # static-shape inference (spconv_amd.pytorch.static): a strided layer with a frozen output
-                # bound builds its rulebook without the device -> host read of the output count
-                static = 0 if (grad_path or self.subm) else int(getattr(self, "static_num_out", 0) or 0)
+                # static shapes (spconv_amd.pytorch.static): a strided layer with a frozen output bound
+                # builds its rulebook without the device -> host read of the output count -- in training
+                # mode too (the Native lists come out of the same build; dead rows are in no pair)
+                static = 0 if self.subm else int(getattr(self, "static_num_out", 0) or 0)
                 with _timed(input, sparse_unique_name or name, "gen_pairs"):
                     rb, _ = ops.build_rulebook(indices, batch_size, spatial_shape, self.kernel_size,
                                                self.stride, self.padding, self.dilation,
                                                self.output_padding, self.subm, self.transposed,
                                                do_sort=MODULE_DO_SORT and not static,
-                                               need_native=(torch.is_grad_enabled() or self.algo == ConvAlgo.Native)
-                                               and not static,
+                                               need_native=torch.is_grad_enabled() or self.algo == ConvAlgo.Native,
                                                static_num_out=static)
                 self._static_n_out_dev = rb.n_out_dev
             except Exception:

@@ -210,12 +210,14 @@ def build_rulebook(indices: torch.Tensor, batch_size: int, spatial_shape: List[i
             mask_fwd = torch.empty((n_out, words), **i32)
             mask_bwd = torch.empty((n_in, words), **i32)
             n_out_dev = torch.empty((2,), **i32)
+            native = torch.empty((2, kv, n_in), **i32) if need_native else None
+            num = torch.empty((kv,), **i32) if need_native else None
             _lib.check(L.spx_conv_rulebook_static(indices.data_ptr(), n_in, ndim, batch_size, *args, n_out,
                                                   out_indices.data_ptr(), pair_fwd.data_ptr(),
                                                   pair_bwd.data_ptr(), mask_fwd.data_ptr(),
-                                                  mask_bwd.data_ptr(), n_out_dev.data_ptr(),
-                                                  ws.data_ptr(), ws.numel(), stream))
-            rb = Rulebook(out_indices, pair_fwd, pair_bwd, mask_fwd, mask_bwd, None, None, n_in, n_out,
+                                                  mask_bwd.data_ptr(), _ptr(native), _ptr(num),
+                                                  n_out_dev.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+            rb = Rulebook(out_indices, pair_fwd, pair_bwd, mask_fwd, mask_bwd, native, num, n_in, n_out,
                           kv, False)
             rb.n_out_dev = n_out_dev
             rb.in_indices, rb.in_shape, rb.out_shape, rb.batch_size = (indices, list(spatial_shape),

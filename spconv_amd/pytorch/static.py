@@ -18,8 +18,12 @@ tables, gather-GEMMs -- can be recorded once and replayed per scene:
     the first `bound` in the canonical order, like the reference's bounded mode)
 
 Live rows of the result are bit-identical to the eager, unbounded forward pass of the same scene
-(tests/test_gpu_static.py).  Inference only (eval mode, no autograd): batch statistics or a
-backward pass over dead rows would not be the reference's.
+(tests/test_gpu_static.py).  `StaticInference` is the eval-mode runner.  A strided layer keeps its
+frozen bound in training mode as well (the Native lists the weight-gradient kernels read come out of
+the same sync-free build; dead rows are in no pair, so dgrad / wgrad of the live rows are the eager
+ones): a step of strided convolutions can be captured whole (bench.py config 3).  What does NOT carry
+over to dead rows is anything that mixes rows: BatchNorm batch statistics, and a SubM layer's centre
+pair (a dead row pairs with itself) -- networks with those train eagerly.
 """
 from typing import Dict, List, Optional, Sequence
 

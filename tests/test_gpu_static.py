@@ -170,8 +170,38 @@ def test_bounds_from_recorded_voxel_counts(cuda):
     used = freeze_bounds(net, margin=1.5)
     assert used == {"0": int(max(sizes) * 1.5) + 1}
     assert list(strided_layers(net).values())[0].static_num_out == used["0"]
-    # a training-mode forward ignores the bound
-    list(strided_layers(net).values())[0].static_num_out = 10
+    assert freeze_bounds(net, {}, margin=0) == {"0": 0}
     f, idx = _scene_tensors(shape, 3500, bs, C, 1, cuda, torch.float16)
     assert net(spconv.SparseConvTensor(f, idx, shape, bs)).indices.shape[0] == sizes[0]
-    assert freeze_bounds(net, {}, margin=0) == {"0": 0}
+
+
+def test_static_training_step_matches_eager(cuda):
+    """A strided layer with a frozen bound keeps it in training mode: the Native lists come out of the same
+    sync-free build, forward / dgrad / wgrad over a padded input equal the eager step on the live rows."""
+    import spconv_amd.pytorch as spconv
+    shape, bs, C, K = [24, 24, 24], 1, 16, 32
+    torch.manual_seed(3)
+    net = spconv.SparseConv3d(C, K, 3, 2, 1, bias=False).to(cuda).half().train()
+    f, idx = _scene_tensors(shape, 4000, bs, C, 11, cuda, torch.float16)
+    fe = f.clone().requires_grad_(True)
+    ye = net(spconv.SparseConvTensor(fe, idx, shape, bs))
+    n_out = ye.features.shape[0]
+    cap, n_static = n_out + 300, 4500
+    g = ((torch.rand((cap, K), device=cuda) - 0.5) * 0.2).half()
+    ye.features.backward(g[:n_out])
+    dw_e, din_e = net.weight.grad.clone(), fe.grad.clone()
+    net.weight.grad = None
+    net.static_num_out = cap
+    fs = torch.zeros((n_static, C), dtype=torch.float16, device=cuda)
+    fs[:f.shape[0]] = f
+    fs.requires_grad_(True)
+    ids = torch.full((n_static, 4), -1, dtype=torch.int32, device=cuda)
+    ids[:idx.shape[0]] = idx
+    ys = net(spconv.SparseConvTensor(fs, ids, shape, bs))
+    assert ys.features.shape[0] == cap
+    assert torch.equal(ys.indices[:n_out], ye.indices) and bool((ys.indices[n_out:] == -1).all())
+    assert torch.equal(ys.features[:n_out], ye.features)
+    ys.features.backward(g)
+    assert torch.equal(fs.grad[:f.shape[0]], din_e) and not bool(fs.grad[f.shape[0]:].any())
+    rel = float((net.weight.grad.float() - dw_e.float()).norm() / dw_e.float().norm())
+    assert rel < 1e-3, rel                      # (the weight-gradient ranges are cut by row count: order differs)
