@@ -385,7 +385,10 @@ int spx_hash_items(void *table_keys, void *table_vals, int capacity, int key_byt
  *                     training, read when not)
  *   save_mean / save_invstd [C] fp32: batch statistics for the backward pass (training)
  *   relu              fuse max(0, .) into the output (and its mask into the backward pass)
- *   ws                spx_batchnorm_ws_bytes(n, C) bytes */
+ *   ws                spx_batchnorm_ws_bytes(n, C) bytes
+ *   n_live            NULL, or a DEVICE int32: only the first *n_live rows are rows of the scene (static-shape
+ *                     tensors, see spx_conv_rulebook_static): statistics over those rows, the others come out
+ *                     as zeros (y and dx) */
 size_t spx_batchnorm_ws_bytes(int n, int C);
 /* weight / bias / running_mean / running_var: [C] vectors of dtype `param_dtype` (SPX_F32, or the
  * 16-bit dtype of a model converted with .half() / .bfloat16()); any of them may be NULL.
@@ -395,14 +398,14 @@ int spx_batchnorm_fwd(const void *x, void *y, int n, int C, int dtype, const voi
                       const void *bias, void *running_mean, void *running_var,
                       long long *num_batches_tracked, int param_dtype, int training, float momentum,
                       float eps, int relu, float *save_mean, float *save_invstd, void *ws,
-                      size_t ws_bytes, spx_stream_t stream);
+                      size_t ws_bytes, const int32_t *n_live, spx_stream_t stream);
 /* use_batch_stats = 1: `mean` / `invstd` are the saved fp32 batch statistics (training);
  * 0: fp32 copies of running_mean and 1 / sqrt(running_var + eps) (evaluation mode with gradients).
  * dweight / dbias: [C] of `param_dtype`, or NULL. */
 int spx_batchnorm_bwd(const void *x, const void *dy, void *dx, int n, int C, int dtype,
                       const void *weight, const void *bias, int param_dtype, const float *mean,
                       const float *invstd, int use_batch_stats, int relu, void *dweight, void *dbias,
-                      void *ws, size_t ws_bytes, spx_stream_t stream);
+                      void *ws, size_t ws_bytes, const int32_t *n_live, spx_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -52,9 +52,9 @@ SIGNATURES = {
     "spx_batchnorm_ws_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "spx_batchnorm_fwd": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int,
-                                         vp, vp, vp, ctypes.c_size_t, vp]),
+                                         vp, vp, vp, ctypes.c_size_t, vp, vp]),
     "spx_batchnorm_bwd": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int,
-                                         vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_size_t, vp]),
+                                         vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_size_t, vp, vp]),
     "spx_mask_argsort_ws_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "spx_mask_argsort": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_size_t, vp]),
     "spx_native_to_table": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 5 + [vp, vp, vp]),

@@ -94,6 +94,15 @@ __device__ __forceinline__ void stp(void *p, int dt, int i, float v) {
   else static_cast<uint16_t *>(p)[i] = static_cast<uint16_t>(Vec<SPX_BF16>::rne(v));
 }
 
+// Static-shape tensors (spconv_amd/pytorch/static.py): only the first *n_live rows are rows of the scene,
+// the rest is padding ("dead rows").  Statistics run over the live rows; dead rows come out as zeros in
+// both directions, so nothing downstream (a SubM layer's centre pair, a weight gradient) sees them.
+__device__ __forceinline__ int live_rows(const int32_t *n_live, int n) {
+  if (!n_live) return n;
+  const int v = *n_live;
+  return v < 0 ? 0 : (v < n ? v : n);
+}
+
 // A block owns rows [r0, r1); thread t reads the 16-byte piece (t % P) of rows r0 + t / P + i * (kT / P),
 // P = pieces per row = C / VPL (a power of two <= 64 is not required: kT / P rows per sweep, threads past
 // (kT / P) * P idle).
@@ -165,11 +174,12 @@ __device__ __forceinline__ void piece_reduce(float (&a)[VPL], float (&b)[VPL], i
 // partial[b][0][c] = rows of block b, [1] = mean, [2] = M2 (sum of squared deviations)
 template <int DT>
 __global__ void __launch_bounds__(kT)
-bn_partial_kernel(const u32x4 *__restrict__ x, int n, int C, float *__restrict__ partial) {
+bn_partial_kernel(const u32x4 *__restrict__ x, int n, int C, float *__restrict__ partial,
+                  const int32_t *__restrict__ n_live) {
   constexpr int VPL = Vec<DT>::VPL;
   __shared__ float lds[2][kT][VPL + 1];
   const int P = C / VPL;
-  const RowSplit s = row_split(n, P, gridDim.x);
+  const RowSplit s = row_split(live_rows(n_live, n), P, gridDim.x);
   float shift[VPL], sum[VPL], sq[VPL];
 #pragma unroll
   for (int i = 0; i < VPL; ++i) shift[i] = sum[i] = sq[i] = 0.f;
@@ -268,7 +278,7 @@ __global__ void __launch_bounds__(kT)
 bn_apply_kernel(const u32x4 *__restrict__ x, u32x4 *__restrict__ y, long long pieces, int C,
                 const void *__restrict__ stat1, const void *__restrict__ stat2,
                 const void *__restrict__ weight, const void *__restrict__ bias, int pdt, float eps,
-                int stat_is_var, int relu) {
+                int stat_is_var, int relu, const int32_t *__restrict__ n_live, int n) {
   constexpr int VPL = Vec<DT>::VPL;
   __shared__ __attribute__((aligned(16))) float l_sc[kT], l_sh[kT];
   if (threadIdx.x < C) {
@@ -281,6 +291,7 @@ bn_apply_kernel(const u32x4 *__restrict__ x, u32x4 *__restrict__ y, long long pi
   }
   __syncthreads();
   const int P = C / VPL;
+  const long long live = static_cast<long long>(live_rows(n_live, n)) * P;
   for (long long i = static_cast<long long>(blockIdx.x) * kT + threadIdx.x; i < pieces;
        i += static_cast<long long>(gridDim.x) * kT) {
     const int c0 = static_cast<int>(i % P) * VPL;
@@ -290,7 +301,7 @@ bn_apply_kernel(const u32x4 *__restrict__ x, u32x4 *__restrict__ y, long long pi
     for (int e = 0; e < VPL; ++e) {
       float v = f[e] * l_sc[c0 + e] + l_sh[c0 + e];
       if (relu) v = v > 0.f ? v : 0.f;
-      f[e] = v;
+      f[e] = i < live ? v : 0.f;
     }
     __builtin_nontemporal_store(Vec<DT>::pack(f), &y[i]);      // (not read again by this launch)
   }
@@ -302,11 +313,11 @@ __global__ void __launch_bounds__(kT)
 bn_bwd_partial_kernel(const u32x4 *__restrict__ x, const u32x4 *__restrict__ dy, int n, int C,
                       const float *__restrict__ mean, const float *__restrict__ invstd,
                       const void *__restrict__ weight, const void *__restrict__ bias, int pdt, int relu,
-                      float *__restrict__ partial) {
+                      float *__restrict__ partial, const int32_t *__restrict__ n_live) {
   constexpr int VPL = Vec<DT>::VPL;
   __shared__ float lds[2][kT][VPL + 1];
   const int P = C / VPL;
-  const RowSplit s = row_split(n, P, gridDim.x);
+  const RowSplit s = row_split(live_rows(n_live, n), P, gridDim.x);
   float s1[VPL], s2[VPL], mu[VPL], is[VPL], w[VPL], bb[VPL];
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
@@ -376,13 +387,14 @@ bn_bwd_apply_kernel(const u32x4 *__restrict__ x, const u32x4 *__restrict__ dy, u
                     long long pieces, int n, int C, const float *__restrict__ mean,
                     const float *__restrict__ invstd, const void *__restrict__ weight,
                     const void *__restrict__ bias, int pdt, const float *__restrict__ sums, int relu,
-                    int use_batch_stats) {
+                    int use_batch_stats, const int32_t *__restrict__ n_live) {
   constexpr int VPL = Vec<DT>::VPL;
   // xhat = x * l_a + l_b;  relu mask: xhat * l_w + l_bias <= 0;  dx = l_g * (dy' - l_c1 - xhat * l_c2)
   __shared__ __attribute__((aligned(16))) float l_a[kT], l_b[kT], l_w[kT], l_bias[kT], l_g[kT], l_c1[kT], l_c2[kT];
+  const int n_eff = live_rows(n_live, n);
   if (threadIdx.x < C) {
     const int c = threadIdx.x;
-    const float inv_n = (use_batch_stats && n > 0) ? 1.f / static_cast<float>(n) : 0.f;
+    const float inv_n = (use_batch_stats && n_eff > 0) ? 1.f / static_cast<float>(n_eff) : 0.f;
     const float w = weight ? ldp(weight, pdt, c) : 1.f;
     l_a[c] = invstd[c];
     l_b[c] = -mean[c] * invstd[c];
@@ -394,6 +406,7 @@ bn_bwd_apply_kernel(const u32x4 *__restrict__ x, const u32x4 *__restrict__ dy, u
   }
   __syncthreads();
   const int P = C / VPL;
+  const long long live = static_cast<long long>(n_eff) * P;
   for (long long i = static_cast<long long>(blockIdx.x) * kT + threadIdx.x; i < pieces;
        i += static_cast<long long>(gridDim.x) * kT) {
     const int c0 = static_cast<int>(i % P) * VPL;
@@ -406,7 +419,7 @@ bn_bwd_apply_kernel(const u32x4 *__restrict__ x, const u32x4 *__restrict__ dy, u
       const float xh = f[e] * l_a[c] + l_b[c];
       float gg = g[e];
       if (relu && xh * l_w[c] + l_bias[c] <= 0.f) gg = 0.f;
-      f[e] = l_g[c] * (gg - l_c1[c] - xh * l_c2[c]);
+      f[e] = i < live ? l_g[c] * (gg - l_c1[c] - xh * l_c2[c]) : 0.f;
     }
     __builtin_nontemporal_store(Vec<DT>::pack(f), &dx[i]);
   }
@@ -451,7 +464,7 @@ int spx_batchnorm_fwd(const void *x, void *y, int n, int C, int dtype, const voi
                       const void *bias, void *running_mean, void *running_var,
                       long long *num_batches_tracked, int param_dtype, int training, float momentum,
                       float eps, int relu, float *save_mean, float *save_invstd, void *ws,
-                      size_t ws_bytes, spx_stream_t stream) {
+                      size_t ws_bytes, const int32_t *n_live, spx_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   SPX_CHECK(bn_shape_ok(C, dtype), "batchnorm: C = %d must be a multiple of %d (<= 256), dtype f16/bf16/f32", C,
             dtype == SPX_F32 ? 4 : 8);
@@ -467,7 +480,7 @@ int spx_batchnorm_fwd(const void *x, void *y, int n, int C, int dtype, const voi
               "training needs save_mean / save_invstd and the workspace");
     const int G = bn_blocks(n);
     float *partial = static_cast<float *>(ws);
-#define SPX_BN_PARTIAL(D) hipLaunchKernelGGL(bn_partial_kernel<D>, dim3(G), dim3(kT), 0, s, xv, n, C, partial)
+#define SPX_BN_PARTIAL(D) hipLaunchKernelGGL(bn_partial_kernel<D>, dim3(G), dim3(kT), 0, s, xv, n, C, partial, n_live)
     SPX_BN_DISPATCH(dtype, SPX_BN_PARTIAL);
 #undef SPX_BN_PARTIAL
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(kT), 0, s, partial, G, C, eps, momentum, save_mean,
@@ -475,7 +488,7 @@ int spx_batchnorm_fwd(const void *x, void *y, int n, int C, int dtype, const voi
 #define SPX_BN_APPLY(D)                                                                                    \
   hipLaunchKernelGGL(bn_apply_kernel<D>, dim3(stream_grid(pieces)), dim3(kT), 0, s, xv, yv, pieces, C,     \
                      static_cast<const void *>(save_mean), static_cast<const void *>(save_invstd), weight,  \
-                     bias, param_dtype, eps, 0, relu)
+                     bias, param_dtype, eps, 0, relu, n_live, n)
     SPX_BN_DISPATCH(dtype, SPX_BN_APPLY);
 #undef SPX_BN_APPLY
   } else {
@@ -483,7 +496,7 @@ int spx_batchnorm_fwd(const void *x, void *y, int n, int C, int dtype, const voi
 #define SPX_BN_APPLY(D)                                                                                    \
   hipLaunchKernelGGL(bn_apply_kernel<D>, dim3(stream_grid(pieces)), dim3(kT), 0, s, xv, yv, pieces, C,     \
                      static_cast<const void *>(running_mean), static_cast<const void *>(running_var),      \
-                     weight, bias, param_dtype, eps, 1, relu)
+                     weight, bias, param_dtype, eps, 1, relu, n_live, n)
     SPX_BN_DISPATCH(dtype, SPX_BN_APPLY);
 #undef SPX_BN_APPLY
   }
@@ -494,7 +507,7 @@ int spx_batchnorm_fwd(const void *x, void *y, int n, int C, int dtype, const voi
 int spx_batchnorm_bwd(const void *x, const void *dy, void *dx, int n, int C, int dtype,
                       const void *weight, const void *bias, int param_dtype, const float *mean,
                       const float *invstd, int use_batch_stats, int relu, void *dweight, void *dbias,
-                      void *ws, size_t ws_bytes, spx_stream_t stream) {
+                      void *ws, size_t ws_bytes, const int32_t *n_live, spx_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   SPX_CHECK(bn_shape_ok(C, dtype), "batchnorm: unsupported C = %d / dtype", C);
   SPX_CHECK(param_dtype == SPX_F32 || param_dtype == SPX_F16 || param_dtype == SPX_BF16, "bad parameter dtype");
@@ -514,7 +527,7 @@ int spx_batchnorm_bwd(const void *x, const void *dy, void *dx, int n, int C, int
   const u32x4 *xv = static_cast<const u32x4 *>(x), *gv = static_cast<const u32x4 *>(dy);
 #define SPX_BN_BP(D)                                                                                        \
   hipLaunchKernelGGL(bn_bwd_partial_kernel<D>, dim3(G), dim3(kT), 0, s, xv, gv, n, C, mean, invstd, weight, \
-                     bias, param_dtype, relu, partial)
+                     bias, param_dtype, relu, partial, n_live)
   SPX_BN_DISPATCH(dtype, SPX_BN_BP);
 #undef SPX_BN_BP
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(kT), 0, s, partial, G, C, sums, dweight, dbias,
@@ -522,7 +535,7 @@ int spx_batchnorm_bwd(const void *x, const void *dy, void *dx, int n, int C, int
 #define SPX_BN_BA(D)                                                                                        \
   hipLaunchKernelGGL(bn_bwd_apply_kernel<D>, dim3(stream_grid(pieces)), dim3(kT), 0, s, xv, gv,             \
                      static_cast<u32x4 *>(dx), pieces, n, C, mean, invstd, weight, bias, param_dtype, sums,  \
-                     relu, use_batch_stats)
+                     relu, use_batch_stats, n_live)
   SPX_BN_DISPATCH(dtype, SPX_BN_BA);
 #undef SPX_BN_BA
   SPX_LAUNCH_CHECK();

@@ -343,6 +343,9 @@ class SparseConvolution(SparseModule):
                                                need_native=torch.is_grad_enabled() or self.algo == ConvAlgo.Native,
                                                static_num_out=static)
                 self._static_n_out_dev = rb.n_out_dev
+                rb.in_n_live_dev = getattr(input, "n_live_dev", None)
+                if rb.n_out_dev is not None:      # live output rows: the count found, at most the bound
+                    rb.out_n_live_dev = rb.n_out_dev[:1].clamp(max=rb.n_out)
             except Exception:
                 # reference conv.py:289-297: say what was asked for and keep the inputs for a report
                 print(f"[Exception|rulebook] indices={tuple(indices.shape)},bs={batch_size},ss={spatial_shape},"
@@ -373,8 +376,13 @@ class SparseConvolution(SparseModule):
             out_features += bias_for_training
         if grad_path and not training and add_input is None:
             out_features = _apply_act(out_features, act_type, act_alpha, act_beta)
-        return self._finish(input, out_tensor, out_features, outids, indice_dict, out_spatial_shape, add_input,
-                            is_int8, name, features, t if input.benchmark else None)
+        out = self._finish(input, out_tensor, out_features, outids, indice_dict, out_spatial_shape, add_input,
+                           is_int8, name, features, t if input.benchmark else None)
+        # live rows of a static-shape tensor: SubM keeps the input's, a strided layer has its own count, an
+        # inverse layer returns to the rows its partner started from
+        out.n_live_dev = (rb.in_n_live_dev if self.inverse else
+                          getattr(input, "n_live_dev", None) if self.subm else rb.out_n_live_dev)
+        return out
 
     def _run_kernels(self, grad_path, is_int8, input, features, weight, rb, num_out, algo, bias_for_infer,
                      act_type, act_alpha, act_beta, output_scale, channel_scale, add_input):

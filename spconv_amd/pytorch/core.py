@@ -71,6 +71,9 @@ class Rulebook:
         # static-shape build (ops.build_rulebook(static_num_out=...)): device int32 [2] =
         # {distinct outputs found, hash-table overflow}; rows >= the count are dead.  None otherwise.
         self.n_out_dev = None
+        # live-row counts (device int32 [1] or None = all) of the input / output row sets
+        self.in_n_live_dev = None
+        self.out_n_live_dev = None
 
     def _ensure_native(self) -> None:
         """Inference builds only the dense tables; the ConvAlgo.Native lists (consumed by wgrad
@@ -208,6 +211,9 @@ class SparseConvTensor(metaclass=torch.fx.ProxyableClassMeta):
             self._timer = CUDAKernelTimer(True)
         self.force_algo = force_algo
         self.int8_scale: Optional[np.ndarray] = None
+        # static-shape tensors (spconv_amd/pytorch/static.py): device int32 [1], the number of leading rows
+        # that are rows of the scene (the rest is padding with batch index -1); None = every row
+        self.n_live_dev: Optional[torch.Tensor] = None
 
     def __repr__(self):
         return f"SparseConvTensor[shape={self._features.shape}]"

@@ -95,9 +95,15 @@ class SparseSequential(SparseModule):
                         fuse = (i < len(mods) and type(mods[i]) is nn.ReLU and not mods[i]._forward_hooks
                                 and not mods[i]._forward_pre_hooks and not mods[i]._backward_hooks
                                 and not getattr(mods[i], "_backward_pre_hooks", None))
-                        input = input.replace_feature(norm.batch_norm(input.features, module, relu=fuse))
+                        input = input.replace_feature(norm.batch_norm(input.features, module, relu=fuse,
+                                                                      n_live=getattr(input, "n_live_dev", None)))
                         i += 1 if fuse else 0
                     else:
+                        if (getattr(input, "n_live_dev", None) is not None and getattr(module, "training", False)
+                                and isinstance(module, nn.modules.batchnorm._BatchNorm)):
+                            raise RuntimeError("a static-shape tensor (padding rows) needs the batch statistics of "
+                                               "csrc/norm.hip; this BatchNorm layer takes torch's path "
+                                               "(norm.supported: dtype / channel count / hooks)")
                         input = input.replace_feature(module(input.features))
             else:
                 input = module(input)

@@ -49,7 +49,8 @@ def _param_dtype(*tensors) -> Optional[torch.dtype]:
 
 class _BatchNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu, nbt=None):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu, nbt=None,
+                n_live=None):
         L = _lib.load()
         x = x.contiguous()
         n, C = x.shape
@@ -63,13 +64,14 @@ class _BatchNormFn(torch.autograd.Function):
             _lib.check(L.spx_batchnorm_fwd(x.data_ptr(), y.data_ptr(), n, C, _DT[x.dtype], p(weight), p(bias),
                                            p(running_mean), p(running_var), p(nbt), _DT[pdt], int(training), float(momentum),
                                            float(eps), int(relu), stats[0].data_ptr(), stats[1].data_ptr(),
-                                           ws.data_ptr(), ws.numel(), torch._C._cuda_getCurrentRawStream(dev.index)))
+                                           ws.data_ptr(), ws.numel(), p(n_live),
+                                           torch._C._cuda_getCurrentRawStream(dev.index)))
         if training:
             mean, invstd = stats[0], stats[1]
         else:
             mean, invstd = running_mean.float(), torch.rsqrt(running_var.float() + eps)
         ctx.save_for_backward(x, weight, bias, mean, invstd)
-        ctx.training, ctx.relu, ctx.pdt = bool(training), bool(relu), pdt
+        ctx.training, ctx.relu, ctx.pdt, ctx.n_live = bool(training), bool(relu), pdt, n_live
         return y
 
     @staticmethod
@@ -89,12 +91,15 @@ class _BatchNormFn(torch.autograd.Function):
             _lib.check(L.spx_batchnorm_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), n, C, _DT[x.dtype], p(weight),
                                            p(bias), _DT[ctx.pdt], mean.data_ptr(), invstd.data_ptr(),
                                            int(ctx.training), int(ctx.relu), p(dw), p(db), ws.data_ptr(), ws.numel(),
-                                           torch._C._cuda_getCurrentRawStream(dev.index)))
-        return dx, dw, db, None, None, None, None, None, None, None
+                                           p(ctx.n_live), torch._C._cuda_getCurrentRawStream(dev.index)))
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
-def batch_norm(features: torch.Tensor, bn: nn.BatchNorm1d, relu: bool = False) -> torch.Tensor:
-    """``relu(bn(features))`` (relu optional) with torch.nn.BatchNorm1d's bookkeeping."""
+def batch_norm(features: torch.Tensor, bn: nn.BatchNorm1d, relu: bool = False,
+               n_live: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``relu(bn(features))`` (relu optional) with torch.nn.BatchNorm1d's bookkeeping.  n_live: device
+    int32 scalar of a static-shape tensor (spconv_amd/pytorch/static.py) -- statistics over the first
+    n_live rows, the padding rows come out as zeros in both directions."""
     momentum = 0.0 if bn.momentum is None else bn.momentum
     nbt = None
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
@@ -109,4 +114,4 @@ def batch_norm(features: torch.Tensor, bn: nn.BatchNorm1d, relu: bool = False) -
     update = bn.training and bn.track_running_stats
     return _BatchNormFn.apply(features, bn.weight, bn.bias, bn.running_mean if (update or not use_batch) else None,
                               bn.running_var if (update or not use_batch) else None, use_batch, momentum, bn.eps,
-                              relu, nbt)
+                              relu, nbt, n_live)

@@ -93,6 +93,9 @@ class _SparsePoolBase(SparseModule):
                                    self.padding, self.dilation, [0] * self.ndim, self.subm, False,
                                    need_bwd_table=True, need_native=not static, static_num_out=static)
         self._static_n_out_dev = rb.n_out_dev
+        rb.in_n_live_dev = getattr(input, "n_live_dev", None)
+        if rb.n_out_dev is not None:
+            rb.out_n_live_dev = rb.n_out_dev[:1].clamp(max=rb.n_out)
         outids = rb.out_indices
         if input.benchmark:
             torch.cuda.synchronize()
@@ -135,6 +138,7 @@ class _SparsePoolBase(SparseModule):
         out_tensor.indices = outids
         out_tensor.indice_dict = indice_dict
         out_tensor.spatial_shape = list(out_spatial_shape)
+        out_tensor.n_live_dev = getattr(input, "n_live_dev", None) if self.subm else rb.out_n_live_dev
         return out_tensor
 
 

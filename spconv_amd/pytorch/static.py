@@ -111,6 +111,7 @@ class StaticInference:
         nd = len(self.spatial_shape)
         self.features = torch.zeros((self.max_voxels, in_channels), dtype=dtype, device=self.device)
         self.indices = torch.full((self.max_voxels, nd + 1), -1, dtype=torch.int32, device=self.device)
+        self.n_live = torch.zeros((1,), dtype=torch.int32, device=self.device)   # rows of the current scene
         self._live = 0
         self.graph = None
         self.out = None
@@ -131,6 +132,7 @@ class StaticInference:
 
     def _forward(self):
         x = SparseConvTensor(self.features, self.indices, self.spatial_shape, self.batch_size)
+        x.n_live_dev = self.n_live          # (normalisation layers write zeros into the padding rows)
         return self.net(x)
 
     def load(self, features: torch.Tensor, indices: torch.Tensor) -> None:
@@ -144,6 +146,7 @@ class StaticInference:
         if n < self._live:                          # rows the previous scene used and this one does not
             self.features[n:self._live].zero_()
             self.indices[n:self._live].fill_(-1)
+        self.n_live.fill_(n)
         self._live = n
 
     def __call__(self, features: torch.Tensor, indices: torch.Tensor):

@@ -136,3 +136,37 @@ def test_half_model_parameters_are_read_in_place(cuda):
     assert torch.allclose(bn.running_var.float(), ref.running_var.float(), rtol=2e-3, atol=2e-3)
     assert torch.allclose(bn.weight.grad.float(), ref.weight.grad.float(), rtol=2e-2, atol=2e-2)
     assert torch.allclose(bn.bias.grad.float(), ref.bias.grad.float(), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 2e-3)])
+@pytest.mark.parametrize("n,live,C", [(50_000, 41_237, 32), (5_000, 1, 64), (9_000, 9_000, 16), (3_000, 0, 32)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_batchnorm_over_the_live_rows_of_a_static_tensor(cuda, dtype, tol, n, live, C, relu):
+    """n_live (device int32): the statistics, the affine gradients and dx are those of the first `live` rows
+    alone; padding rows come out as zeros in both directions (spconv_amd/pytorch/static.py)."""
+    from spconv_amd.pytorch import norm
+    torch.manual_seed(n + live + C)
+    x = (torch.randn(n, C, device=cuda) * 1.3 + torch.linspace(-2, 2, C, device=cuda)).to(dtype)
+    x[live:] = 1000.0                              # junk in the padding must not reach the statistics
+    dy = torch.randn(n, C, device=cuda).to(dtype)
+    bn = nn.BatchNorm1d(C, eps=1e-3, momentum=0.1).to(cuda)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    ref = copy.deepcopy(bn)
+    n_live = torch.tensor([live], dtype=torch.int32, device=cuda)
+    xg = x.clone().requires_grad_(True)
+    y = norm.batch_norm(xg, bn, relu=relu, n_live=n_live)
+    y.backward(dy)
+    assert not bool(y[live:].any()) and not bool(xg.grad[live:].any())
+    if live <= 1:
+        return                                     # (torch refuses one value per channel; the zeros are the claim)
+    xr = x[:live].clone().requires_grad_(True)
+    yr = norm.batch_norm(xr, ref, relu=relu)       # the same kernels on the live rows alone
+    yr.backward(dy[:live])
+    scale = float(yr.float().abs().max())
+    assert float((y[:live].float() - yr.float()).abs().max()) <= tol * max(scale, 1.0)
+    assert float((xg.grad[:live].float() - xr.grad.float()).abs().max()) <= tol * max(float(xr.grad.float().abs().max()), 1.0)
+    for a, b in ((bn.weight.grad, ref.weight.grad), (bn.bias.grad, ref.bias.grad),
+                 (bn.running_mean, ref.running_mean), (bn.running_var, ref.running_var)):
+        assert float((a.float() - b.float()).abs().max()) <= 1e-3 * max(float(b.float().abs().max()), 1.0)

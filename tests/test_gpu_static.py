@@ -205,3 +205,45 @@ def test_static_training_step_matches_eager(cuda):
     assert torch.equal(fs.grad[:f.shape[0]], din_e) and not bool(fs.grad[f.shape[0]:].any())
     rel = float((net.weight.grad.float() - dw_e.float()).norm() / dw_e.float().norm())
     assert rel < 1e-3, rel                      # (the weight-gradient ranges are cut by row count: order differs)
+
+
+def test_static_training_step_with_subm_and_batchnorm(cuda):
+    """SubM + BatchNorm + ReLU + strided layers in TRAINING mode over a padded input: the tensors carry the
+    device-side live-row count, the normalisation takes its statistics over the live rows and zeroes the
+    padding in both directions, so parameter gradients and live outputs equal the eager step's (up to
+    the summation order of the statistics)."""
+    import spconv_amd.pytorch as spconv
+    shape, bs, C = [32, 40, 40], 2, 8
+    net = _backbone(spconv, C, cuda, torch.float16).train()
+    eager = copy.deepcopy(net)
+    f, idx = _scene_tensors(shape, 4000, bs, C, 5, cuda, torch.float16)
+    n = f.shape[0]
+    fe = f.clone().requires_grad_(True)
+    ye = eager(spconv.SparseConvTensor(fe, idx, shape, bs))
+    n_out = ye.features.shape[0]
+    names = list(__import__("spconv_amd.pytorch.static", fromlist=["x"]).strided_layers(net))
+    mods = dict(net.named_modules())
+    mods[names[0]].static_num_out, mods[names[1]].static_num_out = 13_000, n_out + 200
+    g = ((torch.rand((n_out + 200, 64), device=cuda) - 0.5) * 0.2).half()
+    ye.features.backward(g[:n_out])
+    n_static = n + 1234
+    fs = torch.zeros((n_static, C), dtype=torch.float16, device=cuda)
+    fs[:n] = f
+    fs.requires_grad_(True)
+    ids = torch.full((n_static, 4), -1, dtype=torch.int32, device=cuda)
+    ids[:n] = idx
+    x = spconv.SparseConvTensor(fs, ids, shape, bs)
+    x.n_live_dev = torch.tensor([n], dtype=torch.int32, device=cuda)
+    ys = net(x)
+    assert int(ys.n_live_dev) == n_out
+    assert torch.equal(ys.indices[:n_out], ye.indices)
+    assert not bool(ys.features[n_out:].any())                    # padding rows: zeros after the last BN + ReLU
+    err = float((ys.features[:n_out].float() - ye.features.float()).abs().max())
+    assert err <= 2e-2 * float(ye.features.float().abs().max()), err
+    ys.features.backward(g)
+    assert not bool(fs.grad[n:].any())
+    for (name, pa), pb in zip(net.named_parameters(), eager.parameters()):
+        rel = float((pa.grad.float() - pb.grad.float()).norm() / pb.grad.float().norm().clamp_min(1e-12))
+        assert rel < 2e-2, (name, rel)
+    rel = float((fs.grad[:n].float() - fe.grad.float()).norm() / fe.grad.float().norm())
+    assert rel < 2e-2, rel
