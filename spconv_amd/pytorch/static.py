@@ -1,4 +1,4 @@
-"""Static-shape inference: one hipGraph for a whole sparse backbone, rulebook builds included.
+"""Static shapes: one hipGraph for a whole sparse backbone -- inference or a training step --, rulebook builds included.
 
 The reference's deployment path sizes every buffer before the first layer runs and bounds the number
 of outputs of each strided layer (num_out_act_bound: spconv/pytorch/ops.py:263-266,644-645; the
@@ -18,12 +18,18 @@ tables, gather-GEMMs -- can be recorded once and replayed per scene:
     the first `bound` in the canonical order, like the reference's bounded mode)
 
 Live rows of the result are bit-identical to the eager, unbounded forward pass of the same scene
-(tests/test_gpu_static.py).  `StaticInference` is the eval-mode runner.  A strided layer keeps its
-frozen bound in training mode as well (the Native lists the weight-gradient kernels read come out of
-the same sync-free build; dead rows are in no pair, so dgrad / wgrad of the live rows are the eager
-ones): a step of strided convolutions can be captured whole (bench.py config 3).  What does NOT carry
-over to dead rows is anything that mixes rows: BatchNorm batch statistics, and a SubM layer's centre
-pair (a dead row pairs with itself) -- networks with those train eagerly.
+(tests/test_gpu_static.py).  `StaticInference` is the eval-mode runner.
+
+Training.  A strided layer keeps its frozen bound in training mode (the Native lists the weight-gradient
+kernels read come out of the same sync-free build; dead rows are in no pair), and every SparseConvTensor
+carries `n_live_dev`, the device-side number of leading live rows (SubM: the input's; strided layer:
+min(count found, bound); inverse convolution: its partner's input).  The BatchNorm kernels
+(spconv_amd/pytorch/norm.py) take their statistics over the live rows and write zeros into the padding
+rows of y and dx, so nothing that mixes rows -- batch statistics, a SubM layer's centre pair (a dead row
+pairs with itself), the weight gradients -- ever sees a dead row.  Conditions: the padding rows of the
+input FEATURES are zero, and either the loss has zero gradient on dead rows or the network ends in a
+normalisation layer.  bench.py (`static_training_steps`) captures the whole training step of BASELINE
+configs 3 and 4 this way and checks it against the eager step before timing it.
 """
 from typing import Dict, List, Optional, Sequence
 
