@@ -67,6 +67,33 @@ def rel_err(a, ref):
     return float(np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-12))
 
 
+HALF_ULP = {"float16": 2.0 ** -11, "bfloat16": 2.0 ** -8, "float32": 2.0 ** -24}
+
+
+def assert_close_abs_sum(a, ref, abs_sum, dtype, c=1e-6, name=""):
+    """Element-wise bound with no free floor: |a - ref| <= u |ref| + c A, where u is half an ulp of the
+    OUTPUT dtype (the one rounding the kernel adds on top of its fp32 accumulator) and A is the same sum
+    with every operand replaced by its magnitude (the oracle run on |f|, |w|, |dout|) -- the quantity
+    fp32 accumulation error is relative to.  c: accumulation in an unknown order over n terms errs by about
+    sqrt(n) 2^-24 A (n <= 27 * 64: 2.5e-6 A); measured on MI355X at the full-size configs 2 / 2b the
+    excess over u |ref| is <= 2.2e-8 A for every element of out, din and dW in fp16 and bf16
+    (tools/tol_probe.py), so c = 1e-6 leaves a factor 50 and still holds a cancelling element to ~1e-6 of
+    its terms instead of to a fraction of the tensor's rms."""
+    a = np.asarray(a, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    A = np.asarray(abs_sum, dtype=np.float64)
+    assert a.shape == ref.shape == A.shape, (a.shape, ref.shape, A.shape)
+    if ref.size == 0:
+        return
+    u = HALF_ULP[str(dtype).replace("torch.", "")]
+    bound = u * np.abs(ref) * (1 + 1e-6) + c * A + 1e-30
+    bad = np.abs(a - ref) > bound
+    if bad.any():
+        i = np.unravel_index(np.argmax((np.abs(a - ref) - bound) * bad), a.shape)
+        raise AssertionError(f"{name}: {int(bad.sum())} of {a.size} elements outside u|ref| + {c:g} A; worst at {i}: "
+                             f"got {a[i]:.8g}, want {ref[i]:.8g}, A {A[i]:.6g}")
+
+
 def assert_close_elementwise(a, ref, rtol, floor_frac=None, name=""):
     """Element-wise |a - ref| <= rtol * |ref| + floor, floor = floor_frac * rms(ref): every
     element within rtol of ITS OWN reference value, except that elements much smaller than the
