@@ -97,7 +97,7 @@ __device__ __forceinline__ int table_insert_min(const Table &t, hkey_t key, int3
         if (static_cast<uint32_t>(cur) > static_cast<uint32_t>(val)) atomicMin(&slots[slot], want);
         return static_cast<int>(slot);
       }
-      slot = (slot + 1) & t.mask;
+      slot = (slot + (1u << t.gbits)) & t.mask;      // (stays in its in-line position, see hash_key)
     }
     return -1;
   }
@@ -115,7 +115,7 @@ __device__ __forceinline__ int table_insert_min(const Table &t, hkey_t key, int3
         atomicMin(reinterpret_cast<unsigned int *>(&t.vals[slot]), static_cast<unsigned int>(val));
       return static_cast<int>(slot);
     }
-    slot = (slot + 1) & t.mask;
+    slot = (slot + (1u << t.gbits)) & t.mask;
   }
   return -1;
 }
@@ -130,7 +130,7 @@ __device__ __forceinline__ int32_t table_find(const Table &t, hkey_t key) {
       const unsigned long long v = slots[slot];
       if (static_cast<uint32_t>(v >> 32) == k32 && v != kEmptySlot) return static_cast<int32_t>(v);
       if (v == kEmptySlot) return -1;
-      slot = (slot + 1) & t.mask;
+      slot = (slot + (1u << t.gbits)) & t.mask;
     }
     return -1;
   }
@@ -139,7 +139,7 @@ __device__ __forceinline__ int32_t table_find(const Table &t, hkey_t key) {
     const hkey_t k = t.keys[slot];
     if (k == key) return t.vals[slot];
     if (k == -1LL) return -1;
-    slot = (slot + 1) & t.mask;
+    slot = (slot + (1u << t.gbits)) & t.mask;
   }
   return -1;
 }
@@ -327,7 +327,8 @@ __global__ void __launch_bounds__(kBlock)
 subm_probe4_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table t,
                    const int32_t *__restrict__ slot_of, int32_t *__restrict__ pair_fwd,
                    int32_t *__restrict__ pair_bwd, uint32_t *__restrict__ mask, int words,
-                   int32_t *__restrict__ groupcount, int ngroups) {
+                   int32_t *__restrict__ groupcount, int ngroups, int mask_pass = 0) {
+  // mask_pass: the masks come from a pass over the finished table instead of one atomicOr per entry
   __shared__ int lds_wave[kBlock / 64];
   const int o = blockIdx.x * kBlock + threadIdx.x;
   const int kv = g.kv, center = kv / 2;
@@ -340,7 +341,7 @@ subm_probe4_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table t,
   if (list == center) {
     if (o < n) {
       set(center, o, o);
-      atomicOr(&mask[static_cast<size_t>(o) * words + (center >> 5)], 1u << (center & 31));
+      if (!mask_pass) atomicOr(&mask[static_cast<size_t>(o) * words + (center >> 5)], 1u << (center & 31));
     }
     return;
   }
@@ -357,11 +358,11 @@ subm_probe4_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table t,
     }
     set(k, o, v);                             // own entry, hit or miss
     if (v >= 0) {
-      atomicOr(&mask[static_cast<size_t>(o) * words + (k >> 5)], 1u << (k & 31));
+      if (!mask_pass) atomicOr(&mask[static_cast<size_t>(o) * words + (k >> 5)], 1u << (k & 31));
       const int self = slot_of[o];
       if (self >= 0 && table_val(t, self) == o) {       // first row of its coordinate: mirror entry
         set(list, v, o);
-        atomicOr(&mask[static_cast<size_t>(v) * words + (list >> 5)], 1u << (list & 31));
+        if (!mask_pass) atomicOr(&mask[static_cast<size_t>(v) * words + (list >> 5)], 1u << (list & 31));
       }
     }
   }
@@ -562,11 +563,11 @@ constexpr int kProbeChunk = 9;
 // linear-probe walk of a packed table starting from an already loaded first slot word
 __device__ __forceinline__ int32_t packed_resolve(const unsigned long long *slots, uint32_t tmask,
                                                   uint32_t key32, uint32_t slot,
-                                                  unsigned long long v) {
+                                                  unsigned long long v, int gbits = 0) {
   for (uint32_t probe = 0; probe <= tmask; ++probe) {
     if (v == kEmptySlot) return -1;
     if (static_cast<uint32_t>(v >> 32) == key32) return static_cast<int32_t>(v);
-    slot = (slot + 1) & tmask;
+    slot = (slot + (1u << gbits)) & tmask;
     v = slots[slot];
   }
   return -1;
@@ -628,7 +629,7 @@ subm_probe_all_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table 
     }
     if (k0 == 0) {
       int own = -1;
-      if (hashed) own = PACKED ? packed_resolve(slots, t.mask, static_cast<uint32_t>(own_key), own_slot, own_word)
+      if (hashed) own = PACKED ? packed_resolve(slots, t.mask, static_cast<uint32_t>(own_key), own_slot, own_word, t.gbits)
                                  : table_find(t, own_key);
       first = own == o;
     }
@@ -642,7 +643,7 @@ subm_probe_all_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table 
       } else if (act[j] && (first || k > center)) {
         // a row that is not the first of its coordinate keeps only its k > centre half
         // (unordered_map::insert kept the first one, indices.py:1672: lookups never return it)
-        res = PACKED ? packed_resolve(slots, t.mask, key32[j], slot0[j], word[j]) : table_find(t, wide[PACKED ? 0 : j]);
+        res = PACKED ? packed_resolve(slots, t.mask, key32[j], slot0[j], word[j], t.gbits) : table_find(t, wide[PACKED ? 0 : j]);
       }
       if (live && kin) {
         pair_fwd[static_cast<size_t>(k) * n + o] = res;
@@ -1880,7 +1881,9 @@ int spx_subm_rulebook(const int32_t *indices, int n, int ndim, int batch_size,
   Table t;
   {
     hkey_t *keys = cv.take<hkey_t>(cap);
-    table_place(t, keys, cv.take<int32_t>(cap), cap, keys_fit_u32(g.batch, g.in_dims, 4));
+    // SPX_SUBM_GBITS (experiment): 2^g neighbouring cells of the last axis share a table line
+    table_place(t, keys, cv.take<int32_t>(cap), cap, keys_fit_u32(g.batch, g.in_dims, 4),
+                cap >= 1024 ? option_int("SPX_SUBM_GBITS", 0) : 0);
   }
   int32_t *blockcount = cv.take<int32_t>(static_cast<size_t>(kv) * nblk);
   int32_t *blockoff = cv.take<int32_t>(static_cast<size_t>(kv) * nblk);
@@ -1904,10 +1907,14 @@ int spx_subm_rulebook(const int32_t *indices, int n, int ndim, int batch_size,
       if (pair_bwd) fills.add(pair_bwd + static_cast<size_t>(kv / 2 + 1) * n, half, 0xFFFFFFFFu);
     }
     SPX_HIP(fills.launch(s));
-    hipLaunchKernelGGL(subm_insert_kernel, grid, dim3(kBlock), 0, s, indices, n, g, t, slot_of, mask, words);
+    const int mask_pass = option_int("SPX_SUBM_MASK_PASS", 0);
+    hipLaunchKernelGGL(subm_insert_kernel, grid, dim3(kBlock), 0, s, indices, n, g, t, slot_of,
+                       mask_pass ? static_cast<uint32_t *>(nullptr) : mask, words);
     const bool lists = pair_native || num_per_loc;
     hipLaunchKernelGGL(subm_probe4_kernel, dim3(div_up(n, kBlock), kv / 2 + 1), dim3(kBlock), 0, s, indices, n,
-                       g, t, slot_of, pair_fwd, pair_bwd, mask, words, lists ? groupcount : nullptr, nblk256);
+                       g, t, slot_of, pair_fwd, pair_bwd, mask, words, lists ? groupcount : nullptr, nblk256, mask_pass);
+    if (mask_pass)
+      hipLaunchKernelGGL(mask_from_table_kernel, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, pair_fwd, kv, n, words, mask);
     if (lists) {
       SPX_CHECK(!pair_native || num_per_loc || kv / 2 <= 64, "num_per_loc required for kv > 128");
       hipLaunchKernelGGL(subm_lists_kernel, dim3(nblk, kv / 2 + 1), dim3(kBlock), 0, s, pair_fwd, kv, n,

@@ -66,12 +66,13 @@ class _BatchNormFn(torch.autograd.Function):
                                            float(eps), int(relu), stats[0].data_ptr(), stats[1].data_ptr(),
                                            ws.data_ptr(), ws.numel(), p(n_live),
                                            torch._C._cuda_getCurrentRawStream(dev.index)))
+        # evaluation mode: the backward pass (frozen-BN fine-tuning) derives fp32 mean / 1/std from the running
+        # estimates when it runs -- an inference pass must not pay four small launches per layer for them
         if training:
-            mean, invstd = stats[0], stats[1]
+            ctx.save_for_backward(x, weight, bias, stats[0], stats[1])
         else:
-            mean, invstd = running_mean.float(), torch.rsqrt(running_var.float() + eps)
-        ctx.save_for_backward(x, weight, bias, mean, invstd)
-        ctx.training, ctx.relu, ctx.pdt, ctx.n_live = bool(training), bool(relu), pdt, n_live
+            ctx.save_for_backward(x, weight, bias, running_mean, running_var)
+        ctx.training, ctx.relu, ctx.pdt, ctx.n_live, ctx.eps = bool(training), bool(relu), pdt, n_live, float(eps)
         return y
 
     @staticmethod
@@ -79,6 +80,8 @@ class _BatchNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         L = _lib.load()
         x, weight, bias, mean, invstd = ctx.saved_tensors
+        if not ctx.training:           # saved: the running estimates
+            mean, invstd = mean.float(), torch.rsqrt(invstd.float() + ctx.eps)
         n, C = x.shape
         dev = x.device
         dy = dy.contiguous()
