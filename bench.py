@@ -963,7 +963,7 @@ def static_training_steps(net, data, bs, cin, shape, steps, warm, D: Dist, input
     gradients of scene 0 are compared with the eager, unbounded step before anything is timed."""
     import copy
     import spconv_amd.pytorch as spconv
-    from spconv_amd.pytorch.static import strided_layers
+    from spconv_amd.pytorch.static import StaticTrainingStep, strided_layers
     dev = D.dev
     S = len(data)
     net_e = copy.deepcopy(net)                       # eager, unbounded reference
@@ -976,54 +976,20 @@ def static_training_steps(net, data, bs, cin, shape, steps, warm, D: Dist, input
     for h in hooks:
         h.remove()
     bounds = {k: int(v * 1.1) + 1 for k, v in seen.items()}
-    layers = strided_layers(net)
-    for k, m in layers.items():
-        m.static_num_out = bounds[k]
     n_max = int(max(d[0].shape[0] for d in data) * 1.05) + 1
-    fbuf = torch.zeros((n_max, cin), dtype=torch.float16, device=dev).requires_grad_(input_grad)
-    ibuf = torch.full((n_max, len(shape) + 1), -1, dtype=torch.int32, device=dev)
-    nlive = torch.zeros((1,), dtype=torch.int32, device=dev)
+    layers = strided_layers(net)
     k_last = list(layers.values())[-1].out_channels
     gstat = ((torch.rand((bounds[list(layers)[-1]], k_last), device=dev) - 0.5) * 0.2).half()
-    live = [0]
+    runner = StaticTrainingStep(net, n_max, cin, shape, bs, torch.float16, bounds=bounds, out_grad=gstat,
+                                input_grad=input_grad, device=dev, example=(data[0][1], data[0][0]))
+    fbuf, g = runner.features, runner.graph
 
     def load(si):
-        ind, f, _ = data[si]
-        n = ind.shape[0]
-        with torch.no_grad():
-            fbuf[:n].copy_(f)
-            ibuf[:n].copy_(ind)
-            if n < live[0]:
-                fbuf[n:live[0]].zero_()
-                ibuf[n:live[0]].fill_(-1)
-            nlive.fill_(n)
-        live[0] = n
-
-    def compute():
-        net.zero_grad(set_to_none=True)
-        fbuf.grad = None
-        x = spconv.SparseConvTensor(fbuf, ibuf, shape, bs)
-        x.n_live_dev = nlive
-        y = net(x)
-        y_cap[0] = y
-        y.features.backward(gstat)
-    y_cap = [None]
-    load(0)
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(2):
-            compute()
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        compute()
-    counters = {k: m._static_n_out_dev for k, m in layers.items()}
+        runner.load(data[si][1], data[si][0])
     # parity of the captured step against the eager, unbounded one (scene 0)
     load(0)
     g.replay()
-    y_static = y_cap[0].features.detach()
+    y_static = runner.out.features.detach()
     ind, f, _ = data[0]
     fe = f.clone().requires_grad_(input_grad)
     ye = net_e(spconv.SparseConvTensor(fe, ind, shape, bs))
@@ -1069,10 +1035,8 @@ def static_training_steps(net, data, bs, cin, shape, steps, warm, D: Dist, input
             cnt[0] += 1
             g.replay()
     elapsed = timed_region(D, run_steps, warm, steps)
-    found = {k: v.cpu().tolist() for k, v in counters.items()}
-    over = {k: c for k, (c, o) in found.items() if c > bounds[k] or o}
-    for m in layers.values():
-        m.static_num_out = 0
+    over = runner.overflowed()
+    runner.release_bounds()
     return elapsed, {"bounds": bounds, "padded_input_rows": n_max, "dw_rel_diff_vs_eager": worst, "dw_rel_diff_noise_floor": floor, "out_rel_diff_vs_eager": out_diff,
                      "dw_rel_diff_worst_params": sorted(per_param, reverse=True)[:4],
                      "din_rel_diff_vs_eager": din, "overflowed": over}

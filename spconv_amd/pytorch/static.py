@@ -39,7 +39,7 @@ from spconv_amd.pytorch.conv import SparseConvolution
 from spconv_amd.pytorch.core import SparseConvTensor
 from spconv_amd.pytorch.pool import SparseMaxPool
 
-__all__ = ["StaticInference", "strided_layers", "freeze_bounds", "dense_static"]
+__all__ = ["StaticInference", "StaticTrainingStep", "strided_layers", "freeze_bounds", "dense_static"]
 
 
 def strided_layers(net: torch.nn.Module) -> Dict[str, torch.nn.Module]:
@@ -172,3 +172,91 @@ class StaticInference:
         """Layers whose last replay found more outputs than their bound (or filled their hash table):
         {layer: outputs found}.  Empty = every live row is exact."""
         return {k: c for k, (c, ovf) in self.counts().items() if c > self.bounds[k] or ovf}
+
+
+class StaticTrainingStep:
+    """One captured TRAINING step -- rulebook builds, forward, loss, backward -- for scenes of at most
+    `max_voxels` voxels; the module docstring states the conditions (zero padding in the input features; a loss
+    with zero gradient on dead rows, or a network that ends in a normalisation layer).
+
+        step = StaticTrainingStep(net, max_voxels, in_channels, spatial_shape, batch_size, bounds=...,
+                                  backward=lambda out: loss_of(out).backward())      # or out_grad=<[rows, K] tensor>
+        out = step(features, indices)       # replay: parameter .grad tensors now hold this scene's gradients
+        optimizer.step()                    # (outside the graph; the .grad tensors are static, do not set them to None)
+
+    `backward(out)` runs inside the capture and must be free of host reads; `out.n_live_dev` is the device-side
+    number of live output rows for a masked loss.  `input_grad=True` keeps the gradient of the input features
+    (`step.features.grad`).  `example=(features, indices)`: the scene the warm-up and capture passes run on --
+    they are real training-mode passes (BatchNorm running estimates move); without it they see an empty scene."""
+
+    def __init__(self, net: torch.nn.Module, max_voxels: int, in_channels: int, spatial_shape: Sequence[int],
+                 batch_size: int, dtype: torch.dtype = torch.float16, bounds: Optional[Dict[str, int]] = None,
+                 margin: float = 1.25, backward=None, out_grad: Optional[torch.Tensor] = None,
+                 input_grad: bool = False, device: Optional[torch.device] = None, warmup: int = 2,
+                 example=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("StaticTrainingStep needs the GPU (there is no CPU path)")
+        if (backward is None) == (out_grad is None):
+            raise ValueError("give exactly one of `backward` (callable on the output tensor) and `out_grad`")
+        self.net = net.train()
+        self.device = torch.device(device if device is not None else "cuda")
+        self.max_voxels, self.spatial_shape, self.batch_size = int(max_voxels), list(spatial_shape), int(batch_size)
+        self.bounds = freeze_bounds(net, bounds, margin)
+        self._layers = strided_layers(net)
+        self._backward = backward if backward is not None else (lambda out: out.features.backward(out_grad))
+        nd = len(self.spatial_shape)
+        self.features = torch.zeros((self.max_voxels, in_channels), dtype=dtype,
+                                    device=self.device).requires_grad_(input_grad)
+        self.indices = torch.full((self.max_voxels, nd + 1), -1, dtype=torch.int32, device=self.device)
+        self.n_live = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        self._live = 0
+        self.out = None
+        if example is not None:
+            self.load(*example)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):
+                self._compute()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._compute()                 # gradients land in tensors of the graph's pool: static from here on
+        self._counters = {name: m._static_n_out_dev for name, m in self._layers.items()
+                          if getattr(m, "_static_n_out_dev", None) is not None}
+
+    def _compute(self):
+        self.net.zero_grad(set_to_none=True)
+        self.features.grad = None
+        x = SparseConvTensor(self.features, self.indices, self.spatial_shape, self.batch_size)
+        x.n_live_dev = self.n_live
+        self.out = self.net(x)
+        self._backward(self.out)
+
+    def load(self, features: torch.Tensor, indices: torch.Tensor) -> None:
+        n = features.shape[0]
+        if n > self.max_voxels:
+            raise ValueError(f"scene has {n} voxels, the graph was captured for at most {self.max_voxels}")
+        assert indices.shape[0] == n and indices.dtype == torch.int32
+        with torch.no_grad():
+            self.features[:n].copy_(features)
+            self.indices[:n].copy_(indices)
+            if n < self._live:
+                self.features[n:self._live].zero_()
+                self.indices[n:self._live].fill_(-1)
+            self.n_live.fill_(n)
+        self._live = n
+
+    def __call__(self, features: torch.Tensor, indices: torch.Tensor):
+        self.load(features, indices)
+        self.graph.replay()
+        return self.out
+
+    counts = StaticInference.counts
+    overflowed = StaticInference.overflowed
+
+    def release_bounds(self) -> None:
+        """Clears the frozen bounds of the network's strided layers (eager passes are unbounded again)."""
+        for m in self._layers.values():
+            m.static_num_out = 0

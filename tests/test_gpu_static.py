@@ -247,3 +247,33 @@ def test_static_training_step_with_subm_and_batchnorm(cuda):
         assert rel < 2e-2, (name, rel)
     rel = float((fs.grad[:n].float() - fe.grad.float()).norm() / fe.grad.float().norm())
     assert rel < 2e-2, rel
+
+
+def test_static_training_step_runner(cuda):
+    """StaticTrainingStep: one graph, several scenes; parameter gradients of every replay against the eager step."""
+    import spconv_amd.pytorch as spconv
+    from spconv_amd.pytorch.static import StaticTrainingStep, strided_layers
+    shape, bs, C = [32, 40, 40], 2, 8
+    net = _backbone(spconv, C, cuda, torch.float16).train()
+    eager = copy.deepcopy(net)
+    names = list(strided_layers(net))
+    g = ((torch.rand((1_700, 64), device=cuda) - 0.5) * 0.2).half()
+    scenes = [_scene_tensors(shape, n, bs, C, seed, cuda, torch.float16) for n, seed in ((4000, 1), (1500, 2), (5500, 3))]
+    step = StaticTrainingStep(net, 12_000, C, shape, bs, torch.float16, bounds={names[0]: 13_000, names[1]: 1_700},
+                              out_grad=g, input_grad=True, example=scenes[0])
+    for f, idx in scenes:
+        out = step(f, idx)
+        assert step.overflowed() == {}
+        eager.zero_grad(set_to_none=True)
+        fe = f.clone().requires_grad_(True)
+        ye = eager(spconv.SparseConvTensor(fe, idx, shape, bs))
+        ye.features.backward(g[:ye.features.shape[0]])
+        n_out = ye.features.shape[0]
+        assert int(out.n_live_dev) == n_out and torch.equal(out.indices[:n_out], ye.indices)
+        for (name, pa), pb in zip(net.named_parameters(), eager.parameters()):
+            rel = float((pa.grad.float() - pb.grad.float()).norm() / pb.grad.float().norm().clamp_min(1e-12))
+            assert rel < 3e-2, (name, rel)
+        rel = float((step.features.grad[:f.shape[0]].float() - fe.grad.float()).norm() / fe.grad.float().norm())
+        assert rel < 3e-2, rel
+    step.release_bounds()
+    assert all(m.static_num_out == 0 for m in strided_layers(net).values())
