@@ -207,11 +207,18 @@ class Dist:
         self.backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
         if os.environ.get("BENCH_ONE_DEVICE", "0") == "1":
             self.local_rank = 0
+        # BENCH_SOLO_DIST=1: the distributed code path (process group brought up after graph capture, gradient
+        # bucket all-reduced on the side stream, barriers) with a world of ONE rank -- the only way to run the real
+        # RCCL backend through that path on a one-GPU box
+        self.multi = self.world > 1 or os.environ.get("BENCH_SOLO_DIST", "0") == "1"
+        if self.multi and self.world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         self.up = False
         self.dev = None
 
     def init(self):
-        if self.world > 1 and not self.up:
+        if self.multi and not self.up:
             import torch.distributed as dist
             if self.backend == "nccl":
                 dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
@@ -220,12 +227,12 @@ class Dist:
             self.up = True
 
     def barrier(self):
-        if self.world > 1:
+        if self.multi:
             import torch.distributed as dist
             dist.barrier()
 
     def reduce_max_sum(self, elapsed, n):
-        if self.world == 1:
+        if not self.multi:
             return elapsed, n, 1
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=self.dev, dtype=torch.float64)
@@ -452,7 +459,7 @@ def run_layer(args, D: Dist):
         scenes.append(sc)
     n = scenes[0].n
     tiled = scenes[0].tp is not None
-    bucket = GradBucket(net.parameters()) if world > 1 else None   # fp16 gradient, reduced in place
+    bucket = GradBucket(net.parameters()) if D.multi else None   # fp16 gradient, reduced in place
 
     def compute(sc):
         net.weight.grad = None
@@ -491,7 +498,7 @@ def run_layer(args, D: Dist):
                     for u in range(U):
                         compute(scenes[u % S])
                         dws_a.append(net.weight.grad)
-                if world > 1:
+                if D.multi:
                     graph_b = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph_b):
                         for u in range(U):
@@ -532,7 +539,7 @@ def run_layer(args, D: Dist):
     # own gradient buffers -- runs; a graph is replayed again only after its bucket's all-reduce has finished.
     # One RCCL call of U x 221 KB per U steps instead of a blocking small-message call behind every step.
     overlap = None
-    if world > 1 and graph_b is not None:
+    if D.multi and graph_b is not None:
         import torch.distributed as dist
         side_ar = torch.cuda.Stream()
         numel = net.weight.numel()
@@ -592,7 +599,7 @@ def run_layer(args, D: Dist):
 
     elapsed = timed_region(D, run_steps, args.warmup, args.steps)
     warm_ms = None
-    if world == 1 and S > 1:             # the same K steps on ONE scene (Infinity-Cache-resident)
+    if not D.multi and S > 1:             # the same K steps on ONE scene (Infinity-Cache-resident)
         run_steps(min(args.warmup, 50), warm=True)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -600,7 +607,7 @@ def run_layer(args, D: Dist):
         torch.cuda.synchronize()
         warm_ms = (time.perf_counter() - t1) / args.steps * 1e3
     single_replay_ms = None
-    if graph_u is not None and world == 1:   # the rotating K steps with one step per replay, for reference
+    if graph_u is not None and not D.multi:   # the rotating K steps with one step per replay, for reference
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(args.steps):
@@ -717,8 +724,8 @@ def run_layer(args, D: Dist):
                    "mask_sort": scenes[0].rb.argsort_fwd is not None, "tile_plan": tiled,
                    "parallelism": f"dp{world}",
                    "ranks_seen": ranks_seen,
-                   "dist_backend": D.backend if world > 1 else None,
-                   "gradient_exchange": None if world == 1 else (
+                   "dist_backend": D.backend if D.multi else None,
+                   "gradient_exchange": None if not D.multi else (
                        f"one flat-bucket all-reduce (average) of the {U} dW of a replay ({U} x {net.weight.numel() * s} B) "
                        f"on a side stream, overlapped with the next replay (two graphs with their own gradient "
                        f"buffers alternate)" if overlap is not None else "blocking all-reduce of dW after every step")},
@@ -852,7 +859,7 @@ def run_net(args, D: Dist):
         ind = torch.from_numpy(idx_np).to(dev)
         f = torch.randn(idx_np.shape[0], cin, device=dev).half()
         data.append((ind, f, shape))
-    bucket = GradBucket(net.parameters()) if world > 1 else None
+    bucket = GradBucket(net.parameters()) if D.multi else None
     D.init()
     cnt = [0]
     last = {}
@@ -878,7 +885,7 @@ def run_net(args, D: Dist):
     steps = min(args.steps, 200)
     elapsed = timed_region(D, run_steps, warm, steps)
     eager_ms, static_info = None, None
-    if not args.no_graph and world == 1:
+    if not args.no_graph and not D.multi:
         # the same step with static shapes, captured (rulebooks included); `value` is from this loop when it
         # ran clean, the eager loop's time rides along
         try:
@@ -925,13 +932,13 @@ def run_net(args, D: Dist):
            "data": "synthetic",
            "config": {"workload": f"{name}, fp16, {bs} {kind} scene(s) of ~{voxels} voxels per GPU per step "
                                   f"({int(n_mean)} input voxels), fresh rulebooks every step, forward + backward"
-                                  + (" + flat-bucket RCCL gradient all-reduce" if world > 1 else ""),
+                                  + (" + flat-bucket RCCL gradient all-reduce" if D.multi else ""),
                       "input_voxels_per_gpu": int(n_mean), "layer_voxels": [[r["n_in"], r["n_out"]] for r in recs],
                       "scenes_rotated": S,
                       "launch": "eager" if eager_ms is None else "hipGraph replay of the whole step (static shapes: "
                                 "rulebook builds + forward + backward captured once, one graph for every scene)",
                       "static_shapes": static_info, "parallelism": f"dp{world}", "ranks_seen": ranks_seen,
-                      "dist_backend": D.backend if world > 1 else None},
+                      "dist_backend": D.backend if D.multi else None},
            "roofline": roofline_obj("step", total, ms, "whole step: rulebook builders + igemm_v4 / igemm_bwd / "
                                     "wgrad_reduce2 of every layer (+ the bn_* BatchNorm+ReLU kernels at config 4)", None,
                                     {"memory_level": "HBM (activations of a step exceed the Infinity Cache)",

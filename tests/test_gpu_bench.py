@@ -51,3 +51,17 @@ def test_bench_config4_two_ranks(cuda):
               "--scenes", "1"], {"BENCH_DIST_BACKEND": "gloo", "BENCH_ONE_DEVICE": "1"})
     assert r["n_gpus"] == 2 and r["config"]["ranks_seen"] == 2
     assert len(r["config"]["layer_voxels"]) == 12
+
+
+def test_rccl_path_with_a_world_of_one_rank(cuda):
+    """BENCH_SOLO_DIST=1: the N > 1 control flow -- process group brought up AFTER graph capture with
+    device_id, flat gradient bucket all-reduced by the real RCCL backend on the side stream under the next replay,
+    barriers, the reductions of the timing -- with a single rank (a one-GPU box cannot host two RCCL ranks)."""
+    r = _run(["--steps", "24", "--warmup", "8", "--no-cpu-baseline", "--no-also", "--scenes", "2"],
+             {"BENCH_SOLO_DIST": "1"})
+    assert r["n_gpus"] == 1 and r["config"]["dist_backend"] == "nccl"
+    assert r["config"]["steps_per_replay"] == 8 and "side stream" in r["config"]["gradient_exchange"]
+    assert r["value"] > 0
+    r = _run(["--config", "4", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--scenes", "2"],
+             {"BENCH_SOLO_DIST": "1"})
+    assert r["config"]["dist_backend"] == "nccl" and "all-reduce" in r["config"]["workload"] and r["value"] > 0
