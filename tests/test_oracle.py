@@ -321,9 +321,16 @@ def test_gather_scatter_add_equal_reference_executed_vectors():
     acc = torch.from_numpy(d["acc_before"].copy())
     oracle._scatter_add(acc, buf, d["scatter_inds"], False)
     np.testing.assert_array_equal(acc.numpy(), d["acc_after"])
-    acc2 = torch.from_numpy(d["acc_before"].copy())               # the row-parallel variant: same sums, same order
-    oracle._scatter_add(acc2, buf, d["scatter_inds"], True)
-    np.testing.assert_allclose(acc2.numpy(), d["acc_after"], rtol=1e-6, atol=1e-6)
+    # the row-parallel variant (bench.py's cpu_baseline leg) is only defined for DISTINCT destination rows --
+    # what one filter offset produces -- so it is compared on the first occurrence of every destination
+    inds = d["scatter_inds"]
+    first = np.sort(np.unique(inds, return_index=True)[1])
+    sub_buf, sub_inds = buf[torch.from_numpy(first)].contiguous(), np.ascontiguousarray(inds[first])
+    want = torch.from_numpy(d["acc_before"].copy())
+    oracle._scatter_add(want, sub_buf, sub_inds, False)
+    acc2 = torch.from_numpy(d["acc_before"].copy())
+    oracle._scatter_add(acc2, sub_buf, sub_inds, True)
+    np.testing.assert_array_equal(acc2.numpy(), want.numpy())
 
 
 def test_native_conv_loop_with_the_reference_gather_code():
