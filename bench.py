@@ -1114,12 +1114,38 @@ def run_infer(args, D: Dist):
             cnt[0] += 1
             runner(f, ind)
     elapsed = timed_region(D, graph_steps, warm, steps)
+    for m in strided_layers(net).values():
+        m.static_num_out = 0
+    # deployment form: BatchNorm folded into the convolution weights, ReLU in the kernel's epilogue
+    # (quantization/utils.py fold_sequential_eval: 12 layers instead of 36), captured the same way; checked
+    # against ITS eager pass (folding rescales fp16 weights, so it is not bit-identical to the unfolded net)
+    from spconv_amd.pytorch.quantization.utils import fold_sequential_eval
+    folded_ms, folded_ok = None, None
+    try:
+        fnet = fold_sequential_eval(net)
+        with torch.no_grad():
+            fwant = [fnet(spconv.SparseConvTensor(f, ind, shape, bs)) for ind, f, _ in data]
+            fwant = [(y.indices.clone(), y.features.clone()) for y in fwant]
+        frunner = StaticInference(fnet, int(n_max * 1.05) + 1, 4, shape, bs, torch.float16,
+                                  bounds={k2: bounds[k] for k, k2 in zip(strided_layers(net), strided_layers(fnet))})
+        folded_ok = True
+        for (ind, f, _), (wi, wf) in zip(data, fwant):
+            got = frunner(f, ind)
+            folded_ok &= bool(torch.equal(got.indices[:wi.shape[0]], wi) and torch.equal(got.features[:wi.shape[0]], wf))
+
+        def folded_steps(k):
+            for _ in range(k):
+                ind, f, _ = data[cnt[0] % S]
+                cnt[0] += 1
+                frunner(f, ind)
+        folded_ms = timed_region(D, folded_steps, warm, steps) / steps * 1e3
+    except Exception as e:
+        folded_ok = f"{type(e).__name__}: {e}"[:200]
+        torch.cuda.synchronize()
     n_mean = sum(d[0].shape[0] for d in data) / S
     elapsed, n_total, ranks_seen = D.reduce_max_sum(elapsed, n_mean)
     if rank != 0:
         return None
-    for m in strided_layers(net).values():
-        m.static_num_out = 0
     ms = elapsed / steps * 1e3
     return {"metric": "active-voxels/sec, inference forward through the SECOND-style VoxelBackBone8x, static-shape "
                       "graph replay (BASELINE config 4 network)",
@@ -1128,6 +1154,7 @@ def run_infer(args, D: Dist):
             "data": "synthetic",
             "eager_ms_per_step": t_eager / steps * 1e3, "graph_ms_per_step": ms,
             "live_rows_identical_to_eager": identical,
+            "bn_folded_graph_ms_per_step": folded_ms, "bn_folded_live_rows_identical_to_its_eager_pass": folded_ok,
             "roofline": roofline_obj("step", ab[0] / S, ms, "whole inference pass: rulebook builders + igemm_v4 of every "
                                      "layer + eval BatchNorm / ReLU", None,
                                      {"note": "algorithmic bytes = conv layers' forward only (SURVEY.md 8d formulas per "
@@ -1171,7 +1198,8 @@ def also_block(args, D: Dist):
         if "kernels" in r:
             c["kernels_ms"] = {k: v["ms"] for k, v in r["kernels"].items()}
         for k in ("rulebook_device_ms", "eager_device_ms_per_step", "graph_ms_per_step", "eager_ms_per_step",
-                  "live_rows_identical_to_eager"):
+                  "live_rows_identical_to_eager", "bn_folded_graph_ms_per_step",
+                  "bn_folded_live_rows_identical_to_its_eager_pass"):
             if k in r:
                 c[k] = r[k]
         c["wall_s"] = round(time.perf_counter() - t0, 1)

@@ -46,3 +46,31 @@ def fuse_spconv_act_eval(conv, act):
     else:
         raise NotImplementedError
     return fused
+
+
+def fold_sequential_eval(seq):
+    """A copy of a ``SparseSequential`` (eval mode) in which every ``[sparse conv, BatchNorm1d, (ReLU |
+    LeakyReLU)]`` run is ONE convolution with the normalisation folded into weight / bias and the
+    activation in the kernel's epilogue -- the deployment form the two functions above exist for (reference
+    ``quantization/utils.py:5-53`` + the fused ``intrinsic`` containers); nested SparseSequentials are folded
+    recursively, everything else is kept."""
+    from spconv_amd.pytorch.conv import SparseConvolution
+    from spconv_amd.pytorch.modules import SparseSequential
+    assert not seq.training, "Fusion only for eval!"
+    mods = list(seq.children())
+    out, i = [], 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, SparseSequential):
+            m = fold_sequential_eval(m)
+        elif (isinstance(m, SparseConvolution) and not m.conv1x1 and m.act_type == Activation.None_
+              and i + 1 < len(mods) and type(mods[i + 1]) is torch.nn.BatchNorm1d
+              and mods[i + 1].running_mean is not None):
+            m = fuse_spconv_bn_eval(m, mods[i + 1])
+            i += 1
+            if i + 1 < len(mods) and isinstance(mods[i + 1], (torch.nn.ReLU, torch.nn.LeakyReLU)):
+                m = fuse_spconv_act_eval(m, mods[i + 1])
+                i += 1
+        out.append(m)
+        i += 1
+    return SparseSequential(*out).eval()

@@ -277,3 +277,24 @@ def test_static_training_step_runner(cuda):
         assert rel < 3e-2, rel
     step.release_bounds()
     assert all(m.static_num_out == 0 for m in strided_layers(net).values())
+
+
+def test_fold_sequential_eval_matches_the_unfolded_network(cuda):
+    """quantization.utils.fold_sequential_eval: [conv, BatchNorm1d, ReLU] runs become one convolution each; the
+    folded network equals the original in eval mode up to the fp16 rounding of the rescaled weights."""
+    import spconv_amd.pytorch as spconv
+    from spconv_amd.pytorch.conv import SparseConvolution
+    from spconv_amd.pytorch.quantization.utils import fold_sequential_eval
+    shape, bs, C = [32, 40, 40], 2, 8
+    net = _backbone(spconv, C, cuda, torch.float16)
+    folded = fold_sequential_eval(net)
+    kids = list(folded.children())
+    assert sum(isinstance(m, SparseConvolution) for m in kids) == 6 and not any(isinstance(m, torch.nn.BatchNorm1d) for m in kids)
+    assert len(kids) == 7          # only the ReLU behind the layer that has no BatchNorm is left as a module
+    f, idx = _scene_tensors(shape, 3000, bs, C, 6, cuda, torch.float16)
+    with torch.no_grad():
+        a = net(spconv.SparseConvTensor(f, idx, shape, bs))
+        b = folded(spconv.SparseConvTensor(f, idx, shape, bs))
+    assert torch.equal(a.indices, b.indices)
+    err = float((a.features.float() - b.features.float()).abs().max() / a.features.float().abs().max())
+    assert err < 2e-2, err
