@@ -298,3 +298,33 @@ def test_fold_sequential_eval_matches_the_unfolded_network(cuda):
     assert torch.equal(a.indices, b.indices)
     err = float((a.features.float() - b.features.float()).abs().max() / a.features.float().abs().max())
     assert err < 2e-2, err
+
+
+def test_captured_unet_with_inverse_convolution(cuda):
+    """Encoder / decoder: SubM -> strided conv (indice_key) -> SubM -> inverse conv back onto the input rows.
+    The inverse layer reuses its partner's static rulebook; its output has the INPUT's live rows."""
+    import spconv_amd.pytorch as spconv
+    from spconv_amd.pytorch.static import StaticInference, strided_layers
+    from torch import nn
+    shape, bs, C = [24, 32, 32], 2, 8
+    torch.manual_seed(11)
+    net = spconv.SparseSequential(
+        spconv.SubMConv3d(C, 16, 3, bias=False, indice_key="s0"), nn.BatchNorm1d(16), nn.ReLU(),
+        spconv.SparseConv3d(16, 32, 3, 2, 1, bias=False, indice_key="down"), nn.BatchNorm1d(32), nn.ReLU(),
+        spconv.SubMConv3d(32, 32, 3, bias=False, indice_key="s1"), nn.ReLU(),
+        spconv.SparseInverseConv3d(32, 16, 3, indice_key="down", bias=False), nn.BatchNorm1d(16), nn.ReLU(),
+        spconv.SubMConv3d(16, 16, 3, bias=True, indice_key="s0"),
+    ).to(cuda).half().eval()
+    eager = copy.deepcopy(net)
+    (name, _), = strided_layers(net).items()
+    runner = StaticInference(net, 9_000, C, shape, bs, torch.float16, bounds={name: 9_000})
+    for n, seed in ((3000, 1), (4400, 2), (900, 3)):
+        f, idx = _scene_tensors(shape, n, bs, C, seed, cuda, torch.float16)
+        with torch.no_grad():
+            want = eager(spconv.SparseConvTensor(f, idx, shape, bs))
+        got = runner(f, idx)
+        assert runner.overflowed() == {}
+        n_rows = f.shape[0]
+        assert int(got.n_live_dev) == n_rows and want.features.shape[0] == n_rows
+        assert torch.equal(got.indices[:n_rows], idx) and bool((got.indices[n_rows:, 0] < 0).all())
+        assert torch.equal(got.features[:n_rows], want.features)
