@@ -2311,7 +2311,15 @@ int spx_igemm_fwd_int8(const void *feat, const void *weight, void *out, const in
     case 16: return launch_v4<16, 2, 2>(p, s);
     case 32: return launch_v4<32, 2, 2>(p, s);
     case 64: return launch_v4<64, 2, 2>(p, s);
-    case 128: return launch_v4<128, 2, 2>(p, s);
+    case 128: {
+      // tile height by density class: tables in tile order = a rulebook the host classified as SPARSE
+      // (ops.sparse_neighbourhoods) -> 64-row tiles (70 instead of 165 registers per lane, five workgroups per CU
+      // instead of three: 27.3 -> 25.7 us at BASELINE config 5); dense neighbourhoods keep 128 rows (LiDAR-like
+      // 200 k: 104 vs 113 us, fixture 74 vs 83 us).  SPX_I8_MB = 1 / 2 forces one.
+      const int forced = option_int("SPX_I8_MB", 0);
+      if (forced == 1 || (forced == 0 && p.tile_order)) return launch_v4<128, 1, 2>(p, s);
+      return launch_v4<128, 2, 2>(p, s);
+    }
     case 256: return launch_v4<256, 1, 2>(p, s);
   }
   return -1;
