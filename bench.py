@@ -52,6 +52,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SHAPE = [40, 1280, 1600]       # z, y, x (KITTI-shape, SURVEY.md section 8d cfg 2)
+# hipGraph captures in this script run in THREAD-LOCAL error mode: at N > 1 the process group is up while rank 0
+# still captures kernel-group timing graphs, and RCCL's watchdog thread polls its work events (hipEventQuery) at any
+# time -- under the default global mode that poll fails with "operation not permitted when stream is capturing" and
+# takes the process down (seen with BENCH_SOLO_DIST=1 on the real backend; gloo has no such thread)
+CAPTURE_MODE = "thread_local"
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 METRIC = "active-voxels/sec fwd+bwd, 3x3x3 SubMConv3d C=64, ~100k voxels/scene"
 
@@ -143,7 +148,7 @@ def event_time_ms(fn, iters=80, warm=10, span=0):
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                 for i in range(span):
                     fn(i)
         except Exception as e:
@@ -488,25 +493,25 @@ def run_layer(args, D: Dist):
             graphs = []
             for sc in scenes:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                     compute(sc)
                 graphs.append(g)
                 graph_grads.append(net.weight.grad)   # each graph writes dW into its own pool buffer
             if U > 1:
                 graph_u = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph_u):
+                with torch.cuda.graph(graph_u, capture_error_mode=CAPTURE_MODE):
                     for u in range(U):
                         compute(scenes[u % S])
                         dws_a.append(net.weight.grad)
                 if D.multi:
                     graph_b = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph_b):
+                    with torch.cuda.graph(graph_b, capture_error_mode=CAPTURE_MODE):
                         for u in range(U):
                             compute(scenes[u % S])
                             dws_b.append(net.weight.grad)
                 else:
                     graph_w = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph_w):
+                    with torch.cuda.graph(graph_w, capture_error_mode=CAPTURE_MODE):
                         for u in range(U):
                             compute(scenes[0])
             launch = "hipgraph"
@@ -788,7 +793,7 @@ def run_int8(args, D: Dist):
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                 for i in range(S):
                     fwd(i)
             graphs = g
@@ -988,7 +993,8 @@ def static_training_steps(net, data, bs, cin, shape, steps, warm, D: Dist, input
     k_last = list(layers.values())[-1].out_channels
     gstat = ((torch.rand((bounds[list(layers)[-1]], k_last), device=dev) - 0.5) * 0.2).half()
     runner = StaticTrainingStep(net, n_max, cin, shape, bs, torch.float16, bounds=bounds, out_grad=gstat,
-                                input_grad=input_grad, device=dev, example=(data[0][1], data[0][0]))
+                                input_grad=input_grad, device=dev, example=(data[0][1], data[0][0]),
+                                capture_error_mode=CAPTURE_MODE)
     fbuf, g = runner.features, runner.graph
 
     def load(si):
@@ -1099,7 +1105,8 @@ def run_infer(args, D: Dist):
     t_eager = timed_region(D, eager_steps, warm, steps)
     bounds = {k: int(v * 1.1) + 1 for k, v in seen.items()}
     n_max = max(d[0].shape[0] for d in data)
-    runner = StaticInference(net, int(n_max * 1.05) + 1, 4, shape, bs, torch.float16, bounds=bounds)
+    runner = StaticInference(net, int(n_max * 1.05) + 1, 4, shape, bs, torch.float16, bounds=bounds,
+                             capture_error_mode=CAPTURE_MODE)
     identical = True
     for (ind, f, _), (wi, wf) in zip(data, want):
         got = runner(f, ind)
@@ -1127,7 +1134,8 @@ def run_infer(args, D: Dist):
             fwant = [fnet(spconv.SparseConvTensor(f, ind, shape, bs)) for ind, f, _ in data]
             fwant = [(y.indices.clone(), y.features.clone()) for y in fwant]
         frunner = StaticInference(fnet, int(n_max * 1.05) + 1, 4, shape, bs, torch.float16,
-                                  bounds={k2: bounds[k] for k, k2 in zip(strided_layers(net), strided_layers(fnet))})
+                                  bounds={k2: bounds[k] for k, k2 in zip(strided_layers(net), strided_layers(fnet))},
+                                  capture_error_mode=CAPTURE_MODE)
         folded_ok = True
         for (ind, f, _), (wi, wf) in zip(data, fwant):
             got = frunner(f, ind)

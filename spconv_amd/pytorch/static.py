@@ -104,7 +104,7 @@ class StaticInference:
     def __init__(self, net: torch.nn.Module, max_voxels: int, in_channels: int,
                  spatial_shape: Sequence[int], batch_size: int, dtype: torch.dtype = torch.float16,
                  bounds: Optional[Dict[str, int]] = None, margin: float = 1.25,
-                 device: Optional[torch.device] = None, warmup: int = 2):
+                 device: Optional[torch.device] = None, warmup: int = 2, capture_error_mode: str = "global"):
         if not torch.cuda.is_available():
             raise RuntimeError("StaticInference needs the GPU (there is no CPU path)")
         self.net = net.eval()
@@ -129,7 +129,9 @@ class StaticInference:
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(g):
+        # capture_error_mode="thread_local": needed when another thread may touch HIP during the capture (the
+        # watchdog of an initialised RCCL process group polls its events at any time)
+        with torch.no_grad(), torch.cuda.graph(g, capture_error_mode=capture_error_mode):
             self.out = self._forward()
         self.graph = g
         # the device-side counters of the captured pass (static tensors of the graph's pool)
@@ -193,7 +195,7 @@ class StaticTrainingStep:
                  batch_size: int, dtype: torch.dtype = torch.float16, bounds: Optional[Dict[str, int]] = None,
                  margin: float = 1.25, backward=None, out_grad: Optional[torch.Tensor] = None,
                  input_grad: bool = False, device: Optional[torch.device] = None, warmup: int = 2,
-                 example=None):
+                 example=None, capture_error_mode: str = "global"):
         if not torch.cuda.is_available():
             raise RuntimeError("StaticTrainingStep needs the GPU (there is no CPU path)")
         if (backward is None) == (out_grad is None):
@@ -221,7 +223,7 @@ class StaticTrainingStep:
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):      # (see StaticInference)
             self._compute()                 # gradients land in tensors of the graph's pool: static from here on
         self._counters = {name: m._static_n_out_dev for name, m in self._layers.items()
                           if getattr(m, "_static_n_out_dev", None) is not None}
