@@ -121,18 +121,19 @@ class StaticInference:
         self._live = 0
         self.graph = None
         self.out = None
-        side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(max(warmup, 1)):        # allocator / option caches warm, nothing captured yet
-                self._forward()
-        torch.cuda.current_stream(self.device).wait_stream(side)
-        torch.cuda.synchronize(self.device)
-        g = torch.cuda.CUDAGraph()
-        # capture_error_mode="thread_local": needed when another thread may touch HIP during the capture (the
-        # watchdog of an initialised RCCL process group polls its events at any time)
-        with torch.no_grad(), torch.cuda.graph(g, capture_error_mode=capture_error_mode):
-            self.out = self._forward()
+        with torch.cuda.device(self.device):       # (capture and replay belong to the device the buffers live on)
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(max(warmup, 1)):    # allocator / option caches warm, nothing captured yet
+                    self._forward()
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            # capture_error_mode="thread_local": needed when another thread may touch HIP during the capture (the
+            # watchdog of an initialised RCCL process group polls its events at any time)
+            with torch.no_grad(), torch.cuda.graph(g, capture_error_mode=capture_error_mode):
+                self.out = self._forward()
         self.graph = g
         # the device-side counters of the captured pass (static tensors of the graph's pool)
         self._counters = {name: m._static_n_out_dev for name, m in self._layers.items()
@@ -158,8 +159,9 @@ class StaticInference:
         self._live = n
 
     def __call__(self, features: torch.Tensor, indices: torch.Tensor):
-        self.load(features, indices)
-        self.graph.replay()
+        with torch.cuda.device(self.device):
+            self.load(features, indices)
+            self.graph.replay()
         return self.out
 
     def counts(self) -> Dict[str, List[int]]:
@@ -213,18 +215,19 @@ class StaticTrainingStep:
         self.n_live = torch.zeros((1,), dtype=torch.int32, device=self.device)
         self._live = 0
         self.out = None
-        if example is not None:
-            self.load(*example)
-        side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side):
-            for _ in range(max(warmup, 1)):
-                self._compute()
-        torch.cuda.current_stream(self.device).wait_stream(side)
-        torch.cuda.synchronize(self.device)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):      # (see StaticInference)
-            self._compute()                 # gradients land in tensors of the graph's pool: static from here on
+        with torch.cuda.device(self.device):
+            if example is not None:
+                self.load(*example)
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                for _ in range(max(warmup, 1)):
+                    self._compute()
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):      # (see StaticInference)
+                self._compute()             # gradients land in tensors of the graph's pool: static from here on
         self._counters = {name: m._static_n_out_dev for name, m in self._layers.items()
                           if getattr(m, "_static_n_out_dev", None) is not None}
 
@@ -251,8 +254,9 @@ class StaticTrainingStep:
         self._live = n
 
     def __call__(self, features: torch.Tensor, indices: torch.Tensor):
-        self.load(features, indices)
-        self.graph.replay()
+        with torch.cuda.device(self.device):
+            self.load(features, indices)
+            self.graph.replay()
         return self.out
 
     counts = StaticInference.counts
