@@ -284,6 +284,20 @@ int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t 
                     int K, int kv, int dtype, int subm, void *ws, size_t ws_bytes,
                     spx_stream_t stream);
 
+/* Backward of a NARROW layer (C, K in {16, 32}, 16-bit features, kernel volume <= 27) from one gather per pair
+ * (csrc/igemm_bwdn.hip): a walk over 128-row tiles of the input rows feeds every gathered dout tile to the
+ * input gradient AND to the weight gradient.  Same role as spx_igemm_bwd (ConvGemmOps.implicit_gemm_backward,
+ * pytorch/ops.py:1667-1896), without the Native lists and the range plan:
+ *   table [kv, n_in], mask [n_in]: the dgrad table (SubM: pair_fwd; regular conv: pair_bwd) and its mask words
+ *   weight_t [kv, C, K]: weight slice of TABLE ROW r with the dout channel contiguous, i.e.
+ *                        weight_t[r][c][k'] = weight[k'][mirror ? kv-1-r : r][c]
+ *   din [n_in, C] or NULL;  dw KRSC [K, kv, C] in `dtype`, fully overwritten (deterministic)
+ *   ws: spx_igemm_bwd_rows_ws_bytes (per-workgroup fp32 partial weight gradients) */
+size_t spx_igemm_bwd_rows_ws_bytes(int n_in, int C, int K, int kv);
+int spx_igemm_bwd_rows(const void *feat, const void *dout, const void *weight_t, void *din, void *dw,
+                       const int32_t *table, const uint32_t *mask, int n_in, int n_out, int C, int K,
+                       int kv, int mirror, int dtype, void *ws, size_t ws_bytes, spx_stream_t stream);
+
 /* Backward of one layer: din (as spx_igemm_dgrad) and dw (as spx_igemm_wgrad) from ONE kernel
  * launch plus the wgrad second stage.  Replaces ConvGemmOps.implicit_gemm_backward /
  * indice_conv_backward as a whole (pytorch/ops.py:1667-1896,1103-1447), which also return both

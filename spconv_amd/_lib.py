@@ -49,6 +49,8 @@ SIGNATURES = {
     "spx_igemm_fwd_tiled": (ctypes.c_int, [vp, vp, vp, vp, vp] + [ctypes.c_int] * 7
                             + [vp, ctypes.c_int, ctypes.c_float, vp]),
     "spx_igemm_dgrad_tiled": (ctypes.c_int, [vp, vp, vp, vp, vp] + [ctypes.c_int] * 7 + [vp]),
+    "spx_igemm_bwd_rows_ws_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),
+    "spx_igemm_bwd_rows": (ctypes.c_int, [vp] * 7 + [ctypes.c_int] * 7 + [vp, ctypes.c_size_t, vp]),
     "spx_batchnorm_ws_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "spx_batchnorm_fwd": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int,

@@ -711,7 +711,7 @@ def igemm_bwd(features: torch.Tensor, out_bp: torch.Tensor, filters: torch.Tenso
               table: torch.Tensor, mask: Optional[torch.Tensor], argsort: Optional[torch.Tensor],
               native: torch.Tensor, num_per_loc: torch.Tensor, subm: bool,
               plan: Optional[torch.Tensor] = None, need_din: bool = True,
-              tile_plan: Optional[torch.Tensor] = None, tile_order: bool = False):
+              tile_plan: Optional[torch.Tensor] = None, tile_order: bool = False, dense_rows: bool = False):
     """(din, dW) of one layer from one launch (+ the wgrad second stage).  need_din=False (the
     input does not require grad: a network's first layer) computes dW only and returns None.
     `tile_plan` (dense neighbourhoods): dgrad takes the halo kernel, wgrad its own launch -- there
@@ -720,6 +720,11 @@ def igemm_bwd(features: torch.Tensor, out_bp: torch.Tensor, filters: torch.Tenso
     K0, C0 = filters.shape[0], filters.shape[-1]
     m = _lane_mult(out_bp.dtype)
     kvf = filters.numel() // (K0 * C0)
+    if ((_BWD_ROWS is True or (_BWD_ROWS == "auto" and dense_rows))
+            and out_bp.dtype in (torch.float16, torch.bfloat16) and K0 in (16, 32) and C0 in (16, 32)
+            and kvf <= 27 and table is not None and mask is not None and mask.shape[1] == 1 and argsort is None
+            and not tile_order and tile_plan is None):
+        return _igemm_bwd_rows(features, out_bp, filters, table, mask, subm, need_din, K0, C0, kvf)
     if tile_plan is not None and not tile_order and need_din and _halo_ok(out_bp.dtype, K0, C0, kvf):
         din = igemm_dgrad(out_bp, filters, table, mask, argsort, features.shape[0], subm, tile_plan)
         return din, igemm_wgrad(features, out_bp, filters.shape, native, num_per_loc, subm, plan)
@@ -742,6 +747,47 @@ def igemm_bwd(features: torch.Tensor, out_bp: torch.Tensor, filters: torch.Tenso
                                int(tile_order), native.data_ptr(), num_per_loc.data_ptr(), _ptr(plan), n_in,
                                out_bp.shape[0], C, K, kv, _dtype_code(out_bp), int(subm),
                                ws.data_ptr(), ws.numel(), _stream(out_bp)))
+    return din, dw
+
+
+# Narrow layers (16 / 32 channels): the backward from one gather per pair (csrc/igemm_bwdn.hip).  Its tile
+# walk visits every table row of a 128-row tile, so it pays where neighbourhoods are DENSE (level 2 of a LiDAR
+# backbone, 15 pairs per voxel: 185 -> 114 us) and loses where they are not (level 1, 5 pairs per voxel: 98 ->
+# 108 us; a uniform scene far more).  The pairs-per-voxel count lives on the device; what the host knows without
+# a read-back is the OCCUPANCY of the grid the table's rows live in (voxels / cells), which grows with it:
+# 0.1 % at level 1, 0.66 % at level 2, 1.8 % at level 3 of the config-4 network.
+# SPCONV_AMD_BWD_ROWS: "auto" (default: occupancy >= _BWD_ROWS_OCC), "1" always, "0" never.
+_BWD_ROWS = {"0": False, "1": True}.get(os.environ.get("SPCONV_AMD_BWD_ROWS", "auto"), "auto")
+_BWD_ROWS_OCC = float(os.environ.get("SPCONV_AMD_BWD_ROWS_OCC", "0.003"))
+
+
+def _dense_rows(rb: Optional[Rulebook], n_rows: int, which: str) -> bool:
+    """Occupancy of the grid that the rows of table `which` ("fwd": output rows, "bwd": input rows) live in."""
+    if rb is None:
+        return False
+    dims = rb.out_shape if which == "fwd" else rb.in_shape
+    if not dims:
+        return False
+    cells = float(rb.batch_size)
+    for d in dims:
+        cells *= float(d)
+    return n_rows >= _BWD_ROWS_OCC * cells
+
+
+@_on_device
+def _igemm_bwd_rows(features, out_bp, filters, table, mask, subm, need_din, K, C, kv):
+    L = _lib.load()
+    features, out_bp = features.contiguous(), out_bp.contiguous()
+    n_in = features.shape[0]
+    # weight slice of table row r with the dout channel contiguous; SubM tables pair row r with slice kv-1-r
+    wt = filters.reshape(K, kv, C).permute(1, 2, 0)
+    wt = (wt.flip(0) if subm else wt).contiguous()
+    din = torch.empty((n_in, C), dtype=out_bp.dtype, device=out_bp.device) if need_din else None
+    dw = torch.empty_like(filters)
+    ws = _ws(L.spx_igemm_bwd_rows_ws_bytes(n_in, C, K, kv), features.device)
+    _lib.check(L.spx_igemm_bwd_rows(features.data_ptr(), out_bp.data_ptr(), wt.data_ptr(), _ptr(din), dw.data_ptr(),
+                                    table.data_ptr(), mask.data_ptr(), n_in, out_bp.shape[0], C, K, kv, int(subm),
+                                    _dtype_code(out_bp), ws.data_ptr(), ws.numel(), _stream(out_bp)))
     return din, dw
 
 
@@ -875,7 +921,8 @@ def indice_conv_backward(features: torch.Tensor, filters: torch.Tensor, out_bp: 
     tp = tile_plan(rb, which) if (rb is not None and need_din and argsort is None) else None
     if (native.shape[2] == n_in and not BWD_OVERLAP) or not need_din:
         return igemm_bwd(features, out_bp, filters, table, mask, argsort, native, indice_pair_num,
-                         subm, plan, need_din, tile_plan=tp, tile_order=tile_order)
+                         subm, plan, need_din, tile_plan=tp, tile_order=tile_order,
+                         dense_rows=_dense_rows(rb, n_in, which) if rb is not None else False)
     return _backward_pair(
         lambda: igemm_dgrad(out_bp, filters, table, mask, argsort, n_in, subm, tile_order=tile_order),
         lambda: igemm_wgrad(features, out_bp, filters.shape, native, indice_pair_num, subm, plan),
@@ -951,7 +998,8 @@ def implicit_gemm_backward(features: torch.Tensor, filters: torch.Tensor, out_bp
             tp = tile_plan(rb, "bwd") if (need_din and argsort is None) else None
     if (native.shape[2] == n_in and not BWD_OVERLAP) or not need_din:
         return igemm_bwd(features, out_bp, filters, table, mask, argsort, native, num, is_subm, plan,
-                         need_din, tile_plan=tp, tile_order=tile_order)
+                         need_din, tile_plan=tp, tile_order=tile_order,
+                         dense_rows=_dense_rows(rb, n_in, "fwd" if is_subm else "bwd"))
     return _backward_pair(
         lambda: igemm_dgrad(out_bp, filters, table, mask, argsort, n_in, is_subm, tile_order=tile_order),
         lambda: igemm_wgrad(features, out_bp, filters.shape, native, num, is_subm, plan),

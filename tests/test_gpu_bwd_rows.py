@@ -1,0 +1,120 @@
+"""GPU: the backward of a narrow layer from one gather per pair (csrc/igemm_bwdn.hip, spx_igemm_bwd_rows)
+against the pair-list kernels it replaces for C, K in {16, 32} (spx_igemm_bwd) and against the CPU oracle
+(ops.py:1164-1253 restated): input gradient and weight gradient, SubM (mirrored weight order) and strided
+convolution (pair_bwd table), every channel combination, row counts that are not multiples of the 128-row tile,
+dead tile rows, fp16 / bf16, dW-only calls, bit-reproducibility."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from util import dense_scene, gpu_rulebook, rel_err, scene
+
+pytestmark = pytest.mark.gpu
+TOL = {torch.float16: 2e-3, torch.bfloat16: 1.2e-2}
+
+
+def _tensors(rng, n_in, n_out, C, K, dtype, dev):
+    f = torch.from_numpy(rng.uniform(-1, 1, (n_in, C)).astype(np.float32)).to(dev, dtype)
+    w = torch.from_numpy(rng.uniform(-1, 1, (K, 3, 3, 3, C)).astype(np.float32)).to(dev, dtype)
+    d = torch.from_numpy(rng.uniform(-0.2, 0.2, (n_out, K)).astype(np.float32)).to(dev, dtype)
+    return f, w, d
+
+
+def _both(fn):
+    from spconv_amd.pytorch import ops
+    old = ops._BWD_ROWS
+    try:
+        ops._BWD_ROWS = False
+        a = fn()
+        ops._BWD_ROWS = True
+        b = fn()
+    finally:
+        ops._BWD_ROWS = old
+    torch.cuda.synchronize()
+    return a, b
+
+
+@pytest.mark.parametrize("C,K", [(16, 16), (32, 32), (16, 32), (32, 16)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape,n,dense", [([40, 200, 200], 20_001, False), ([24, 24, 24], 3_001, True),
+                                           ([10, 10, 10], 77, True)])
+def test_subm_backward_rows_vs_pair_lists_and_oracle(cuda, C, K, dtype, shape, n, dense):
+    from spconv_amd.pytorch import ops
+    idx = dense_scene(shape, n, 1, 3) if dense else scene(shape, n, 1, 3)
+    rb, _ = gpu_rulebook(idx, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True)
+    rng = np.random.default_rng(C + K)
+    f, w, d = _tensors(rng, rb.n_in, rb.n_out, C, K, dtype, cuda)
+    plan = ops._plan_of(rb)
+    run = lambda: ops.igemm_bwd(f, d, w, rb.pair_fwd, rb.mask_fwd, None, rb.pair_native, rb.num_per_loc, True, plan)
+    (din_a, dw_a), (din_b, dw_b) = _both(run)
+    tol = TOL[dtype]
+    assert rel_err(din_b.float().cpu().numpy(), din_a.float().cpu().numpy()) <= tol
+    assert rel_err(dw_b.float().cpu().numpy(), dw_a.float().cpu().numpy()) <= tol
+    _, pair, num, _ = oracle.get_indice_pairs(idx, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, subm=True)
+    din_ref, dw_ref = oracle.indice_conv_backward(f.float().cpu(), w.float().cpu(), d.float().cpu(), pair, num, subm=True)
+    assert rel_err(din_b.float().cpu().numpy(), din_ref.numpy()) <= tol
+    assert rel_err(dw_b.float().cpu().numpy(), dw_ref.numpy()) <= tol
+
+
+@pytest.mark.parametrize("C,K", [(16, 32), (32, 32)])
+def test_strided_conv_backward_rows(cuda, C, K):
+    """regular convolution: the dgrad table is pair_bwd over the INPUT rows, no mirrored weight order, n_out != n_in"""
+    from spconv_amd.pytorch import ops
+    shape = [30, 30, 30]
+    idx = dense_scene(shape, 6000, 2, 7)
+    rb, _ = gpu_rulebook(idx, 2, shape, [3] * 3, [2] * 3, [1] * 3, [1] * 3, False)
+    rng = np.random.default_rng(5)
+    f, w, d = _tensors(rng, rb.n_in, rb.n_out, C, K, torch.float16, cuda)
+    plan = ops._plan_of(rb)
+    run = lambda: ops.igemm_bwd(f, d, w, rb.pair_bwd, rb.mask_bwd, None, rb.pair_native, rb.num_per_loc, False, plan)
+    (din_a, dw_a), (din_b, dw_b) = _both(run)
+    assert rel_err(din_b.float().cpu().numpy(), din_a.float().cpu().numpy()) <= 2e-3
+    assert rel_err(dw_b.float().cpu().numpy(), dw_a.float().cpu().numpy()) <= 2e-3
+    _, pair, num, _ = oracle.get_indice_pairs(idx, 2, shape, [3] * 3, [2] * 3, [1] * 3, [1] * 3, subm=False)
+    din_ref, dw_ref = oracle.indice_conv_backward(f.float().cpu(), w.float().cpu(), d.float().cpu(), pair, num, subm=False)
+    assert rel_err(din_b.float().cpu().numpy(), din_ref.numpy()) <= 2e-3
+    assert rel_err(dw_b.float().cpu().numpy(), dw_ref.numpy()) <= 2e-3
+
+
+def test_dw_only_and_reproducible(cuda):
+    from spconv_amd.pytorch import ops
+    shape = [24, 24, 24]
+    idx = dense_scene(shape, 3000, 1, 9)
+    rb, _ = gpu_rulebook(idx, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True)
+    rng = np.random.default_rng(6)
+    f, w, d = _tensors(rng, rb.n_in, rb.n_out, 32, 32, torch.float16, cuda)
+    plan = ops._plan_of(rb)
+    runs = [ops.igemm_bwd(f, d, w, rb.pair_fwd, rb.mask_fwd, None, rb.pair_native, rb.num_per_loc, True, plan)
+            for _ in range(5)]
+    none, dw_only = ops.igemm_bwd(f, d, w, rb.pair_fwd, rb.mask_fwd, None, rb.pair_native, rb.num_per_loc, True, plan,
+                                  need_din=False)
+    torch.cuda.synchronize()
+    assert none is None and torch.equal(dw_only, runs[0][1])
+    assert all(torch.equal(r[0], runs[0][0]) and torch.equal(r[1], runs[0][1]) for r in runs)
+
+
+def test_module_training_step_takes_the_rows_kernel(cuda, monkeypatch):
+    """SubMConv3d 32 -> 32 through autograd: the narrow-layer backward is the one that runs, gradients equal the
+    pair-list kernels' within fp16 tolerance."""
+    import spconv_amd.pytorch as spconv
+    from spconv_amd.pytorch import ops
+    calls = []
+    real = ops._igemm_bwd_rows
+    monkeypatch.setattr(ops, "_igemm_bwd_rows", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    shape = [24, 24, 24]
+    idx = torch.from_numpy(dense_scene(shape, 3000, 1, 4)).to(cuda)
+    torch.manual_seed(0)
+    net = spconv.SubMConv3d(32, 32, 3, bias=False).to(cuda).half().train()
+    f0 = (torch.rand(idx.shape[0], 32, device=cuda) - 0.5).half()
+    g = ((torch.rand(idx.shape[0], 32, device=cuda) - 0.5) * 0.2).half()
+
+    def step():
+        net.weight.grad = None
+        f = f0.clone().requires_grad_(True)
+        net(spconv.SparseConvTensor(f, idx, shape, 1)).features.backward(g)
+        return f.grad.clone(), net.weight.grad.clone()
+    (din_a, dw_a), (din_b, dw_b) = _both(step)
+    assert calls, "the rows kernel did not run"
+    assert rel_err(din_b.float().cpu().numpy(), din_a.float().cpu().numpy()) <= 2e-3
+    assert rel_err(dw_b.float().cpu().numpy(), dw_a.float().cpu().numpy()) <= 2e-3
