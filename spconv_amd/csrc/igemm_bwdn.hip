@@ -78,16 +78,25 @@ struct BwdnParams {
 constexpr int kBnRows = 2;        // steps whose dout rows are in flight
 constexpr int kBnMaxTiles = 64;   // tiles per persistent workgroup
 
-template <bool BF16, int C, int K>
-__global__ void __launch_bounds__(kThreads, 2)
+// W8: 512-thread workgroups -- a wave owns 16 rows for dgrad, and the four weight-gradient tiles are shared by wave
+// PAIRS that split the table rows by parity (wave w < 4: even rows, w >= 4: odd rows: in a pair step the two
+// halves of the workgroup read one stage each), 14 accumulator tiles per wave instead of 27: ~128 registers per
+// lane, four waves per SIMD instead of two.
+template <bool BF16, int C, int K, bool W8>
+__global__ void __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2)
 bwdn_kernel(BwdnParams p) {
+  constexpr int NT = W8 ? 512 : 256;             // threads
+  constexpr int MB = W8 ? 1 : 2;                 // 16-row m-blocks per wave
+  constexpr int RPW = MB * 16;                   // dgrad rows per wave
+  constexpr int NACC = W8 ? (kBnMaxKv + 1) / 2 : kBnMaxKv;
+  constexpr int ROWS = (W8 && C == 32) ? 1 : kBnRows;      // ring depth (the 128-register form of C = 32 affords one)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char *sF = smem;                               // the tile's feat rows
   char *sG = smem + kBnStage;                    // 2 x 2 stages of gathered dout rows (a pair of table rows per step)
   __shared__ uint32_t s_tmask[kBnMaxTiles + 1];
   constexpr int NBC = C / 16, NBK = K / 16;      // 16-channel blocks
   constexpr int SLK = K / 8, SLC = C / 8;        // 16-byte slots per row
-  constexpr int FPT = kBnTile * SLC / kThreads;  // 16-byte pieces of the feat tile per thread (1 or 2)
+  constexpr int FPT = (kBnTile * SLC + NT - 1) / NT;   // 16-byte pieces of the feat tile per thread (1 or 2)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lrow = lane & 15, lgrp = lane >> 4;
   const uint32_t rowD = K * 2u, rowF = C * 2u;
@@ -96,8 +105,9 @@ bwdn_kernel(BwdnParams p) {
   const __amdgpu_buffer_rsrc_t rT = make_rsrc(p.table, static_cast<uint32_t>(p.kv) * static_cast<uint32_t>(p.n_in) * 4u);
   const __amdgpu_buffer_rsrc_t rM = make_rsrc(p.mask, static_cast<uint32_t>(p.n_in) * 4u);
   const __amdgpu_buffer_rsrc_t rW = make_rsrc(p.wt, static_cast<uint32_t>(p.kv) * C * K * 2u);
-  const bool wg_live = wave < NBC * NBK;         // this wave owns a weight-gradient tile
-  const int kb = wave / NBC, cb = wave % NBC;
+  const int wt = W8 ? (wave & 3) : wave, par = W8 ? (wave >> 2) : 0;
+  const bool wg_live = wt < NBC * NBK;           // this wave owns (a parity class of) a weight-gradient tile
+  const int kb = wt / NBC, cb = wt % NBC;
   // lanes whose 16-byte piece lies beyond a 16-channel row never load (their fragment half is zero)
   const uint32_t dcol = lgrp < SLK ? static_cast<uint32_t>(lgrp) * 16u : kOob;
   const uint32_t kvmask = p.kv >= 32 ? 0xffffffffu : ((1u << p.kv) - 1u);
@@ -128,9 +138,9 @@ bwdn_kernel(BwdnParams p) {
     __syncthreads();
   }
 
-  f32x4 acc_w[kBnMaxKv];
+  f32x4 acc_w[NACC];
 #pragma unroll
-  for (int r = 0; r < kBnMaxKv; ++r) acc_w[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < NACC; ++r) acc_w[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- look-ahead over the (tile, table row) items of this workgroup, in processing order (all wave-uniform)
   int la_j = -1;
@@ -149,17 +159,17 @@ bwdn_kernel(BwdnParams p) {
     r_of = __builtin_ctz(la_bits);
     la_bits &= la_bits - 1u;
   };
-  auto load_idx = [&](int tile_of, int r, int (&ix)[2]) __attribute__((always_inline)) {
+  auto load_idx = [&](int tile_of, int r, int (&ix)[MB]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-      const int row = tile_of * kBnTile + wave * 32 + mb * 16 + lrow;
+    for (int mb = 0; mb < MB; ++mb) {
+      const int row = tile_of * kBnTile + wave * RPW + mb * 16 + lrow;
       const uint32_t off = (tile_of >= 0 && row < p.n_in) ? (static_cast<uint32_t>(r) * p.n_in + row) * 4u : kOob;
       ix[mb] = static_cast<int>(__builtin_amdgcn_raw_buffer_load_b32(rT, off, 0, SPX_AUX_TABLE));
     }
   };
-  auto load_rows = [&](const int (&ix)[2], uint4 (&g)[2]) __attribute__((always_inline)) {
+  auto load_rows = [&](const int (&ix)[MB], uint4 (&g)[MB]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
+    for (int mb = 0; mb < MB; ++mb) {
       // (a table word that was never loaded -- past the end -- reads as 0: row 0, harmless and never used)
       const uint32_t off = ix[mb] >= 0 ? (static_cast<uint32_t>(ix[mb]) * rowD + dcol) | (dcol & kOob) : kOob;
       g[mb] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rD, off, 0, 0));
@@ -176,22 +186,24 @@ bwdn_kernel(BwdnParams p) {
   auto load_feat = [&](int tile_of, uint4 (&f)[FPT]) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < FPT; ++q) {
-      const int pc = tid + q * kThreads, r = pc / SLC, sl = pc % SLC;
+      const int pc = tid + q * NT, r = pc / SLC, sl = pc % SLC;
       const int row = tile_of * kBnTile + r;
-      const uint32_t off = (tile_of >= 0 && row < p.n_in) ? static_cast<uint32_t>(row) * rowF + sl * 16u : kOob;
+      const uint32_t off = (tile_of >= 0 && row < p.n_in && pc < kBnTile * SLC) ? static_cast<uint32_t>(row) * rowF + sl * 16u : kOob;
       f[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rF, off, 0, 0));
     }
   };
 
   // pipeline: g[j] / w[j] = dout rows / weight fragments of the item j steps ahead (j < kBnRows),
   // ixn = table words of the item kBnRows steps ahead
-  uint4 g[kBnRows][2], w[kBnRows][NBC];
-  int ixn[2] = {-1, -1};
+  uint4 g[ROWS][MB], w[ROWS][NBC];
+  int ixn[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) ixn[mb] = -1;
   int la_t_pending = -1, la_r_pending = 0;        // the item whose table words are in `ixn`
   {
 #pragma unroll
-    for (int j = 0; j < kBnRows; ++j) {
-      int t_of, r_of, ix[2];
+    for (int j = 0; j < ROWS; ++j) {
+      int t_of, r_of, ix[MB];
       la_next(t_of, r_of);
       load_idx(t_of, r_of, ix);
       load_rows(ix, g[j]);                        // (prologue: waits for the words, once per workgroup)
@@ -210,20 +222,21 @@ bwdn_kernel(BwdnParams p) {
     __syncthreads();                             // the previous tile's stages are no longer read
 #pragma unroll
     for (int q = 0; q < FPT; ++q) {
-      const int pc = tid + q * kThreads;
-      *reinterpret_cast<uint4 *>(sF + ctr_slot(pc / SLC, pc % SLC)) = fpre[q];
+      const int pc = tid + q * NT;
+      if (pc < kBnTile * SLC) *reinterpret_cast<uint4 *>(sF + ctr_slot(pc / SLC, pc % SLC)) = fpre[q];
     }
     load_feat(j + 1 < my_tiles ? tile + G : -1, fpre);      // the next tile's rows: in flight during this tile
 
-    f32x4 acc_d[2][NBC];
+    f32x4 acc_d[MB][NBC];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int nb = 0; nb < NBC; ++nb) acc_d[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     // the tile's feat fragments of this wave's weight-gradient tile: the same for every table row, read once
     __syncthreads();
-    uint4 ffr[kBnTile / 32];
-    if (wg_live)
+    // (the 512-thread form has no registers to spare for them: it reads them per step)
+    uint4 ffr[W8 ? 1 : kBnTile / 32];
+    if (wg_live && !W8)
 #pragma unroll
       for (int ks = 0; ks < kBnTile / 32; ++ks) ffr[ks] = ctr_frag(sF, ks * 32 + lgrp * 8, lrow, cb);
 
@@ -236,30 +249,30 @@ bwdn_kernel(BwdnParams p) {
       if (!a0 && !a1) return;
       char *sg0 = sG + (stage * 2) * kBnStage, *sg1 = sg0 + kBnStage;
       auto consume = [&](char *sg) __attribute__((always_inline)) {
-        uint4 g_c[2], w_c[NBC];
+        uint4 g_c[MB], w_c[NBC];
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) g_c[mb] = g[0][mb];
+        for (int mb = 0; mb < MB; ++mb) g_c[mb] = g[0][mb];
 #pragma unroll
         for (int nb = 0; nb < NBC; ++nb) w_c[nb] = w[0][nb];
         // shift the ring, refill its tail: rows of the item kBnRows ahead (its table words arrived a step ago),
         // table words of the item after that
 #pragma unroll
-        for (int q = 0; q + 1 < kBnRows; ++q) {
+        for (int q = 0; q + 1 < ROWS; ++q) {
 #pragma unroll
-          for (int mb = 0; mb < 2; ++mb) g[q][mb] = g[q + 1][mb];
+          for (int mb = 0; mb < MB; ++mb) g[q][mb] = g[q + 1][mb];
 #pragma unroll
           for (int nb = 0; nb < NBC; ++nb) w[q][nb] = w[q + 1][nb];
         }
-        load_rows(ixn, g[kBnRows - 1]);
-        load_w(la_r_pending, w[kBnRows - 1]);
+        load_rows(ixn, g[ROWS - 1]);
+        load_w(la_r_pending, w[ROWS - 1]);
         la_next(la_t_pending, la_r_pending);
         load_idx(la_t_pending, la_r_pending, ixn);
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-          if (lgrp < SLK) *reinterpret_cast<uint4 *>(sg + ctr_slot(wave * 32 + mb * 16 + lrow, lgrp)) = g_c[mb];
+        for (int mb = 0; mb < MB; ++mb)
+          if (lgrp < SLK) *reinterpret_cast<uint4 *>(sg + ctr_slot(wave * RPW + mb * 16 + lrow, lgrp)) = g_c[mb];
         // dgrad: din[rows] += G . W_r   (one 32-deep MFMA step: the reduction index is the dout channel)
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
           for (int nb = 0; nb < NBC; ++nb) acc_d[mb][nb] = mfma16<BF16>(g_c[mb], w_c[nb], acc_d[mb][nb]);
       };
@@ -268,15 +281,27 @@ bwdn_kernel(BwdnParams p) {
       __syncthreads();                            // stages complete (the other two were last read one step ago)
       // wgrad: dW_r[k'][c] += G^T . F over the tile's 128 rows (four 32-row MFMA steps per table row)
       if (wg_live) {
-        if (a0)
-#pragma unroll
-          for (int ks = 0; ks < kBnTile / 32; ++ks)
-            acc_w[r0] = mfma16<BF16>(ctr_frag(sg0, ks * 32 + lgrp * 8, lrow, kb), ffr[ks], acc_w[r0]);
-        if constexpr (r1 < kBnMaxKv) {
-          if (a1)
+        if constexpr (W8) {
+          // the two halves of the workgroup take one member of the pair each (accumulator index = the pair)
+          constexpr int qi = r0 / 2;
+          if (par == 0 ? a0 : a1) {
+            const char *sgp = par == 0 ? sg0 : sg1;
 #pragma unroll
             for (int ks = 0; ks < kBnTile / 32; ++ks)
-              acc_w[r1] = mfma16<BF16>(ctr_frag(sg1, ks * 32 + lgrp * 8, lrow, kb), ffr[ks], acc_w[r1]);
+              acc_w[qi] = mfma16<BF16>(ctr_frag(sgp, ks * 32 + lgrp * 8, lrow, kb),
+                                       ctr_frag(sF, ks * 32 + lgrp * 8, lrow, cb), acc_w[qi]);
+          }
+        } else {
+          if (a0)
+#pragma unroll
+            for (int ks = 0; ks < kBnTile / 32; ++ks)
+              acc_w[r0] = mfma16<BF16>(ctr_frag(sg0, ks * 32 + lgrp * 8, lrow, kb), ffr[ks], acc_w[r0]);
+          if constexpr (r1 < kBnMaxKv) {
+            if (a1)
+#pragma unroll
+              for (int ks = 0; ks < kBnTile / 32; ++ks)
+                acc_w[r1] = mfma16<BF16>(ctr_frag(sg1, ks * 32 + lgrp * 8, lrow, kb), ffr[ks], acc_w[r1]);
+          }
         }
       }
       stage ^= 1;
@@ -285,12 +310,12 @@ bwdn_kernel(BwdnParams p) {
     if (p.din) {
       uint16_t *din = static_cast<uint16_t *>(p.din);
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
+      for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int nb = 0; nb < NBC; ++nb)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const int row = base + wave * 32 + mb * 16 + lgrp * 4 + e;
+            const int row = base + wave * RPW + mb * 16 + lgrp * 4 + e;
             if (row < p.n_in) din[static_cast<size_t>(row) * C + nb * 16 + lrow] = from_float<BF16>(acc_d[mb][nb][e]);
           }
     }
@@ -298,12 +323,13 @@ bwdn_kernel(BwdnParams p) {
   // ---- partial weight gradient of this workgroup: [kv][K][C] fp32, D layout (k' = 4 (lane >> 4) + e, c = lane & 15)
   if (wg_live) {
     float *dst = p.partial + static_cast<size_t>(blockIdx.x) * p.kv * (K * C);
-    static_for<0, kBnMaxKv>([&](auto rc) __attribute__((always_inline)) {
-      constexpr int r = decltype(rc)::value;
+    static_for<0, NACC>([&](auto rc) __attribute__((always_inline)) {
+      constexpr int a = decltype(rc)::value;
+      const int r = W8 ? 2 * a + par : a;        // the table row accumulator `a` of this wave belongs to
       if (r < p.kv) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          dst[static_cast<size_t>(r) * (K * C) + (kb * 16 + lgrp * 4 + e) * C + cb * 16 + lrow] = acc_w[r][e];
+          dst[static_cast<size_t>(r) * (K * C) + (kb * 16 + lgrp * 4 + e) * C + cb * 16 + lrow] = acc_w[a][e];
       }
     });
   }
@@ -390,13 +416,15 @@ int spx_igemm_bwd_rows(const void *feat, const void *dout, const void *weight_t,
   p.ntiles = div_up(n_in, kBnTile);
   const int G = bwdn_groups(p.ntiles);
   const size_t smem = 5 * static_cast<size_t>(kBnStage);
-  // (80 KB of dynamic LDS: above the 64 KB a kernel gets without asking)
+  // measured on level 1 / 2 of the config-4 network: C = K = 16: 91 us with 8 waves, 99 with 4; C = K = 32: 115 vs 107
+  // (the 8-wave form of C = 32 spills and affords a ring depth of one).  All four numbers sit near what the
+  // gathered LINES cost -- a 64- (32-) byte row pulls a whole 128-byte line out of the L2 -- which is why neither
+  // occupancy nor a deeper ring, fewer barriers or fewer LDS reads moved them.
+  const bool w8 = option_int("SPX_BWDN_WAVES", (C == 16 && K == 16) ? 8 : 4) == 8;
 #define SPX_BWDN(BF, CC, KK)                                                                                   \
   do {                                                                                                         \
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&bwdn_kernel<BF, CC, KK>), \
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)); \
-    SPX_HIP(attr);                                                                                             \
-    hipLaunchKernelGGL((bwdn_kernel<BF, CC, KK>), dim3(G), dim3(kThreads), smem, s, p);                        \
+    if (w8) hipLaunchKernelGGL((bwdn_kernel<BF, CC, KK, true>), dim3(G), dim3(512), smem, s, p);               \
+    else hipLaunchKernelGGL((bwdn_kernel<BF, CC, KK, false>), dim3(G), dim3(256), smem, s, p);                 \
   } while (0)
   const bool bf = dtype == SPX_BF16;
   if (C == 16 && K == 16) { if (bf) SPX_BWDN(true, 16, 16); else SPX_BWDN(false, 16, 16); }
