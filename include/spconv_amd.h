@@ -289,8 +289,8 @@ int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t 
  * input gradient AND to the weight gradient.  Same role as spx_igemm_bwd (ConvGemmOps.implicit_gemm_backward,
  * pytorch/ops.py:1667-1896), without the Native lists and the range plan:
  *   table [kv, n_in], mask [n_in]: the dgrad table (SubM: pair_fwd; regular conv: pair_bwd) and its mask words
- *   weight_t [kv, C, K]: weight slice of TABLE ROW r with the dout channel contiguous, i.e.
- *                        weight_t[r][c][k'] = weight[k'][mirror ? kv-1-r : r][c]
+ *   weight_t [kv, C, K]: the weights with the dout channel contiguous, weight_t[k][c][k'] = weight[k'][k][c];
+ *                        mirror = 1 (SubM): table row r pairs with slice kv-1-r
  *   din [n_in, C] or NULL;  dw KRSC [K, kv, C] in `dtype`, fully overwritten (deterministic)
  *   ws: spx_igemm_bwd_rows_ws_bytes (per-workgroup fp32 partial weight gradients) */
 size_t spx_igemm_bwd_rows_ws_bytes(int n_in, int C, int K, int kv);

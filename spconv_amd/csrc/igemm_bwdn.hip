@@ -64,6 +64,7 @@ struct BwdnParams {
   const int32_t *table;    // [kv, n_in]: dout row of (table row r, input row i), or -1
   const uint32_t *mask;    // [n_in]: bit r <=> table[r][i] >= 0
   int n_in, n_out, kv, ntiles;
+  int mirror;              // table row r pairs with weight slice kv - 1 - r (SubM)
 };
 
 // C, K in {16, 32}.  256 threads: wave w owns input rows [32 w, 32 w + 32) of a tile for dgrad and output
@@ -175,11 +176,12 @@ bwdn_kernel(BwdnParams p) {
       g[mb] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rD, off, 0, 0));
     }
   };
-  // weight fragments of table row r (the mirrored weight order of SubM is folded into `wt` on the host)
+  // weight fragments of table row r: slice r, or kv - 1 - r with the mirrored weight order of SubM
   auto load_w = [&](int r, uint4 (&w)[NBC]) __attribute__((always_inline)) {
+    const int kw = p.mirror ? p.kv - 1 - r : r;
 #pragma unroll
     for (int nb = 0; nb < NBC; ++nb) {
-      const uint32_t off = (static_cast<uint32_t>(r) * C + nb * 16 + lrow) * rowD;
+      const uint32_t off = (static_cast<uint32_t>(kw) * C + nb * 16 + lrow) * rowD;
       w[nb] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rW, (off + dcol) | (dcol & kOob), 0, 0));
     }
   };
@@ -414,6 +416,7 @@ int spx_igemm_bwd_rows(const void *feat, const void *dout, const void *weight_t,
   p.n_out = n_out;
   p.kv = kv;
   p.ntiles = div_up(n_in, kBnTile);
+  p.mirror = mirror;
   const int G = bwdn_groups(p.ntiles);
   const size_t smem = 5 * static_cast<size_t>(kBnStage);
   // measured on level 1 / 2 of the config-4 network: C = K = 16: 91 us with 8 waves, 99 with 4; C = K = 32: 115 vs 107

@@ -779,9 +779,9 @@ def _igemm_bwd_rows(features, out_bp, filters, table, mask, subm, need_din, K, C
     L = _lib.load()
     features, out_bp = features.contiguous(), out_bp.contiguous()
     n_in = features.shape[0]
-    # weight slice of table row r with the dout channel contiguous; SubM tables pair row r with slice kv-1-r
-    wt = filters.reshape(K, kv, C).permute(1, 2, 0)
-    wt = (wt.flip(0) if subm else wt).contiguous()
+    # the weights with the dout channel contiguous ([kv, C, K]: one small copy; SubM's mirrored slice order is the
+    # kernel's business)
+    wt = filters.reshape(K, kv, C).permute(1, 2, 0).contiguous()
     din = torch.empty((n_in, C), dtype=out_bp.dtype, device=out_bp.device) if need_din else None
     dw = torch.empty_like(filters)
     ws = _ws(L.spx_igemm_bwd_rows_ws_bytes(n_in, C, K, kv), features.device)

@@ -29,7 +29,14 @@ for level, C in ((1, 16), (2, 32), (3, 64)):
     r["fwd_us"] = t(lambda i: ops.igemm_fwd(f, w, rb.pair_fwd, rb.mask_fwd, None, n, 13))
     r["dgrad_us"] = t(lambda i: ops.igemm_dgrad(d, w, rb.pair_fwd, rb.mask_fwd, None, n, True))
     r["wgrad_us"] = t(lambda i: ops.igemm_wgrad(f, d, w.shape, rb.pair_native, rb.num_per_loc, True, plan))
+    ops._BWD_ROWS = False
     r["fused_bwd_us"] = t(lambda i: ops.igemm_bwd(f, d, w, rb.pair_fwd, rb.mask_fwd, None, rb.pair_native, rb.num_per_loc, True, plan))
+    if C <= 32:                       # the one-gather backward of narrow layers (csrc/igemm_bwdn.hip), forced on
+        ops._BWD_ROWS = True
+        r["bwd_rows_us"] = t(lambda i: ops.igemm_bwd(f, d, w, rb.pair_fwd, rb.mask_fwd, None, rb.pair_native, rb.num_per_loc, True, plan))
+        r["occupancy"] = round(n / (4.0 * shape[0] * shape[1] * shape[2]), 5)
+        r["auto_picks_rows"] = ops._dense_rows(rb, n, "fwd")
+    ops._BWD_ROWS = "auto"
     ab = bench.algorithmic_bytes(n, n, C, C, 27, 2)
     r["fwd_frac"] = round(ab["fwd"] / (r["fwd_us"] * 1e-6) / 8e12, 3)
     r["bwd_frac"] = round(ab["bwd"] / (r["fused_bwd_us"] * 1e-6) / 8e12, 3)
