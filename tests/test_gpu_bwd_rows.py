@@ -118,3 +118,55 @@ def test_module_training_step_takes_the_rows_kernel(cuda, monkeypatch):
     assert calls, "the rows kernel did not run"
     assert rel_err(din_b.float().cpu().numpy(), din_a.float().cpu().numpy()) <= 2e-3
     assert rel_err(dw_b.float().cpu().numpy(), dw_a.float().cpu().numpy()) <= 2e-3
+
+
+@pytest.mark.parametrize("ndim,ksize,stride,subm", [(2, 3, 1, True), (3, 2, 2, False), (2, 3, 2, False)])
+def test_other_kernel_volumes(cuda, ndim, ksize, stride, subm):
+    """kv = 9 (2-d SubM), kv = 8 (k2 s2 in 3-d: exactly one candidate per input), kv = 9 strided in 2-d"""
+    from spconv_amd.pytorch import ops
+    shape = [40] * ndim if ndim == 3 else [96, 96]
+    rng = np.random.default_rng(ndim * 10 + ksize)
+    vol = int(np.prod(shape))
+    lin = rng.choice(vol, size=vol // 5, replace=False)
+    coords = np.stack(np.unravel_index(lin, shape), -1).astype(np.int32)
+    idx = np.concatenate([np.zeros((coords.shape[0], 1), np.int32), coords], 1)
+    pad = [ksize // 2] * ndim if subm else ([1] * ndim if ksize == 3 else [0] * ndim)
+    rb, _ = gpu_rulebook(idx, 1, shape, [ksize] * ndim, [stride] * ndim, pad, [1] * ndim, subm)
+    C = K = 32
+    f = torch.from_numpy(rng.uniform(-1, 1, (rb.n_in, C)).astype(np.float32)).to(cuda).half()
+    w = torch.from_numpy(rng.uniform(-1, 1, (K, *([ksize] * ndim), C)).astype(np.float32)).to(cuda).half()
+    d = torch.from_numpy(rng.uniform(-0.2, 0.2, (rb.n_out, K)).astype(np.float32)).to(cuda).half()
+    table, mask = (rb.pair_fwd, rb.mask_fwd) if subm else (rb.pair_bwd, rb.mask_bwd)
+    plan = ops._plan_of(rb)
+    run = lambda: ops.igemm_bwd(f, d, w, table, mask, None, rb.pair_native, rb.num_per_loc, subm, plan)
+    (din_a, dw_a), (din_b, dw_b) = _both(run)
+    assert rel_err(din_b.float().cpu().numpy(), din_a.float().cpu().numpy()) <= 2e-3
+    assert rel_err(dw_b.float().cpu().numpy(), dw_a.float().cpu().numpy()) <= 2e-3
+
+
+def test_padded_rows_of_a_static_tensor(cuda):
+    """dead rows (batch index -1, mask 0, zero features) in the table: no contribution, zero input gradient"""
+    from spconv_amd.pytorch import ops
+    shape = [24, 24, 24]
+    idx = dense_scene(shape, 3000, 1, 2)
+    n, n_static = idx.shape[0], idx.shape[0] + 700
+    padded = np.concatenate([idx, np.full((n_static - n, 4), -1, np.int32)], 0)
+    rb, _ = gpu_rulebook(idx, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True)
+    rbp, _ = gpu_rulebook(padded, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True)
+    rng = np.random.default_rng(8)
+    f, w, d = _tensors(rng, n, n, 32, 32, torch.float16, cuda)
+    fp = torch.zeros((n_static, 32), dtype=torch.float16, device=cuda)
+    fp[:n] = f
+    dp = torch.zeros((n_static, 32), dtype=torch.float16, device=cuda)
+    dp[:n] = d
+    old = ops._BWD_ROWS
+    try:
+        ops._BWD_ROWS = True
+        din, dw = ops.igemm_bwd(f, d, w, rb.pair_fwd, rb.mask_fwd, None, rb.pair_native, rb.num_per_loc, True, ops._plan_of(rb))
+        dinp, dwp = ops.igemm_bwd(fp, dp, w, rbp.pair_fwd, rbp.mask_fwd, None, rbp.pair_native, rbp.num_per_loc, True,
+                                  ops._plan_of(rbp))
+    finally:
+        ops._BWD_ROWS = old
+    torch.cuda.synchronize()
+    assert torch.equal(dinp[:n], din) and not bool(dinp[n:].any())
+    assert rel_err(dwp.float().cpu().numpy(), dw.float().cpu().numpy()) <= 1e-3      # (another tile partition: summation order)
