@@ -297,6 +297,10 @@ class SparseConvTensor(metaclass=torch.fx.ProxyableClassMeta):
         return self.indice_dict.get(key, None)
 
     def dense(self, channels_first: bool = True) -> torch.Tensor:
+        if self.n_live_dev is not None:
+            # a static-shape tensor: padding rows carry batch index -1, which plain indexing would wrap around
+            from spconv_amd.pytorch.static import dense_static
+            return dense_static(self, channels_first)
         out_shape = [self.batch_size] + list(self.spatial_shape) + [self.features.shape[1]]
         res = scatter_nd(self.indices.to(self.features.device).long(), self.features, out_shape)
         if not channels_first:

@@ -133,6 +133,7 @@ def test_captured_backbone_is_bit_identical_to_eager(cuda, pool, dtype):
         if not pool:                                            # (a max pool leaves `lowest` in its dead rows)
             assert torch.isfinite(got.features.float()).all()
         assert torch.equal(dense_static(got), want.dense())
+        assert torch.equal(got.dense(), want.dense())           # (.dense() of a static tensor takes the same path)
         counts = runner.counts()
         assert counts[names[1]][0] == n_live
 
