@@ -389,3 +389,91 @@ def test_device_guard_switches_to_the_tensor_device(monkeypatch):
     assert driver(fake(0)) == "ok" and entered == []                               # already current: no guard
     assert driver(torch.zeros(2)) == "ok" and entered == []                        # CPU tensor: no guard
     assert driver(None, extra=fake(1)) == "ok" and entered == []                   # only positional tensors decide
+
+
+def test_compact_candidates_of_a_strided_convolution():
+    """Python restatement of csrc/rulebook.hip CandIter (third-generation strided-conv rulebook): the valid
+    offsets of an axis as a bit set computed WITHOUT integer division (float32 multiply by 1/s + round, exact
+    below 2^21), their product walked in ascending offset index.  Against the brute force over all offsets with
+    the reference's integer formula (query_npq, indices.py:174-203): same candidates, same order, and never more
+    than prod ceil(k gcd(d, s) / s) of them (conv_max_out, the bound the [MJ, N] arrays are sized by)."""
+    import math
+    rng = np.random.default_rng(0)
+
+    def bits(c, k, s, p, d, out):
+        inv = np.float32(1.0) / np.float32(s)
+        m = 0
+        for r in range(k):
+            h = c + p - r * d
+            q = int(np.rint(np.float32(h) * inv))
+            if q * s == h and 0 <= q < out:
+                m |= 1 << r
+        return m
+
+    for trial in range(400):
+        nd = int(rng.integers(1, 4))
+        k = [int(rng.integers(1, 6)) for _ in range(nd)]
+        s = [int(rng.integers(1, 5)) for _ in range(nd)]
+        d = [int(rng.integers(1, 4)) for _ in range(nd)]
+        p = [int(rng.integers(0, 3)) for _ in range(nd)]
+        dims = [int(rng.integers(1, 2_000_000)) if trial % 7 == 0 else int(rng.integers(1, 40)) for _ in range(nd)]
+        out = [(dims[i] + 2 * p[i] - d[i] * (k[i] - 1) - 1) // s[i] + 1 for i in range(nd)]
+        if min(out) <= 0:
+            continue
+        bound = math.prod(min(k[i], -(-k[i] * math.gcd(d[i], s[i]) // s[i])) for i in range(nd))
+        for _ in range(20):
+            c = [int(rng.integers(0, dims[i])) for i in range(nd)]
+            # brute force, ascending offset index (last axis fastest)
+            want = []
+            for kk in range(math.prod(k)):
+                r, rest = [], kk
+                for i in reversed(range(nd)):
+                    r.append(rest % k[i])
+                    rest //= k[i]
+                r = r[::-1]
+                h = [c[i] + p[i] - r[i] * d[i] for i in range(nd)]
+                if all(h[i] % s[i] == 0 and 0 <= h[i] // s[i] < out[i] for i in range(nd)):
+                    want.append((kk, tuple(h[i] // s[i] for i in range(nd))))
+            # the bit-set odometer
+            vm = [bits(c[i], k[i], s[i], p[i], d[i], out[i]) for i in range(nd)]
+            got = []
+            if all(vm):
+                v = list(vm)
+                while True:
+                    r = [(x & -x).bit_length() - 1 for x in v]
+                    kk = 0
+                    for i in range(nd):
+                        kk = kk * k[i] + r[i]
+                    got.append((kk, tuple((c[i] + p[i] - r[i] * d[i]) // s[i] for i in range(nd))))
+                    i = nd - 1
+                    while i >= 0:
+                        v[i] &= v[i] - 1
+                        if v[i]:
+                            break
+                        v[i] = vm[i]
+                        i -= 1
+                    if i < 0:
+                        break
+            assert got == want, (k, s, p, d, dims, c)
+            assert len(got) <= bound, (len(got), bound, k, s, d)
+
+
+def test_first_seen_ranks_from_a_bit_map():
+    """The numbering scheme of the same builder: first-seen flags of one table row as a bit map; the output number
+    of an entry = entries of earlier blocks (scan of the block popcounts) + set bits of earlier words in its
+    2048-bit block + set bits below it in its word.  Must equal the running count in input order."""
+    rng = np.random.default_rng(1)
+    n = 10_000
+    flags = rng.random(n) < 0.3
+    words = np.zeros((n + 31) // 32, np.uint32)
+    for i in np.nonzero(flags)[0]:
+        words[i >> 5] |= np.uint32(1 << (i & 31))
+    pop = np.array([bin(int(w)).count("1") for w in words])
+    nblk = (n + 2047) // 2048
+    blockcount = np.array([pop[b * 64:(b + 1) * 64].sum() for b in range(nblk)])
+    blockoff = np.concatenate([[0], np.cumsum(blockcount)[:-1]])
+    wordpre = np.concatenate([np.concatenate([[0], np.cumsum(pop[b * 64:(b + 1) * 64])[:-1]]) for b in range(nblk)])
+    want = np.cumsum(flags) - 1
+    for i in np.nonzero(flags)[0]:
+        below = bin(int(words[i >> 5]) & ((1 << (i & 31)) - 1)).count("1")
+        assert blockoff[i // 2048] + wordpre[i >> 5] + below == want[i]
