@@ -2,7 +2,8 @@
 # round 3 final evidence: full GPU test suite, smoke, default bench, rocprof + PMC sets of configs 2, 2b, 5
 cd "$(dirname "$0")/.."
 O=gpurun_out
-(time timeout -k 10 1500 python -m pytest tests -q -m gpu) > $O/r3s_pytest.txt 2>&1
+ulimit -c 0
+(time timeout -k 10 900 python -m pytest tests -q -m gpu) > $O/r3s_pytest.txt 2>&1
 echo "rc=$?" >> $O/r3s_pytest.txt
 tail -5 $O/r3s_pytest.txt
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
