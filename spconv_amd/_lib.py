@@ -111,7 +111,7 @@ def build(force: bool = False) -> str:
     """Compile the HIP sources for gfx950 (no GPU needed)."""
     script = os.path.join(_HERE, "csrc", "build.sh")
     if force:
-        for f in ("rulebook.o", "igemm.o", "igemm_gen1.o", "igemm5.o", "igemm_sp.o", "pool.o", "tileplan.o", "norm.o", "common.o", "libspconv_amd.so"):
+        for f in ("rulebook.o", "igemm.o", "igemm_gen1.o", "igemm5.o", "igemm_sp.o", "igemm_bwdn.o", "pool.o", "tileplan.o", "norm.o", "common.o", "libspconv_amd.so"):
             p = os.path.join(_HERE, "lib", f)
             if os.path.exists(p):
                 os.remove(p)
