@@ -12,6 +12,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A kernel that never returns must cost ONE test, not the whole GPU run: every GPU test gets a wall-clock
+    limit (pytest-timeout, thread method: the process dumps its stacks and exits -- a blocked HIP call cannot be
+    interrupted by a signal).  The slowest tests (bench.py end to end, full-size oracle comparisons) take < 60 s."""
+    try:
+        import pytest_timeout  # noqa: F401
+    except ImportError:
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") is not None and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(600, method="thread"))
+
+
 @pytest.fixture(scope="session")
 def cuda():
     import torch
