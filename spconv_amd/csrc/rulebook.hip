@@ -1907,7 +1907,10 @@ int spx_subm_rulebook(const int32_t *indices, int n, int ndim, int batch_size,
       if (pair_bwd) fills.add(pair_bwd + static_cast<size_t>(kv / 2 + 1) * n, half, 0xFFFFFFFFu);
     }
     SPX_HIP(fills.launch(s));
-    const int mask_pass = option_int("SPX_SUBM_MASK_PASS", 0);
+    // masks from a pass over the finished table instead of one atomicOr per entry: the extra launch costs 5-10 us at
+    // 100 k voxels, the saved atomics (20-25 G/s device-wide) win from ~250 k (400 k: 162 -> 151 us); -1 = by size
+    const int mp_opt = option_int("SPX_SUBM_MASK_PASS", -1);
+    const int mask_pass = mp_opt < 0 ? (n >= 250000 ? 1 : 0) : mp_opt;
     hipLaunchKernelGGL(subm_insert_kernel, grid, dim3(kBlock), 0, s, indices, n, g, t, slot_of,
                        mask_pass ? static_cast<uint32_t *>(nullptr) : mask, words);
     const bool lists = pair_native || num_per_loc;

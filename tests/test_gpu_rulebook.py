@@ -300,3 +300,27 @@ def test_num_out_act_bound_caps_the_outputs(cuda):
     # a bound above the real count changes nothing
     same, _ = ops.build_rulebook(*args, False, num_out_act_bound=full.n_out + 10)
     assert same.n_out == full.n_out
+
+
+def test_subm_masks_from_a_table_pass_equal_the_atomic_form(cuda):
+    """From 250 k voxels the SubM builder derives the mask words from the finished table instead of one atomicOr
+    per entry (SPX_SUBM_MASK_PASS: -1 = by size): both forms, same tables and masks, at a size where the default
+    switches."""
+    from spconv_amd import _lib
+    from spconv_amd.utils import synthetic
+    shape = [41, 1600, 1408]
+    idx = synthetic.lidar_like_scene(shape, 150_000, 2, seed=3)
+    assert idx.shape[0] >= 250_000
+    L = _lib.load()
+    got = {}
+    try:
+        for v in (0, 1, -1):
+            _lib.check(L.spx_set_option(b"SPX_SUBM_MASK_PASS", v))
+            rb, _ = gpu_rulebook(idx, 2, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True, need_bwd_table=True)
+            got[v] = [t.clone() for t in (rb.pair_fwd, rb.pair_bwd, rb.mask_fwd, rb.pair_native, rb.num_per_loc)]
+    finally:
+        _lib.check(L.spx_set_option(b"SPX_SUBM_MASK_PASS", -1))
+    for v in (1, -1):
+        assert all(torch.equal(a, b) for a, b in zip(got[0], got[v])), v
+    centre = 1 << 13
+    assert bool(((got[0][2].view(-1) & centre) != 0).all())       # every row has its centre bit
