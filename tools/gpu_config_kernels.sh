@@ -1,5 +1,5 @@
 #!/bin/bash
-kernel stats of config 3 (eager + captured static steps)
+# kernel stats of config 3 (eager + captured static steps)
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

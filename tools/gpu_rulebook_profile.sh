@@ -1,5 +1,5 @@
 #!/bin/bash
-compact-candidate regular-conv rulebook (SPX_CONV_V=3) -- parity, then device times v2 vs v3
+# compact-candidate regular-conv rulebook (SPX_CONV_V=3) -- parity, then device times v2 vs v3
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

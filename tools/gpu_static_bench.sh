@@ -1,5 +1,5 @@
 #!/bin/bash
-static-shape training step (configs 3 / 4 captured whole) + inference pass (4i)
+# static-shape training step (configs 3 / 4 captured whole) + inference pass (4i)
 cd "$(dirname "$0")/.."
 O=gpurun_out
 timeout -k 10 900 python -m pytest tests/test_gpu_static.py tests/test_gpu_norm.py tests/test_gpu_modules.py -x -q 2>&1 | grep -v amdgpu.ids | tail -15 > $O/r3y_tests.txt
