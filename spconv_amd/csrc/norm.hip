@@ -185,14 +185,27 @@ bn_partial_kernel(const u32x4 *__restrict__ x, int n, int C, float *__restrict__
   for (int i = 0; i < VPL; ++i) shift[i] = sum[i] = sq[i] = 0.f;
   if (s.active && s.r0 < s.r1) Vec<DT>::unpack(x[static_cast<size_t>(s.r0) * P + s.piece], shift);
   if (s.active) {
-    for (int r = s.r0 + s.lane_row; r < s.r1; r += s.rows_per_sweep) {
-      float f[VPL];
-      Vec<DT>::unpack(x[static_cast<size_t>(r) * P + s.piece], f);
+    // four rows of loads in flight per thread (a block owns ~390 rows: without this a thread's 3-4 loads were a
+    // chain of memory round trips); rows past the block's end are predicated, not branched around
+    for (int r = s.r0 + s.lane_row; r < s.r1; r += 4 * s.rows_per_sweep) {
+      u32x4 v[4];
 #pragma unroll
-      for (int i = 0; i < VPL; ++i) {
-        const float d = f[i] - shift[i];
-        sum[i] += d;
-        sq[i] += d * d;
+      for (int u = 0; u < 4; ++u) {
+        const int ru = r + u * s.rows_per_sweep;
+        v[u] = ru < s.r1 ? x[static_cast<size_t>(ru) * P + s.piece] : u32x4{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (r + u * s.rows_per_sweep < s.r1) {
+          float f[VPL];
+          Vec<DT>::unpack(v[u], f);
+#pragma unroll
+          for (int i = 0; i < VPL; ++i) {
+            const float d = f[i] - shift[i];
+            sum[i] += d;
+            sq[i] += d * d;
+          }
+        }
       }
     }
   }
@@ -329,16 +342,29 @@ bn_bwd_partial_kernel(const u32x4 *__restrict__ x, const u32x4 *__restrict__ dy,
     bb[i] = (s.active && bias) ? ldp(bias, pdt, c) : 0.f;
   }
   if (s.active) {
-    for (int r = s.r0 + s.lane_row; r < s.r1; r += s.rows_per_sweep) {
-      float f[VPL], g[VPL];
-      Vec<DT>::unpack(x[static_cast<size_t>(r) * P + s.piece], f);
-      Vec<DT>::unpack(dy[static_cast<size_t>(r) * P + s.piece], g);
+    for (int r = s.r0 + s.lane_row; r < s.r1; r += 4 * s.rows_per_sweep) {      // (as bn_partial_kernel)
+      u32x4 vx[4], vg[4];
 #pragma unroll
-      for (int i = 0; i < VPL; ++i) {
-        const float xh = (f[i] - mu[i]) * is[i];
-        const float gg = (relu && xh * w[i] + bb[i] <= 0.f) ? 0.f : g[i];
-        s1[i] += gg;
-        s2[i] += gg * xh;
+      for (int u = 0; u < 4; ++u) {
+        const int ru = r + u * s.rows_per_sweep;
+        const bool ok = ru < s.r1;
+        vx[u] = ok ? x[static_cast<size_t>(ru) * P + s.piece] : u32x4{0u, 0u, 0u, 0u};
+        vg[u] = ok ? dy[static_cast<size_t>(ru) * P + s.piece] : u32x4{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (r + u * s.rows_per_sweep < s.r1) {
+          float f[VPL], g[VPL];
+          Vec<DT>::unpack(vx[u], f);
+          Vec<DT>::unpack(vg[u], g);
+#pragma unroll
+          for (int i = 0; i < VPL; ++i) {
+            const float xh = (f[i] - mu[i]) * is[i];
+            const float gg = (relu && xh * w[i] + bb[i] <= 0.f) ? 0.f : g[i];
+            s1[i] += gg;
+            s2[i] += gg * xh;
+          }
+        }
       }
     }
   }
