@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import dense_scene, gpu_rulebook, oracle_rulebook, scene, to_np
+from util import gpu_rulebook, oracle_rulebook, scene, to_np
 
 pytestmark = pytest.mark.gpu
 
