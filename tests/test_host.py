@@ -477,3 +477,31 @@ def test_first_seen_ranks_from_a_bit_map():
     for i in np.nonzero(flags)[0]:
         below = bin(int(words[i >> 5]) & ((1 << (i & 31)) - 1)).count("1")
         assert blockoff[i // 2048] + wordpre[i >> 5] + below == want[i]
+
+
+def test_static_shape_bookkeeping_on_the_host():
+    """strided_layers / freeze_bounds (spconv_amd/pytorch/static.py) and the occupancy rule that picks the
+    one-gather backward (ops._dense_rows): pure host logic."""
+    import spconv_amd.pytorch as spconv
+    from spconv_amd.pytorch import ops
+    from spconv_amd.pytorch.core import Rulebook
+    from spconv_amd.pytorch.static import freeze_bounds, strided_layers
+    from spconv_amd.utils import nets
+    net = nets.second_backbone(4)
+    layers = strided_layers(net)
+    assert len(layers) == 4 and all(not m.subm for m in layers.values())          # the four down-sampling convs
+    names = list(layers)
+    with pytest.raises(ValueError, match="no recorded voxel count"):
+        freeze_bounds(net)
+    used = freeze_bounds(net, {n: 1000 * (i + 1) for i, n in enumerate(names)})
+    assert [layers[n].static_num_out for n in names] == [1000, 2000, 3000, 4000] == list(used.values())
+    assert freeze_bounds(net, {}, margin=0) == {n: 0 for n in names}
+    pool = spconv.SparseSequential(spconv.SparseMaxPool3d(2, 2), spconv.SubMConv3d(4, 4, 3), spconv.SparseConv3d(4, 4, 1))
+    assert list(strided_layers(pool)) == ["0"]                                      # a 1x1x1 conv makes no new voxels
+
+    rb = Rulebook(None, None, None, None, None, None, None, 400_000, 400_000, 27, True)
+    rb.in_shape, rb.out_shape, rb.batch_size = [41, 1600, 1408], [41, 1600, 1408], 4
+    assert not ops._dense_rows(rb, 400_000, "fwd")                                  # 0.1 % of the cells: pair lists
+    rb.in_shape = rb.out_shape = [21, 800, 704]
+    assert ops._dense_rows(rb, 313_127, "fwd") and ops._dense_rows(rb, 313_127, "bwd")   # 0.66 %: the tile walk
+    assert not ops._dense_rows(None, 10, "fwd")
