@@ -81,8 +81,13 @@ def parse(argv=None):
     ap.add_argument("--no-also", action="store_true",
                     help="config 2 at N = 1 only: skip the compact block of the other configurations")
     ap.add_argument("--sort", choices=["auto", "on", "off"], default="auto",
-                    help="row order of the rulebook tables: auto = density-aware (ops.build_rulebook(do_sort='auto'): "
-                         "sparse SubM rulebooks are mask-sorted, dense ones stay in row order), on / off = forced")
+                    help="row order of the rulebook tables: auto = the layer modules' default (density-aware rows "
+                         "layout built on the device inside the rulebook build), on = the reference's explicit mask "
+                         "sort (SPCONV_DO_SORT=1), off = input order (SPCONV_DO_SORT=0)")
+    ap.add_argument("--prewarm", type=int, default=400,
+                    help="untimed steps run BEFORE the contract's W warm-up steps (clock ramp, allocator and "
+                         "cache state): with a short --steps the timed region is then steady state; stated in "
+                         "config.prewarm_steps")
     ap.add_argument("--graph-steps", type=int, default=8,
                     help="steps captured per hipGraph at N = 1 (a replay boundary costs ~5 us; with N > 1 "
                          "the gradient all-reduce follows every step, so one step per replay)")
@@ -427,6 +432,9 @@ def run_layer(args, D: Dist):
     C = K = args.channels or 64
     S = max(1, args.scenes)
     torch.manual_seed(0)
+    import spconv_amd.pytorch.conv as conv_mod
+    if args.sort != "auto":              # A/B runs only: what SPCONV_DO_SORT=1 / 0 would select
+        conv_mod.MODULE_DO_SORT = {"on": True, "off": False}[args.sort]
     net = spconv.SubMConv3d(C, K, 3, bias=False, indice_key="bench").to(dev, dtype)
     net.train()
 
@@ -443,10 +451,18 @@ def run_layer(args, D: Dist):
         sc.feats = (torch.rand((sc.n, C), generator=g) * 2 - 1).to(dev, dtype).requires_grad_(True)
         sc.dout = ((torch.rand((sc.n, K), generator=g) * 2 - 1) * 0.2).to(dev, dtype)
 
-        def build(sc=sc):
+        # the rulebook is the one the MODULE builds: net(x) with a default environment (density-aware rows layout
+        # made on the device inside the build), cached under the layer's indice_key and reused by every later step
+        # exactly as a second SubM layer of a backbone stage reuses it (docs/USAGE.md:104-105)
+        with torch.no_grad():
+            y0 = net(spconv.SparseConvTensor(sc.feats.detach(), sc.indices, sc.shape, 1))
+        sc.rb = y0.indice_dict["bench"].rulebook
+        sc.x = spconv.SparseConvTensor(sc.feats, sc.indices, sc.shape, 1, indice_dict=y0.indice_dict)
+        del y0
+
+        def build(sc=sc):            # what the module's first call runs (conv.py: ops.build_rulebook)
             return ops.build_rulebook(sc.indices, 1, sc.shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3,
-                                      True, do_sort={"auto": "auto", "on": True, "off": False}[args.sort])[0]
-        sc.rb = build()
+                                      True, do_sort=conv_mod.MODULE_DO_SORT)[0]
         torch.cuda.synchronize()
         if si == 0:                      # rulebook build: timed separately (wall, incl. enqueue)
             for _ in range(5):
@@ -455,15 +471,11 @@ def run_layer(args, D: Dist):
                 torch.cuda.synchronize()
                 rule_ms.append((time.perf_counter() - t0) * 1e3)
             t_rule_dev = event_time_ms(lambda i: build(), iters=10, warm=2)
-        sc.x = spconv.SparseConvTensor(sc.feats, sc.indices, sc.shape, 1)
-        sc.x.indice_dict["bench"] = net._make_indice_data(sc.rb, sc.indices, sc.shape, sc.shape, net.algo)
         ops._plan_of(sc.rb)
-        sc.tp = ops.tile_plan(sc.rb, "fwd")          # dense neighbourhoods: spatial tiles + halo lists
         num = sc.rb.num_per_loc.cpu().numpy()
         sc.P = int(sc.n + 2 * num[:13].sum())                      # pairs incl. centre
         scenes.append(sc)
     n = scenes[0].n
-    tiled = scenes[0].tp is not None
     bucket = GradBucket(net.parameters()) if D.multi else None   # fp16 gradient, reduced in place
 
     def compute(sc):
@@ -602,6 +614,7 @@ def run_layer(args, D: Dist):
         for _ in range(k):
             step(warm)
 
+    run_steps(args.prewarm)              # untimed, stated in config.prewarm_steps; the contract's W + K follow
     elapsed = timed_region(D, run_steps, args.warmup, args.steps)
     warm_ms = None
     if not D.multi and S > 1:             # the same K steps on ONE scene (Infinity-Cache-resident)
@@ -634,18 +647,18 @@ def run_layer(args, D: Dist):
         def fwd(i):
             sc = scenes[pick(i)]
             pair, mask, order, to = ops.tables_of(sc.rb, "fwd", K)
-            ops.igemm_fwd(sc.feats.detach(), w, pair, mask, order, sc.n, 13, plan=sc.tp, tile_order=to)
+            ops.igemm_fwd(sc.feats.detach(), w, pair, mask, order, sc.n, 13, tile_order=to)
 
         def bwd(i):
             sc = scenes[pick(i)]
             pair, mask, order, to = ops.tables_of(sc.rb, "fwd", C)
             ops.igemm_bwd(sc.feats.detach(), sc.dout, w, pair, mask, order, sc.rb.pair_native,
-                          sc.rb.num_per_loc, True, plan[pick(i)], tile_plan=sc.tp, tile_order=to)
+                          sc.rb.num_per_loc, True, plan[pick(i)], tile_order=to)
 
         def dgrad(i):
             sc = scenes[pick(i)]
             pair, mask, order, to = ops.tables_of(sc.rb, "fwd", C)
-            ops.igemm_dgrad(sc.dout, w, pair, mask, order, sc.n, True, plan=sc.tp, tile_order=to)
+            ops.igemm_dgrad(sc.dout, w, pair, mask, order, sc.n, True, tile_order=to)
 
         def wgrad(i):
             sc = scenes[pick(i)]
@@ -679,15 +692,11 @@ def run_layer(args, D: Dist):
     t_sort_dev = None
     if scenes[0].rb.argsort_fwd is not None:      # mask sort + tile-order table copies: once per rulebook
         t_sort_dev = round(event_time_ms(lambda i: ops.sort_rulebook(scenes[0].rb), iters=10, warm=2), 4)
-    t_plan_dev = None
-    if tiled:            # building a plan (spatial sort + halo lists): once per rulebook, like the rulebook itself
-
-        def replan(i):
-            scenes[0].rb.tile_plans.clear()
-            ops.tile_plan(scenes[0].rb, "fwd")
-        mode, ops._TILE_MODE = ops._TILE_MODE, "1"       # (skip the density read-back: time the build only)
-        t_plan_dev = round(event_time_ms(replan, iters=10, warm=2), 4)
-        ops._TILE_MODE = mode
+    t_layout_dev, layout_info = None, None
+    if scenes[0].rb.layout is not None:           # the rows layout alone (count -> scan -> scatter), part of every build
+        t_layout_dev = round(event_time_ms(lambda i: ops.rows_layout(scenes[0].rb), iters=10, warm=2), 4)
+        head = scenes[0].rb.layout[:4].cpu().tolist()
+        layout_info = {"class": "regrouped" if head[0] else "identity", "rows_with_a_neighbour": head[1]}
     s = scenes[0].feats.element_size()
     P = sum(sc.P for sc in scenes) / S
     ab = algorithmic_bytes(n_mean, n_mean, C, K, 27, s)
@@ -696,9 +705,7 @@ def run_layer(args, D: Dist):
     strict = {"fwd": ab["fwd"], "bwd": s * n_mean * K + 2 * s * n_mean * C + 4 * 27 * n_mean + 8 * P
               + 2 * s * 27 * C * K}
     dt = args.dtype
-    kname = ({"fwd": f"igemm_halo_kernel<{K},{dt},fwd>",
-              "bwd": f"igemm_halo_kernel<{C},{dt},dgrad> + wgrad_tr_kernel + wgrad_reduce2_kernel"} if tiled else
-             {"fwd": f"igemm_v4_kernel<{K},2,{dt},fwd>", "bwd": f"igemm_bwd_kernel<{C},2,{dt}> + wgrad_reduce2_kernel"})
+    kname = {"fwd": f"igemm_v4_kernel<{K},2,{dt},fwd>", "bwd": f"igemm_bwd_kernel<{C},2,{dt}> + wgrad_reduce2_kernel"}
     tkey = f"{kind}-{dt}-c{C}-n{voxels}"
 
     def roof(t, label):
@@ -726,7 +733,10 @@ def run_layer(args, D: Dist):
                                f"{S} distinct scenes per GPU visited round-robin, rulebook reused via indice_key",
                    "voxels_per_gpu": int(n_mean), "pairs_per_voxel": round(P / n_mean, 4), "launch": launch,
                    "steps_per_replay": U if launch == "hipgraph" else None, "scenes_rotated": S,
-                   "mask_sort": scenes[0].rb.argsort_fwd is not None, "tile_plan": tiled,
+                   "rulebook_source": "net(x): the module's own build, default environment" if args.sort == "auto"
+                                      else f"net(x) with SPCONV_DO_SORT={'1' if args.sort == 'on' else '0'}",
+                   "rows_layout": layout_info, "mask_sort": scenes[0].rb.argsort_fwd is not None,
+                   "prewarm_steps": args.prewarm,
                    "parallelism": f"dp{world}",
                    "ranks_seen": ranks_seen,
                    "dist_backend": D.backend if D.multi else None,
@@ -747,7 +757,7 @@ def run_layer(args, D: Dist):
         "ms_per_step_one_step_per_replay": None if single_replay_ms is None else round(single_replay_ms, 5),
         "rulebook_ms": round(statistics.median(rule_ms), 4),
         "rulebook_device_ms": round(t_rule_dev, 4),
-        "tile_plan_device_ms": t_plan_dev,
+        "rows_layout_device_ms": t_layout_dev,
         "mask_sort_device_ms": t_sort_dev,
     }
     if world == 1 and not args.no_cpu_baseline:
@@ -771,7 +781,9 @@ def run_int8(args, D: Dist):
         idx_np, shape = make_scene(args.scene or "uniform", voxels, seed=D.rank * S + si)
         ind = torch.from_numpy(idx_np).to(dev)
         rb = ops.build_rulebook(ind, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True,
-                                need_native=False, do_sort={"auto": "auto", "on": True, "off": False}[args.sort])[0]
+                                need_native=False, do_sort={"auto": "layout", "on": True, "off": False}[args.sort])[0]
+        ops.sparse_neighbourhoods(rb)     # host view of the class (one read per rulebook, outside the timed loop):
+                                          # the int8 launch picks its tile height by it
         f = torch.from_numpy(rng.integers(-127, 128, (idx_np.shape[0], C), dtype=np.int8)).to(dev)
         scenes.append((idx_np, shape, rb, f))
     n = scenes[0][0].shape[0]
@@ -780,7 +792,8 @@ def run_int8(args, D: Dist):
         _, _, rb, f = scenes[i % S]
         pair, mask, order, to = ops.tables_of(rb, "fwd", K)
         return ops.igemm_fwd_int8(f, w, pair, mask, order, n, 13, scale, bias, None, 0.0,
-                                  torch.int8, ops.Activation.ReLU, 0.0, tile_order=to)
+                                  torch.int8, ops.Activation.ReLU, 0.0, tile_order=to,
+                                  sparse_hint=rb.sparse_class is True)
     graphs = None
     if not args.no_graph:
         try:
@@ -1240,6 +1253,12 @@ def main(argv=None):
         result = run_net(args, D)
     if D.rank == 0 and D.world == 1 and args.config == "2" and not args.no_also:
         result["also"] = also_block(args, D)
+        # the same, compact, inside the object the driver's record keeps whole
+        result["roofline"]["also"] = {
+            cfg: ({"error": c["error"]} if "error" in c else
+                  {"value": c["value"], "unit": c["unit"], "ms": c["ms_per_step"], "frac": c["roofline"].get("frac"),
+                   "traffic": c["roofline"].get("traffic"), "group": c["roofline"].get("group")})
+            for cfg, c in result["also"].items()}
     if D.rank == 0:
         print(json.dumps(result), flush=True)
     D.finish()

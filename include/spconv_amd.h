@@ -62,7 +62,7 @@ const char *spx_last_error(void);
 int spx_version(void);
 
 /* Run-time override of a kernel-selection switch (same names as the SPX_* environment variables the
- * library reads, e.g. "SPX_GEMM_V" = 4 | 5: generation of the gather-GEMM kernels).  Stands in for the
+ * library reads, e.g. "SPX_CONV_V" = 2 | 3: generation of the strided-conv rulebook passes).  Stands in for the
  * per-process tuner state of the reference (ConvTunerSimple, csrc/sparse/convops.py:919-1466): tests and
  * the benchmark use it to run two kernel generations against each other inside one process.  Host only. */
 int spx_set_option(const char *name_h, int value);
@@ -215,14 +215,6 @@ int spx_igemm_fwd_int8(const void *feat, const void *weight, void *out, const in
                        const void *add, float add_scale, int out_dtype, int act, float act_alpha,
                        spx_stream_t stream);
 
-/* ---- tile plans: the dense-neighbourhood path ------------------------------------------------
- * The reference sorts the rows of a rulebook by mask (SpconvOps.sort_1d_by_key_allocator,
- * all.py:935-991, on by default through SPCONV_DO_SORT) so that its implicit-GEMM tiles skip
- * offsets; here the rows are ordered SPATIALLY instead, which lets a tile stage the unique source
- * rows of all its pairs once in LDS (csrc/tileplan.hip, csrc/igemm.hip: igemm_halo_kernel).
- * A plan belongs to one pair table [kv, n_dst] (kv <= 32) and the coordinates of its destination
- * rows: pair_fwd + out_indices for the forward pass (and, for SubM, for dgrad as well),
- * pair_bwd + the input indices for the dgrad of a regular convolution. */
 /* Copies of a pair table [kv, n] and its mask words in TILE ORDER (row t <- row order[t], order =
  * spx_mask_argsort's output): with tile_order = 1, spx_igemm_fwd / _dgrad / _bwd read `pair` and
  * `mask` by tile position and use `argsort` only for the operand / output rows, so a mask-sorted
@@ -231,22 +223,37 @@ int spx_igemm_fwd_int8(const void *feat, const void *weight, void *out, const in
 int spx_permute_tables(const int32_t *pair, const uint32_t *mask, const int32_t *order, int kv, int n,
                        int words, int32_t *pair_t, uint32_t *mask_t, spx_stream_t stream);
 
-size_t spx_tile_plan_bytes(int n_dst, int kv);
-size_t spx_tile_plan_ws_bytes(int n_dst);
-int spx_tile_plan_build(const int32_t *dst_indices, int n_dst, int ndim, int batch_size,
-                        const int *dst_shape, const int32_t *pair, int kv, int32_t *plan, void *ws,
-                        size_t ws_bytes, spx_stream_t stream);
-
-/* spx_igemm_fwd / spx_igemm_dgrad over a tile plan: same results (bit-identical), dense scenes
- * run ~2x faster.  16-bit dtypes with C <= 64 (forward) / K <= 64 (dgrad) and output widths
- * 16 / 32 / 64 take the halo kernel, everything else falls back to the plain kernels. */
-int spx_igemm_fwd_tiled(const void *feat, const void *weight, void *out, const int32_t *pair,
-                        const int32_t *plan, int n_in, int n_out, int C, int K, int kv, int dtype,
-                        int identity_k, const void *bias, int act, float act_alpha,
-                        spx_stream_t stream);
-int spx_igemm_dgrad_tiled(const void *dout, const void *weight, void *din, const int32_t *pair,
-                          const int32_t *plan, int n_out, int n_in, int C, int K, int kv, int dtype,
-                          int subm, spx_stream_t stream);
+/* ---- density-aware row layout: the DEFAULT row order of a SubM rulebook -----------------------
+ * The reference sorts the rows of every rulebook by mask (SPCONV_DO_SORT = "1", constants.py:121;
+ * pytorch/ops.py:346,550,763-785 -> SpconvOps.sort_1d_by_key_allocator, all.py:935-991) so that its
+ * implicit-GEMM tiles skip the offsets none of their rows has.  spx_subm_layout does that job INSIDE
+ * the rulebook build -- no sort, nothing read back: the masks of the finished tables are classified
+ * on the device and, for a SPARSE rulebook (fewer than a quarter of the rows have any neighbour), the
+ * rows are regrouped by a stable counting partition (wave ballots + prefix sums): rows that only
+ * have their centre pair first, in their order, then the rows with neighbours grouped by their lowest
+ * neighbour offset.  A DENSE rulebook (LiDAR) keeps its row order (regrouping loses there).
+ * The result is ONE int32 blob the gather-GEMM reads (pass it as `argsort` with tile_order =
+ * SPX_ROWS_LAYOUT; spx_igemm_fwd_int8: OR SPX_ROWS_LAYOUT_ACT into `act`):
+ *   [0] class: 1 = regrouped, 0 = identity order     [1] rows with a neighbour   [2] n   [3] kv
+ *   [64, 64 + npad)            order:  tile position t -> row            (npad = n rounded up to 64)
+ *   [64 + npad, 64 + 2 npad)   mask words in tile order
+ *   [64 + 2 npad, ... + kv n)  pair table in tile order -- class 1 only, and only the columns of the
+ *                              rows with a neighbour (+ the 256 positions ahead of them) are written:
+ *                              a tile of centre-only rows never reads its table.  Class 0: the
+ *                              kernels read the caller's row-order `pair` (selected on the device).
+ * The class word stays on the device: a launch is the same for both classes (hipGraph-safe). */
+#define SPX_ROWS_LAYOUT 2
+#define SPX_ROWS_LAYOUT_ACT 0x400
+/* OR-ed into `act` of spx_igemm_fwd_int8 next to SPX_ROWS_LAYOUT_ACT: the HOST knows the class word is 1 (it may
+ * read it once per rulebook, outside any timed or captured region) -- a launch-shape hint only: 64-row instead
+ * of 128-row tiles at 128 output channels (the role of the reference's per-problem tuner cache,
+ * csrc/sparse/convops.py:1150,1283-1297).  Results never depend on it. */
+#define SPX_SPARSE_HINT 0x800
+#define SPX_LAYOUT_HEADER 64
+size_t spx_subm_layout_bytes(int n, int kv);
+size_t spx_subm_layout_ws_bytes(int n);
+int spx_subm_layout(const int32_t *pair_fwd, const uint32_t *mask, int n, int kv, int32_t *layout,
+                    void *ws, size_t ws_bytes, spx_stream_t stream);
 
 /* Scratch for dgrad (always 0: the weight transpose happens inside the kernel). */
 size_t spx_igemm_dgrad_ws_bytes(int C, int K, int kv, int dtype);

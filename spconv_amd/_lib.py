@@ -42,13 +42,9 @@ SIGNATURES = {
     "spx_conv_rulebook_static": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
                                  + [c_int_p] * 6 + [ctypes.c_int, ctypes.c_int] + [vp] * 8
                                  + [vp, ctypes.c_size_t, vp]),
-    "spx_tile_plan_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
-    "spx_tile_plan_ws_bytes": (ctypes.c_size_t, [ctypes.c_int]),
-    "spx_tile_plan_build": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_int_p, vp,
-                                           ctypes.c_int, vp, vp, ctypes.c_size_t, vp]),
-    "spx_igemm_fwd_tiled": (ctypes.c_int, [vp, vp, vp, vp, vp] + [ctypes.c_int] * 7
-                            + [vp, ctypes.c_int, ctypes.c_float, vp]),
-    "spx_igemm_dgrad_tiled": (ctypes.c_int, [vp, vp, vp, vp, vp] + [ctypes.c_int] * 7 + [vp]),
+    "spx_subm_layout_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "spx_subm_layout_ws_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "spx_subm_layout": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_size_t, vp]),
     "spx_igemm_bwd_rows_ws_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),
     "spx_igemm_bwd_rows": (ctypes.c_int, [vp] * 7 + [ctypes.c_int] * 7 + [vp, ctypes.c_size_t, vp]),
     "spx_batchnorm_ws_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
@@ -111,7 +107,7 @@ def build(force: bool = False) -> str:
     """Compile the HIP sources for gfx950 (no GPU needed)."""
     script = os.path.join(_HERE, "csrc", "build.sh")
     if force:
-        for f in ("rulebook.o", "igemm.o", "igemm_gen1.o", "igemm5.o", "igemm_sp.o", "igemm_bwdn.o", "pool.o", "tileplan.o", "norm.o", "common.o", "libspconv_amd.so"):
+        for f in ("rulebook.o", "igemm.o", "igemm_gen1.o", "igemm_bwdn.o", "pool.o", "rowsort.o", "norm.o", "common.o", "libspconv_amd.so"):
             p = os.path.join(_HERE, "lib", f)
             if os.path.exists(p):
                 os.remove(p)

@@ -1,12 +1,14 @@
 """Flags of the path (subset of spconv/constants.py:30-121 that still has a meaning here)."""
 import os
 
-# spconv/constants.py:119-121: sort output rows by mask so that whole tiles skip offsets.
+# spconv/constants.py:119-121: sort output rows by mask so that whole tiles skip offsets (reference
+# default "1").  ops.get_indice_pairs_implicit_gemm keeps that meaning for its do_sort argument.
 SPCONV_DO_SORT = os.getenv("SPCONV_DO_SORT", "1") == "1"
-# The layer modules sort only when SPCONV_DO_SORT=1 is set EXPLICITLY: here the sort costs ~170 us
-# per rulebook and buys ~2.5 us per kernel at 100k voxels, so unlike the
-# reference it is not the default; ops.get_indice_pairs_implicit_gemm keeps the reference default.
-MODULE_DO_SORT = os.getenv("SPCONV_DO_SORT", "") == "1"
+# The layer modules: unset (default) = the density-aware rows layout built inside the rulebook build
+# (ops.rows_layout: classified and regrouped on the device, no sort, nothing read back -- the drop-in
+# analogue of the reference's default); "1" = the reference's explicit mask sort of every rulebook
+# (radix argsort + tables copied into tile order: ~100 us per rulebook); "0" = rows stay in input order.
+MODULE_DO_SORT = {"1": True, "0": False}.get(os.getenv("SPCONV_DO_SORT", ""), "layout")
 # spconv/constants.py:36: layout of checkpoints produced by spconv 1.x / 2.1 ("KRSC", "RSKC", "RSCK").
 SAVED_WEIGHT_LAYOUT = os.getenv("SPCONV_SAVED_WEIGHT_LAYOUT", "")
 # run dgrad and wgrad of one layer on two HIP streams (they are independent).  Off by default:

@@ -11,7 +11,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value -mllvm -amdgpu-kernarg-preload-count=16"
 for v in ${@:-0 1 2 3 4 5}; do
   ( $HIPCC $FLAGS -DSPX_ABLATE=$v -c igemm.hip -o $OUT/abl/igemm$v.o &&
-    $HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT/libspconv_amd_abl$v.so $OUT/rulebook.o $OUT/abl/igemm$v.o $OUT/pool.o $OUT/tileplan.o $OUT/norm.o $OUT/common.o &&
+    $HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT/libspconv_amd_abl$v.so $OUT/rulebook.o $OUT/abl/igemm$v.o $OUT/pool.o $OUT/rowsort.o $OUT/norm.o $OUT/common.o &&
     echo built $OUT/libspconv_amd_abl$v.so ) &
 done
 wait

@@ -9,13 +9,11 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ml
 $HIPCC $FLAGS -c rulebook.hip -o $OUT/dbg/rulebook.o &
 $HIPCC $FLAGS -c igemm.hip -o $OUT/dbg/igemm.o &
 $HIPCC $FLAGS -c pool.hip -o $OUT/dbg/pool.o &
-$HIPCC $FLAGS -c igemm5.hip -o $OUT/dbg/igemm5.o &
 $HIPCC $FLAGS -c igemm_gen1.hip -o $OUT/dbg/igemm_gen1.o &
-$HIPCC $FLAGS -c igemm_sp.hip -o $OUT/dbg/igemm_sp.o &
 $HIPCC $FLAGS -c igemm_bwdn.hip -o $OUT/dbg/igemm_bwdn.o &
-$HIPCC $FLAGS -c tileplan.hip -o $OUT/dbg/tileplan.o &
+$HIPCC $FLAGS -c rowsort.hip -o $OUT/dbg/rowsort.o &
 $HIPCC $FLAGS -c norm.hip -o $OUT/dbg/norm.o &
 $HIPCC $FLAGS -x hip -c common.cpp -o $OUT/dbg/common.o &
 wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT/libspconv_amd_dbg.so $OUT/dbg/rulebook.o $OUT/dbg/igemm.o $OUT/dbg/pool.o $OUT/dbg/igemm5.o $OUT/dbg/igemm_gen1.o $OUT/dbg/igemm_sp.o $OUT/dbg/igemm_bwdn.o $OUT/dbg/tileplan.o $OUT/dbg/norm.o $OUT/dbg/common.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT/libspconv_amd_dbg.so $OUT/dbg/rulebook.o $OUT/dbg/igemm.o $OUT/dbg/pool.o $OUT/dbg/igemm_gen1.o $OUT/dbg/igemm_bwdn.o $OUT/dbg/rowsort.o $OUT/dbg/norm.o $OUT/dbg/common.o
 echo built $OUT/libspconv_amd_dbg.so

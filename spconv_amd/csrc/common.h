@@ -96,51 +96,10 @@ inline Geom make_geom(int ndim, int batch, const int *in_dims, const int *out_di
 
 }  // namespace spx
 
-// ---- tile plan (tileplan.hip builds it, igemm.hip's halo kernel consumes it) ---------------------
-// A plan orders the destination rows of a pair table spatially (Morton order of their coordinates),
-// cuts them into tiles of kTileRows consecutive rows and lists, per tile, the UNIQUE source rows its
-// pairs reference (the tile's input halo: ~1.4 x the tile's rows on LiDAR data instead of ~6.3 pair
-// gathers per row) plus, per (offset, row), the halo slot that holds the pair's source row.
-// Layout of the int32 blob:
-//   [0 .. 16)                          header: magic, n_dst, ntiles, kv, halo slots per tile
-//   order     [ntiles * kTileRows]     tile position -> destination row (-1 past the end)
-//   tile_info [ntiles * 4]             offsets present in the tile (bit k), staged halo rows,
-//                                      1 if some pairs did not fit the halo, unused
-//   halo_rows [ntiles * kHaloMax]      source rows, by halo slot
-//   plocal    [ntiles * kv * kTileRows] uint16: halo slot of (offset k, tile row r), kNoPair when the
-//                                      pair does not exist, kSpilled when it did not fit (the kernel
-//                                      then reads the pair table)
+// ---- row orders (rowsort.hip) ---------------------------------------------------------------------
 namespace spx {
-constexpr int kTileRows = 128;
-constexpr int kHaloMax = 384;                 // 48 KB of LDS at 128-byte rows
-constexpr int kPlanHeader = 16;
-constexpr int kPlanMagic = 0x54504c31;        // "TPL1"
-constexpr uint16_t kNoPair = 0xFFFFu, kSpilled = 0xFFFEu;
-
-struct PlanView {
-  const int32_t *order, *tile_info, *halo_rows;
-  const uint16_t *plocal;
-  int ntiles;
-};
-
-inline size_t plan_ints(int n_dst, int kv) {
-  const size_t nt = static_cast<size_t>((n_dst + kTileRows - 1) / kTileRows);
-  return kPlanHeader + nt * kTileRows + nt * 4 + nt * kHaloMax + (nt * kv * kTileRows + 1) / 2 + 64;
-}
-
-// stable LSD radix argsort shared by the tile plans and spx_mask_argsort (tileplan.hip)
+// stable LSD radix argsort behind spx_mask_argsort (rowsort.hip)
 size_t radix_argsort_ws_bytes(int n);
 int radix_argsort(const uint32_t *keys, int n, int nbits, int32_t *order_out, void *ws, hipStream_t s);
 
-inline PlanView plan_view(const int32_t *plan, int n_dst, int kv) {
-  const size_t nt = static_cast<size_t>((n_dst + kTileRows - 1) / kTileRows);
-  PlanView v;
-  v.ntiles = static_cast<int>(nt);
-  v.order = plan + kPlanHeader;
-  v.tile_info = v.order + nt * kTileRows;
-  v.halo_rows = v.tile_info + nt * 4;
-  v.plocal = reinterpret_cast<const uint16_t *>(v.halo_rows + nt * kHaloMax);
-  (void)kv;
-  return v;
-}
 }  // namespace spx

@@ -122,6 +122,16 @@ __device__ __forceinline__ void unpack_gemm_args(GemmParams &p, const void *argA
   p.out_dtype = rest.out_dtype;
   p.dbg = rest.dbg;
   p.xcd_rot = 0;
+  // rows layout (bit 12): everything derives from the preloaded arguments -- `argsort` points at the blob's order
+  // array (64 words behind its class word, 2 * npad ahead of its tile-order pair table), `pair` is the row-order table
+  p.cls = nullptr;
+  p.pair_rows = nullptr;
+  if ((b_reverse >> 12) & 1) {
+    const size_t npad = (static_cast<size_t>(n_dst) + 63) & ~static_cast<size_t>(63);
+    p.cls = arg_argsort - SPX_LAYOUT_HEADER;
+    p.pair_rows = arg_pair;
+    p.pair = arg_argsort + 2 * npad;
+  }
 }
 
 template <int COUT, int MB, int DT, bool BT, int NKS>
@@ -150,6 +160,12 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   SPX_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntiles = (p.n_dst + TM - 1) / TM;
+  // Rows layout (spx_subm_layout): the class of the rulebook is a DEVICE word -- 1: rows regrouped, tables in tile
+  // order; 0: identity order, the pair table is the row-order one.  It rides at the head of the vector-memory queue
+  // (loads return in order: the wait for the mask words below covers it, no trip of its own) and is consumed where
+  // the first pair words are requested; `order` and the mask words come from the blob in both classes.  Unconditional
+  // (a launch without a layout reads a zero-sized resource) so that the counted waits stay exact.
+  const uint32_t cls_raw = __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(p.cls, p.cls ? 4u : 0u), 0, 0, 0);
   // Tables in tile order = rows sorted by mask word: the tiles at the END hold the rows with the most
   // offsets (the identity-only rows sort first), and a launch lasts as long as its slowest workgroup.
   // Those tiles are handed to the FIRST blocks (longest work first), one after the other to different
@@ -158,8 +174,15 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   // Only when the launch has more tiles than resident workgroups (the host sets `lpt`): a single-round
   // launch keeps the XCD mapping, which lets the dgrad tiles and the wgrad ranges of one row eighth share
   // the gradient rows in one L2 (config 2 backward: 57 vs 67 MB of HBM traffic).
-  const int tile = (p.tile_order && p.lpt) ? ntiles - 1 - block
-                                : (p.xcd_rot ? xcd_tile_rot(block, ntiles, p.xcd_rot) : xcd_tile(block, ntiles));
+  // (a launch of that size over a layout blob waits for the class word here: identity order keeps the XCD ranges)
+  int tile;
+  if (p.tile_order && p.lpt) {
+    typedef const int32_t __attribute__((address_space(4))) *cls_ptr_t;
+    const int big_cls = p.cls ? *(cls_ptr_t)(p.cls) : 1;           // (a blocking scalar load, multi-round launches only)
+    tile = big_cls ? ntiles - 1 - block : xcd_tile(block, ntiles);
+  } else {
+    tile = p.xcd_rot ? xcd_tile_rot(block, ntiles, p.xcd_rot) : xcd_tile(block, ntiles);
+  }
   const int lrow = lane & 15, lgrp = lane >> 4;
   const int slot = tid & 7, r0 = tid >> 3;
   // Output-channel permutation: MFMA row (g = i >> 2, e = i & 3) of channel block nb carries
@@ -178,6 +201,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   const uint32_t a_bytes = static_cast<uint32_t>(p.n_src) * rowB;
   const uint32_t w_bytes = static_cast<uint32_t>(p.COUT) * p.kv * rowB;
   const uint32_t pair_bytes = static_cast<uint32_t>(p.n_dst) * 4u;
+  const int32_t *pairp = p.pair;     // (rows layout: the class picks the table once the mask words are in, below)
 
   // rows of this lane: tile rows wave*16*MB + mb*16 + lrow
   int grow[MB];
@@ -241,8 +265,8 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   auto load_idx = [&](const StepIt &it, auto SET) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
     const int k = it.k < 0 ? 0 : it.k;
-    const __amdgpu_buffer_rsrc_t rP = make_rsrc(p.pair + static_cast<size_t>(k) * p.n_dst,
-                                                (p.pair && it.k >= 0) ? pair_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rP = make_rsrc(pairp + static_cast<size_t>(k) * p.n_dst,
+                                                (pairp && it.k >= 0) ? pair_bytes : 0u);
     // the identity select happens where the words are consumed (load_a): selecting here would
     // make the loop-carried value depend on the load and park the wave on it at the loop end
     identr[S] = it.k == p.identity_k ? 0xffffffffu : 0u;
@@ -367,6 +391,8 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   }
   __syncthreads();
   SPX_STAMP(2);   // mask words arrived, tile mask exchanged
+  // first use of the class word (it arrived ahead of the mask words)
+  if (p.cls && __builtin_amdgcn_readfirstlane(cls_raw) == 0) pairp = p.pair_rows;
   uint32_t tilemask = lds_mask[0] | lds_mask[1] | lds_mask[2] | lds_mask[3];
   tilemask = __builtin_amdgcn_readfirstlane(tilemask);
   if (p.kv - p.kbase < 32) tilemask &= (1u << (p.kv - p.kbase)) - 1u;
@@ -639,7 +665,8 @@ constexpr size_t v4_smem_bytes() {
 
 int v4_flags(const GemmParams &p) {
   const int words = p.mask_words > 0 ? p.mask_words : 1;
-  return p.b_reverse | (p.tile_order << 1) | ((words - 1) << 2) | (p.kbase << 4) | ((p.lpt ? 1 : 0) << 11);
+  return p.b_reverse | (p.tile_order << 1) | ((words - 1) << 2) | (p.kbase << 4) | ((p.lpt ? 1 : 0) << 11) |
+         ((p.cls ? 1 : 0) << 12);
 }
 
 bool v4_ok(const GemmParams &p, int es = 2, int out_es = 2) {
@@ -666,7 +693,7 @@ int launch_v4(const GemmParams &p, hipStream_t s) {
   const bool half = p.CIN * es <= 64;        // narrow rows: only the first 64 bytes of a piece exist
 #define SPX_LAUNCH_V4(BTV, NKSV)                                                                     \
   hipLaunchKernelGGL((igemm_v4_kernel<COUT, MB, DT, BTV, NKSV>), dim3(ntiles), dim3(kThreads),          \
-                     (v4_smem_bytes<COUT, MB, DT>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,  \
+                     (v4_smem_bytes<COUT, MB, DT>()), s, p.A, p.B, p.mask, p.argsort, (p.cls ? p.pair_rows : p.pair), p.n_dst,  \
                      p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(q), r)
   if (DT == 2 || p.strideD == 1) {
     if (half) SPX_LAUNCH_V4(false, 1);
@@ -676,306 +703,6 @@ int launch_v4(const GemmParams &p, hipStream_t s) {
     else SPX_LAUNCH_V4(true, 2);
   }
 #undef SPX_LAUNCH_V4
-  SPX_LAUNCH_CHECK();
-  return 0;
-}
-
-// --------------------------------------------------------------------------
-// gather-GEMM over a tile plan ("halo" kernel): the dense-neighbourhood regime.
-//
-// igemm_v4_kernel fetches every (row, offset) pair's source row from global memory: on real point
-// clouds (~6 pairs per voxel) each feature row crosses the CU's vector-memory path six times and
-// the kernel is bound there, not at HBM.  Here a workgroup owns a spatially compact tile of 128
-// destination rows (tileplan.hip) and stages the tile's input halo -- the UNIQUE source rows of all
-// its pairs, ~1.4 x the tile's rows on LiDAR data -- ONCE in LDS (16-byte pieces XOR-swizzled by the
-// slot number).  Every step then reads its gathered operand from LDS by slot: the (offset, row) ->
-// slot table of the tile is staged next to the halo, a missing pair points at a zero row.  Weights
-// take the same two-stage LDS ring as v4, the epilogue is v4's (each lane stores consecutive
-// channels of its row straight from registers).  The per-row arithmetic (offset order, MFMA
-// sequence) is identical to v4, so both kernels return bit-identical tensors.
-// Limits: 16-bit operands, rows of at most 128 bytes (C <= 64), kernel volume <= 32; pairs whose
-// source row did not fit the halo (kSpilled: > 384 unique rows in a tile) are fetched from global
-// memory through the pair table.
-constexpr int kHaloPlocalBytes = 32 * kTileRows * 2;      // 8 KB: kv <= 32
-
-template <int COUT>
-constexpr size_t halo_smem_bytes() {
-  return 2 * static_cast<size_t>(COUT) * kRowBytes + kHaloPlocalBytes + (kHaloMax + 1) * kRowBytes;
-}
-
-template <int COUT, int DT, bool BT, int NKS>
-__global__ void __launch_bounds__(kThreads, 2)
-igemm_halo_kernel(const void *argA, const void *argB, const int32_t *plan_order,
-                  const int32_t *plan_info, const int32_t *plan_halo, const uint16_t *plan_local,
-                  const int32_t *arg_pair, int n_dst, int n_src, int CIN, int kv, int b_reverse,
-                  int ntiles, int identity_k, GemmRest rest, int dbg) {
-  // dbg != 0 (SPX_HALO_DBG, measurements only, results are wrong): 1 = weights staged once, 2 = also no
-  // barrier per step, 3 = no MFMAs, 4 = no gathered-operand reads
-  constexpr bool BF16 = DT == 1;
-  constexpr int ES = 2, MB = 2, NB = COUT / 16, CPL = NB * 4;
-  constexpr int B_BYTES = COUT * kRowBytes;
-  constexpr int BROWS = !BT ? (COUT + 31) / 32 : 2 * ((COUT + 63) / 64);
-  constexpr int BA = BROWS < 2 ? 2 : BROWS;
-  constexpr int HP = kHaloMax * 8 / kThreads;             // halo pieces per thread (12)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char *ldsP = smem + 2 * B_BYTES;
-  char *ldsH = ldsP + kHaloPlocalBytes;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile = xcd_tile(blockIdx.x, ntiles);
-  const int lrow = lane & 15, lgrp = lane >> 4;
-  const int slot8 = tid & 7, r0 = tid >> 3;
-  auto swzB = [](int row, int sl) __attribute__((always_inline)) {
-    const int x = ((row >> 1) & 1) | (((row / CPL) & 3) << 1);
-    return row * kRowBytes + ((sl ^ x) << 4);
-  };
-  const uint32_t rowB = static_cast<uint32_t>(CIN) * ES;          // <= 128
-  const int ctail = static_cast<int>(rowB);
-  const uint32_t a_bytes = static_cast<uint32_t>(n_src) * rowB;
-  const uint32_t w_bytes = static_cast<uint32_t>(COUT) * kv * rowB;
-
-  const int4 info = *reinterpret_cast<const int4 *>(plan_info + static_cast<size_t>(tile) * 4);
-  const uint32_t kmask = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(info.x));
-  const int H = __builtin_amdgcn_readfirstlane(info.y);
-  const bool spilled = __builtin_amdgcn_readfirstlane(info.z) != 0;
-
-  // ---- weight slice loads / stores (as igemm_v4_kernel) -----------------------------------------
-  uint32_t boff[BA];
-  if constexpr (!BT) {
-#pragma unroll
-    for (int j = 0; j < BROWS; ++j) {
-      const int n = r0 + 32 * j;
-      const uint32_t o = static_cast<uint32_t>(n) * static_cast<uint32_t>(rest.strideN) * ES + slot8 * 16u;
-      boff[j] = (n < COUT && slot8 * 16 < ctail) ? o : kOob;
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < BROWS; ++j) {
-      const int d = 2 * r0 + (j & 1);
-      const int n = (j >> 1) * 64 + slot8 * 8;
-      const uint32_t o = (static_cast<uint32_t>(d) * static_cast<uint32_t>(rest.strideD) + n) * ES;
-      boff[j] = (n < COUT && d * ES < ctail) ? o : kOob;
-    }
-  }
-  u32x4 breg[BA];
-  auto load_b = [&](int k) __attribute__((always_inline)) {
-    const int kk = k < 0 ? 0 : k;
-    const int kb = b_reverse ? kv - 1 - kk : kk;
-    const uint32_t so = static_cast<uint32_t>(kb) * static_cast<uint32_t>(rest.strideK) * ES;
-    const __amdgpu_buffer_rsrc_t r = make_rsrc(argB, k >= 0 ? w_bytes : 0u);
-#pragma unroll
-    for (int j = 0; j < BROWS; ++j) breg[j] = __builtin_amdgcn_raw_buffer_load_b128(r, boff[j], so, 0);
-  };
-  auto store_b = [&](char *ldsB) __attribute__((always_inline)) {
-    if constexpr (!BT) {
-#pragma unroll
-      for (int j = 0; j < BROWS; ++j) {
-        const int n = r0 + 32 * j;
-        if (COUT >= 32 * (j + 1) || n < COUT) *reinterpret_cast<u32x4 *>(ldsB + swzB(n, slot8)) = breg[j];
-      }
-    } else {
-#pragma unroll
-      for (int jj = 0; jj < BROWS / 2; ++jj) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int n = jj * 64 + slot8 * 8 + e;
-          const uint32_t ev = breg[2 * jj][e >> 1], od = breg[2 * jj + 1][e >> 1];
-          const uint32_t v = (e & 1) ? __builtin_amdgcn_perm(od, ev, 0x07060302u)
-                                     : __builtin_amdgcn_perm(od, ev, 0x05040100u);
-          if (COUT >= 64 * (jj + 1) || n < COUT)
-            *reinterpret_cast<uint32_t *>(ldsB + swzB(n, r0 >> 2) + (r0 & 3) * 4) = v;
-        }
-      }
-    }
-  };
-
-  // ---- prologue: first weights, slot table, halo ------------------------------------------------
-  // step order as in igemm_v4_kernel (SubM: the identity offset first, then ascending), so that
-  // both kernels add a row's terms in the same order and return bit-identical results
-  uint32_t rest_bits = kmask;
-  int k0;
-  if (identity_k >= 0) {
-    k0 = identity_k;
-    rest_bits &= ~(1u << identity_k);
-  } else {
-    k0 = rest_bits ? __builtin_ctz(rest_bits) : -1;
-    rest_bits = rest_bits ? (rest_bits & (rest_bits - 1)) : 0u;
-  }
-  load_b(k0);
-  int grow[MB];
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
-    grow[mb] = plan_order[static_cast<size_t>(tile) * kTileRows + (wave * MB + mb) * 16 + lrow];
-  {
-    // (offset, row) -> slot table of the tile: kv * 256 bytes, 16 bytes per thread and round
-    const char *src = reinterpret_cast<const char *>(plan_local) + static_cast<size_t>(tile) * kv * (kTileRows * 2);
-    const __amdgpu_buffer_rsrc_t rP = make_rsrc(src, static_cast<uint32_t>(kv) * (kTileRows * 2));
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const uint32_t o = static_cast<uint32_t>(tid + i * kThreads) * 16u;
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rP, o, 0, 0);       // zeros past the table
-      *reinterpret_cast<u32x4 *>(ldsP + o) = v;
-    }
-  }
-  {
-    // halo rows: 8 lanes per row, one 16-byte piece each; piece q of slot s lands at position
-    // q ^ (s & 7) of the row's 128 bytes; pieces past the row end are written as zeros
-    const __amdgpu_buffer_rsrc_t rH = make_rsrc(plan_halo + static_cast<size_t>(tile) * kHaloMax,
-                                                static_cast<uint32_t>(H) * 4u);
-    const __amdgpu_buffer_rsrc_t rA = make_rsrc(argA, a_bytes);
-    uint32_t gsrc[HP];
-#pragma unroll
-    for (int i = 0; i < HP; ++i) {
-      const int s = (tid + i * kThreads) >> 3;
-      gsrc[i] = __builtin_amdgcn_raw_buffer_load_b32(rH, s < H ? static_cast<uint32_t>(s) * 4u : kOob, 0, 0);
-    }
-    u32x4 hv[HP];
-    const uint32_t qoff = slot8 * 16u < rowB ? slot8 * 16u : kOob;
-#pragma unroll
-    for (int i = 0; i < HP; ++i) {
-      const int s = (tid + i * kThreads) >> 3;
-      const uint32_t vo = s < H ? (gsrc[i] * rowB + qoff) | (qoff & kOob) : kOob;
-      hv[i] = __builtin_amdgcn_raw_buffer_load_b128(rA, vo, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < HP; ++i) {
-      const int s = (tid + i * kThreads) >> 3;
-      if (s < H) *reinterpret_cast<u32x4 *>(ldsH + s * kRowBytes + ((slot8 ^ (s & 7)) << 4)) = hv[i];
-    }
-    if (tid < 8) *reinterpret_cast<u32x4 *>(ldsH + kHaloMax * kRowBytes + tid * 16) = u32x4{0u, 0u, 0u, 0u};
-  }
-  store_b(smem);
-  int k1 = rest_bits ? __builtin_ctz(rest_bits) : -1;
-  rest_bits = rest_bits ? (rest_bits & (rest_bits - 1)) : 0u;
-  load_b(k1);
-  __syncthreads();
-
-  f32x4 acc[NB][MB];
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const uint16_t *lp = reinterpret_cast<const uint16_t *>(ldsP);
-  const int prow = wave * (MB * 16) + lrow;                       // tile row of m-block 0
-  auto read_slots = [&](int k, uint32_t (&sl)[MB]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) sl[mb] = k >= 0 ? lp[k * kTileRows + prow + mb * 16] : kNoPair;
-  };
-  uint32_t slots[MB];
-  read_slots(k0, slots);
-
-  // ---- main loop: one step per offset present in the tile ---------------------------------------
-  // stage `stage` of the ring holds this step's weights, breg the next step's (loaded a step ago)
-  int stage = 0;
-  while (k0 >= 0) {
-    if (dbg != 1 && dbg != 2) store_b(smem + (1 - stage) * B_BYTES);   // (last read before the previous barrier)
-    const int k2 = rest_bits ? __builtin_ctz(rest_bits) : -1;
-    rest_bits = rest_bits ? (rest_bits & (rest_bits - 1)) : 0u;
-    if (dbg != 1 && dbg != 2) load_b(k2);
-    // gathered operand of this step from the halo (zero row for a missing pair)
-    u32x4 areg[MB][NKS];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      const uint32_t s = slots[mb] < static_cast<uint32_t>(kHaloMax) ? slots[mb] : static_cast<uint32_t>(kHaloMax);
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks)
-        areg[mb][ks] = dbg == 4 ? u32x4{s, s, s, s}
-                                : *reinterpret_cast<const u32x4 *>(ldsH + s * kRowBytes + (((ks * 4 + lgrp) ^ (s & 7)) << 4));
-    }
-    if (spilled) {       // rare: pairs whose source row did not fit the halo come through the pair table
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        if (slots[mb] == kSpilled && grow[mb] >= 0) {
-          const int src = arg_pair[static_cast<size_t>(k0) * n_dst + grow[mb]];
-          const __amdgpu_buffer_rsrc_t rA = make_rsrc(argA, a_bytes);
-#pragma unroll
-          for (int ks = 0; ks < NKS; ++ks) {
-            const uint32_t c = static_cast<uint32_t>(ks * 64 + lgrp * 16);
-            const uint32_t vo = (src >= 0 && c < rowB) ? static_cast<uint32_t>(src) * rowB + c : kOob;
-            areg[mb][ks] = __builtin_amdgcn_raw_buffer_load_b128(rA, vo, 0, 0);
-          }
-        }
-      }
-    }
-    uint32_t nslots[MB];
-    read_slots(k1, nslots);
-    const char *cur = smem + stage * B_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const uint4 fa = *reinterpret_cast<const uint4 *>(
-            cur + swzB((lrow >> 2) * CPL + nb * 4 + (lrow & 3), ks * 4 + lgrp));
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-          if (dbg == 3) acc[nb][mb][0] += __builtin_bit_cast(float, fa.x ^ areg[mb][ks][0]);
-          else acc[nb][mb] = mfma16<BF16>(fa, __builtin_bit_cast(uint4, areg[mb][ks]), acc[nb][mb]);
-        }
-      }
-    }
-    if (dbg != 2) __syncthreads();     // the other stage is complete; this stage's reads are done
-    if (dbg != 1 && dbg != 2) stage ^= 1;
-    k0 = k1;
-    k1 = k2;
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) slots[mb] = nslots[mb];
-  }
-
-  // ---- epilogue (as igemm_v4_kernel) ---------------------------------------------------------------
-  const bool plain = rest.bias == nullptr && rest.act == SPX_ACT_NONE;
-  const __amdgpu_buffer_rsrc_t rO = make_rsrc(rest.out, static_cast<uint32_t>(n_dst) * (COUT * ES));
-  float bv[CPL];
-#pragma unroll
-  for (int q = 0; q < CPL; ++q) bv[q] = 0.f;
-  if (rest.bias) {
-#pragma unroll
-    for (int q = 0; q < CPL; ++q) bv[q] = to_float<BF16>(static_cast<const uint16_t *>(rest.bias)[lgrp * CPL + q]);
-  }
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-    uint32_t d[CPL / 2];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        float v0 = acc[nb][mb][2 * h], v1 = acc[nb][mb][2 * h + 1];
-        if (!plain) {
-          v0 = apply_act(v0 + bv[nb * 4 + 2 * h], rest.act, rest.act_alpha);
-          v1 = apply_act(v1 + bv[nb * 4 + 2 * h + 1], rest.act, rest.act_alpha);
-        }
-        d[nb * 2 + h] = pack2<BF16>(v0, v1);
-      }
-    }
-    const uint32_t vo = grow[mb] < 0 ? kOob : static_cast<uint32_t>(grow[mb]) * (COUT * ES) + lgrp * (CPL * ES);
-    store_dwords<CPL / 2>(d, rO, vo);
-  }
-}
-
-template <int COUT, int DT>
-int launch_halo(const GemmParams &p, const PlanView &pv, hipStream_t s) {
-  const GemmRest r = rest_of(p);
-  const bool half = p.CIN * 2 <= 64;
-#define SPX_LAUNCH_HALO(BTV, NKSV)                                                                      \
-  {                                                                                                      \
-    static const hipError_t attr = hipFuncSetAttribute(                                                  \
-        reinterpret_cast<const void *>(&igemm_halo_kernel<COUT, DT, BTV, NKSV>),                          \
-        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(halo_smem_bytes<COUT>()));           \
-    (void)attr;                                                                                          \
-  }                                                                                                      \
-  hipLaunchKernelGGL((igemm_halo_kernel<COUT, DT, BTV, NKSV>), dim3(pv.ntiles), dim3(kThreads),           \
-                     (halo_smem_bytes<COUT>()), s, p.A, p.B, pv.order, pv.tile_info, pv.halo_rows,        \
-                     pv.plocal, p.pair, p.n_dst, p.n_src, p.CIN, p.kv, p.b_reverse, pv.ntiles,            \
-                     p.identity_k, r, dbg)
-  static const int dbg = env_int("SPX_HALO_DBG", 0);
-  if (p.strideD == 1) {
-    if (half) { SPX_LAUNCH_HALO(false, 1); }
-    else { SPX_LAUNCH_HALO(false, 2); }
-  } else {
-    if (half) { SPX_LAUNCH_HALO(true, 1); }
-    else { SPX_LAUNCH_HALO(true, 2); }
-  }
-#undef SPX_LAUNCH_HALO
   SPX_LAUNCH_CHECK();
   return 0;
 }
@@ -1955,14 +1682,8 @@ bool mfma_ok(int dtype, int cin, int cout, int kv, const uint32_t *mask) {
 
 template <bool BF16>
 int dispatch_gather_gemm(const GemmParams &p, hipStream_t s) {
-  const int version = option_int("SPX_GEMM_V", 4);          // kernel generation (spx_set_option / environment)
   static const int mb_forced = env_int("SPX_GEMM_MB", 0);
-  if (version == 6 && !mb_forced && v4_ok(p) && sp_ok(p, BF16 ? SPX_BF16 : SPX_F16))
-    return launch_sp(p, rest_of(p), BF16 ? SPX_BF16 : SPX_F16, s);
-  // v5 (igemm5.hip): persistent loader / consumer workgroups; shapes it does not cover take v4
-  if (version == 5 && !mb_forced && v4_ok(p) && v5_ok(p, BF16 ? SPX_BF16 : SPX_F16))
-    return launch_v5(p, rest_of(p), BF16 ? SPX_BF16 : SPX_F16, s);
-  if (version >= 4 && v4_ok(p)) {
+  if (v4_ok(p)) {
     // 64-row tiles while the grid would otherwise leave CUs idle, 128-row tiles beyond -- except
     // for 128 output channels, whose 128-row variant holds 64 accumulator registers per lane and
     // drops to two waves per SIMD (measured at C = K = 128: 28 vs 37 us at 100 k uniform voxels,
@@ -1978,6 +1699,11 @@ int dispatch_gather_gemm(const GemmParams &p, hipStream_t s) {
       case 128: return mb == 1 ? launch_v4<128, 1, BF16 ? 1 : 0>(p, s) : launch_v4<128, 2, BF16 ? 1 : 0>(p, s);
       case 256: return launch_v4<256, 1, BF16 ? 1 : 0>(p, s);
     }
+  }
+  if (p.cls) {                     // a rows layout is a hint: the first-generation kernel reads the tables by row
+    GemmParams q = p;
+    drop_rows_layout(q);
+    return launch_gather_gemm_gen1(q, BF16, s);
   }
   if (p.tile_order) {
     set_error("tables in tile order need the direct-fragment kernel (tensor beyond 32-bit offsets?)");
@@ -2038,6 +1764,11 @@ int run_gather_gemm_single(const GemmParams &p, int dtype, hipStream_t s) {
     return dispatch_gather_gemm_f32(p, s);
   if (dtype != SPX_F32 && mfma_ok(dtype, p.CIN, p.COUT, p.kv, p.mask) && (p.kv <= 32 || grouped))
     return dtype == SPX_BF16 ? dispatch_gather_gemm<true>(p, s) : dispatch_gather_gemm<false>(p, s);
+  if (p.cls) {                     // (as above: the generic kernel reads the tables by row)
+    GemmParams q = p;
+    drop_rows_layout(q);
+    return run_gather_gemm_single(q, dtype, s);
+  }
   if (p.tile_order) {
     set_error("tables in tile order are supported by the MFMA kernels only (channel counts / kernel volume)");
     return -1;
@@ -2056,24 +1787,6 @@ int run_gather_gemm_single(const GemmParams &p, int dtype, hipStream_t s) {
   }
   SPX_LAUNCH_CHECK();
   return 0;
-}
-
-// plan-driven path (dense neighbourhoods): falls back to the plain gather-GEMM for shapes the halo
-// kernel is not instantiated for
-int run_gather_gemm_planned(const GemmParams &p, int dtype, const int32_t *plan, hipStream_t s) {
-  if (p.n_dst == 0) return 0;
-  const bool ok = plan && (dtype == SPX_F16 || dtype == SPX_BF16) && p.CIN % 8 == 0 && p.CIN * 2 <= kRowBytes &&
-                  (p.COUT == 16 || p.COUT == 32 || p.COUT == 64) && p.kv <= 32 && p.pair && !p.argsort &&
-                  v4_ok(p);
-  if (!ok) return run_gather_gemm(p, dtype, s);
-  const PlanView pv = plan_view(plan, p.n_dst, p.kv);
-  const bool bf = dtype == SPX_BF16;
-  switch (p.COUT) {
-    case 16: return bf ? launch_halo<16, 1>(p, pv, s) : launch_halo<16, 0>(p, pv, s);
-    case 32: return bf ? launch_halo<32, 1>(p, pv, s) : launch_halo<32, 0>(p, pv, s);
-    case 64: return bf ? launch_halo<64, 1>(p, pv, s) : launch_halo<64, 0>(p, pv, s);
-  }
-  return -1;
 }
 
 int wgrad_chunk(int n_in) {
@@ -2194,12 +1907,12 @@ int launch_bwd(const GemmParams &p, const Wgrad2Params &q, int n_wgrad_blocks, h
   pl.lpt = p.tile_order && n_dgrad + n_wgrad_blocks > 1024;           // (see launch_v4)
   if (p.CIN * (DT == 3 ? 4 : 2) <= 64)     // dgrad's reduction rows (dout channels) fit half a piece
     hipLaunchKernelGGL((igemm_bwd_kernel<COUT, MB, DT, 1>), dim3(n_dgrad + n_wgrad_blocks), dim3(kThreads),
-                       (bwd_smem_bytes<COUT, MB, DT>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,
+                       (bwd_smem_bytes<COUT, MB, DT>()), s, p.A, p.B, p.mask, p.argsort, (p.cls ? p.pair_rows : p.pair), p.n_dst,
                        p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(pl), rest_of(p),
                        wgrad_first ? ~n_wgrad_blocks : n_dgrad, q);
   else
     hipLaunchKernelGGL((igemm_bwd_kernel<COUT, MB, DT, 2>), dim3(n_dgrad + n_wgrad_blocks), dim3(kThreads),
-                       (bwd_smem_bytes<COUT, MB, DT>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,
+                       (bwd_smem_bytes<COUT, MB, DT>()), s, p.A, p.B, p.mask, p.argsort, (p.cls ? p.pair_rows : p.pair), p.n_dst,
                        p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(pl), rest_of(p),
                        wgrad_first ? ~n_wgrad_blocks : n_dgrad, q);
   SPX_LAUNCH_CHECK();
@@ -2254,7 +1967,7 @@ int spx_igemm_fwd(const void *feat, const void *weight, void *out, const int32_t
   p.kv = kv;
   p.identity_k = identity_k;
   p.b_reverse = 0;
-  p.tile_order = (tile_order && argsort) ? 1 : 0;
+  apply_rows_layout(p, tile_order);
   p.act = act & 0xff;
   if (act & SPX_OUT_CACHED) p.dbg = 0x400;       // plain result stores: the next launch reads the rows
   p.act_alpha = act_alpha;
@@ -2296,7 +2009,7 @@ int spx_igemm_fwd_int8(const void *feat, const void *weight, void *out, const in
   p.kv = kv;
   p.identity_k = identity_k;
   p.b_reverse = 0;
-  p.tile_order = ((act & SPX_TILE_ORDER) && argsort) ? 1 : 0;
+  apply_rows_layout(p, (act & SPX_ROWS_LAYOUT_ACT) ? SPX_ROWS_LAYOUT : ((act & SPX_TILE_ORDER) ? 1 : 0));
   p.act = act & 0xff;
   p.act_alpha = act_alpha;
   p.scale = scale;
@@ -2317,48 +2030,13 @@ int spx_igemm_fwd_int8(const void *feat, const void *weight, void *out, const in
       // instead of three: 27.3 -> 25.7 us at BASELINE config 5); dense neighbourhoods keep 128 rows (LiDAR-like
       // 200 k: 104 vs 113 us, fixture 74 vs 83 us).  SPX_I8_MB = 1 / 2 forces one.
       const int forced = option_int("SPX_I8_MB", 0);
-      if (forced == 1 || (forced == 0 && p.tile_order)) return launch_v4<128, 1, 2>(p, s);
+      if (forced == 1 || (forced == 0 && p.tile_order && (!p.cls || (act & SPX_SPARSE_HINT))))
+        return launch_v4<128, 1, 2>(p, s);
       return launch_v4<128, 2, 2>(p, s);
     }
     case 256: return launch_v4<256, 1, 2>(p, s);
   }
   return -1;
-}
-
-int spx_igemm_fwd_tiled(const void *feat, const void *weight, void *out, const int32_t *pair,
-                        const int32_t *plan, int n_in, int n_out, int C, int K, int kv, int dtype,
-                        int identity_k, const void *bias, int act, float act_alpha,
-                        spx_stream_t stream) {
-  SPX_CHECK(C > 0 && K > 0 && kv > 0 && n_in >= 0 && n_out >= 0, "bad sizes");
-  if (n_out == 0) return 0;
-  SPX_CHECK((feat || n_in == 0) && weight && out && pair && plan, "null tensor pointer");
-  GemmParams p{};
-  p.A = feat;
-  p.B = weight;
-  p.out = out;
-  p.pair = pair;
-  p.bias = bias;
-  p.strideK = C;
-  p.strideN = static_cast<long long>(kv) * C;
-  p.strideD = 1;
-  p.n_src = n_in;
-  p.n_dst = n_out;
-  p.CIN = C;
-  p.COUT = K;
-  p.kv = kv;
-  p.identity_k = identity_k;
-  p.act = act;
-  p.act_alpha = act_alpha;
-  return run_gather_gemm_planned(p, dtype, plan, static_cast<hipStream_t>(stream));
-}
-
-int spx_igemm_dgrad_tiled(const void *dout, const void *weight, void *din, const int32_t *pair,
-                          const int32_t *plan, int n_out, int n_in, int C, int K, int kv, int dtype,
-                          int subm, spx_stream_t stream) {
-  if (n_in == 0) return 0;
-  SPX_CHECK((dout || n_out == 0) && weight && din && pair && plan, "null tensor pointer");
-  const GemmParams p = dgrad_params(dout, weight, din, pair, nullptr, nullptr, n_out, n_in, C, K, kv, subm);
-  return run_gather_gemm_planned(p, dtype, plan, static_cast<hipStream_t>(stream));
 }
 
 size_t spx_igemm_dgrad_ws_bytes(int C, int K, int kv, int dtype) {
@@ -2374,7 +2052,7 @@ int spx_igemm_dgrad(const void *dout, const void *weight, void *din, const int32
   SPX_CHECK((dout || n_out == 0) && weight && din, "null tensor pointer");
   SPX_CHECK(pair || kv == 1, "pair table required");
   GemmParams p = dgrad_params(dout, weight, din, pair, mask, argsort, n_out, n_in, C, K, kv, subm);
-  p.tile_order = (tile_order && argsort) ? 1 : 0;
+  apply_rows_layout(p, tile_order);
   if (ws && ws_bytes >= spx_igemm_acc_bytes(n_in, C, kv) && kv > 32) p.acc = static_cast<float *>(ws);
   return run_gather_gemm(p, dtype, static_cast<hipStream_t>(stream));
 }
@@ -2571,7 +2249,7 @@ int spx_igemm_bwd(const void *feat, const void *dout, const void *weight, void *
   SPX_CHECK(ws_bytes >= spx_igemm_wgrad_ws_bytes(n_in, C, K, kv), "workspace too small");
   static const int fuse = env_int("SPX_BWD_FUSE", 1);             // tuning knob (A/B runs)
   GemmParams p = dgrad_params(dout, weight, din, pair, mask, argsort, n_out, n_in, C, K, kv, subm);
-  p.tile_order = (tile_order && argsort) ? 1 : 0;
+  apply_rows_layout(p, tile_order);
   const bool small_offsets = static_cast<unsigned long long>(n_out) * K * 2ull < 0x7fff0000ull &&
                              static_cast<unsigned long long>(n_in) * C * 2ull < 0x7fff0000ull &&
                              static_cast<unsigned long long>(n_in) * 4ull * (kv + 1) < 0x7fff0000ull;   // both lists of an offset through one resource
@@ -2648,19 +2326,6 @@ int spx_bias_act_inplace(void *out, const void *bias, int n, int K, int dtype, i
   SPX_LAUNCH_CHECK();
   return 0;
 }
-
-#ifdef SPX_ABLATE
-// measurement build only: resident workgroups per CU the runtime reports for the two gather-GEMMs
-int spx_debug_occupancy(int *halo_wgs, int *v4_wgs) {
-  hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_halo_kernel<64, 0, false, 2>),
-                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(halo_smem_bytes<64>()));
-  SPX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(halo_wgs, igemm_halo_kernel<64, 0, false, 2>, kThreads,
-                                                       halo_smem_bytes<64>()));
-  SPX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(v4_wgs, igemm_v4_kernel<64, 2, 0, false, 2>, kThreads,
-                                                       v4_smem_bytes<64, 2>()));
-  return 0;
-}
-#endif
 
 #ifdef SPX_TIMELINE
 // debug builds only: copies the timeline table (8192 workgroups x 8 stamps, uint64) to host memory

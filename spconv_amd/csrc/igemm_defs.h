@@ -1,5 +1,5 @@
 // Shared definitions of the gather-GEMM translation units (igemm.hip: the 128-row direct-fragment
-// kernels, wgrad, dispatch and the C ABI; igemm5.hip: the persistent loader/consumer gather-GEMM).
+// kernels, wgrad, dispatch and the C ABI; igemm_gen1.hip; igemm_bwdn.hip).
 #pragma once
 #include "common.h"
 
@@ -55,7 +55,45 @@ struct GemmParams {
   int dbg;                // ablation builds only (-DSPX_ABLATE, tools/dense_probe.py)
   int xcd_rot;            // blocks of the launch ahead of this kernel body's first one, mod 8 (fused backward)
   int lpt;                // tables in tile order AND more tiles than resident workgroups: longest tiles first
+  // rows layout of a SubM rulebook (spx_subm_layout, tile_order = SPX_ROWS_LAYOUT): `argsort`, `mask`, `pair` point into
+  // the layout blob, `cls` at its class word -- 1: the rows are regrouped, tables in tile order; 0: identity order,
+  // the pair table is the caller's row-order one (`pair_rows`).  `mask_rows`: the caller's row-order mask words,
+  // for the paths that read their tables by row (generic kernels).
+  const int32_t *cls;
+  const int32_t *pair_rows;
+  const uint32_t *mask_rows;
 };
+
+// tile_order = SPX_ROWS_LAYOUT: the caller passed a layout blob as `argsort` (include/spconv_amd.h)
+inline void apply_rows_layout(GemmParams &p, int tile_order) {
+  p.cls = nullptr;
+  p.pair_rows = nullptr;
+  p.mask_rows = nullptr;
+  if (tile_order == SPX_ROWS_LAYOUT && p.argsort && p.pair && p.mask) {
+    const int32_t *blob = p.argsort;
+    const size_t npad = (static_cast<size_t>(p.n_dst) + 63) & ~static_cast<size_t>(63);
+    p.cls = blob;
+    p.pair_rows = p.pair;
+    p.mask_rows = p.mask;
+    p.argsort = blob + SPX_LAYOUT_HEADER;
+    p.mask = reinterpret_cast<const uint32_t *>(blob + SPX_LAYOUT_HEADER + npad);
+    p.pair = blob + SPX_LAYOUT_HEADER + 2 * npad;
+    p.tile_order = 1;
+  } else {
+    p.tile_order = (tile_order == 1 && p.argsort) ? 1 : 0;
+    if (tile_order == SPX_ROWS_LAYOUT) p.argsort = nullptr;       // (a blob without tables: row order)
+  }
+}
+
+// back to the row-order tables (paths that do not read tables by tile position)
+inline void drop_rows_layout(GemmParams &p) {
+  if (!p.cls) return;
+  p.pair = p.pair_rows;
+  p.mask = p.mask_rows;
+  p.argsort = nullptr;
+  p.tile_order = 0;
+  p.cls = nullptr;
+}
 
 // DT: 0 = f16, 1 = bf16, 2 = int8 (i32 accumulate, quantised epilogue; forward only), 3 = fp32
 // (v_mfma_f32_16x16x4_f32, exact fp32 at 1/16 of the 16-bit MFMA rate).  All
@@ -82,13 +120,6 @@ struct GemmRest {
 
 // igemm_gen1.hip: first-generation gather-GEMM (tensors beyond 32-bit buffer offsets)
 int launch_gather_gemm_gen1(const GemmParams &p, bool bf16, hipStream_t s);
-// igemm5.hip: persistent loader / consumer gather-GEMM (16-bit operands, <= 64 output channels)
-bool v5_ok(const GemmParams &p, int dtype);
-int launch_v5(const GemmParams &p, const GemmRest &r, int dtype, hipStream_t s);
-// igemm_sp.hip: one autonomous wave per 32 rows (sparse neighbourhoods; reduction index contiguous)
-bool sp_ok(const GemmParams &p, int dtype);
-int launch_sp(const GemmParams &p, const GemmRest &r, int dtype, hipStream_t s);
-
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

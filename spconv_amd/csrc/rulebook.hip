@@ -1834,7 +1834,151 @@ int user_hash_dispatch2(int what, void *tkeys, void *tvals, int cap, const void 
 
 using namespace spx;
 
+namespace spx {
+namespace {
+// ---------------------------------------------------------------- SubM row layout
+// The default row order of a SubM rulebook (include/spconv_amd.h, spx_subm_layout): the reference sorts the rows of
+// every rulebook by mask (SPCONV_DO_SORT, constants.py:121; ops.py:763-785 -> all.py:935-991); here the finished
+// masks are classified and, for a sparse rulebook, regrouped by a stable counting partition -- bucket 0 = rows
+// that only have their centre pair (they keep their order and lead), bucket 1 + j = rows whose lowest neighbour
+// offset is j.  count -> scan (one block per bucket) -> scatter; ranks inside a block come from wave ballots,
+// every position is a function of the masks alone (no order-dependent atomics).  Nothing is read back: the
+// class lands in the blob, the gather-GEMM picks its tables by it.
+constexpr int kLayBuckets = 33;       // centre-only + lowest neighbour offset 0 .. 31
+constexpr int kLayItems = 1024;       // rows per block (4 rounds of 256)
+constexpr int kLayGuard = 256;        // positions ahead of the regrouped rows whose table columns are written too
+                                      // (the tile that holds the first regrouped row starts at most that far back)
+
+__device__ __forceinline__ int lay_bucket(uint32_t m, int centre) {
+  m &= ~(1u << centre);
+  return m ? 1 + __builtin_ctz(m) : 0;
+}
+
+__global__ void __launch_bounds__(kBlock)
+layout_count_kernel(const uint32_t *__restrict__ mask, int n, int kv, int nblk, int32_t *__restrict__ cnt) {
+  __shared__ int h[kLayBuckets];
+  if (threadIdx.x < kLayBuckets) h[threadIdx.x] = 0;
+  __syncthreads();
+  const int centre = kv / 2, begin = blockIdx.x * kLayItems;
+#pragma unroll
+  for (int it = 0; it < kLayItems / kBlock; ++it) {
+    const int i = begin + it * kBlock + threadIdx.x;
+    if (i < n) atomicAdd(&h[lay_bucket(mask[i], centre)], 1);      // (counts: the order of the adds is immaterial)
+  }
+  __syncthreads();
+  if (threadIdx.x < kLayBuckets) cnt[static_cast<size_t>(threadIdx.x) * nblk + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(kBlock)
+layout_scatter_kernel(const int32_t *__restrict__ pair, const uint32_t *__restrict__ mask, int n, int kv, int nblk,
+                      const int32_t *__restrict__ off, const int32_t *__restrict__ totals,
+                      int32_t *__restrict__ blob, int npad) {
+  __shared__ int base[kLayBuckets];              // first position of (bucket, this block)
+  __shared__ int wcnt[kBlock / 64][kLayBuckets]; // rows of a bucket per wave, this round
+  const int centre = kv / 2, begin = blockIdx.x * kLayItems;
+  const int heavy = n - totals[0];
+  const int cls = (heavy > 0 && 4ll * heavy < n) ? 1 : 0;
+  int32_t *order = blob + SPX_LAYOUT_HEADER;
+  uint32_t *mask_t = reinterpret_cast<uint32_t *>(blob + SPX_LAYOUT_HEADER + npad);
+  int32_t *pair_t = blob + SPX_LAYOUT_HEADER + 2 * static_cast<size_t>(npad);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    blob[0] = cls;
+    blob[1] = heavy;
+    blob[2] = n;
+    blob[3] = kv;
+  }
+  if (!cls) {                                    // identity order: the kernels read the row-order pair table
+#pragma unroll
+    for (int it = 0; it < kLayItems / kBlock; ++it) {
+      const int i = begin + it * kBlock + threadIdx.x;
+      if (i < n) {
+        order[i] = i;
+        mask_t[i] = mask[i];
+      }
+    }
+    return;
+  }
+  if (threadIdx.x < kLayBuckets) {
+    int b = 0;
+    for (int j = 0; j < static_cast<int>(threadIdx.x); ++j) b += totals[j];
+    base[threadIdx.x] = b + off[static_cast<size_t>(threadIdx.x) * nblk + blockIdx.x];
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int first_col = n - heavy - kLayGuard;   // table columns from here on are read by some tile
+  for (int it = 0; it < kLayItems / kBlock; ++it) {
+    for (int j = threadIdx.x; j < (kBlock / 64) * kLayBuckets; j += kBlock) (&wcnt[0][0])[j] = 0;
+    __syncthreads();                             // (also publishes `base` in the first round)
+    const int i = begin + it * kBlock + threadIdx.x;
+    const bool ok = i < n;
+    const uint32_t m = ok ? mask[i] : 0u;
+    const int b = ok ? lay_bucket(m, centre) : -1;
+    // rank among the rows of the same bucket in this wave: one ballot per DISTINCT bucket present (1-3 on a
+    // sparse rulebook)
+    int rank = 0;
+    unsigned long long todo = __ballot(ok);
+    while (todo) {
+      const int leader = __builtin_ctzll(todo);
+      const int lb = __builtin_amdgcn_readlane(b, leader);
+      const unsigned long long same = __ballot(ok && b == lb);
+      if (b == lb) rank = __popcll(same & ((1ull << lane) - 1ull));
+      if (lane == leader) wcnt[wave][lb] = __popcll(same);
+      todo &= ~same;
+    }
+    __syncthreads();
+    if (ok) {
+      int pos = base[b] + rank;
+      for (int w = 0; w < wave; ++w) pos += wcnt[w][b];
+      order[pos] = i;
+      mask_t[pos] = m;
+      if (pos >= first_col)
+        for (int k = 0; k < kv; ++k)
+          pair_t[static_cast<size_t>(k) * n + pos] = pair[static_cast<size_t>(k) * n + i];
+    }
+    __syncthreads();
+    if (threadIdx.x < kLayBuckets) {
+      int add = 0;
+#pragma unroll
+      for (int w = 0; w < kBlock / 64; ++w) add += wcnt[w][threadIdx.x];
+      base[threadIdx.x] += add;
+    }
+    __syncthreads();                             // wcnt is cleared by the next round
+  }
+}
+}  // namespace
+}  // namespace spx
+
 extern "C" {
+
+size_t spx_subm_layout_bytes(int n, int kv) {
+  const size_t nn = n > 0 ? n : 1, npad = (nn + 63) & ~static_cast<size_t>(63);
+  return (SPX_LAYOUT_HEADER + 2 * npad + static_cast<size_t>(kv) * nn) * sizeof(int32_t);
+}
+
+size_t spx_subm_layout_ws_bytes(int n) {
+  const size_t nblk = div_up(n > 0 ? n : 1, kLayItems);
+  return 2 * align_up(static_cast<size_t>(kLayBuckets) * nblk * sizeof(int32_t), 256) + 256;
+}
+
+int spx_subm_layout(const int32_t *pair_fwd, const uint32_t *mask, int n, int kv, int32_t *layout, void *ws,
+                    size_t ws_bytes, spx_stream_t stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  SPX_CHECK(kv >= 1 && kv <= 32, "a rows layout needs a kernel volume <= 32 (one mask word), got %d", kv);
+  if (n <= 0) return 0;
+  SPX_CHECK(pair_fwd && mask && layout && ws, "null pointer");
+  SPX_CHECK(ws_bytes >= spx_subm_layout_ws_bytes(n), "workspace too small");
+  const int nblk = div_up(n, kLayItems);
+  const int npad = (n + 63) & ~63;
+  Carver cv(ws);
+  int32_t *cnt = cv.take<int32_t>(static_cast<size_t>(kLayBuckets) * nblk);
+  int32_t *off = cv.take<int32_t>(static_cast<size_t>(kLayBuckets) * nblk);
+  int32_t *totals = cv.take<int32_t>(64);
+  hipLaunchKernelGGL(layout_count_kernel, dim3(nblk), dim3(kBlock), 0, s, mask, n, kv, nblk, cnt);
+  hipLaunchKernelGGL(scan_kernel, dim3(kLayBuckets), dim3(kBlock), 0, s, cnt, off, nblk, totals);
+  hipLaunchKernelGGL(layout_scatter_kernel, dim3(nblk), dim3(kBlock), 0, s, pair_fwd, mask, n, kv, nblk, off,
+                     totals, layout, npad);
+  SPX_LAUNCH_CHECK();
+  return 0;
+}
 
 size_t spx_subm_rulebook_ws_bytes(int n, int kv) {
   const uint32_t cap = table_capacity(n > 0 ? n : 1);

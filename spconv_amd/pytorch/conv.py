@@ -339,7 +339,7 @@ class SparseConvolution(SparseModule):
                     rb, _ = ops.build_rulebook(indices, batch_size, spatial_shape, self.kernel_size,
                                                self.stride, self.padding, self.dilation,
                                                self.output_padding, self.subm, self.transposed,
-                                               do_sort=MODULE_DO_SORT and not static,
+                                               do_sort=False if static else MODULE_DO_SORT,
                                                need_native=torch.is_grad_enabled() or self.algo == ConvAlgo.Native,
                                                static_num_out=static)
                 self._static_n_out_dev = rb.n_out_dev
@@ -406,9 +406,8 @@ class SparseConvolution(SparseModule):
             which = "bwd" if self.inverse else "fwd"
             table, mask, argsort, tile_order = ops.tables_of(rb, which, w.shape[0])
             ident = rb.kv // 2 if (self.subm and not self.inverse) else -1
-            tp = ops.tile_plan(rb, "fwd") if (not self.inverse and argsort is None) else None
             out_features = ops.igemm_fwd(features, w, table, mask, argsort, num_out, ident,
-                                         bias_for_infer, act_type, act_alpha, plan=tp, tile_order=tile_order)
+                                         bias_for_infer, act_type, act_alpha, tile_order=tile_order)
         return out_features
 
     def _finish(self, input, out_tensor, out_features, outids, indice_dict, out_spatial_shape, add_input,
@@ -421,7 +420,7 @@ class SparseConvolution(SparseModule):
         if not self.subm and not self.inverse and self.record_voxel_count:
             buf = getattr(self, _MAX_NUM_VOXELS_DURING_TRAINING, None)
             if buf is not None:
-                buf.clamp_(min=outids.shape[0])
+                ops.record_voxel_count_(buf, rb, outids.shape[0])
         out_tensor = out_tensor.replace_feature(out_features)
         out_tensor.indices = outids
         out_tensor.indice_dict = indice_dict

@@ -55,13 +55,14 @@ class Rulebook:
         self.argsort_bwd = argsort_bwd
         self.wgrad_plan = None          # built lazily by ops._plan_of
         self._native_swapped = None
-        # geometry of the two row sets (set by ops.build_rulebook) and the tile plans built from it
-        # on first use (ops.tile_plan: spatial row order + per-tile halo lists, csrc/tileplan.hip)
+        # geometry of the two row sets (set by ops.build_rulebook)
         self.in_indices = None
         self.in_shape = None
         self.out_shape = None
         self.batch_size = 1
-        self.tile_plans = {}
+        # rows layout of a SubM rulebook (ops.rows_layout: int32 blob of spx_subm_layout -- class word,
+        # row order, mask words and pair table in tile order), None without one
+        self.layout = None
         # copies of the tables in mask-sorted tile order (ops.sort_rulebook): [pair, mask] per
         # direction, None while unsorted; sort_decided: the automatic mode looked at this rulebook
         self.sorted_tables = {}

@@ -66,10 +66,17 @@ class _BatchNormFn(torch.autograd.Function):
                                            float(eps), int(relu), stats[0].data_ptr(), stats[1].data_ptr(),
                                            ws.data_ptr(), ws.numel(), p(n_live),
                                            torch._C._cuda_getCurrentRawStream(dev.index)))
-        # evaluation mode: the backward pass (frozen-BN fine-tuning) derives fp32 mean / 1/std from the running
-        # estimates when it runs -- an inference pass must not pay four small launches per layer for them
+        # evaluation mode: an inference pass must not pay four small launches per layer for fp32 mean / 1/std; a
+        # pass that will be differentiated (frozen-BN fine-tuning) snapshots them NOW -- the kernels update the
+        # running buffers through raw pointers (no autograd version bump), so a training-mode pass of the same
+        # module between this forward and its backward must not change what the backward normalises with
+        ctx.snap = False
         if training:
             ctx.save_for_backward(x, weight, bias, stats[0], stats[1])
+        elif any(ctx.needs_input_grad[:3]):
+            ctx.snap = True
+            ctx.save_for_backward(x, weight, bias, running_mean.float().clone(),
+                                  torch.rsqrt(running_var.float() + float(eps)))
         else:
             ctx.save_for_backward(x, weight, bias, running_mean, running_var)
         ctx.training, ctx.relu, ctx.pdt, ctx.n_live, ctx.eps = bool(training), bool(relu), pdt, n_live, float(eps)
@@ -80,7 +87,7 @@ class _BatchNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         L = _lib.load()
         x, weight, bias, mean, invstd = ctx.saved_tensors
-        if not ctx.training:           # saved: the running estimates
+        if not ctx.training and not ctx.snap:           # saved: the running estimates themselves
             mean, invstd = mean.float(), torch.rsqrt(invstd.float() + ctx.eps)
         n, C = x.shape
         dev = x.device

@@ -117,6 +117,8 @@ def _ptr(t: Optional[torch.Tensor]):
 # the caches -- SparseSequential opens it around a convolution whose output a BatchNorm reads next
 _OUT_CACHED = 0x100
 _TILE_ORDER = 0x200           # SPX_TILE_ORDER: tables of the int8 forward are stored in tile order
+_ROWS_LAYOUT_ACT = 0x400      # SPX_ROWS_LAYOUT_ACT: `argsort` of the int8 forward is a rows layout blob
+_SPARSE_HINT = 0x800          # SPX_SPARSE_HINT: the host has seen class word 1 (launch-shape hint)
 _out_policy = threading.local()
 
 
@@ -151,7 +153,7 @@ def build_rulebook(indices: torch.Tensor, batch_size: int, spatial_shape: List[i
                    ksize: List[int], stride: List[int], padding: List[int],
                    dilation: List[int], out_padding: List[int], subm: bool = False,
                    transpose: bool = False, need_bwd_table: bool = False,
-                   do_sort: bool = False, need_native: bool = True,
+                   do_sort=False, need_native: bool = True,
                    num_out_act_bound: int = -1, static_num_out: int = 0) -> Tuple[Rulebook, List[int]]:
     """One call builds every artefact (dense tables, masks, Native lists).  need_native=False
     (inference) leaves the ConvAlgo.Native lists out -- three launches and two thirds of the
@@ -161,7 +163,11 @@ def build_rulebook(indices: torch.Tensor, batch_size: int, spatial_shape: List[i
     output tensor has static_num_out rows, nothing is read back from the device (the whole build can
     be captured in a graph), rows past the real output count are dead (out_indices -1, no pairs) and
     `rb.n_out_dev` holds {outputs found, table overflow} on the device.  Input rows with a negative
-    batch index are dead rows in every mode."""
+    batch index are dead rows in every mode.
+
+    do_sort: False = rows stay in input order; "layout" (the modules' default; "auto" is an alias) =
+    density-aware rows layout of a SubM rulebook, built on the device (rows_layout); True = the
+    reference's explicit mask sort (sort_rulebook)."""
     _require_gpu(indices, "indices")
     assert indices.dtype == torch.int32 and indices.ndim == 2
     L = _lib.load()
@@ -250,55 +256,75 @@ def build_rulebook(indices: torch.Tensor, batch_size: int, spatial_shape: List[i
         rb = Rulebook(out_indices, pair_fwd, pair_bwd, mask_fwd, mask_bwd, native, num, n_in,
                       n_out, kv, False)
     rb.in_indices, rb.in_shape, rb.out_shape, rb.batch_size = indices, list(spatial_shape), list(out_shape), batch_size
-    if do_sort == "auto":
-        do_sort = sparse_neighbourhoods(rb)
-    if do_sort and words == 1:
+    if do_sort in ("layout", "auto"):
+        # the default row order: classified and regrouped on the device inside the build (SubM; nothing
+        # read back).  Strided layers keep their row order (dense by construction: every output has
+        # several inputs), small rulebooks are launch-bound either way.
+        if subm and 1 < kv <= 32 and n_in >= _LAYOUT_MIN_ROWS:
+            rows_layout(rb)
+    elif do_sort and words == 1:
         sort_rulebook(rb)
     return rb, out_shape
 
 
-# Density-aware layout (the reference tunes per problem and caches the choice: convops.py:1150 tune_and_cache,
-# :1311 get_tuned_algo; here the choice is a property of the RULEBOOK, made once and cached on it).
-# do_sort="auto" sorts the rows of a SPARSE SubM rulebook by mask (stable: rows that only have their
-# centre pair keep their order, the few rows with neighbours move to the end, grouped by offset), which
-# turns "every 128-row tile walks ~4 extra offsets" into "97 % of the tiles walk none, the last tiles
-# 2-3 each": forward 13.3 -> 11.2 us, dgrad 13.9 -> 11.7 us at BASELINE config 2.  Dense (LiDAR)
-# rulebooks stay in row order (sorting them costs 19 % there).  The decision needs
-# ONE small device -> host read per rulebook (share of rows with a neighbour), which is why it is an
-# explicit mode and not the module default: a backbone that builds four SubM rulebooks per step would
-# pay four synchronisations.
-_SPARSE_SHARE = 0.25
+# Density-aware row order = the DEFAULT of the layer modules (the reference sorts every rulebook by mask:
+# SPCONV_DO_SORT = "1", constants.py:121, ops.py:346,550,763-785).  spx_subm_layout classifies the finished
+# masks on the device and, for a SPARSE rulebook (fewer than a quarter of the rows have any neighbour),
+# regroups the rows by a stable counting partition -- centre-only rows first, then the rows with
+# neighbours grouped by offset -- which turns "every 128-row tile walks ~4 extra offsets" into "97 % of
+# the tiles walk none, the last tiles 2-3 each" (forward 13.3 -> 11.1 us, dgrad 13.9 -> 11.7 us at
+# BASELINE config 2); a dense (LiDAR) rulebook keeps its row order (regrouping loses 19 % there).  No
+# sort, no read-back: the class is a word in the blob that the gather-GEMM launch reads, so the same
+# launch serves both classes and the whole thing sits in a hipGraph.
+_LAYOUT_MIN_ROWS = 32768
+_ROWS_LAYOUT = 2              # SPX_ROWS_LAYOUT: `argsort` of a gather-GEMM call is a layout blob
+
+
+@_on_device
+def rows_layout(rb: Rulebook) -> None:
+    """Builds rb.layout (int32 blob, include/spconv_amd.h: spx_subm_layout) for a SubM rulebook."""
+    L = _lib.load()
+    n, kv = rb.n_out, rb.kv
+    dev = rb.pair_fwd.device
+    blob = torch.empty((L.spx_subm_layout_bytes(n, kv) // 4,), dtype=torch.int32, device=dev)
+    ws = _ws(L.spx_subm_layout_ws_bytes(n), dev)
+    _lib.check(L.spx_subm_layout(rb.pair_fwd.data_ptr(), rb.mask_fwd.data_ptr(), n, kv, blob.data_ptr(),
+                                 ws.data_ptr(), ws.numel(), _stream(rb.pair_fwd)))
+    rb.layout = blob
+    rb.sort_decided = True
+
+
+def layout_views(rb: Rulebook):
+    """(class word [1], order [n], mask words in tile order [n], pair table in tile order [kv, n]) of
+    rb.layout -- views for tests and tools; the pair table is only defined for a regrouped rulebook, and
+    there only for the columns of rows with a neighbour."""
+    n, kv, blob = rb.n_out, rb.kv, rb.layout
+    npad = (n + 63) // 64 * 64
+    return (blob[:4], blob[64:64 + n], blob[64 + npad:64 + npad + n],
+            blob[64 + 2 * npad:64 + 2 * npad + kv * n].view(kv, n))
 
 
 def sparse_neighbourhoods(rb: Rulebook) -> bool:
-    """True for a SubM rulebook of >= 32 k rows in which fewer than a quarter of the rows have any pair
-    besides their centre pair (one read-back; cached on the rulebook)."""
+    """True for a rulebook whose rows were regrouped (one device -> host read of the class word; cached
+    on the rulebook).  A HOST-side view for tools and for choices that change a launch's shape (the
+    int8 tile height); the kernels themselves read the class on the device."""
     cached = getattr(rb, "sparse_class", None)
     if cached is not None:
         return cached
     ok = False
-    if rb.subm and 1 < rb.kv <= 32 and rb.n_out >= _SORT_MIN_ROWS and rb.mask_fwd is not None:
+    if rb.layout is not None:
+        ok = bool(int(rb.layout[0].item()))
+    elif rb.subm and 1 < rb.kv <= 32 and rb.n_out >= _LAYOUT_MIN_ROWS and rb.mask_fwd is not None:
         centre = 1 << (rb.kv // 2)
-        ok = float((rb.mask_fwd.view(-1) != centre).float().mean().item()) < _SPARSE_SHARE
+        ok = float((rb.mask_fwd.view(-1) != centre).float().mean().item()) < 0.25
     rb.sparse_class = ok
     return ok
 
 
-# SPCONV_AMD_SORT: "0" (default) = rows are sorted by mask only when asked (do_sort / SPCONV_DO_SORT=1,
-# the reference's switch); "auto" = SubM rulebooks of >= 32 k rows with dense neighbourhoods get sorted
-# on first use.  Sorting is what the reference does for every rulebook (tiles of equal-mask rows skip the
-# offsets none of their rows has: 14 steps per 128-row tile instead of 27 on its LiDAR fixture), and with
-# the tables copied into tile order the sorted launch no longer pays scattered table reads (59 -> 43 us
-# forward on the fixture) -- but measured end to end it is a wash there (43.5 vs 40.0 us: the kernel is
-# bound by instruction issue and load latency, not by its step count, DESIGN.md section 6), +19 % on the
-# synthetic LiDAR-like scene, and the sort + density read-back cost a single-scene training step 1 ms.
-_SORT_MODE = os.environ.get("SPCONV_AMD_SORT", "0")
-_SORT_MIN_ROWS = 32768
-
-
 def sort_rulebook(rb: Rulebook) -> None:
-    """argsort of the mask words + copies of the tables in that order (both directions of a
-    regular-conv rulebook).  The gather-GEMM then reads pair / mask by tile position."""
+    """The reference's explicit mask sort (SPCONV_DO_SORT=1): argsort of the mask words + copies of the
+    tables in that order (both directions of a regular-conv rulebook).  The gather-GEMM then reads
+    pair / mask by tile position."""
     dev = rb.pair_fwd.device
     if dev.type == "cuda" and dev.index != torch.cuda.current_device():
         with torch.cuda.device(dev):                   # launches belong to the device the tables live on
@@ -323,29 +349,23 @@ def sort_rulebook(rb: Rulebook) -> None:
 
 def tables_of(rb: Rulebook, which: str, cout: int = 64):
     """(pair, mask, argsort, tile_order) the gather-GEMM should read for `which` ("fwd": pair_fwd
-    over the output rows, "bwd": pair_bwd over the input rows).  Automatic mode decides here, once
-    per rulebook, whether the rows get sorted.  `cout`: output width of the GEMM (widths beyond the
-    MFMA instantiations take the generic kernel, which reads the tables by row)."""
+    over the output rows, "bwd": pair_bwd over the input rows).  tile_order 0: tables by row (argsort,
+    if any, permutes the rows); 1: copies in tile order (explicit mask sort); 2: `argsort` is the rows
+    layout blob and pair / mask the row-order tables (the device picks).  `cout`: output width of the
+    GEMM (widths beyond the MFMA instantiations take the generic kernel, which reads the tables by row)."""
     if cout > _MFMA_COUT[-1] or rb.kv > 32:
-        return ((rb.pair_fwd, rb.mask_fwd, None, False) if which == "fwd"
-                else (rb.pair_bwd, rb.mask_bwd, None, False))
-    if not rb.sort_decided:
-        rb.sort_decided = True
-        if (_SORT_MODE == "auto" and rb.subm and rb.kv <= 32 and rb.kv > 1 and rb.n_out >= _SORT_MIN_ROWS
-                and rb.argsort_fwd is None):
-            # dense neighbourhoods?  share of rows with more than their own (centre) pair; one small
-            # reduction + read-back per rulebook (uniform-random scenes: ~3 %, LiDAR: ~100 %)
-            centre = 1 << (rb.kv // 2)
-            if float((rb.mask_fwd.view(-1) != centre).float().mean().item()) >= 0.5:
-                sort_rulebook(rb)
+        return ((rb.pair_fwd, rb.mask_fwd, None, 0) if which == "fwd"
+                else (rb.pair_bwd, rb.mask_bwd, None, 0))
     if which == "fwd":
         pair, mask, order = rb.pair_fwd, rb.mask_fwd, rb.argsort_fwd
     else:
         pair, mask, order = rb.pair_bwd, rb.mask_bwd, rb.argsort_bwd
     st = rb.sorted_tables.get(which)
     if order is not None and st is not None:
-        return st[0], st[1], order, True
-    return pair, mask, order, False
+        return st[0], st[1], order, 1
+    if order is None and which == "fwd" and rb.subm and rb.layout is not None:
+        return pair, mask, rb.layout, _ROWS_LAYOUT
+    return pair, mask, order, 0
 
 
 @_on_device
@@ -358,59 +378,6 @@ def mask_argsort(mask: torch.Tensor) -> torch.Tensor:
     _lib.check(L.spx_mask_argsort(mask.data_ptr(), n, words, out.data_ptr(), ws.data_ptr(),
                                   ws.numel(), _stream(mask)))
     return out
-
-
-# ---------------------------------------------------------------- tile plans
-# SPCONV_AMD_TILE_PLAN: "0" (default) = never; "auto" = SubM rulebooks of >= 32 k rows whose
-# neighbourhoods are dense get a plan on first use; "1" = every eligible table.  Off by default:
-# measured on the reference's LiDAR fixture the halo kernel needs 74 KB of LDS per workgroup (two
-# per CU) and runs 57 us where the plain kernel runs 41 us (three per CU) -- the gathered operand was
-# not what bounds the dense regime; mask-sorted rows (below) are.
-_TILE_MODE = os.environ.get("SPCONV_AMD_TILE_PLAN", "0")
-_TILE_MIN_ROWS = 32768
-
-
-def _halo_ok(dtype: torch.dtype, cin: int, cout: int, kv: int) -> bool:
-    """Shapes igemm_halo_kernel is instantiated for (csrc/igemm.hip)."""
-    return (dtype in (torch.float16, torch.bfloat16) and cin % 8 == 0 and cin * 2 <= 128
-            and cout in (16, 32, 64) and kv <= 32)
-
-
-def tile_plan(rb: Optional[Rulebook], direction: str) -> Optional[torch.Tensor]:
-    """Plan of a rulebook's table for the dense-neighbourhood kernel, or None when the plain kernel
-    is the better choice.  direction "fwd": pair_fwd over the output rows; "bwd": the table dgrad
-    reads (SubM: pair_fwd again -- one plan serves both passes; regular conv: pair_bwd over the
-    input rows).  Built once per rulebook and direction, cached on the rulebook."""
-    if rb is None or _TILE_MODE == "0" or rb.kv > 32 or rb.in_indices is None:
-        return None
-    if rb.subm:
-        direction = "fwd"
-    if direction in rb.tile_plans:
-        return rb.tile_plans[direction]
-    plan = None
-    if direction == "fwd":
-        table, mask, inds, shape, n_dst = rb.pair_fwd, rb.mask_fwd, rb.out_indices, rb.out_shape, rb.n_out
-    else:
-        table, mask, inds, shape, n_dst = rb.pair_bwd, rb.mask_bwd, rb.in_indices, rb.in_shape, rb.n_in
-    want = table is not None and n_dst > 0
-    if want and _TILE_MODE != "1":
-        want = rb.subm and n_dst >= _TILE_MIN_ROWS
-        if want:
-            # dense neighbourhoods?  share of rows with more than their own (centre) pair; one
-            # small reduction + read-back per rulebook (uniform-random scenes: ~3 %, LiDAR: ~100 %)
-            centre = 1 << (rb.kv // 2)
-            want = float((mask.view(-1) != centre).float().mean().item()) >= 0.5
-    if want:
-        L = _lib.load()
-        plan = torch.empty((L.spx_tile_plan_bytes(n_dst, rb.kv) // 4,), dtype=torch.int32, device=table.device)
-        ws = _ws(L.spx_tile_plan_ws_bytes(n_dst), table.device)
-        inds = inds.contiguous()
-        with torch.cuda.device(table.device):          # (the launch belongs to the device the table lives on)
-            _lib.check(L.spx_tile_plan_build(inds.data_ptr(), n_dst, inds.shape[1] - 1, int(rb.batch_size),
-                                             _lib.ints(shape), table.data_ptr(), rb.kv, plan.data_ptr(),
-                                             ws.data_ptr(), ws.numel(), _stream(table)))
-    rb.tile_plans[direction] = plan
-    return plan
 
 
 def attach_rulebook(t: torch.Tensor, rb: Rulebook) -> torch.Tensor:
@@ -454,7 +421,7 @@ def get_indice_pairs_implicit_gemm(indices: torch.Tensor, batch_size: int,
     kv = _kv(ksize)
     rb, _ = build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation,
                            out_padding, subm, transpose, need_bwd_table=subm and is_train,
-                           do_sort=do_sort and kv <= 32, num_out_act_bound=num_out_act_bound)
+                           do_sort=do_sort if kv <= 32 else False, num_out_act_bound=num_out_act_bound)
     masks = [np.array([0xffffffff], dtype=np.uint32)]
     arg_fwd = rb.argsort_fwd if rb.argsort_fwd is not None else torch.arange(
         rb.n_out, dtype=torch.int32, device=indices.device)
@@ -494,7 +461,7 @@ def igemm_fwd_int8(features: torch.Tensor, filters: torch.Tensor, pair: torch.Te
                    bias: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None,
                    add_scale: float = 0.0, out_dtype: torch.dtype = torch.int8,
                    act_type: int = Activation.None_, act_alpha: float = 0.0,
-                   tile_order: bool = False) -> torch.Tensor:
+                   tile_order: int = 0, sparse_hint: bool = False) -> torch.Tensor:
     """int8 inference forward (i32 accumulate on v_mfma_i32_16x16x64_i8):
     ``v = acc * scale[k] + bias[k] + add * add_scale; v = act(v)``; int8 output =
     ``clip(round_half_even(v), -128, 127)`` (reference numerics test/test_all_algo.py:272-287)."""
@@ -526,7 +493,9 @@ def igemm_fwd_int8(features: torch.Tensor, filters: torch.Tensor, pair: torch.Te
                                     _ptr(mask), _ptr(argsort), features.shape[0], n_out, C, K, kv,
                                     identity_k, _ptr(scale), _ptr(bias), _ptr(add), float(add_scale),
                                     _OUT_CODES[out_dtype],
-                                    int(act_type) | (_TILE_ORDER if (tile_order and argsort is not None) else 0),
+                                    int(act_type) | (0 if argsort is None else
+                                                     {0: 0, 1: _TILE_ORDER, 2: _ROWS_LAYOUT_ACT}[int(tile_order)])
+                                    | (_SPARSE_HINT if sparse_hint else 0),
                                     float(act_alpha), _stream(features)))
     return out if K == K0 else out[:, :K0].contiguous()
 
@@ -563,25 +532,13 @@ def igemm_fwd(features: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
               mask: Optional[torch.Tensor], argsort: Optional[torch.Tensor], n_out: int,
               identity_k: int = -1, bias: Optional[torch.Tensor] = None,
               act_type: int = Activation.None_, act_alpha: float = 0.0,
-              plan: Optional[torch.Tensor] = None, tile_order: bool = False) -> torch.Tensor:
-    """out[o] = act(bias + sum_k feat[pair[k][o]] @ W[:, k, :].T); filters KRSC.  `plan`: tile plan of
-    `pair` (ops.tile_plan) -> the dense-neighbourhood kernel, same results."""
+              tile_order: int = 0) -> torch.Tensor:
+    """out[o] = act(bias + sum_k feat[pair[k][o]] @ W[:, k, :].T); filters KRSC.  tile_order: see tables_of."""
     _check_feat(features, filters)
     L = _lib.load()
     K0, C0 = filters.shape[0], filters.shape[-1]
     assert features.shape[1] == C0, "channel size mismatch"
     kv = filters.numel() // (K0 * C0)
-    if plan is not None and not tile_order and _halo_ok(features.dtype, C0, K0, kv):
-        features, filters = features.contiguous(), filters.contiguous()
-        out = torch.empty((n_out, K0), dtype=features.dtype, device=features.device)
-        if bias is not None:
-            bias = bias.to(features.dtype).contiguous()
-        _lib.check(L.spx_igemm_fwd_tiled(features.data_ptr(), filters.data_ptr(), out.data_ptr(), pair.data_ptr(),
-                                         plan.data_ptr(), features.shape[0], n_out, C0, K0, kv,
-                                         _dtype_code(features), int(identity_k), _ptr(bias), int(act_type),
-                                         float(act_alpha),
-                                         _stream(features)))
-        return out
     # Shapes the MFMA kernels are not instantiated for (a backbone's first layer has 3-5 input
     # channels; widths like 48 or 96) are zero-padded to the next supported shape instead of
     # falling to the one-thread-per-output generic kernel (two orders of magnitude slower): the
@@ -613,19 +570,12 @@ def igemm_fwd(features: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
 @_on_device
 def igemm_dgrad(out_bp: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
                 mask: Optional[torch.Tensor], argsort: Optional[torch.Tensor], n_in: int,
-                subm: bool, plan: Optional[torch.Tensor] = None, tile_order: bool = False) -> torch.Tensor:
+                subm: bool, tile_order: int = 0) -> torch.Tensor:
     """din[i] = sum_k dout[pair[k][i]] @ W[:, k, :] (SubM: pass the forward table, subm=True)."""
     _check_feat(out_bp, filters)
     L = _lib.load()
     K0, C0 = filters.shape[0], filters.shape[-1]
     kv = filters.numel() // (K0 * C0)
-    if plan is not None and not tile_order and _halo_ok(out_bp.dtype, K0, C0, kv):
-        out_bp, filters = out_bp.contiguous(), filters.contiguous()
-        din = torch.empty((n_in, C0), dtype=out_bp.dtype, device=out_bp.device)
-        _lib.check(L.spx_igemm_dgrad_tiled(out_bp.data_ptr(), filters.data_ptr(), din.data_ptr(), pair.data_ptr(),
-                                           plan.data_ptr(), out_bp.shape[0], n_in, C0, K0, kv,
-                                           _dtype_code(out_bp), int(subm), _stream(out_bp)))
-        return din
     # same padding rule as igemm_fwd: here K is the reduction length and C the output width
     K = -(-K0 // _lane_mult(out_bp.dtype)) * _lane_mult(out_bp.dtype)
     C = _round_cout(C0) if kv <= 128 else C0
@@ -711,23 +661,20 @@ def igemm_bwd(features: torch.Tensor, out_bp: torch.Tensor, filters: torch.Tenso
               table: torch.Tensor, mask: Optional[torch.Tensor], argsort: Optional[torch.Tensor],
               native: torch.Tensor, num_per_loc: torch.Tensor, subm: bool,
               plan: Optional[torch.Tensor] = None, need_din: bool = True,
-              tile_plan: Optional[torch.Tensor] = None, tile_order: bool = False, dense_rows: bool = False):
+              tile_order: int = 0, dense_rows: bool = False):
     """(din, dW) of one layer from one launch (+ the wgrad second stage).  need_din=False (the
     input does not require grad: a network's first layer) computes dW only and returns None.
-    `tile_plan` (dense neighbourhoods): dgrad takes the halo kernel, wgrad its own launch -- there
-    the two halves are long enough that sharing a launch buys ~5 %, the halo kernel ~2x."""
+    `table` / `mask` are row-order tables unless tile_order == 1 (see tables_of)."""
     _check_feat(out_bp, filters)
     K0, C0 = filters.shape[0], filters.shape[-1]
     m = _lane_mult(out_bp.dtype)
     kvf = filters.numel() // (K0 * C0)
     if ((_BWD_ROWS is True or (_BWD_ROWS == "auto" and dense_rows))
             and out_bp.dtype in (torch.float16, torch.bfloat16) and K0 in (16, 32) and C0 in (16, 32)
-            and kvf <= 27 and table is not None and mask is not None and mask.shape[1] == 1 and argsort is None
-            and not tile_order and tile_plan is None):
+            and kvf <= 27 and table is not None and mask is not None and mask.shape[1] == 1
+            and (argsort is None or tile_order == _ROWS_LAYOUT) and tile_order != 1):
+        # (the rows walk reads the row-order tables: a rows layout does not concern it)
         return _igemm_bwd_rows(features, out_bp, filters, table, mask, subm, need_din, K0, C0, kvf)
-    if tile_plan is not None and not tile_order and need_din and _halo_ok(out_bp.dtype, K0, C0, kvf):
-        din = igemm_dgrad(out_bp, filters, table, mask, argsort, features.shape[0], subm, tile_plan)
-        return din, igemm_wgrad(features, out_bp, filters.shape, native, num_per_loc, subm, plan)
     if not need_din or K0 % m or C0 not in _MFMA_COUT or kvf > 32:      # (kv > 32: dgrad in groups of 32 offsets)
         din = igemm_dgrad(out_bp, filters, table, mask, argsort, features.shape[0], subm,
                           tile_order=tile_order) if need_din else None
@@ -812,6 +759,17 @@ def bias_act_inplace(out: torch.Tensor, bias: Optional[torch.Tensor], act_type: 
     return out
 
 
+def record_voxel_count_(buf: torch.Tensor, rb: Rulebook, rows: int) -> None:
+    """max_num_voxels_during_training (reference conv.py:44,131-138): the running maximum of a strided layer's
+    output count.  A static-shape build has `rows` = the frozen BOUND, not the count -- recording that would
+    inflate every bound later derived from the buffer (freeze_bounds: recorded * margin) -- so there the count
+    the build found on the device is folded in, without a read-back."""
+    if rb.n_out_dev is not None:
+        buf.copy_(torch.maximum(buf, rb.n_out_dev[:1].to(buf.dtype).reshape(buf.shape)))
+    else:
+        buf.clamp_(min=int(rows))
+
+
 def maximum_value_int_(ten: torch.Tensor, value: int) -> torch.Tensor:
     """In-place ``ten = max(ten, value)`` for integer tensors (reference ops.py:2099-2105; used by the
     voxeliser to clamp counts)."""
@@ -858,16 +816,15 @@ def indice_conv(features: torch.Tensor, filters: torch.Tensor, indice_pairs: tor
     _check_feat(features, filters)
     rb: Optional[Rulebook] = rulebook_of(indice_pairs)
     kv = indice_pairs.shape[1]
-    argsort, tile_order, tp = None, False, None
+    argsort, tile_order = None, 0
     if rb is not None and not inverse:
         table, mask, argsort, tile_order = tables_of(rb, "fwd", filters.shape[0])
-        tp = tile_plan(rb, "fwd") if argsort is None else None
     elif rb is not None and inverse and rb.pair_bwd is not None:
         table, mask, argsort, tile_order = tables_of(rb, "bwd", filters.shape[0])
     else:
         table, mask = _table_from_native(indice_pairs, indice_pair_num, num_activate_out, subm, inverse)
     return igemm_fwd(features, filters, table, mask, argsort, num_activate_out,
-                     kv // 2 if subm else -1, bias, act_type, act_alpha, plan=tp, tile_order=tile_order)
+                     kv // 2 if subm else -1, bias, act_type, act_alpha, tile_order=tile_order)
 
 
 _SIDE_STREAMS = {}
@@ -905,7 +862,7 @@ def indice_conv_backward(features: torch.Tensor, filters: torch.Tensor, out_bp: 
     _check_feat(features, filters)
     rb: Optional[Rulebook] = rulebook_of(indice_pairs)
     n_in = features.shape[0]
-    argsort, tile_order, which = None, False, None
+    argsort, tile_order, which = None, 0, None
     if rb is not None:
         # dgrad gathers dout rows for every input row: SubM reads the forward table (mirrored
         # weights), a regular conv the table indexed by its input rows, an inverse conv the forward one
@@ -918,10 +875,9 @@ def indice_conv_backward(features: torch.Tensor, filters: torch.Tensor, out_bp: 
         native = rb.native_swapped() if rb is not None else torch.stack(
             [indice_pairs[1], indice_pairs[0]]).contiguous()
     plan = _plan_of(rb)
-    tp = tile_plan(rb, which) if (rb is not None and need_din and argsort is None) else None
     if (native.shape[2] == n_in and not BWD_OVERLAP) or not need_din:
         return igemm_bwd(features, out_bp, filters, table, mask, argsort, native, indice_pair_num,
-                         subm, plan, need_din, tile_plan=tp, tile_order=tile_order,
+                         subm, plan, need_din, tile_order=tile_order,
                          dense_rows=_dense_rows(rb, n_in, which) if rb is not None else False)
     return _backward_pair(
         lambda: igemm_dgrad(out_bp, filters, table, mask, argsort, n_in, subm, tile_order=tile_order),
@@ -942,7 +898,7 @@ def implicit_gemm(features: torch.Tensor, filters: torch.Tensor, pair_fwd: torch
     the last two exist for signature parity (this wgrad does not consume tile masks)."""
     mask = pair_mask_fwd_splits[0] if pair_mask_fwd_splits else None
     rb: Optional[Rulebook] = rulebook_of(pair_fwd)
-    argsort, tile_order = (rb.argsort_fwd if rb is not None else None), False
+    argsort, tile_order = (rb.argsort_fwd if rb is not None else None), 0
     kv = pair_fwd.shape[0]
     if rb is not None and pair_fwd is rb.pair_fwd:
         pair_fwd, mask, argsort, tile_order = tables_of(rb, "fwd", filters.shape[0])
@@ -954,15 +910,15 @@ def implicit_gemm(features: torch.Tensor, filters: torch.Tensor, pair_fwd: torch
         beta = output_add_scale / output_scale if output_add is not None else 0.0
         out = igemm_fwd_int8(features, filters, pair_fwd, mask, argsort, num_activate_out,
                              kv // 2 if is_subm else -1, scale, bias, output_add, beta, out_dt,
-                             act_type, act_alpha, tile_order=tile_order)
+                             act_type, act_alpha, tile_order=tile_order,
+                             sparse_hint=rb is not None and rb.sparse_class is True)
         if out_dt == torch.int8 and features.is_quantized:
             out = torch._make_per_tensor_quantized_tensor(out, float(output_scale), 0)
         return out, None, -1
     if scale is not None or output_add is not None:
         raise NotImplementedError("scale / output_add belong to the int8 path")
-    tp = tile_plan(rb, "fwd") if (rb is not None and pair_fwd is rb.pair_fwd and argsort is None) else None
     out = igemm_fwd(features, filters, pair_fwd, mask, argsort, num_activate_out,
-                    kv // 2 if is_subm else -1, bias, act_type, act_alpha, plan=tp, tile_order=tile_order)
+                    kv // 2 if is_subm else -1, bias, act_type, act_alpha, tile_order=tile_order)
     return out, None, -1
 
 
@@ -983,22 +939,20 @@ def implicit_gemm_backward(features: torch.Tensor, filters: torch.Tensor, out_bp
     else:
         native, num = _native_from_table(pair_fwd if is_subm else pair_bwd, is_subm)
     plan = _plan_of(rb)
-    tile_order, tp = False, None
+    tile_order = 0
     if is_subm:
         table, mask = pair_fwd, pair_mask_fwd_splits[0]
         argsort = rb.argsort_fwd if rb is not None else None
         if rb is not None and pair_fwd is rb.pair_fwd:
             table, mask, argsort, tile_order = tables_of(rb, "fwd", filters.shape[-1])
-            tp = tile_plan(rb, "fwd") if (need_din and argsort is None) else None
     else:
         table, mask = pair_bwd, pair_mask_bwd_splits[0]
         argsort = rb.argsort_bwd if rb is not None else None
         if rb is not None and pair_bwd is rb.pair_bwd:
             table, mask, argsort, tile_order = tables_of(rb, "bwd", filters.shape[-1])
-            tp = tile_plan(rb, "bwd") if (need_din and argsort is None) else None
     if (native.shape[2] == n_in and not BWD_OVERLAP) or not need_din:
         return igemm_bwd(features, out_bp, filters, table, mask, argsort, native, num, is_subm, plan,
-                         need_din, tile_plan=tp, tile_order=tile_order,
+                         need_din, tile_order=tile_order,
                          dense_rows=_dense_rows(rb, n_in, "fwd" if is_subm else "bwd"))
     return _backward_pair(
         lambda: igemm_dgrad(out_bp, filters, table, mask, argsort, n_in, is_subm, tile_order=tile_order),

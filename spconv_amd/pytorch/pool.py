@@ -86,12 +86,16 @@ class _SparsePoolBase(SparseModule):
             t = time.time()
         if self.indice_key is not None and input.find_indice_pair(self.indice_key) is not None:
             raise ValueError(f"indice key {self.indice_key} exists")
-        # static-shape inference (spconv_amd.pytorch.static): frozen output bound, no read-back
-        static = 0 if (self.training or self.subm or self.algo == ConvAlgo.Native
-                       or torch.is_grad_enabled()) else int(getattr(self, "static_num_out", 0) or 0)
+        # static shapes (spconv_amd.pytorch.static): frozen output bound, no read-back -- inference and training
+        # (the reference's bounded mode covers pools too: pool.py:99-248 via ops.py:263-266).  The table-driven
+        # backward kernels skip dead rows by construction (no pair); ConvAlgo.Native takes its lists from the same
+        # sync-free build.
+        static = 0 if self.subm else int(getattr(self, "static_num_out", 0) or 0)
         rb, _ = ops.build_rulebook(indices, batch_size, spatial_shape, self.kernel_size, self.stride,
                                    self.padding, self.dilation, [0] * self.ndim, self.subm, False,
-                                   need_bwd_table=True, need_native=not static, static_num_out=static)
+                                   need_bwd_table=True,
+                                   need_native=(not static) or self.algo == ConvAlgo.Native,
+                                   static_num_out=static)
         self._static_n_out_dev = rb.n_out_dev
         rb.in_n_live_dev = getattr(input, "n_live_dev", None)
         if rb.n_out_dev is not None:
@@ -133,7 +137,7 @@ class _SparsePoolBase(SparseModule):
         if not self.subm and self.record_voxel_count:
             buf = getattr(self, _MAX_NUM_VOXELS_DURING_TRAINING, None)
             if buf is not None:
-                buf.clamp_(min=outids.shape[0])
+                ops.record_voxel_count_(buf, rb, outids.shape[0])
         out_tensor = out_tensor.replace_feature(out_features)
         out_tensor.indices = outids
         out_tensor.indice_dict = indice_dict

@@ -99,6 +99,10 @@ class StaticInference:
         out = runner(features, indices)         # replay; `out` lives in static buffers
         live = out.indices[:, 0] >= 0           # rows of this scene
         runner.overflowed()                     # one synchronisation: {layer: outputs found} over a bound
+        runner.release_bounds()                 # when done: eager passes of `net` are unbounded again
+
+    Constructing the runner freezes `static_num_out` on the network's strided layers: until `release_bounds()`
+    every pass of `net` -- also an eager one outside the runner -- stays bounded and padded with dead rows.
     """
 
     def __init__(self, net: torch.nn.Module, max_voxels: int, in_channels: int,
@@ -177,6 +181,12 @@ class StaticInference:
         {layer: outputs found}.  Empty = every live row is exact."""
         return {k: c for k, (c, ovf) in self.counts().items() if c > self.bounds[k] or ovf}
 
+    def release_bounds(self) -> None:
+        """Clears the frozen bounds of the network's strided layers (eager passes are unbounded again; the
+        captured graph keeps working, its shapes are baked in)."""
+        for m in self._layers.values():
+            m.static_num_out = 0
+
 
 class StaticTrainingStep:
     """One captured TRAINING step -- rulebook builds, forward, loss, backward -- for scenes of at most
@@ -190,8 +200,10 @@ class StaticTrainingStep:
 
     `backward(out)` runs inside the capture and must be free of host reads; `out.n_live_dev` is the device-side
     number of live output rows for a masked loss.  `input_grad=True` keeps the gradient of the input features
-    (`step.features.grad`).  `example=(features, indices)`: the scene the warm-up and capture passes run on --
-    they are real training-mode passes (BatchNorm running estimates move); without it they see an empty scene."""
+    (`step.features.grad`).  `example=(features, indices)`: the scene the warm-up passes run on (an empty scene
+    without it).  The warm-up passes are real training-mode passes; the buffers they would move -- BatchNorm
+    running estimates and batch counters, recorded voxel counts -- are put back before the capture, so building
+    a runner leaves a (pretrained) model's state as it found it."""
 
     def __init__(self, net: torch.nn.Module, max_voxels: int, in_channels: int, spatial_shape: Sequence[int],
                  batch_size: int, dtype: torch.dtype = torch.float16, bounds: Optional[Dict[str, int]] = None,
@@ -221,8 +233,13 @@ class StaticTrainingStep:
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):
+                saved = [(b, b.detach().clone()) for b in net.buffers()]
                 for _ in range(max(warmup, 1)):
                     self._compute()
+                with torch.no_grad():
+                    for b, v in saved:              # in place: the kernels hold these tensors' addresses
+                        b.copy_(v)
+                del saved
             torch.cuda.current_stream(self.device).wait_stream(side)
             torch.cuda.synchronize(self.device)
             self.graph = torch.cuda.CUDAGraph()
@@ -261,8 +278,4 @@ class StaticTrainingStep:
 
     counts = StaticInference.counts
     overflowed = StaticInference.overflowed
-
-    def release_bounds(self) -> None:
-        """Clears the frozen bounds of the network's strided layers (eager passes are unbounded again)."""
-        for m in self._layers.values():
-            m.static_num_out = 0
+    release_bounds = StaticInference.release_bounds

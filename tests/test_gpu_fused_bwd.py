@@ -98,6 +98,8 @@ def test_cfg2_full_size_fused_bwd_vs_oracle(cuda, dtype):
     shape = [40, 1280, 1600]
     idx = scene(shape, 100_000, 1, 0)
     rb, (f, w, dout), got = _fused_subm(cuda, idx, shape, 64, 64, dtype, seed=0)
+    # what net(x) cached is what bench.py times: the rows layout built inside the rulebook build, regrouped here
+    assert rb.layout is not None and int(rb.layout[0].item()) == 1 and rb.argsort_fwd is None
     ref = oracle_rulebook(idx, 1, shape, K3, ONE, ONE, ONE, True)
     assert_rulebook_equal(rb, ref, True)
     out_ref = oracle.indice_conv(f, w, ref["pair"], ref["num"], ref["n_out"], subm=True)
@@ -111,6 +113,7 @@ def test_cfg2b_lidar_fixture_fused_bwd_vs_oracle(cuda, dtype):
     from golden import lidar_scene
     idx, shape = lidar_scene()
     rb, (f, w, dout), got = _fused_subm(cuda, idx, shape, 64, 64, dtype, seed=1)
+    assert rb.layout is not None and int(rb.layout[0].item()) == 0         # dense: identity order
     ref = oracle_rulebook(idx, 1, shape, K3, ONE, ONE, ONE, True)
     assert_rulebook_equal(rb, ref, True)
     assert int(idx.shape[0] + 2 * ref["num"][:13].sum()) == 788_888

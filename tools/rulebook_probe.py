@@ -14,14 +14,11 @@ from spconv_amd.pytorch import ops  # noqa: E402
 
 def main():
     dev = torch.device("cuda:0")
-    ops._TILE_MODE = "1"
     for kind in ("uniform", "fixture"):
         idx, shape = bench.make_scene(kind, 100_000, 0)
         ind = torch.from_numpy(idx).to(dev)
         for it in range(12):
-            rb = ops.build_rulebook(ind, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True)[0]
-            if kind == "fixture" and it % 3 == 0:
-                ops.tile_plan(rb, "fwd")
+            ops.build_rulebook(ind, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True, do_sort="layout")
         torch.cuda.synchronize()
 
 

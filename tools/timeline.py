@@ -25,8 +25,7 @@ from spconv_amd.utils import synthetic  # noqa: E402
 def main():
     scene = sys.argv[1] if len(sys.argv) > 1 else "uniform"
     centre = len(sys.argv) > 2 and sys.argv[2] == "centre"
-    sp = len(sys.argv) > 2 and sys.argv[2] == "sp"          # igemm_sp_kernel (SPX_GEMM_V = 6): one wave per 32 rows
-    srt = len(sys.argv) > 2 and sys.argv[2] in ("sort", "i8sort")   # mask-sorted rows, tables in tile order
+    srt = len(sys.argv) > 2 and sys.argv[2] in ("sort", "i8sort") and "layout"   # the modules' default rows layout
     i8 = len(sys.argv) > 2 and sys.argv[2] in ("i8", "i8sort")      # BASELINE config 5: int8, C = K = 128, 200 k voxels
     dev = torch.device("cuda:0")
     n, C = (200000, 128) if (len(sys.argv) > 2 and sys.argv[2] in ("i8", "i8sort")) else (100000, 64)
@@ -38,7 +37,7 @@ def main():
     w = (torch.rand(C, 3, 3, 3, C, device=dev) * 2 - 1).half()
     rb, _ = ops.build_rulebook(idx, 1, SHAPE, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True, do_sort=srt)
     mask = torch.full_like(rb.mask_fwd, 1 << 13) if centre else rb.mask_fwd
-    pair, order, to = rb.pair_fwd, None, False
+    pair, order, to = rb.pair_fwd, None, 0
     if srt:
         pair, mask, order, to = ops.tables_of(rb, "fwd", C)
     if i8:
@@ -47,11 +46,9 @@ def main():
         sc = torch.rand(C, device=dev) * 1e-2
         bi = torch.rand(C, device=dev)
     L = _lib.load()
-    getter = L.spx_debug_timeline_sp if sp else L.spx_debug_timeline
+    getter = L.spx_debug_timeline
     getter.restype = ctypes.c_int
     getter.argtypes = [ctypes.c_void_p]
-    if sp:
-        _lib.check(L.spx_set_option(b"SPX_GEMM_V", 6))
     for _ in range(20):
         (ops.igemm_fwd_int8(f, w, pair, mask, order, n, 13, sc, bi, None, 0.0, torch.int8, ops.Activation.ReLU, 0.0,
                             tile_order=to) if i8 else ops.igemm_fwd(f, w, pair, mask, order, n, 13, tile_order=to))
@@ -61,7 +58,7 @@ def main():
     buf = np.zeros((8192, 8), dtype=np.uint64)
     _lib.check(getter(buf.ctypes.data))
     mb = int(os.environ.get("SPX_GEMM_MB", "2"))
-    ntiles = min(8192, (n + 31) // 32) if sp else (n + 64 * mb - 1) // (64 * mb)
+    ntiles = (n + 64 * mb - 1) // (64 * mb)
     if i8:
         ntiles = (n + 127) // 128
     t = buf[:ntiles].astype(np.int64)
