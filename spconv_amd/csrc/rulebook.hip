@@ -36,7 +36,14 @@ struct Table {
   uint32_t mask;   // capacity - 1 (capacity is a power of two)
   int packed;      // 1 when every key fits 32 bits
   int gbits;       // low key bits that pick the slot inside a group of 2^gbits slots (see hash_key)
+  uint32_t max_probe;  // longest probe walk (slots - 1).  A table sized for the guaranteed bound is never more than
+                       // half full and walks a handful of slots; a table sized for the outputs EXPECTED
+                       // (table_shrink: static bound / last ratio) can fill up, and without a cap every insert and
+                       // lookup of a key that no longer fits would walk all of it -- O(capacity) per candidate.
+                       // Inserts and lookups share the cap, so a key that went in is found; one that did not fit
+                       // raises the overflow flag of its pass (the count's read-back / the static form's counter).
 };
+constexpr uint32_t kMaxProbeShrunk = 2047;
 
 constexpr unsigned long long kEmptySlot = ~0ull;
 
@@ -83,7 +90,7 @@ __device__ __forceinline__ int table_insert_min(const Table &t, hkey_t key, int3
     const unsigned long long want =
         (static_cast<unsigned long long>(k32) << 32) | static_cast<uint32_t>(val);
     uint32_t slot = hash_key32(k32, t.gbits) & t.mask;
-    for (uint32_t probe = 0; probe <= t.mask; ++probe) {  // bounded: the table is never full
+    for (uint32_t probe = 0; probe <= t.max_probe; ++probe) {  // bounded: the table is never full (or capped)
       // look before the atomic: a slot only ever goes empty -> key, and its value only decreases, so a
       // (possibly stale) plain read that shows our key with a value <= ours, or another key, is final --
       // several inputs reach the same output on dense scenes, and all but the winner leave here
@@ -102,7 +109,7 @@ __device__ __forceinline__ int table_insert_min(const Table &t, hkey_t key, int3
     return -1;
   }
   uint32_t slot = hash_key(key, t.gbits) & t.mask;
-  for (uint32_t probe = 0; probe <= t.mask; ++probe) {
+  for (uint32_t probe = 0; probe <= t.max_probe; ++probe) {
     unsigned long long prev = LOOK ? static_cast<unsigned long long>(t.keys[slot])     // (as above)
                                    : static_cast<unsigned long long>(-1LL);
     if (prev == static_cast<unsigned long long>(-1LL))
@@ -126,7 +133,7 @@ __device__ __forceinline__ int32_t table_find(const Table &t, hkey_t key) {
     const unsigned long long *slots = reinterpret_cast<const unsigned long long *>(t.keys);
     const uint32_t k32 = static_cast<uint32_t>(key);
     uint32_t slot = hash_key32(k32, t.gbits) & t.mask;
-    for (uint32_t probe = 0; probe <= t.mask; ++probe) {
+    for (uint32_t probe = 0; probe <= t.max_probe; ++probe) {
       const unsigned long long v = slots[slot];
       if (static_cast<uint32_t>(v >> 32) == k32 && v != kEmptySlot) return static_cast<int32_t>(v);
       if (v == kEmptySlot) return -1;
@@ -135,7 +142,7 @@ __device__ __forceinline__ int32_t table_find(const Table &t, hkey_t key) {
     return -1;
   }
   uint32_t slot = hash_key(key, t.gbits) & t.mask;
-  for (uint32_t probe = 0; probe <= t.mask; ++probe) {
+  for (uint32_t probe = 0; probe <= t.max_probe; ++probe) {
     const hkey_t k = t.keys[slot];
     if (k == key) return t.vals[slot];
     if (k == -1LL) return -1;
@@ -549,124 +556,6 @@ subm_center_list_kernel(int32_t *__restrict__ native, int kv, int n) {
   native[static_cast<size_t>(kv) * n + c] = i;
 }
 
-// ------------------------------------------------ SubM, second generation
-// One thread per voxel.  The thread issues the probes of a whole chunk of offsets before it looks
-// at any of them (independent 8-byte loads in flight together) and OWNS column o of every table:
-// each entry -- hit or -1 -- is written exactly once, coalesced along the voxel axis.  Compared
-// with subm_probe3_kernel this needs no -1 pre-fill of the tables (34 MB at 100 k voxels), no
-// scattered mirror stores, no atomicOr on the masks and no slot_of round trip; it probes all kv
-// offsets of a voxel instead of kv/2, which costs less than what it removes.  The per-block hit
-// counts of the offsets above the centre (= the lengths of the ConvAlgo.Native lists, see
-// subm_lists_kernel) fall out of the same pass.
-constexpr int kProbeChunk = 9;
-
-// linear-probe walk of a packed table starting from an already loaded first slot word
-__device__ __forceinline__ int32_t packed_resolve(const unsigned long long *slots, uint32_t tmask,
-                                                  uint32_t key32, uint32_t slot,
-                                                  unsigned long long v, int gbits = 0) {
-  for (uint32_t probe = 0; probe <= tmask; ++probe) {
-    if (v == kEmptySlot) return -1;
-    if (static_cast<uint32_t>(v >> 32) == key32) return static_cast<int32_t>(v);
-    slot = (slot + (1u << gbits)) & tmask;
-    v = slots[slot];
-  }
-  return -1;
-}
-
-template <bool PACKED>
-__global__ void __launch_bounds__(kBlock)
-subm_probe_all_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table t,
-                      int32_t *__restrict__ pair_fwd, int32_t *__restrict__ pair_bwd,
-                      uint32_t *__restrict__ mask, int words, int32_t *__restrict__ blockcount,
-                      int nblk) {
-  __shared__ int lds_cnt[64];                 // hits of offset centre+1+j in this block (kv <= 128)
-  const int o = blockIdx.x * kBlock + threadIdx.x;
-  const int kv = g.kv, center = kv / 2;
-  if (threadIdx.x < 64) lds_cnt[threadIdx.x] = 0;
-  __syncthreads();
-  const bool live = o < n;
-  int b = -1, c[4] = {0, 0, 0, 0};
-  if (live) read_row(indices, o, g.ndim, b, c);
-  const bool hashed = live && b >= 0 && b < g.batch && in_range(c, g.in_dims);
-  const unsigned long long *slots = reinterpret_cast<const unsigned long long *>(t.keys);
-  // the first row of this coordinate (duplicates: the smallest index won the slot); its first
-  // slot word travels with the first chunk's loads
-  const hkey_t own_key = layout_key(b, c, g.in_dims);
-  const uint32_t own_slot = hash_key32(static_cast<uint32_t>(own_key), t.gbits) & t.mask;
-  unsigned long long own_word = kEmptySlot;
-  if (PACKED && hashed) own_word = slots[own_slot];
-  bool first = false;
-  uint32_t mword = 0;
-  int r[4] = {0, 0, 0, 0};                    // offset odometer (ConvOutLocIter::operator++)
-  for (int k0 = 0; k0 < kv; k0 += kProbeChunk) {
-    uint32_t key32[kProbeChunk], slot0[kProbeChunk];
-    unsigned long long word[kProbeChunk];
-    bool act[kProbeChunk];
-    hkey_t wide[PACKED ? 1 : kProbeChunk];
-#pragma unroll
-    for (int j = 0; j < kProbeChunk; ++j) {
-      const int k = k0 + j;
-      int q[4];
-#pragma unroll
-      for (int d = 0; d < 4; ++d) q[d] = c[d] - g.padding[d] + r[d] * g.dilation[d];
-      act[j] = hashed && k < kv && k != center && in_range(q, g.in_dims);
-      const hkey_t wkey = layout_key(b, q, g.in_dims);
-      if (!PACKED) wide[j] = wkey;
-      key32[j] = static_cast<uint32_t>(wkey);
-      slot0[j] = hash_key32(key32[j], t.gbits) & t.mask;
-      word[j] = kEmptySlot;
-      if (PACKED && act[j]) word[j] = slots[slot0[j]];
-      if (++r[3] >= g.ksize[3]) {             // ++r with carry, last dimension fastest
-        r[3] = 0;
-        if (++r[2] >= g.ksize[2]) {
-          r[2] = 0;
-          if (++r[1] >= g.ksize[1]) {
-            r[1] = 0;
-            ++r[0];
-          }
-        }
-      }
-    }
-    if (k0 == 0) {
-      int own = -1;
-      if (hashed) own = PACKED ? packed_resolve(slots, t.mask, static_cast<uint32_t>(own_key), own_slot, own_word, t.gbits)
-                                 : table_find(t, own_key);
-      first = own == o;
-    }
-#pragma unroll
-    for (int j = 0; j < kProbeChunk; ++j) {
-      const int k = k0 + j;
-      const bool kin = k < kv;               // (no break: the loop must unroll, the arrays are registers)
-      int res = -1;
-      if (k == center) {
-        res = live ? o : -1;
-      } else if (act[j] && (first || k > center)) {
-        // a row that is not the first of its coordinate keeps only its k > centre half
-        // (unordered_map::insert kept the first one, indices.py:1672: lookups never return it)
-        res = PACKED ? packed_resolve(slots, t.mask, key32[j], slot0[j], word[j], t.gbits) : table_find(t, wide[PACKED ? 0 : j]);
-      }
-      if (live && kin) {
-        pair_fwd[static_cast<size_t>(k) * n + o] = res;
-        if (pair_bwd) pair_bwd[static_cast<size_t>(kv - 1 - k) * n + o] = res;
-      }
-      if (res >= 0) mword |= 1u << (k & 31);
-      if (live && kin && ((k & 31) == 31 || k == kv - 1)) {
-        mask[static_cast<size_t>(o) * words + (k >> 5)] = mword;
-        mword = 0;
-      }
-      if (blockcount && kin && k > center) {
-        const unsigned long long bal = __ballot(res >= 0);
-        if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&lds_cnt[k - center - 1], __popcll(bal));
-      }
-    }
-  }
-  if (blockcount) {
-    __syncthreads();
-    // list L (< kv/2) is read off row kv-1-L of the table: offset centre+1+j <-> list kv/2-1-j
-    if (threadIdx.x < kv / 2)
-      blockcount[static_cast<size_t>(kv / 2 - 1 - threadIdx.x) * nblk + blockIdx.x] = lds_cnt[threadIdx.x];
-  }
-}
 
 // ConvAlgo.Native lists of a SubM rulebook from the finished table, in the CPU loop's order
 // (ascending input row inside a list, indices.py:1685-1696): blockIdx.y = list L < kv/2 (and its
@@ -1359,12 +1248,14 @@ void table_place(Table &t, hkey_t *keys, int32_t *vals, uint32_t cap, bool packe
   t.mask = cap - 1;
   t.packed = packed ? 1 : 0;
   t.gbits = gbits;
+  t.max_probe = t.mask;
 }
 
 // The same storage as a smaller table (capacity a power of two below the placed one).
 void table_shrink(Table &t, uint32_t cap) {
   if (!t.packed) t.vals = reinterpret_cast<int32_t *>(t.keys + cap);
   t.mask = cap - 1;
+  t.max_probe = t.mask < kMaxProbeShrunk ? t.mask : kMaxProbeShrunk;
 }
 
 // The table's bytes as a 0xFF range of a FillList (see table_clear).
@@ -2036,12 +1927,11 @@ int spx_subm_rulebook(const int32_t *indices, int n, int ndim, int batch_size,
   const int nblk256 = div_up(n, kBlock);
   int32_t *groupcount = cv.take<int32_t>(static_cast<size_t>(kv / 2 + 1) * nblk256);
   const dim3 grid(div_up(n, kBlock));
-  static const int version = env_int("SPX_SUBM_V", 3);          // tuning knob (A/B runs)
   // second generation: 4 launches (table fill, insert, probe, lists), no table pre-fills; beyond
   // ~4 M voxels the lists kernel's in-block prefix over the group counts would dominate
   // third form: fills (table, lower half of pair_fwd [+ pair_bwd's upper half]) -> insert (+ mask
   // clear) -> probe4 (block-local list counts) -> lists: 4 launches, 11 MB of fills instead of 34
-  if (version >= 3 && kv > 1 && kv <= 128 && nblk256 <= 16384) {
+  if (kv > 1 && kv <= 128 && nblk256 <= 16384) {
     FillList fills;
     table_fill(fills, t);
     {
@@ -2071,31 +1961,6 @@ int spx_subm_rulebook(const int32_t *indices, int n, int ndim, int batch_size,
     SPX_LAUNCH_CHECK();
     return 0;
   }
-  const bool gen2 = version == 2 && kv <= 128 && nblk256 <= 16384;
-  if (gen2) {
-    blockcount = groupcount;
-    FillList fills;
-    table_fill(fills, t);
-    SPX_HIP(fills.launch(s));
-    hipLaunchKernelGGL(subm_insert_kernel, grid, dim3(kBlock), 0, s, indices, n, g, t,
-                       static_cast<int32_t *>(nullptr));
-    const bool lists = pair_native || num_per_loc;
-    if (t.packed)
-      hipLaunchKernelGGL(subm_probe_all_kernel<true>, grid, dim3(kBlock), 0, s, indices, n, g, t, pair_fwd,
-                         pair_bwd, mask, words, (lists && kv > 1) ? blockcount : nullptr, nblk256);
-    else
-      hipLaunchKernelGGL(subm_probe_all_kernel<false>, grid, dim3(kBlock), 0, s, indices, n, g, t, pair_fwd,
-                         pair_bwd, mask, words, (lists && kv > 1) ? blockcount : nullptr, nblk256);
-    if (lists) {
-      SPX_CHECK(!pair_native || num_per_loc || kv / 2 <= 64, "num_per_loc required for kv > 128");
-      hipLaunchKernelGGL(subm_lists_kernel, dim3(nblk, kv / 2 + 1), dim3(kBlock), 0, s, pair_fwd, kv, n,
-                         nblk256, blockcount, pair_native, num_per_loc ? num_per_loc : scratch_totals,
-                         num_per_loc ? kv : 0);
-    }
-    SPX_LAUNCH_CHECK();
-    return 0;
-  }
-
   // every fill of this build in one launch: hash table, masks, counts, -1 tables (callers that
   // carve the tables out of one buffer get one contiguous range)
   FillList fills;

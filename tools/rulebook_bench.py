@@ -36,11 +36,17 @@ def main():
         N = ind.shape[0]
         row = dict(scene=kind, batch=bs, voxels=N)
 
-        def subm(native):
+        def subm(native, sort=False):
             return lambda i: ops.build_rulebook(ind, bs, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True,
-                                                need_native=native)
+                                                need_native=native, do_sort=sort)
         row["subm_tables_us"] = round(bench.event_time_ms(subm(False), iters=40, span=4) * 1e3, 1)
         row["subm_with_lists_us"] = round(bench.event_time_ms(subm(True), iters=40, span=4) * 1e3, 1)
+        # what the layer modules build by default: + the rows layout (count -> scan -> scatter, nothing read back)
+        row["subm_tables_layout_us"] = round(bench.event_time_ms(subm(False, "layout"), iters=40, span=4) * 1e3, 1)
+        row["subm_with_lists_layout_us"] = round(bench.event_time_ms(subm(True, "layout"), iters=40, span=4) * 1e3, 1)
+        rb = subm(True, "layout")(0)[0]
+        if rb.layout is not None:
+            row["layout_class"], row["rows_with_a_neighbour"] = rb.layout[:2].cpu().tolist()
         for name, k, s, p in (() if os.environ.get("RB_ONLY_SUBM") == "1" else (("conv_k3s2", 3, 2, 1), ("conv_k2s2", 2, 2, 0))):
             rb, _ = ops.build_rulebook(ind, bs, shape, [k] * 3, [s] * 3, [p] * 3, [1] * 3, [0] * 3, False)
             cap = rb.n_out + 1024
