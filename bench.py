@@ -492,6 +492,7 @@ def run_layer(args, D: Dist):
     U = max(1, args.graph_steps)
     graph_b = None        # N > 1: a second U-step graph with its own gradient buffers (the two alternate)
     dws_a, dws_b = [], [] # the dW tensor each captured step of graph_u / graph_b writes
+    rem_graphs = {}       # r -> (graph of r < U steps, its dW tensors): the tail of a run whose length is no multiple of U
     if not args.no_graph:
         try:
             side = torch.cuda.Stream()
@@ -526,12 +527,22 @@ def run_layer(args, D: Dist):
                     with torch.cuda.graph(graph_w, capture_error_mode=CAPTURE_MODE):
                         for u in range(U):
                             compute(scenes[0])
+                # the steps of a run that do not fill a U-step replay (K mod U, W mod U) get a graph of their own
+                # length: a 20-step run is 2 x 8 + 1 x 4 steps = three launches, not 2 + four single-step replays
+                for r in sorted({args.prewarm % U, args.warmup % U, args.steps % U} - {0}):
+                    g = torch.cuda.CUDAGraph()
+                    dws = []
+                    with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
+                        for u in range(r):
+                            compute(scenes[u % S])
+                            dws.append(net.weight.grad)
+                    rem_graphs[r] = (g, dws)
             launch = "hipgraph"
         except Exception as e:  # capture unsupported -> eager launches, same work
             print(f"[bench] graph capture failed ({type(e).__name__}: {e}); using eager launches",
                   file=sys.stderr)
             graphs = graph_u = graph_w = graph_b = None
-            graph_grads = []
+            graph_grads, rem_graphs = [], {}
             torch.cuda.synchronize()
     if graph_u is None:
         U = 1
@@ -563,19 +574,21 @@ def run_layer(args, D: Dist):
 
         class _Half:
             pass
-        halves = []
-        for g, dws in ((graph_u, dws_a), (graph_b, dws_b)):
+        def _half(g, dws):
             h = _Half()
             h.graph, h.dws = g, dws
-            h.flat = torch.zeros((U, numel), dtype=dws[0].dtype, device=dev)
+            h.flat = torch.zeros((len(dws), numel), dtype=dws[0].dtype, device=dev)
             h.done, h.reduced = torch.cuda.Event(), torch.cuda.Event()
             h.pending = False
-            halves.append(h)
-        overlap = {"halves": halves, "next": 0}
+            return h
+        halves = [_half(graph_u, dws_a), _half(graph_b, dws_b)]
+        rem_halves = {r: _half(g, dws) for r, (g, dws) in rem_graphs.items()}
+        overlap = {"halves": halves, "next": 0, "rem": rem_halves}
 
-        def replay_overlapped():
-            h = overlap["halves"][overlap["next"]]
-            overlap["next"] ^= 1
+        def replay_overlapped(h=None):
+            if h is None:
+                h = overlap["halves"][overlap["next"]]
+                overlap["next"] ^= 1
             main = torch.cuda.current_stream()
             if h.pending:
                 main.wait_event(h.reduced)           # its previous bucket has been reduced: buffers are free
@@ -583,7 +596,7 @@ def run_layer(args, D: Dist):
             h.done.record(main)
             with torch.cuda.stream(side_ar):
                 side_ar.wait_event(h.done)
-                for row, d in zip(h.flat.unbind(0), h.dws):      # U small device-to-device copies into the bucket
+                for row, d in zip(h.flat.unbind(0), h.dws):      # small device-to-device copies into the bucket
                     row.copy_(d.reshape(-1))
                 if D.backend == "nccl":
                     dist.all_reduce(h.flat, op=dist.ReduceOp.AVG)
@@ -594,23 +607,30 @@ def run_layer(args, D: Dist):
             h.pending = True
 
         def drain_overlapped():
-            for h in overlap["halves"]:
+            for h in overlap["halves"] + list(overlap["rem"].values()):
                 if h.pending:
                     torch.cuda.current_stream().wait_event(h.reduced)
                     h.pending = False
 
     def run_steps(k, warm=False):
-        """Exactly k steps: whole U-step replays, then single steps."""
+        """Exactly k steps: whole U-step replays, then the tail (its own graph when one was captured for
+        that length, single steps otherwise)."""
         gu = graph_w if warm else graph_u
         if overlap is not None and not warm:
             for _ in range(k // U):
                 replay_overlapped()
-            drain_overlapped()
             k = k % U
+            if k in overlap["rem"]:
+                replay_overlapped(overlap["rem"][k])
+                k = 0
+            drain_overlapped()
         elif gu is not None:
             for _ in range(k // U):
                 gu.replay()
             k = k % U
+            if not warm and k in rem_graphs:
+                rem_graphs[k][0].replay()
+                k = 0
         for _ in range(k):
             step(warm)
 

@@ -1736,7 +1736,7 @@ namespace {
 // every position is a function of the masks alone (no order-dependent atomics).  Nothing is read back: the
 // class lands in the blob, the gather-GEMM picks its tables by it.
 constexpr int kLayBuckets = 33;       // centre-only + lowest neighbour offset 0 .. 31
-constexpr int kLayItems = 1024;       // rows per block (4 rounds of 256)
+constexpr int kLayItems = 256;        // rows per block: one round (a 100 k-row rulebook must fill 256 CUs: 391 blocks)
 constexpr int kLayGuard = 256;        // positions ahead of the regrouped rows whose table columns are written too
                                       // (the tile that holds the first regrouped row starts at most that far back)
 
