@@ -359,8 +359,10 @@ int spx_avgpool_bwd(const void *dout, void *din, const int32_t *count, const int
  *   returned by calc_point2voxel_meta_data (all.py:1349-1386)
  *   voxels [max_voxels, max_points, nfeat] fp32, indices [max_voxels, ndim] (zyx),
  *   num_per_voxel [max_voxels], pc_voxel_id [n] int64 (-1 = dropped point)
- *   empty_mean: unused slots of a voxel receive the mean of its points; clear_voxels: zero
- *   `voxels` first.  *n_voxels_h receives the number of voxels (one D->H read). */
+ *   empty_mean: 1 = unused slots of a voxel receive the mean of its points; 2 = the fill as the reference's CPU
+ *   loop BEHAVES (pointops.py:663-686: its accumulator is carried from voxel to voxel), bit-identical to that
+ *   code executed, a sequential pass (SPCONV_AMD_REFERENCE_QUIRKS=1 selects it in the Python layer);
+ *   clear_voxels: zero `voxels` first.  *n_voxels_h receives the number of voxels (one D->H read). */
 size_t spx_point2voxel_ws_bytes(int n_points, int max_voxels);
 int spx_point2voxel(const float *points, int n, int nfeat, int ndim, const float *vsize,
                     const float *coors_range, const int *grid_size, int max_voxels, int max_points,

@@ -402,6 +402,29 @@ def maxpool_bwd_ref(features: np.ndarray, out: np.ndarray, dout: np.ndarray, pai
     return din.astype(features.dtype)
 
 
+def indice_maxpool_native(features: np.ndarray, pair: np.ndarray, num_per_loc: np.ndarray, n_out: int):
+    """(out, din_fn) restating the reference's Native max pooling ON THE CPU operation for operation
+    (pytorch/ops.py:1899-1975 over maxpool.py:620-700): fp32, zero-filled output, offsets in list order, pairs in
+    list order, `in > out` replaces, and in the backward pass `in == out` adds dout -- sequential fp32 adds, so the
+    result is bit-comparable with the reference's code executed (oracle.ref.indice_maxpool*)."""
+    f = np.ascontiguousarray(features, dtype=np.float32)
+    out = np.zeros((n_out, f.shape[1]), dtype=np.float32)
+    lists = [(pair[0][k][:int(n)], pair[1][k][:int(n)]) for k, n in enumerate(np.asarray(num_per_loc).tolist()) if n > 0]
+    for ii, oi in lists:
+        for i, o in zip(ii.tolist(), oi.tolist()):
+            np.maximum(out[o], f[i], out=out[o])
+
+    def backward(dout: np.ndarray) -> np.ndarray:
+        d = np.ascontiguousarray(dout, dtype=np.float32)
+        din = np.zeros_like(f)
+        for ii, oi in lists:
+            for i, o in zip(ii.tolist(), oi.tolist()):
+                hit = f[i] == out[o]
+                din[i] = np.where(hit, din[i] + d[o], din[i])
+        return din
+    return out, backward
+
+
 def avgpool_ref(features: np.ndarray, pair: np.ndarray, num_per_loc: np.ndarray, n_out: int,
                 subm: bool = False):
     """(mean over the pairs, count) -- maxpool.py:211-260."""
@@ -416,11 +439,13 @@ def avgpool_ref(features: np.ndarray, pair: np.ndarray, num_per_loc: np.ndarray,
 
 
 def avgpool_bwd_ref(dout: np.ndarray, count: np.ndarray, pair: np.ndarray, num_per_loc: np.ndarray,
-                    n_in: int, subm: bool = False) -> np.ndarray:
-    """Gradient of the mean: din[i] += dout[o] / count[o].  (The reference kernel multiplies by
-    count, maxpool.py:262-300 -- not the derivative of its forward; see DESIGN.md.)"""
+                    n_in: int, subm: bool = False, reference_quirks: bool = False) -> np.ndarray:
+    """Gradient of the mean: din[i] += dout[o] / count[o].  reference_quirks: din[i] += dout[o] * count[o], what
+    the reference kernel computes (maxpool.py:262-300: it multiplies by the count -- not the derivative of its
+    forward; the product does the same under SPCONV_AMD_REFERENCE_QUIRKS=1)."""
     din = np.zeros((n_in, dout.shape[1]), dtype=np.float64)
-    inv = np.where(count > 0, 1.0 / np.maximum(count, 1), 0.0)
+    inv = (count.astype(np.float64) if reference_quirks
+           else np.where(count > 0, 1.0 / np.maximum(count, 1), 0.0))
     for i_inds, o_inds in _pool_lists(pair, num_per_loc, subm, n_in):
         np.add.at(din, i_inds, dout[o_inds].astype(np.float64) * inv[o_inds][:, None])
     return din.astype(dout.dtype)
@@ -429,8 +454,10 @@ def avgpool_bwd_ref(dout: np.ndarray, count: np.ndarray, pair: np.ndarray, num_p
 # --------------------------------------------------------------------------
 # voxeliser (spconv/pytorch/utils.py:23-160 over csrc/sparse/pointops.py Point2VoxelCPU)
 def point2voxel(points: np.ndarray, vsize_zyx, coors_range_zyx, grid_size_zyx, max_voxels: int,
-                max_points: int, empty_mean: bool = False):
-    """-> (voxels [V, max_points, F], indices [V, ndim] zyx, num_per_voxel [V], pc_voxel_id [N])."""
+                max_points: int, empty_mean: bool = False, reference_quirks: bool = False):
+    """-> (voxels [V, max_points, F], indices [V, ndim] zyx, num_per_voxel [V], pc_voxel_id [N]).
+    reference_quirks: the mean fill exactly as the reference's CPU loop behaves (its accumulator is carried from
+    voxel to voxel, pointops.py:663-686) instead of the arithmetic mean."""
     L = lib()
     L.orc_point2voxel.restype = ctypes.c_int
     pts = np.ascontiguousarray(points, dtype=np.float32)
@@ -443,7 +470,7 @@ def point2voxel(points: np.ndarray, vsize_zyx, coors_range_zyx, grid_size_zyx, m
     fl = lambda v: (ctypes.c_float * len(v))(*[float(x) for x in v])
     nv = L.orc_point2voxel(pts.ctypes.data_as(ctypes.c_void_p), n, nfeat, ndim, fl(vsize_zyx),
                            fl(coors_range_zyx), _ints(grid_size_zyx), int(max_voxels), int(max_points),
-                           int(empty_mean), voxels.ctypes.data_as(ctypes.c_void_p),
+                           (2 if reference_quirks else 1) if empty_mean else 0, voxels.ctypes.data_as(ctypes.c_void_p),
                            indices.ctypes.data_as(ctypes.c_void_p), num.ctypes.data_as(ctypes.c_void_p),
                            pid.ctypes.data_as(ctypes.c_void_p))
     return voxels[:nv], indices[:nv], num[:nv], pid

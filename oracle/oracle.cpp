@@ -33,6 +33,7 @@
 #endif
 #include <limits>
 #include <unordered_map>
+#include <vector>
 
 namespace {
 
@@ -326,8 +327,9 @@ void orc_scatter_add_f32_omp(float *out, const float *in, const int32_t *inds,
 
 // Point2VoxelCPU::point_to_voxel (spconv/csrc/sparse/pointops.py, lines 97-196 of the class;
 // zyx = true): sequential, first-seen voxel numbering, first max_points points per voxel.
-// mean fill: the arithmetic mean of the voxel's points (the reference's accumulator is not
-// reset between voxels -- `mean_value.clear()` keeps the old contents -- which is not restated).
+// mean fill: empty_mean = 1 the arithmetic mean of the voxel's points (what the reference's loop means to do and
+// the product's default), empty_mean = 2 the loop as it behaves (accumulator carried from voxel to voxel, below).
+// Both forms are checked against the reference's own code, executed (oracle/_ref, tests/golden/p2v_ref.npz).
 extern "C" int orc_point2voxel(const float *points, int n, int nfeat, int ndim, const float *vsize,
                                const float *coors_range, const int *grid_size, int max_voxels,
                                int max_points, int empty_mean, float *voxels, int32_t *indices,
@@ -373,7 +375,22 @@ extern "C" int orc_point2voxel(const float *points, int n, int nfeat, int ndim, 
       num_per_voxel[voxelidx] += 1;
     }
   }
-  if (empty_mean) {
+  if (empty_mean == 2) {
+    // the reference's loop AS IT BEHAVES (pointops.py:663-686): `mean_value.clear()` does not zero the
+    // accumulator (it only resets the vector's size; the elements keep their values and operator[] does not
+    // check bounds), so voxel v starts from the MEAN of voxel v - 1: mean_v = (mean_{v-1} + sum_j x_j) / num_v,
+    // accumulated point by point in fp32.  Opt-in (SPCONV_AMD_REFERENCE_QUIRKS=1 in the product).
+    std::vector<float> carry(nfeat, 0.f);
+    for (int v = 0; v < voxel_num; ++v) {
+      const int num = num_per_voxel[v];
+      if (num <= 0) continue;
+      for (int j = 0; j < num; ++j)
+        for (int k = 0; k < nfeat; ++k) carry[k] += voxels[(static_cast<size_t>(v) * max_points + j) * nfeat + k];
+      for (int k = 0; k < nfeat; ++k) carry[k] /= num;
+      for (int j = num; j < max_points; ++j)
+        for (int k = 0; k < nfeat; ++k) voxels[(static_cast<size_t>(v) * max_points + j) * nfeat + k] = carry[k];
+    }
+  } else if (empty_mean) {
     for (int v = 0; v < voxel_num; ++v) {
       const int num = num_per_voxel[v];
       if (num <= 0) continue;

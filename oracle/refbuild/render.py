@@ -70,6 +70,8 @@ class FunctionCode:
 def _mark(kind):
     def deco(*dargs, **dkw):
         def wrap(fn, meta=dkw):
+            if kind == "pybind" and getattr(fn, "_pccm", None) is not None:
+                return fn                      # a binding annotation on top of static / member: keep the inner kind
             fn._pccm = dict(kind=kind, **meta)
             return fn
         if len(dargs) == 1 and callable(dargs[0]) and not dkw:      # bare @decorator
@@ -127,6 +129,10 @@ pccm.cuda.static_function = _mark("cuda_static")
 pccm.cuda.member_function = _mark("cuda_member")
 pccm.pybind = types.ModuleType("pccm.pybind")
 pccm.pybind.mark = _mark("pybind")
+pccm.pybind.mark_prop_getter = _mark("pybind")
+pccm.pybind.mark_prop_setter = _mark("pybind")
+pccm.pybind.PybindClassMixin = type("PybindClassMixin", (), {"add_pybind_member": lambda self, *a, **k: None})
+pccm.boolean = lambda v: "true" if v else "false"
 
 
 # ----------------------------------------------------------------- stand-in `cumm` names
@@ -145,6 +151,7 @@ dtypes = types.ModuleType("cumm.dtypes")
 dtypes.DType = DType
 dtypes.int32 = DType("int32_t")
 dtypes.int64 = DType("int64_t")
+dtypes.float32 = DType("float")
 
 
 class TensorGeneric(Class):
@@ -187,8 +194,15 @@ def _install():
     mods["cumm.gemm.core.metaarray"].seq = lambda *a: list(a)
     mods["cumm.gemm.layout"].TensorGeneric = TensorGeneric
     mods["cumm.gemm.layout"].to_stride = lambda s: s
-    for n in ("TensorView", "TensorViewHashKernel", "TensorViewKernel", "ThrustLib", "GemmDTypes"):
+    for n in ("TensorView", "TensorViewHashKernel", "TensorViewKernel", "ThrustLib", "GemmDTypes", "GemmBasic"):
         setattr(mods["cumm.common"], n, type(n, (Class,), {}))
+    # maxpool.py's imports (its GPU classes are defined at import and never called here)
+    for name in ("cumm.gemm.mask_iters", "cumm.gemm.thread_map", "spconv.csrc.utils", "spconv.csrc.utils.launch"):
+        mods[name] = types.ModuleType(name)
+    mods["cumm.gemm.mask_iters"].MaskTileIterator = type("MaskTileIterator", (Class,), {})
+    mods["cumm.gemm.mask_iters"].MaskTileIteratorParams = type("MaskTileIteratorParams", (Class,), {})
+    mods["cumm.gemm"].thread_map = mods["cumm.gemm.thread_map"]
+    mods["spconv.csrc.utils.launch"].LaunchUtils = type("LaunchUtils", (Class,), {})
     co = mods["cumm.gemm.codeops"]
     co.dispatch_ints = _dispatch_ints
     co.unpack = lambda name, rng, left="[", right="]": ", ".join(f"{name}{left}{i}{right}" for i in rng)
@@ -201,6 +215,8 @@ def _install():
     for name in ("spconv", "spconv.csrc", "spconv.csrc.sparse", "spconv.csrc.sparse.cpu_core"):
         mods[name] = types.ModuleType(name)
     mods["spconv.csrc.sparse.cpu_core"].OMPLib = type("OMPLib", (Class,), {})
+    for name in ("spconv", "spconv.csrc", "spconv.csrc.sparse", "spconv.csrc.utils"):
+        mods[name].__path__ = []          # packages: `from ..utils.launch import LaunchUtils` (maxpool.py:29)
     sys.modules.update(mods)
 
 
@@ -221,6 +237,35 @@ def load_reference_gather():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod, path
+
+
+def load_reference_module(fname: str, modname: str):
+    """spconv/csrc/sparse/<fname> loaded FROM WHERE IT LIES under the package name it has in the reference
+    (its relative imports then resolve against the stand-in packages)."""
+    _install()
+    path = os.path.join(REF, "spconv", "csrc", "sparse", fname)
+    spec = importlib.util.spec_from_file_location(modname, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[modname] = mod
+    spec.loader.exec_module(mod)
+    return mod, path
+
+
+def emit_static_functions(obj, namespace: str, names):
+    """The named static functions of a generator class, bodies verbatim, inside `namespace`."""
+    out = [f"namespace {namespace} {{"]
+    seen = []
+    for pyname, meta, fn in obj.functions():
+        if meta["kind"] != "static" or pyname not in names:
+            continue
+        code = fn(obj)
+        out.append(f"{code.ret_type} {_signature(pyname, code)} {{")
+        out += code.blocks
+        out.append("}")
+        seen.append(pyname)
+    assert sorted(seen) == sorted(names), (seen, names)
+    out.append(f"}}  // namespace {namespace}")
+    return "\n".join(out)
 
 
 def emit_gather_class(obj):
@@ -343,6 +388,57 @@ extern "C" int ref_scatter_add(float *out, float *in, int32_t *inds, int nhot, i
 '''
 
 
+C_API_8F = r'''
+// ---- extern "C" entry points of the section-8f code (NOT reference text) ----
+// Point2VoxelCPU::point_to_voxel[_empty_mean]_static on fp32 points, 3-d, zyx index order.  Buffers as the class
+// constructor prepares them (pointops.py:568-578): voxels / indices / num_per_voxel zeroed [max_voxels, ...],
+// densehashdata = the grid filled with -1.  Returns the number of voxels.
+extern "C" int ref_point2voxel(float *points, int n, int nfeat, float *voxels, int32_t *indices,
+                               int32_t *num_per_voxel, int32_t *densehash, int64_t *points_voxel_id,
+                               const float *vsize, const int *grid_size, const int *grid_stride,
+                               const float *coors_range, int max_voxels, int max_points, int empty_mean) {
+  tv::Tensor pts = tv::from_blob(points, {n, nfeat});
+  tv::Tensor vox = tv::from_blob(voxels, {max_voxels, max_points, nfeat});
+  tv::Tensor ind = tv::from_blob(indices, {max_voxels, 3});
+  tv::Tensor num = tv::from_blob(num_per_voxel, {max_voxels});
+  tv::Tensor grid = tv::from_blob(densehash, {grid_size[0], grid_size[1], grid_size[2]});
+  tv::Tensor pid = tv::from_blob(points_voxel_id, {n}, 8);
+  std::array<float, 3> vs{vsize[0], vsize[1], vsize[2]};
+  std::array<int, 3> gs{grid_size[0], grid_size[1], grid_size[2]}, gst{grid_stride[0], grid_stride[1], grid_stride[2]};
+  std::array<float, 6> cr{coors_range[0], coors_range[1], coors_range[2], coors_range[3], coors_range[4], coors_range[5]};
+  try {
+    auto res = empty_mean ? refp2v3::point_to_voxel_empty_mean_static(pts, vox, ind, num, grid, pid, vs, gs, gst, cr, true)
+                          : refp2v3::point_to_voxel_static(pts, vox, ind, num, grid, pid, vs, gs, gst, cr, true);
+    return static_cast<int>(std::get<0>(res).dim(0));
+  } catch (const std::exception &e) {
+    std::fprintf(stderr, "reference code raised: %s\n", e.what());
+    return -2;
+  }
+}
+
+// IndiceMaxPoolCPU::forward / backward (maxpool.py:620-700) on fp32 rows: ONE kernel offset's pair list
+extern "C" int ref_maxpool_fwd(float *out, float *in, int32_t *out_inds, int32_t *in_inds, int nhot, int n_out,
+                               int n_in, int channel) {
+  refpool::forward(tv::from_blob(out, {n_out, channel}), tv::from_blob(in, {n_in, channel}),
+                   tv::from_blob(out_inds, {nhot}), tv::from_blob(in_inds, {nhot}));
+  return 0;
+}
+extern "C" int ref_maxpool_bwd(float *out, float *in, float *dout, float *din, int32_t *out_inds, int32_t *in_inds,
+                               int nhot, int n_out, int n_in, int channel) {
+  refpool::backward(tv::from_blob(out, {n_out, channel}), tv::from_blob(in, {n_in, channel}),
+                    tv::from_blob(dout, {n_out, channel}), tv::from_blob(din, {n_in, channel}),
+                    tv::from_blob(out_inds, {nhot}), tv::from_blob(in_inds, {nhot}));
+  return 0;
+}
+extern "C" int ref_global_pool_rearrange(int32_t *out_indices, int32_t *coords, int32_t *counts, int nhot, int ncol,
+                                         int batch) {
+  refpool::global_pool_rearrange(tv::from_blob(out_indices, {batch, nhot}), tv::from_blob(coords, {nhot, ncol}),
+                                 tv::from_blob(counts, {batch}));
+  return 0;
+}
+'''
+
+
 def main():
     mod, path = load_reference_indices()
     os.makedirs(OUT_DIR, exist_ok=True)
@@ -357,7 +453,18 @@ def main():
     gmod, gpath = load_reference_gather()
     parts.append("// ---- from " + gpath)
     parts.append(emit_gather_class(gmod.GatherCPU()))
+    # the CPU voxeliser (pointops.py:493-766) and the CPU max-pool loops
+    # (maxpool.py:590-703), rendered the same way
+    pmod, ppath = load_reference_module("pointops.py", "spconv.csrc.sparse.pointops")
+    parts.append("// ---- from " + ppath)
+    parts.append(emit_static_functions(pmod.Point2VoxelCPU(dtypes.float32, 3, True), "refp2v3",
+                                       ["point_to_voxel_static", "point_to_voxel_empty_mean_static"]))
+    mmod, mpath = load_reference_module("maxpool.py", "spconv.csrc.sparse.maxpool")
+    parts.append("// ---- from " + mpath)
+    parts.append(emit_static_functions(mmod.IndiceMaxPoolCPU(), "refpool",
+                                       ["forward", "backward", "global_pool_rearrange"]))
     parts.append(C_API)
+    parts.append(C_API_8F)
     out = os.path.join(OUT_DIR, "ref_indices.cpp")
     with open(out, "w") as f:
         f.write("\n".join(parts))

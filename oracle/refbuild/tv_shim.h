@@ -6,7 +6,8 @@
 // /root/reference, so its headers cannot be compiled from where they lie.  The few types below are
 // restated from their documented behaviour -- all of it plain row-major index arithmetic:
 //   tv::array<T, N>                 fixed-size array with element-wise helpers (`op<prod>`)
-//   tv::Tensor                      a non-owning view: data pointer + shape (`dim`, `data_ptr<T>`)
+//   tv::Tensor                      a non-owning view: data pointer + shape (`dim`, `stride`, `data_ptr<T>`, `zero_`,
+//                                   `slice_first_axis`, `tview<T, N>()` = row-major element accessor)
 //   ConvProblem<ND>                 the convolution geometry record (cumm/conv/params.py)
 //   TensorGeneric<ND, Index>        row-major layout: operator() = sum idx[i] * stride[i],
 //                                   inverse() = successive div/mod (cumm/gemm/layout.py)
@@ -14,8 +15,11 @@
 // from_shape of {N, output dims} / {ksize}), :1667-1671 and :1741 (layout_npq applied to an index
 // row / an offset array), :136 (layout_rs.inverse), :1660 (check_npq_not_overflow).
 #pragma once
+#include <array>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <tuple>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -55,24 +59,64 @@ template <typename T, size_t N> struct array {
   }
 };
 
+// row-major element accessor of a view (tensorview's TensorView<T, N>::operator())
+template <typename T, int N> struct TensorViewN {
+  T *ptr;
+  int64_t shape[N];
+  template <typename... I> T &operator()(I... idx) const {
+    static_assert(sizeof...(I) == N, "one index per axis");
+    const int64_t a[N] = {static_cast<int64_t>(idx)...};
+    int64_t off = 0;
+    for (int k = 0; k < N; ++k) off = off * shape[k] + a[k];
+    return ptr[off];
+  }
+};
+
 class Tensor {
  public:
-  Tensor() : ptr_(nullptr) {}
-  Tensor(void *p, std::vector<int64_t> shape) : ptr_(p), shape_(std::move(shape)) {}
+  Tensor() : ptr_(nullptr), itemsize_(4) {}
+  Tensor(void *p, std::vector<int64_t> shape, int itemsize = 4)
+      : ptr_(p), shape_(std::move(shape)), itemsize_(itemsize) {}
   int64_t dim(int i) const { return shape_[i]; }
   int ndim() const { return static_cast<int>(shape_.size()); }
+  int64_t stride(int i) const {        // contiguous row-major views only
+    int64_t s = 1;
+    for (int k = ndim() - 1; k > i; --k) s *= shape_[k];
+    return s;
+  }
+  int64_t size() const {
+    int64_t s = 1;
+    for (int64_t d : shape_) s *= d;
+    return s;
+  }
   int dtype() const { return 0; }      // (fp32 views only, see tv::dispatch below)
   int device() const { return -1; }
   template <typename T> T *data_ptr() { return static_cast<T *>(ptr_); }
   template <typename T> T *data_ptr() const { return static_cast<T *>(ptr_); }
+  Tensor &zero_() {
+    std::memset(ptr_, 0, static_cast<size_t>(size()) * itemsize_);
+    return *this;
+  }
+  Tensor slice_first_axis(int64_t begin, int64_t end) const {
+    std::vector<int64_t> sh = shape_;
+    sh[0] = end - begin;
+    return Tensor(static_cast<char *>(ptr_) + begin * stride(0) * itemsize_, sh, itemsize_);
+  }
+  template <typename T, int N> TensorViewN<T, N> tview() const {
+    TensorViewN<T, N> v;
+    v.ptr = static_cast<T *>(ptr_);
+    for (int k = 0; k < N; ++k) v.shape[k] = shape_[k];
+    return v;
+  }
 
  private:
   void *ptr_;
   std::vector<int64_t> shape_;
+  int itemsize_;
 };
 
-inline Tensor from_blob(void *p, std::initializer_list<int64_t> shape) {
-  return Tensor(p, std::vector<int64_t>(shape));
+inline Tensor from_blob(void *p, std::initializer_list<int64_t> shape, int itemsize = 4) {
+  return Tensor(p, std::vector<int64_t>(shape), itemsize);
 }
 
 // gather.py's element-type dispatch and 1-d loop helper: the oracle drives the reference's gather /
@@ -92,6 +136,7 @@ template <typename... Ts> inline std::string ssprint(const Ts &...xs) {
 }  // namespace tv
 
 #define TV_DECLTYPE(x) std::decay_t<decltype(x)>
+#define TV_IF_CONSTEXPR constexpr
 #define TV_ASSERT_RT_ERR(cond, ...)                                                   \
   do {                                                                                \
     if (!(cond)) throw std::runtime_error(std::string(#cond " failed: ") + tv::ssprint(__VA_ARGS__)); \

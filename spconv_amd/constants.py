@@ -17,6 +17,12 @@ BWD_OVERLAP = os.getenv("SPCONV_AMD_BWD_OVERLAP", "0") == "1"
 # spconv/constants.py:112: skip the constructor checks of SparseConvTensor while torch.fx traces a
 # model (its arguments are Proxies then)
 SPCONV_FX_TRACE_MODE = os.getenv("SPCONV_FX_TRACE_MODE", "0") == "1"
+# "Identical to the reference" where the reference's own behaviour is a slip: =1 reproduces (a) the average-pool
+# backward that MULTIPLIES by the window count (csrc/sparse/maxpool.py:262-300; the default divides: the derivative
+# of the forward) and (b) the CPU voxeliser's mean fill whose accumulator is carried from voxel to voxel
+# (csrc/sparse/pointops.py:663-686: `mean_value.clear()`; the default fills with the voxel's own mean).  The
+# native library reads the same variable for (a).
+REFERENCE_QUIRKS = os.getenv("SPCONV_AMD_REFERENCE_QUIRKS", "0") == "1"
 ALL_WEIGHT_IS_KRSC = True
 FILTER_HWIO = False
 

@@ -2010,6 +2010,8 @@ int spx_igemm_fwd_int8(const void *feat, const void *weight, void *out, const in
   p.identity_k = identity_k;
   p.b_reverse = 0;
   apply_rows_layout(p, (act & SPX_ROWS_LAYOUT_ACT) ? SPX_ROWS_LAYOUT : ((act & SPX_TILE_ORDER) ? 1 : 0));
+  const bool hinted = p.cls && (act & SPX_SPARSE_HINT);
+  if (hinted) p.cls = nullptr;     // the host has seen class word 1: the blob's tables ARE tables in tile order, no device read
   p.act = act & 0xff;
   p.act_alpha = act_alpha;
   p.scale = scale;
@@ -2030,8 +2032,7 @@ int spx_igemm_fwd_int8(const void *feat, const void *weight, void *out, const in
       // instead of three: 27.3 -> 25.7 us at BASELINE config 5); dense neighbourhoods keep 128 rows (LiDAR-like
       // 200 k: 104 vs 113 us, fixture 74 vs 83 us).  SPX_I8_MB = 1 / 2 forces one.
       const int forced = option_int("SPX_I8_MB", 0);
-      if (forced == 1 || (forced == 0 && p.tile_order && (!p.cls || (act & SPX_SPARSE_HINT))))
-        return launch_v4<128, 1, 2>(p, s);
+      if (forced == 1 || (forced == 0 && p.tile_order && !p.cls)) return launch_v4<128, 1, 2>(p, s);
       return launch_v4<128, 2, 2>(p, s);
     }
     case 256: return launch_v4<256, 1, 2>(p, s);

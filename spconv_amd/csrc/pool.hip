@@ -20,6 +20,7 @@ struct PoolParams {
   void *dst;              // [n_dst, C]
   int32_t *count_out;     // avg-pool forward: valid pairs per output row, or null
   const int32_t *count;   // avg-pool backward: the same counts
+  int quirk_mul;          // avg-pool backward: multiply by the count like the reference kernel (SPCONV_AMD_REFERENCE_QUIRKS)
   const int32_t *pair;    // [kv, n_dst]
   const uint32_t *mask;   // [n_dst, ceil(kv / 32)] or null
   int n_dst, C, kv, init_zero;
@@ -131,14 +132,14 @@ __global__ void __launch_bounds__(kBlock) pool_kernel(PoolParams p) {
   } else {
     // gradient of the mean: din[i] = sum_o dout[o] / count[o].  (The reference kernel,
     // maxpool.py:262-300, MULTIPLIES by count[o]; that is not the derivative of its own
-    // forward and is deliberately not reproduced -- DESIGN.md.)
+    // forward -- DESIGN.md.  SPCONV_AMD_REFERENCE_QUIRKS=1 reproduces it: quirk_mul.)
     float acc[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) acc[e] = 0.f;
     for_each_pair(p, r, [&](int, int o) {
       const P d = *reinterpret_cast<const P *>(src + static_cast<size_t>(o) * p.C + c);
       const int cnt = p.count[o];
-      const float inv = cnt > 0 ? 1.f / static_cast<float>(cnt) : 0.f;
+      const float inv = p.quirk_mul ? static_cast<float>(cnt) : (cnt > 0 ? 1.f / static_cast<float>(cnt) : 0.f);
 #pragma unroll
       for (int e = 0; e < V; ++e) acc[e] += Elem<T>::to_f(d.v[e]) * inv;
     });
@@ -247,6 +248,7 @@ int spx_avgpool_bwd(const void *dout, void *din, const int32_t *count, const int
   p.src = dout;
   p.dst = din;
   p.count = count;
+  p.quirk_mul = option_int("SPCONV_AMD_REFERENCE_QUIRKS", 0) ? 1 : 0;
   p.pair = pair_bwd;
   p.mask = mask_bwd;
   p.n_dst = n_in;

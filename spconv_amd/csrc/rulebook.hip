@@ -1547,6 +1547,27 @@ p2v_mean_kernel(float *__restrict__ voxels, const int32_t *__restrict__ num_per_
   for (int j = num; j < max_points; ++j) base[static_cast<size_t>(j) * nfeat] = mean;
 }
 
+// The reference's CPU loop AS IT BEHAVES (pointops.py:663-686): `mean_value.clear()` leaves the accumulator's
+// contents in place, so voxel v starts from the mean of voxel v - 1:  m_v = (m_{v-1} + sum_j x_j) / num_v, point by
+// point in fp32.  A sequential recurrence over the voxels in their (first-seen) order: one thread per feature
+// walks all of them.  Opt-in (empty_mean = 2: SPCONV_AMD_REFERENCE_QUIRKS=1), bit-identical to the reference's code
+// executed (tests/golden/p2v_ref.npz); milliseconds, not microseconds.
+__global__ void p2v_mean_carry_kernel(float *__restrict__ voxels, const int32_t *__restrict__ num_per_voxel,
+                                      const int32_t *__restrict__ n_voxels, int max_points, int nfeat) {
+  const int k = threadIdx.x;
+  if (k >= nfeat) return;
+  const int nv = *n_voxels;
+  float carry = 0.f;
+  for (int v = 0; v < nv; ++v) {
+    const int num = num_per_voxel[v];
+    if (num <= 0) continue;
+    float *base = voxels + static_cast<size_t>(v) * max_points * nfeat + k;
+    for (int j = 0; j < num; ++j) carry += base[static_cast<size_t>(j) * nfeat];
+    carry /= static_cast<float>(num);
+    for (int j = num; j < max_points; ++j) base[static_cast<size_t>(j) * nfeat] = carry;
+  }
+}
+
 __global__ void p2v_clamp_count_kernel(const int32_t *total, int max_voxels, int32_t *n_voxels) {
   *n_voxels = *total < max_voxels ? *total : max_voxels;
 }
@@ -2391,7 +2412,11 @@ int spx_point2voxel(const float *points, int n, int nfeat, int ndim, const float
   hipLaunchKernelGGL(p2v_segment_kernel, gp, dim3(kBlock), 0, s, w.kA, n, w.seg_start);
   hipLaunchKernelGGL(p2v_scatter_kernel, gp, dim3(kBlock), 0, s, points, nfeat, w.kA, w.order, n,
                      w.seg_start, max_points, voxels, num_per_voxel);
-  if (empty_mean) {
+  if (empty_mean == 2) {
+    SPX_CHECK(nfeat <= 1024, "reference-quirk mean fill: at most 1024 point features");
+    hipLaunchKernelGGL(p2v_mean_carry_kernel, dim3(1), dim3(((nfeat + 63) / 64) * 64), 0, s, voxels, num_per_voxel,
+                       w.n_voxels, max_points, nfeat);
+  } else if (empty_mean) {
     const long long total = static_cast<long long>(max_voxels) * nfeat;
     hipLaunchKernelGGL(p2v_mean_kernel, dim3(static_cast<unsigned>((total + kBlock - 1) / kBlock)),
                        dim3(kBlock), 0, s, voxels, num_per_voxel, w.n_voxels, max_points, nfeat);

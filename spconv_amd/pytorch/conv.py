@@ -377,7 +377,7 @@ class SparseConvolution(SparseModule):
         if grad_path and not training and add_input is None:
             out_features = _apply_act(out_features, act_type, act_alpha, act_beta)
         out = self._finish(input, out_tensor, out_features, outids, indice_dict, out_spatial_shape, add_input,
-                           is_int8, name, features, t if input.benchmark else None)
+                           is_int8, name, features, t if input.benchmark else None, rb)
         # live rows of a static-shape tensor: SubM keeps the input's, a strided layer has its own count, an
         # inverse layer returns to the rows its partner started from
         out.n_live_dev = (rb.in_n_live_dev if self.inverse else
@@ -411,7 +411,7 @@ class SparseConvolution(SparseModule):
         return out_features
 
     def _finish(self, input, out_tensor, out_features, outids, indice_dict, out_spatial_shape, add_input,
-                is_int8, name, features, t0):
+                is_int8, name, features, t0, rb):
         if t0 is not None:
             torch.cuda.synchronize()
             out_tensor.benchmark_record[name]["time"].append(time.time() - t0)

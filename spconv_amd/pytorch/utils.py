@@ -13,7 +13,7 @@ from typing import List, Union
 import numpy as np
 import torch
 
-from spconv_amd import _lib
+from spconv_amd import _lib, constants
 
 
 def calc_point2voxel_meta_data(vsize_xyz: List[float], coors_range_xyz: List[float]):
@@ -84,7 +84,8 @@ class PointToVoxel(object):
             _lib.check(L.spx_point2voxel(
                 pc.data_ptr(), n, self.num_point_features, self.ndim, f(self.vsize), f(self.coors_range),
                 _lib.ints(self.grid_size), self.max_num_voxels, self.max_num_points_per_voxel,
-                int(empty_mean), int(clear_voxels), self.voxels.data_ptr(), self.indices.data_ptr(),
+                (2 if constants.REFERENCE_QUIRKS else 1) if empty_mean else 0, int(clear_voxels),
+                self.voxels.data_ptr(), self.indices.data_ptr(),
                 self.num_per_voxel.data_ptr(), pc_voxel_id.data_ptr(), ctypes.byref(nv), ws.data_ptr(),
                 ws.numel(), torch.cuda.current_stream(pc.device).cuda_stream))
             num_voxels = int(nv.value)

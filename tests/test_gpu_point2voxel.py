@@ -70,3 +70,31 @@ def test_point2voxel_feeds_a_sparse_conv(cuda):
     back = gather_features_by_pc_voxel_id(y.features, pid, invalid_value=-1)
     assert back.shape == (8000, 16) and bool((back[pid < 0] == -1).all())
     assert torch.equal(back[pid >= 0], y.features[pid[pid >= 0]])
+
+
+@pytest.mark.parametrize("tag", ["plain", "mean", "capped_mean"])
+def test_point2voxel_equals_the_reference_code_executed(cuda, tag, monkeypatch):
+    """tests/golden/p2v_ref.npz: what the reference's own Point2VoxelCPU (pointops.py:493-766) returned.  Voxel set,
+    numbering, stored points, counts and per-point ids are identical by default; with SPCONV_AMD_REFERENCE_QUIRKS=1
+    the mean fill of the empty slots is too (the reference's accumulator is carried from voxel to voxel)."""
+    import os
+    from spconv_amd import constants
+    from spconv_amd.pytorch.utils import PointToVoxel
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "p2v_ref.npz"))
+    mv, mp, mean = (int(v) for v in d[f"{tag}_args"])
+    gen = PointToVoxel([0.1, 0.1, 0.2], [0, -4, -2, 8, 4, 2], 4, mv, mp, device=cuda)
+    np.testing.assert_array_equal(np.asarray(gen.grid_size), d["grid_size"])
+    np.testing.assert_array_equal(np.asarray(gen.vsize, dtype=np.float32), d["vsize"])
+    pts = torch.from_numpy(d["points"]).to(cuda)
+    monkeypatch.setattr(constants, "REFERENCE_QUIRKS", True)
+    v, i, c, pid = gen.generate_voxel_with_id(pts, True, bool(mean))
+    np.testing.assert_array_equal(i.cpu().numpy(), d[f"{tag}_indices"])
+    np.testing.assert_array_equal(c.cpu().numpy(), d[f"{tag}_num"])
+    np.testing.assert_array_equal(pid.cpu().numpy(), d[f"{tag}_pid"])
+    np.testing.assert_array_equal(v.cpu().numpy(), d[f"{tag}_voxels"])
+    monkeypatch.setattr(constants, "REFERENCE_QUIRKS", False)
+    v2, i2, c2, pid2 = gen.generate_voxel_with_id(pts, True, bool(mean))
+    np.testing.assert_array_equal(i2.cpu().numpy(), d[f"{tag}_indices"])
+    np.testing.assert_array_equal(pid2.cpu().numpy(), d[f"{tag}_pid"])
+    stored = (np.arange(mp)[None, :] < d[f"{tag}_num"][:, None])
+    np.testing.assert_array_equal(v2.cpu().numpy()[stored], d[f"{tag}_voxels"][stored])

@@ -108,3 +108,58 @@ def test_avgpool_module_and_global_pools(cuda):
         rows = torch.from_numpy(idx[:, 0] == b)
         assert torch.allclose(gm[b].cpu(), f[rows].max(dim=0)[0])
         assert torch.allclose(ga[b].cpu(), f[rows].mean(dim=0), atol=1e-6)
+
+
+def _golden(name):
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
+
+
+def test_native_maxpool_equals_the_reference_code_executed(cuda):
+    """tests/golden/pool_ref.npz: what the reference's own CPU loops (IndiceMaxPoolCPU, maxpool.py:590-703, driven as
+    pytorch/ops.py:1899-1975 drives them) returned -- forward, backward and global_pool_rearrange, bit for bit."""
+    from spconv_amd.pytorch import ops
+    d = _golden("pool_ref.npz")
+    idx, shape = d["indices"], [int(v) for v in d["shape"]]
+    rb, _ = gpu_rulebook(idx, 2, shape, [3] * 3, [2] * 3, [1] * 3, [1] * 3, False, need_bwd_table=True)
+    np.testing.assert_array_equal(to_np(rb.pair_native), d["pair"])
+    np.testing.assert_array_equal(to_np(rb.num_per_loc), d["num"])
+    f, dout = torch.from_numpy(d["features"]).to(cuda), torch.from_numpy(d["dout"]).to(cuda)
+    native = ops.attach_rulebook(rb.pair_native, rb)
+    out = ops.indice_maxpool(f, native, rb.num_per_loc, rb.n_out)
+    np.testing.assert_array_equal(to_np(out), d["out"])
+    din = ops.indice_maxpool_backward(f, out, dout, native, rb.num_per_loc)
+    np.testing.assert_array_equal(to_np(din), d["din"])
+    gp_out, gp_cnt = ops.global_pool_rearrange(torch.from_numpy(d["gp_coords"]).to(cuda), 2)
+    np.testing.assert_array_equal(to_np(gp_cnt), d["gp_counts"])
+    for b in range(2):          # (the reference leaves the tail of a row uninitialised: compare the defined part)
+        c = int(d["gp_counts"][b])
+        np.testing.assert_array_equal(to_np(gp_out)[b, :c], d["gp_out"][b, :c])
+
+
+def test_reference_quirks_switch_avgpool_backward(cuda):
+    """SPCONV_AMD_REFERENCE_QUIRKS=1: the average-pool backward multiplies by the window count, as the reference
+    kernel does (maxpool.py:262-300); the default divides."""
+    from spconv_amd import _lib
+    from spconv_amd.pytorch import ops
+    shape, bs, C = [24, 24, 24], 1, 16
+    idx = dense_scene(shape, 2500, bs, 3)
+    ref = oracle_rulebook(idx, bs, shape, [3] * 3, [2] * 3, [1] * 3, [1] * 3, False)
+    rb, _ = gpu_rulebook(idx, bs, shape, [3] * 3, [2] * 3, [1] * 3, [1] * 3, False, need_bwd_table=True)
+    rng = np.random.default_rng(9)
+    f = (rng.integers(-8, 9, (idx.shape[0], C)) / 4.0).astype(np.float32)
+    dout = (rng.integers(-16, 17, (ref["n_out"], C)) / 8.0).astype(np.float32)
+    fg, dg = torch.from_numpy(f).to(cuda), torch.from_numpy(dout).to(cuda)
+    _, cnt = ops.indice_avgpool_implicit_gemm(fg, ops.attach_rulebook(rb.pair_fwd, rb), rb.n_out, True)
+    pb = ops.attach_rulebook(rb.pair_bwd, rb)
+    L = _lib.load()
+    try:
+        _lib.check(L.spx_set_option(b"SPCONV_AMD_REFERENCE_QUIRKS", 1))
+        quirk = to_np(ops.indice_avgpool_implicit_gemm_backward(dg, pb, cnt))
+    finally:
+        _lib.check(L.spx_set_option(b"SPCONV_AMD_REFERENCE_QUIRKS", 0))
+    plain = to_np(ops.indice_avgpool_implicit_gemm_backward(dg, pb, cnt))
+    want_q = oracle.avgpool_bwd_ref(dout, to_np(cnt), ref["pair"], ref["num"], ref["n_in"], False, reference_quirks=True)
+    want_p = oracle.avgpool_bwd_ref(dout, to_np(cnt), ref["pair"], ref["num"], ref["n_in"], False)
+    np.testing.assert_array_equal(quirk, want_q)                 # dyadic data: products and sums are exact
+    assert rel_err(plain, want_p) < 1e-6 and not np.array_equal(quirk, plain)

@@ -4,6 +4,8 @@
  (b) the reference's numpy per-offset formula (test/test_all_algo.py:222-288),
  (c) the committed golden fixtures (regression pin, tests/golden/make_golden.py),
  (d) the pair statistics SURVEY.md section 0.5 measured on the reference's LiDAR fixture."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -361,3 +363,96 @@ def test_native_conv_loop_with_the_reference_gather_code():
             res.append((y, din, dw))
         for a, b in zip(*res):
             assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the voxeliser and the pooling loops, pinned to the reference's own CPU code, executed
+# (oracle/_ref: Point2VoxelCPU, pointops.py:493-766; IndiceMaxPoolCPU, maxpool.py:590-703; vectors made by
+# tests/golden/make_ref_8f_golden.py)
+def _npz(name):
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
+
+
+@pytest.mark.parametrize("tag", ["plain", "mean", "capped_mean"])
+def test_point2voxel_restatement_equals_reference_executed_vectors(tag):
+    d = _npz("p2v_ref.npz")
+    mv, mp, mean = (int(v) for v in d[f"{tag}_args"])
+    pts, vs, cr, grid = d["points"], d["vsize"], d["coors_range"], d["grid_size"]
+    # the loop AS IT BEHAVES in the reference (mean accumulator carried from voxel to voxel): bit for bit
+    v, i, c, pid = oracle.point2voxel(pts, vs, cr, grid, mv, mp, bool(mean), reference_quirks=True)
+    np.testing.assert_array_equal(i, d[f"{tag}_indices"])
+    np.testing.assert_array_equal(c, d[f"{tag}_num"])
+    np.testing.assert_array_equal(pid, d[f"{tag}_pid"])
+    np.testing.assert_array_equal(v, d[f"{tag}_voxels"])
+    assert (pid == -1).any() and c.max() == mp                      # range check and the per-voxel cap are exercised
+    # the default form (arithmetic mean): identical voxel set / numbering / stored points; only the FILL of the
+    # empty slots differs, and only from the second voxel on (the first voxel starts from a zero accumulator)
+    v2, i2, c2, pid2 = oracle.point2voxel(pts, vs, cr, grid, mv, mp, bool(mean))
+    np.testing.assert_array_equal(i2, i)
+    np.testing.assert_array_equal(c2, c)
+    np.testing.assert_array_equal(pid2, pid)
+    stored = np.arange(mp)[None, :] < c[:, None]
+    np.testing.assert_array_equal(v2[stored], v[stored])
+    if mean:
+        np.testing.assert_array_equal(v2[0], v[0])
+        want = np.stack([v[k, :c[k]].astype(np.float64).mean(0) for k in range(len(c))])
+        for k in np.nonzero(c < mp)[0][:200]:
+            np.testing.assert_allclose(v2[k, c[k]:], np.broadcast_to(want[k], v2[k, c[k]:].shape), rtol=1e-6, atol=1e-7)
+        assert not np.array_equal(v2, v), "the carried accumulator must show in the reference's fill"
+    else:
+        np.testing.assert_array_equal(v2, v)
+
+
+def test_maxpool_restatements_equal_reference_executed_vectors():
+    d = _npz("pool_ref.npz")
+    pair, num, n_out, f, dout = d["pair"], d["num"], int(d["n_out"]), d["features"], d["dout"]
+    # the rulebook the vectors were made on is the restatement's own
+    idx, shape = d["indices"], [int(v) for v in d["shape"]]
+    _, pair2, num2, _ = oracle.get_indice_pairs(idx, 2, shape, [3] * 3, [2] * 3, [1] * 3, [1] * 3, None, False, False)
+    np.testing.assert_array_equal(pair2, pair)
+    np.testing.assert_array_equal(num2, num)
+    # operation-for-operation restatement of ops.py:1899-1975 over maxpool.py:620-700
+    out, bwd = oracle.indice_maxpool_native(f, pair, num, n_out)
+    np.testing.assert_array_equal(out, d["out"])
+    np.testing.assert_array_equal(bwd(dout), d["din"])
+    # the vectorised forms the GPU tests use (Native path: zero-filled output; dyadic data: sums exact in any order)
+    np.testing.assert_array_equal(oracle.maxpool_ref(f, pair, num, n_out, init_zero=True), d["out"])
+    np.testing.assert_array_equal(oracle.maxpool_bwd_ref(f, d["out"], dout, pair, num), d["din"])
+    assert (d["din"] != 0).any() and (np.count_nonzero(d["din"], axis=0) > 0).all()
+
+
+def test_global_pool_rearrange_reference_executed_vector():
+    """IndiceMaxPoolCPU::global_pool_rearrange (maxpool.py:598-618): rows of scene b in their order, counts; rows with a
+    negative batch index belong to no scene."""
+    d = _npz("pool_ref.npz")
+    coords, out, cnt = d["gp_coords"], d["gp_out"], d["gp_counts"]
+    for b in range(2):
+        rows = np.nonzero(coords[:, 0] == b)[0]
+        assert cnt[b] == len(rows)
+        np.testing.assert_array_equal(out[b, :cnt[b]], rows)
+    assert cnt.sum() == (coords[:, 0] >= 0).sum() < coords.shape[0]
+
+
+def test_section_8f_restatements_equal_the_live_reference_library():
+    """Where oracle/_ref exists (this container; it travels to the GPU box): fresh seeds against the library."""
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    rng = np.random.default_rng(8)
+    for seed in range(3):
+        pts = rng.uniform((-1, -5, -3, 0), (9, 5, 3, 1), (3000, 4)).astype(np.float32)
+        pts[:1500, :3] = pts[:1500, :3] * 0.03 + np.float32(2.0)
+        vs, cr, grid = [0.2, 0.1, 0.1], [-2, -4, 0, 2, 4, 8], [20, 80, 80]
+        for mean in (False, True):
+            a = oracle.point2voxel(pts, vs, cr, grid, 900 + 2000 * seed, 4, mean, reference_quirks=True)
+            b = ref.point2voxel(pts, vs, cr, grid, 900 + 2000 * seed, 4, mean)
+            for x, y in zip(a, b):
+                np.testing.assert_array_equal(x, y)
+    idx = scene([16, 16, 16], 1200, 2, 5)
+    _, pair, num, _ = oracle.get_indice_pairs(idx, 2, [16] * 3, [2] * 3, [2] * 3, [0] * 3, [1] * 3, None, False, False)
+    n_out = int(pair[1].max()) + 1
+    f = (rng.integers(-64, 65, (idx.shape[0], 5)) / 64.0).astype(np.float32)
+    dout = (rng.integers(-32, 33, (n_out, 5)) / 64.0).astype(np.float32)
+    out, bwd = oracle.indice_maxpool_native(f, pair, num, n_out)
+    np.testing.assert_array_equal(out, ref.indice_maxpool(f, pair, num, n_out))
+    np.testing.assert_array_equal(bwd(dout), ref.indice_maxpool_backward(f, out, dout, pair, num))
