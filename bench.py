@@ -668,6 +668,26 @@ def run_layer(args, D: Dist):
             step()
         torch.cuda.synchronize()
         single_replay_ms = (time.perf_counter() - t1) / args.steps * 1e3
+    # BENCH_CHECK_EXCHANGE=1 (tests): the overlapped exchange, checked numerically -- after one more replay of a graph,
+    # row u of its reduced bucket must equal the mean over the ranks of step u's dW (every rank has its own scenes)
+    exchange_check = None
+    if overlap is not None and os.environ.get("BENCH_CHECK_EXCHANGE") == "1":
+        import torch.distributed as dist
+        worst = 0.0
+        for h in overlap["halves"] + list(overlap["rem"].values()):
+            replay_overlapped(h)
+            drain_overlapped()
+            torch.cuda.synchronize()
+            for u, dw in enumerate(h.dws):
+                mine = dw.detach().float().reshape(-1).contiguous()
+                everyone = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(everyone, mine)
+                want = torch.stack(everyone).mean(0)
+                scale = float(want.abs().max()) or 1.0
+                worst = max(worst, float((h.flat[u].float() - want).abs().max()) / scale)
+        distinct = float((torch.stack(everyone)[0] - torch.stack(everyone)[-1]).abs().max()) > 0
+        exchange_check = {"max_rel_err": worst, "ranks_have_distinct_gradients": bool(distinct),
+                          "buckets_checked": len(overlap["halves"]) + len(overlap["rem"])}
     n_mean = sum(sc.n for sc in scenes) / S
     elapsed, n_total, ranks_seen = D.reduce_max_sum(elapsed, n_mean)
     ms_per_step = elapsed / args.steps * 1e3
@@ -772,7 +792,7 @@ def run_layer(args, D: Dist):
                    "rulebook_source": "net(x): the module's own build, default environment" if args.sort == "auto"
                                       else f"net(x) with SPCONV_DO_SORT={'1' if args.sort == 'on' else '0'}",
                    "rows_layout": layout_info, "mask_sort": scenes[0].rb.argsort_fwd is not None,
-                   "prewarm_steps": args.prewarm,
+                   "prewarm_steps": args.prewarm, "gradient_exchange_check": exchange_check,
                    "parallelism": f"dp{world}",
                    "ranks_seen": ranks_seen,
                    "dist_backend": D.backend if D.multi else None,

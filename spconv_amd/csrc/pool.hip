@@ -87,12 +87,20 @@ __global__ void __launch_bounds__(kBlock) pool_kernel(PoolParams p) {
     P cur;
 #pragma unroll
     for (int e = 0; e < V; ++e) cur.v[e] = p.init_zero ? Elem<T>::from_f(0.f) : Elem<T>::lowest();
+    bool any = false;
     for_each_pair(p, r, [&](int, int idx) {
       const P in = *reinterpret_cast<const P *>(src + static_cast<size_t>(idx) * p.C + c);
+      any = true;
 #pragma unroll
       for (int e = 0; e < V; ++e)
         if (Elem<T>::to_f(cur.v[e]) < Elem<T>::to_f(in.v[e])) cur.v[e] = in.v[e];
     });
+    // a row without a single pair is a DEAD row of a static-shape tensor (a real output has at least the pair that
+    // created it): zeros, like every other padding row, not the lowest value
+    if (!any) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) cur.v[e] = Elem<T>::from_f(0.f);
+    }
     *reinterpret_cast<P *>(dst + static_cast<size_t>(r) * p.C + c) = cur;
   } else if (OP == kMaxBwd) {
     // maxpool.py:142-209: din[i] = sum of dout[o] over the outputs whose maximum this input is

@@ -38,8 +38,11 @@ def test_bench_single_gpu_contract(cuda):
 
 def test_bench_gpus_2_spawns_two_ranks(cuda):
     r = _run(["--gpus", "2", "--steps", "20", "--warmup", "8", "--scenes", "2"],
-             {"BENCH_DIST_BACKEND": "gloo", "BENCH_ONE_DEVICE": "1"})
+             {"BENCH_DIST_BACKEND": "gloo", "BENCH_ONE_DEVICE": "1", "BENCH_CHECK_EXCHANGE": "1"})
     assert r["n_gpus"] == 2
+    # the overlapped exchange is numerically what it claims: bucket row u == mean over the ranks of step u's dW
+    chk = r["config"]["gradient_exchange_check"]
+    assert chk["ranks_have_distinct_gradients"] and chk["buckets_checked"] >= 3 and chk["max_rel_err"] < 2e-3, chk
     # the gradient exchange is off the critical path: 8 steps per replay also at N > 1, one bucket per replay
     assert r["config"]["steps_per_replay"] == 8 and "side stream" in r["config"]["gradient_exchange"]
     assert r["config"]["ranks_seen"] == 2 and r["config"]["parallelism"] == "dp2"

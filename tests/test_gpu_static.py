@@ -250,18 +250,26 @@ def test_static_training_step_with_subm_and_batchnorm(cuda):
     assert rel < 2e-2, rel
 
 
-def test_static_training_step_runner(cuda):
-    """StaticTrainingStep: one graph, several scenes; parameter gradients of every replay against the eager step."""
+@pytest.mark.parametrize("pool", [False, True])
+def test_static_training_step_runner(cuda, pool):
+    """StaticTrainingStep: one graph, several scenes; parameter gradients of every replay against the eager step.
+    pool: the second strided layer is a SparseMaxPool3d -- pooling layers take their frozen bound in training mode
+    too (the reference's bounded mode covers them: pool.py:99-248 via ops.py:263-266)."""
     import spconv_amd.pytorch as spconv
     from spconv_amd.pytorch.static import StaticTrainingStep, strided_layers
     shape, bs, C = [32, 40, 40], 2, 8
-    net = _backbone(spconv, C, cuda, torch.float16).train()
+    net = _backbone(spconv, C, cuda, torch.float16, pool=pool).train()
+    before = {k: v.clone() for k, v in net.state_dict().items()}
     eager = copy.deepcopy(net)
     names = list(strided_layers(net))
     g = ((torch.rand((1_700, 64), device=cuda) - 0.5) * 0.2).half()
     scenes = [_scene_tensors(shape, n, bs, C, seed, cuda, torch.float16) for n, seed in ((4000, 1), (1500, 2), (5500, 3))]
     step = StaticTrainingStep(net, 12_000, C, shape, bs, torch.float16, bounds={names[0]: 13_000, names[1]: 1_700},
                               out_grad=g, input_grad=True, example=scenes[0])
+    # building the runner leaves the model as it found it: the warm-up passes are real training-mode passes, the
+    # buffers they moved (BatchNorm running estimates, batch counters) are put back (ADVICE r3)
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, before[k]), k
     for f, idx in scenes:
         out = step(f, idx)
         assert step.overflowed() == {}
