@@ -136,7 +136,7 @@ def test_layout_int8_forward_is_bit_identical(cuda, sparse):
     pair, mask, blob, to = ops.tables_of(rb, "fwd", K)
     ref = ops.igemm_fwd_int8(f, w, rb.pair_fwd, rb.mask_fwd, None, rb.n_out, 13, sc, bias, None, 0.0, torch.int8,
                              ops.Activation.ReLU, 0.0)
-    for hint in (False, True):            # the host hint only changes the tile height
+    for hint in ((False, True) if sparse else (False,)):   # the hint ("the host has SEEN class 1") only changes the launch shape
         got = ops.igemm_fwd_int8(f, w, pair, mask, blob, rb.n_out, 13, sc, bias, None, 0.0, torch.int8,
                                  ops.Activation.ReLU, 0.0, tile_order=to, sparse_hint=hint)
         assert torch.equal(ref, got)
