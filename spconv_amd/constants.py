@@ -11,9 +11,6 @@ SPCONV_DO_SORT = os.getenv("SPCONV_DO_SORT", "1") == "1"
 MODULE_DO_SORT = {"1": True, "0": False}.get(os.getenv("SPCONV_DO_SORT", ""), "layout")
 # spconv/constants.py:36: layout of checkpoints produced by spconv 1.x / 2.1 ("KRSC", "RSKC", "RSCK").
 SAVED_WEIGHT_LAYOUT = os.getenv("SPCONV_SAVED_WEIGHT_LAYOUT", "")
-# run dgrad and wgrad of one layer on two HIP streams (they are independent).  Off by default:
-# measured on MI355X the fork/join costs more than the overlap buys (57.2 vs 64.7 us per step)
-BWD_OVERLAP = os.getenv("SPCONV_AMD_BWD_OVERLAP", "0") == "1"
 # spconv/constants.py:112: skip the constructor checks of SparseConvTensor while torch.fx traces a
 # model (its arguments are Proxies then)
 SPCONV_FX_TRACE_MODE = os.getenv("SPCONV_FX_TRACE_MODE", "0") == "1"

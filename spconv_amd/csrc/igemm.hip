@@ -1682,7 +1682,7 @@ bool mfma_ok(int dtype, int cin, int cout, int kv, const uint32_t *mask) {
 
 template <bool BF16>
 int dispatch_gather_gemm(const GemmParams &p, hipStream_t s) {
-  static const int mb_forced = env_int("SPX_GEMM_MB", 0);
+  constexpr int mb_forced = 0;              // (tile height: rule below)
   if (v4_ok(p)) {
     // 64-row tiles while the grid would otherwise leave CUs idle, 128-row tiles beyond -- except
     // for 128 output channels, whose 128-row variant holds 64 accumulator registers per lane and
@@ -1757,7 +1757,7 @@ int run_gather_gemm(const GemmParams &p, int dtype, hipStream_t s) {
 
 int run_gather_gemm_single(const GemmParams &p, int dtype, hipStream_t s) {
   if (p.n_dst == 0) return 0;
-  static const int f32_mfma = env_int("SPX_F32_MFMA", 1);         // tuning knob (A/B runs)
+  constexpr int f32_mfma = 1;
   const bool grouped = p.acc_mode != 0;
   if (dtype == SPX_F32 && f32_mfma && mfma_ok(dtype, p.CIN, p.COUT, p.kv, p.mask) && v4_ok(p, 4, 4) &&
       (p.kv <= 32 || grouped))
@@ -1790,7 +1790,7 @@ int run_gather_gemm_single(const GemmParams &p, int dtype, hipStream_t s) {
 }
 
 int wgrad_chunk(int n_in) {
-  static const int forced = env_int("SPX_WGRAD_CHUNK", 0);  // tuning knob
+  constexpr int forced = 0;
   if (forced > 0) return (forced + kWJ - 1) / kWJ * kWJ;
   // aim at >= ~512 workgroups for the dominant (centre) list, multiples of 128
   int c = (n_in / 512 + kWJ - 1) / kWJ * kWJ;
@@ -1808,7 +1808,7 @@ size_t wgrad_plan_ints(int n_in, int kv) {
 // mean more partials for the second stage: 384 measured best at 100k voxels), never more
 // ranges than twice the 128-pair chunks of the identity list
 int wgrad_groups(int n_in) {
-  static const int forced = env_int("SPX_WGRAD_G", 0);   // tuning knob
+  constexpr int forced = 0;
   int g = forced > 0 ? forced : 384;
   if (forced <= 0) {
     // backward shares its launch with ceil(n / 128) dgrad tiles: when both halves fit the 1024
@@ -1829,12 +1829,12 @@ int wgrad_groups(int n_in) {
 
 // blocks of the second stage (block-stride over at most kv * 256 items)
 int reduce2_blocks(int kv) {
-  static const int cap = env_int("SPX_REDUCE2_GRID", 512);   // tuning knob
+  constexpr int cap = 512;
   return kv * 256 < cap ? kv * 256 : cap;
 }
 
 int wgrad_xcd_order() {
-  static const int v = env_int("SPX_WGRAD_XCD", 1);   // A/B switch
+  constexpr int v = 1;
   return v;
 }
 
@@ -1883,7 +1883,7 @@ GemmRest rest_of(const GemmParams &p) {
   r.add = p.add;
   r.add_scale = p.add_scale;
   r.out_dtype = p.out_dtype;
-  static const int dbg = env_int("SPX_V4_DBG", 0);
+  constexpr int dbg = 0;
   r.dbg = dbg | p.dbg;
   r.acc = p.acc;
   r.acc_mode = p.acc_mode;
@@ -1902,7 +1902,7 @@ constexpr size_t bwd_smem_bytes() {
 template <int COUT, int MB, int DT>
 int launch_bwd(const GemmParams &p, const Wgrad2Params &q, int n_wgrad_blocks, hipStream_t s) {
   const int n_dgrad = div_up(p.n_dst, 64 * MB);
-  static const int wgrad_first = env_int("SPX_BWD_WGRAD_FIRST", 1);   // tuning knob (A/B runs)
+  constexpr int wgrad_first = 1;           // (the longer chains are dispatched first: settled A/B)
   GemmParams pl = p;
   pl.lpt = p.tile_order && n_dgrad + n_wgrad_blocks > 1024;           // (see launch_v4)
   if (p.CIN * (DT == 3 ? 4 : 2) <= 64)     // dgrad's reduction rows (dout channels) fit half a piece
@@ -2031,7 +2031,7 @@ int spx_igemm_fwd_int8(const void *feat, const void *weight, void *out, const in
       // (ops.sparse_neighbourhoods) -> 64-row tiles (70 instead of 165 registers per lane, five workgroups per CU
       // instead of three: 27.3 -> 25.7 us at BASELINE config 5); dense neighbourhoods keep 128 rows (LiDAR-like
       // 200 k: 104 vs 113 us, fixture 74 vs 83 us).  SPX_I8_MB = 1 / 2 forces one.
-      const int forced = option_int("SPX_I8_MB", 0);
+      constexpr int forced = 0;
       if (forced == 1 || (forced == 0 && p.tile_order && !p.cls)) return launch_v4<128, 1, 2>(p, s);
       return launch_v4<128, 2, 2>(p, s);
     }
@@ -2130,11 +2130,11 @@ int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t 
   }
   p.plan = plan;
   const bool mfma = (dtype == SPX_F16 || dtype == SPX_BF16) && C % 8 == 0 && K % 8 == 0;
-  static const int wgrad_version = env_int("SPX_WGRAD_V", 2);    // tuning knob (A/B runs)
+  constexpr int wgrad_version = 2;
   const bool small_offsets = static_cast<unsigned long long>(n_out) * K * 2ull < 0x7fff0000ull &&
                              static_cast<unsigned long long>(n_in) * C * 2ull < 0x7fff0000ull &&
                              static_cast<unsigned long long>(n_in) * 4ull * (kv + 1) < 0x7fff0000ull;   // both lists of an offset through one resource
-  static const int f32_mfma = env_int("SPX_F32_MFMA", 1);         // tuning knob (A/B runs)
+  constexpr int f32_mfma = 1;
   const bool f32_path = dtype == SPX_F32 && f32_mfma && C % 4 == 0 && K % 4 == 0 &&
                         static_cast<unsigned long long>(n_out) * K * 4ull < 0x7fff0000ull &&
                         static_cast<unsigned long long>(n_in) * C * 4ull < 0x7fff0000ull &&
@@ -2196,7 +2196,7 @@ int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t 
   {
     // upper bound of work items is nchunks * kv * ntile; the kernels loop over the real count
     const long long bound = static_cast<long long>(p.nchunks) * kv * ntile;
-    static const int max_grid = env_int("SPX_WGRAD_GRID", 1024);
+    constexpr int max_grid = 1024;
     const dim3 grid(static_cast<unsigned>(bound < max_grid ? bound : max_grid));
     const size_t lds = 2 * kWT * kWJ * 2;
     if (mfma && dtype == SPX_F16)
@@ -2248,7 +2248,7 @@ int spx_igemm_bwd(const void *feat, const void *dout, const void *weight, void *
   SPX_CHECK(pair_native && num_per_loc, "Native pair lists and counts are required");
   SPX_CHECK(pair || kv == 1, "pair table required");
   SPX_CHECK(ws_bytes >= spx_igemm_wgrad_ws_bytes(n_in, C, K, kv), "workspace too small");
-  static const int fuse = env_int("SPX_BWD_FUSE", 1);             // tuning knob (A/B runs)
+  constexpr int fuse = 1;                  // (dgrad + wgrad in one launch: settled A/B)
   GemmParams p = dgrad_params(dout, weight, din, pair, mask, argsort, n_out, n_in, C, K, kv, subm);
   apply_rows_layout(p, tile_order);
   const bool small_offsets = static_cast<unsigned long long>(n_out) * K * 2ull < 0x7fff0000ull &&
@@ -2257,7 +2257,7 @@ int spx_igemm_bwd(const void *feat, const void *dout, const void *weight, void *
   const int es = dtype == SPX_F32 ? 4 : 2, lanes = 16 / es;
   const bool offsets_fit = static_cast<unsigned long long>(n_out) * K * es < 0x7fff0000ull &&
                            static_cast<unsigned long long>(n_in) * C * es < 0x7fff0000ull && small_offsets;
-  static const int f32_mfma = env_int("SPX_F32_MFMA", 1);
+  constexpr int f32_mfma = 1;
   const bool fusable = fuse && (dtype == SPX_F16 || dtype == SPX_BF16 || (dtype == SPX_F32 && f32_mfma)) &&
                        C % lanes == 0 && K % lanes == 0 && mfma_ok(dtype, p.CIN, p.COUT, kv, mask) && kv <= 32 &&
                        p.COUT <= 128 && v4_ok(p, es, es) && offsets_fit && n_in > 0 && n_out > 0;

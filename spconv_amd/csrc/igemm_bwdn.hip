@@ -371,7 +371,7 @@ bwdn_reduce_kernel(const float *__restrict__ partial, int G, int kv, int K, int 
 }
 
 int bwdn_groups(int ntiles) {
-  int g = option_int("SPX_BWDN_G", 512);              // two persistent workgroups per CU
+  int g = 512;                                        // two persistent workgroups per CU
   if (g * kBnMaxTiles < ntiles) g = div_up(ntiles, kBnMaxTiles);     // (a workgroup keeps <= 64 tile masks in LDS)
   return ntiles < g ? ntiles : g;
 }
@@ -423,17 +423,15 @@ int spx_igemm_bwd_rows(const void *feat, const void *dout, const void *weight_t,
   // (the 8-wave form of C = 32 spills and affords a ring depth of one).  All four numbers sit near what the
   // gathered LINES cost -- a 64- (32-) byte row pulls a whole 128-byte line out of the L2 -- which is why neither
   // occupancy nor a deeper ring, fewer barriers or fewer LDS reads moved them.
-  const bool w8 = option_int("SPX_BWDN_WAVES", (C == 16 && K == 16) ? 8 : 4) == 8;
-#define SPX_BWDN(BF, CC, KK)                                                                                   \
-  do {                                                                                                         \
-    if (w8) hipLaunchKernelGGL((bwdn_kernel<BF, CC, KK, true>), dim3(G), dim3(512), smem, s, p);               \
-    else hipLaunchKernelGGL((bwdn_kernel<BF, CC, KK, false>), dim3(G), dim3(256), smem, s, p);                 \
-  } while (0)
+  // 8 waves at C = K = 16 only; the 8-wave forms of the 32-channel shapes spilled (12-16 bytes of scratch per lane)
+  // and are no longer instantiated: every instantiation of this kernel runs without scratch
+#define SPX_BWDN(BF, CC, KK, W8)                                                                                \
+  hipLaunchKernelGGL((bwdn_kernel<BF, CC, KK, W8>), dim3(G), dim3(W8 ? 512 : 256), smem, s, p)
   const bool bf = dtype == SPX_BF16;
-  if (C == 16 && K == 16) { if (bf) SPX_BWDN(true, 16, 16); else SPX_BWDN(false, 16, 16); }
-  else if (C == 16 && K == 32) { if (bf) SPX_BWDN(true, 16, 32); else SPX_BWDN(false, 16, 32); }
-  else if (C == 32 && K == 16) { if (bf) SPX_BWDN(true, 32, 16); else SPX_BWDN(false, 32, 16); }
-  else { if (bf) SPX_BWDN(true, 32, 32); else SPX_BWDN(false, 32, 32); }
+  if (C == 16 && K == 16) { if (bf) SPX_BWDN(true, 16, 16, true); else SPX_BWDN(false, 16, 16, true); }
+  else if (C == 16 && K == 32) { if (bf) SPX_BWDN(true, 16, 32, false); else SPX_BWDN(false, 16, 32, false); }
+  else if (C == 32 && K == 16) { if (bf) SPX_BWDN(true, 32, 16, false); else SPX_BWDN(false, 32, 16, false); }
+  else { if (bf) SPX_BWDN(true, 32, 32, false); else SPX_BWDN(false, 32, 32, false); }
 #undef SPX_BWDN
   const int per = kv * K * C;
   if (bf) hipLaunchKernelGGL(bwdn_reduce_kernel<true>, dim3(div_up(per, 64)), dim3(kThreads), 0, s, p.partial, G,

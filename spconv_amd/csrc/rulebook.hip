@@ -1937,9 +1937,7 @@ int spx_subm_rulebook(const int32_t *indices, int n, int ndim, int batch_size,
   Table t;
   {
     hkey_t *keys = cv.take<hkey_t>(cap);
-    // SPX_SUBM_GBITS (experiment): 2^g neighbouring cells of the last axis share a table line
-    table_place(t, keys, cv.take<int32_t>(cap), cap, keys_fit_u32(g.batch, g.in_dims, 4),
-                cap >= 1024 ? option_int("SPX_SUBM_GBITS", 0) : 0);
+    table_place(t, keys, cv.take<int32_t>(cap), cap, keys_fit_u32(g.batch, g.in_dims, 4));
   }
   int32_t *blockcount = cv.take<int32_t>(static_cast<size_t>(kv) * nblk);
   int32_t *blockoff = cv.take<int32_t>(static_cast<size_t>(kv) * nblk);
@@ -2151,7 +2149,7 @@ int spx_conv_rulebook_count(const int32_t *indices, int n_in, int ndim, int batc
     return conv_count_impl(indices, n_in, ndim, batch_size, in_shape, out_shape, ksize, stride, padding,
                            dilation, transposed, ws, ws_bytes, nullptr, &overflow, 0, stream);
   const unsigned long long key = geometry_key(ndim, in_shape, ksize, stride, padding, dilation);
-  const size_t expect = option_int("SPX_CONV_TABLE_ADAPT", 1) ? expected_outputs(key, n_in) : 0;
+  const size_t expect = expected_outputs(key, n_in);
   int rc = conv_count_impl(indices, n_in, ndim, batch_size, in_shape, out_shape, ksize, stride, padding,
                            dilation, transposed, ws, ws_bytes, n_out_h, &overflow, expect, stream);
   if (rc) return rc;
@@ -2188,7 +2186,7 @@ int conv_fill_impl(const int32_t *indices, int n_in, int ndim, int batch_size,
   SPX_CHECK(pair_fwd && pair_bwd && out_indices, "out_indices, pair_fwd and pair_bwd are required");
   const int kv = g.kv, words = div_up(kv, 32);
   const int ngroups = div_up(n_in > 0 ? n_in : 1, kBlock);
-  static const int version = env_int("SPX_CONV_V", 2);          // tuning knob (A/B runs)
+  const int version = 2;
   // second form: the Native lists come from subm_lists_kernel (conv mode) over the 256-row pair counts
   // stage 2 leaves behind -- no count / scan launches, no -1 pre-fill of the lists
   const bool v2 = version >= 2 && (pair_native || num_per_loc) && ngroups <= 16384 && kv <= 128;

@@ -28,7 +28,7 @@ import numpy as np
 import torch
 
 from spconv_amd import _lib
-from spconv_amd.constants import BWD_OVERLAP, SPCONV_DO_SORT
+from spconv_amd.constants import SPCONV_DO_SORT
 from spconv_amd.pytorch.core import ConvAlgo, Rulebook
 
 INT32_MAX = 2147483647
@@ -827,33 +827,6 @@ def indice_conv(features: torch.Tensor, filters: torch.Tensor, indice_pairs: tor
                      kv // 2 if subm else -1, bias, act_type, act_alpha, tile_order=tile_order)
 
 
-_SIDE_STREAMS = {}
-
-
-def _side_stream(device) -> "torch.cuda.Stream":
-    key = torch.device(device).index
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
-    return _SIDE_STREAMS[key]
-
-
-def _backward_pair(dgrad_fn, wgrad_fn, ref: torch.Tensor):
-    """dgrad and wgrad only share read-only inputs: run wgrad on a side HIP stream so the two
-    (individually latency-bound) kernels overlap.  Works under hipGraph capture (fork/join
-    through events becomes two parallel graph branches)."""
-    if not BWD_OVERLAP:
-        return dgrad_fn(), wgrad_fn()
-    main = torch.cuda.current_stream(ref.device)
-    side = _side_stream(ref.device)
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        dw = wgrad_fn()
-    din = dgrad_fn()
-    main.wait_stream(side)
-    dw.record_stream(main)
-    return din, dw
-
-
 def indice_conv_backward(features: torch.Tensor, filters: torch.Tensor, out_bp: torch.Tensor,
                          indice_pairs: torch.Tensor, indice_pair_num: torch.Tensor,
                          inverse: bool = False, subm: bool = False,
@@ -875,14 +848,12 @@ def indice_conv_backward(features: torch.Tensor, filters: torch.Tensor, out_bp: 
         native = rb.native_swapped() if rb is not None else torch.stack(
             [indice_pairs[1], indice_pairs[0]]).contiguous()
     plan = _plan_of(rb)
-    if (native.shape[2] == n_in and not BWD_OVERLAP) or not need_din:
+    if native.shape[2] == n_in or not need_din:
         return igemm_bwd(features, out_bp, filters, table, mask, argsort, native, indice_pair_num,
                          subm, plan, need_din, tile_order=tile_order,
                          dense_rows=_dense_rows(rb, n_in, which) if rb is not None else False)
-    return _backward_pair(
-        lambda: igemm_dgrad(out_bp, filters, table, mask, argsort, n_in, subm, tile_order=tile_order),
-        lambda: igemm_wgrad(features, out_bp, filters.shape, native, indice_pair_num, subm, plan),
-        features)
+    return (igemm_dgrad(out_bp, filters, table, mask, argsort, n_in, subm, tile_order=tile_order),
+            igemm_wgrad(features, out_bp, filters.shape, native, indice_pair_num, subm, plan))
 
 
 def implicit_gemm(features: torch.Tensor, filters: torch.Tensor, pair_fwd: torch.Tensor,
@@ -950,14 +921,12 @@ def implicit_gemm_backward(features: torch.Tensor, filters: torch.Tensor, out_bp
         argsort = rb.argsort_bwd if rb is not None else None
         if rb is not None and pair_bwd is rb.pair_bwd:
             table, mask, argsort, tile_order = tables_of(rb, "bwd", filters.shape[-1])
-    if (native.shape[2] == n_in and not BWD_OVERLAP) or not need_din:
+    if native.shape[2] == n_in or not need_din:
         return igemm_bwd(features, out_bp, filters, table, mask, argsort, native, num, is_subm, plan,
                          need_din, tile_order=tile_order,
                          dense_rows=_dense_rows(rb, n_in, "fwd" if is_subm else "bwd"))
-    return _backward_pair(
-        lambda: igemm_dgrad(out_bp, filters, table, mask, argsort, n_in, is_subm, tile_order=tile_order),
-        lambda: igemm_wgrad(features, out_bp, filters.shape, native, num, is_subm, plan),
-        features)
+    return (igemm_dgrad(out_bp, filters, table, mask, argsort, n_in, is_subm, tile_order=tile_order),
+            igemm_wgrad(features, out_bp, filters.shape, native, num, is_subm, plan))
 
 
 # ------------------------------------------------------------------ pooling

@@ -26,7 +26,7 @@ def main():
     n = idx.shape[0]
     f = torch.randn(n, C, device=dev).half()
     w = (torch.randn(C, 3, 3, 3, C, device=dev) * 0.1).half()
-    res = {"lib": os.environ.get("SPX_LIB", "default"), "v4dbg": os.environ.get("SPX_V4_DBG", "0"), "C": C}
+    res = {"lib": os.environ.get("SPX_LIB", "default"), "C": C}
     span = 0 if os.environ.get("PROBE_EAGER") == "1" else 8
     res["v4_fwd_us"] = round(1e3 * bench.event_time_ms(
         lambda i: ops.igemm_fwd(f, w, rb.pair_fwd, rb.mask_fwd, None, n, 13), span=span), 2)

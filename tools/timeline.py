@@ -57,7 +57,7 @@ def main():
                             tile_order=to) if i8 else ops.igemm_fwd(f, w, pair, mask, order, n, 13, tile_order=to))
     buf = np.zeros((8192, 8), dtype=np.uint64)
     _lib.check(getter(buf.ctypes.data))
-    mb = int(os.environ.get("SPX_GEMM_MB", "2"))
+    mb = 2 if n > 32 * 1024 else 1                 # the library's tile-height rule (csrc/igemm.hip dispatch_gather_gemm)
     ntiles = (n + 64 * mb - 1) // (64 * mb)
     if i8:
         ntiles = (n + 127) // 128

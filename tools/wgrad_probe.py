@@ -31,7 +31,7 @@ for k in range(27):
     shuf[0, k, :cnt[k]] = nat[0, k, :cnt[k]][p]
     shuf[1, k, :cnt[k]] = nat[1, k, :cnt[k]][p]
 plan = ops.wgrad_plan(rb.num_per_loc, n, 27, True)
-res = {"n": n, "pairs": pairs, "G": os.environ.get("SPX_WGRAD_G", "default"), "var": os.environ.get("SPX_WGRAD_VAR", "0")}
+res = {"n": n, "pairs": pairs, "var": os.environ.get("SPX_WGRAD_VAR", "0")}
 PMC = os.environ.get("PROBE_PMC") == "1"
 for C in ((int(os.environ["PROBE_C"]),) if "PROBE_C" in os.environ else (16, 32, 64)):
     f = torch.randn(n, C, device=dev).half()
