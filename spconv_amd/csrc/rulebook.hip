@@ -260,11 +260,17 @@ void table_fill(FillList &f, const Table &t);
 __global__ void __launch_bounds__(kBlock)
 subm_insert_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table t,
                    int32_t *__restrict__ slot_of, uint32_t *__restrict__ mask_zero = nullptr,
-                   int words = 0) {
+                   int words = 0, int32_t *__restrict__ fill_fwd = nullptr, int32_t *__restrict__ fill_bwd = nullptr) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   if (mask_zero)      // the probe kernel ORs bits into the masks: clear them here (no fill launch)
     for (int w = 0; w < words; ++w) mask_zero[static_cast<size_t>(i) * words + w] = 0u;
+  // the half of the tables that only receives scattered mirror entries starts as -1: written here, by the row's
+  // own thread (coalesced along the rows), instead of by the fill launch -- whose job shrinks to the hash table
+  if (fill_fwd)
+    for (int k = 0; k < g.kv / 2; ++k) fill_fwd[static_cast<size_t>(k) * n + i] = -1;
+  if (fill_bwd)
+    for (int k = g.kv / 2 + 1; k < g.kv; ++k) fill_bwd[static_cast<size_t>(k) * n + i] = -1;
   int b, c[4];
   read_row(indices, i, g.ndim, b, c);
   // rows with a batch index outside [0, batch) ("deleted" points, docs/USAGE.md:150)
@@ -1951,21 +1957,15 @@ int spx_subm_rulebook(const int32_t *indices, int n, int ndim, int batch_size,
   // third form: fills (table, lower half of pair_fwd [+ pair_bwd's upper half]) -> insert (+ mask
   // clear) -> probe4 (block-local list counts) -> lists: 4 launches, 11 MB of fills instead of 34
   if (kv > 1 && kv <= 128 && nblk256 <= 16384) {
-    FillList fills;
-    table_fill(fills, t);
-    {
-      const size_t half = sizeof(int32_t) * static_cast<size_t>(kv / 2) * n;      // rows k < centre
-      fills.add(pair_fwd, half, 0xFFFFFFFFu);
-      // pair_bwd[kv-1-kk] mirrors pair_fwd[kk]: its rows above the centre are the scattered ones
-      if (pair_bwd) fills.add(pair_bwd + static_cast<size_t>(kv / 2 + 1) * n, half, 0xFFFFFFFFu);
-    }
+    FillList fills;                    // the hash table only: the -1 halves of the tables ride in the insert kernel
+    table_fill(fills, t);              // (pair_fwd rows k < centre; pair_bwd[kv-1-kk] mirrors pair_fwd[kk]: its rows above)
     SPX_HIP(fills.launch(s));
     // masks from a pass over the finished table instead of one atomicOr per entry: the extra launch costs 5-10 us at
     // 100 k voxels, the saved atomics (20-25 G/s device-wide) win from ~250 k (400 k: 162 -> 151 us); -1 = by size
     const int mp_opt = option_int("SPX_SUBM_MASK_PASS", -1);
     const int mask_pass = mp_opt < 0 ? (n >= 250000 ? 1 : 0) : mp_opt;
     hipLaunchKernelGGL(subm_insert_kernel, grid, dim3(kBlock), 0, s, indices, n, g, t, slot_of,
-                       mask_pass ? static_cast<uint32_t *>(nullptr) : mask, words);
+                       mask_pass ? static_cast<uint32_t *>(nullptr) : mask, words, pair_fwd, pair_bwd);
     const bool lists = pair_native || num_per_loc;
     hipLaunchKernelGGL(subm_probe4_kernel, dim3(div_up(n, kBlock), kv / 2 + 1), dim3(kBlock), 0, s, indices, n,
                        g, t, slot_of, pair_fwd, pair_bwd, mask, words, lists ? groupcount : nullptr, nblk256, mask_pass);

@@ -340,7 +340,8 @@ class SparseConvolution(SparseModule):
                                                self.stride, self.padding, self.dilation,
                                                self.output_padding, self.subm, self.transposed,
                                                do_sort=False if static else MODULE_DO_SORT,
-                                               need_native=torch.is_grad_enabled() or self.algo == ConvAlgo.Native,
+                                               need_native=self._needs_native_lists(features, indices, batch_size,
+                                                                                      spatial_shape),
                                                static_num_out=static)
                 self._static_n_out_dev = rb.n_out_dev
                 rb.in_n_live_dev = getattr(input, "n_live_dev", None)
@@ -384,14 +385,31 @@ class SparseConvolution(SparseModule):
                           getattr(input, "n_live_dev", None) if self.subm else rb.out_n_live_dev)
         return out
 
+    def _needs_native_lists(self, features, indices, batch_size, spatial_shape) -> bool:
+        """The ConvAlgo.Native lists (and the range plan built from them) feed the pair-list weight gradient; an
+        inference pass does not need them, and neither does a SubM layer whose backward takes the rows walk (16 / 32
+        channels on a dense level: ops.rows_backward_expected).  Left out of the build, they are derived from the
+        table if something asks for them later (Rulebook.pair_native)."""
+        if self.algo == ConvAlgo.Native:           # the lists ARE this algorithm's rulebook (IndiceData)
+            return True
+        if not torch.is_grad_enabled():
+            return False
+        if self.subm and not self.inverse:
+            kv = int(np.prod(self.kernel_size))
+            if ops.rows_backward_expected(features.dtype, self.in_channels, self.out_channels, kv, indices.shape[0],
+                                          batch_size, spatial_shape):
+                return False
+        return True
+
     def _run_kernels(self, grad_path, is_int8, input, features, weight, rb, num_out, algo, bias_for_infer,
                      act_type, act_alpha, act_beta, output_scale, channel_scale, add_input):
         if grad_path:
             # autograd path; bias is added outside the kernel like the reference
-            pair_native = ops.attach_rulebook(rb.pair_native, rb)
+            pair_native, pair_num = (ops.attach_rulebook(rb.pair_native, rb), rb.num_per_loc) if self.inverse \
+                else rb.native_handle()
             fn = (Fsp.indice_subm_conv if self.subm
                   else Fsp.indice_inverse_conv if self.inverse else Fsp.indice_conv)
-            out_features = fn(features, weight, pair_native, rb.num_per_loc, num_out, algo)
+            out_features = fn(features, weight, pair_native, pair_num, num_out, algo)
         elif is_int8:
             # quantised inference (conv.py:463-490): add + activation are fused in the kernel
             out_features, _, _ = ops.implicit_gemm(

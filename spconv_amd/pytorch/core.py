@@ -85,6 +85,22 @@ class Rulebook:
             self._pair_native, self._num_per_loc = ops._native_from_table(table, self.subm)
 
     @property
+    def has_native(self) -> bool:
+        """The ConvAlgo.Native lists exist already (built with the rulebook or derived since)."""
+        return self._pair_native is not None
+
+    def native_handle(self):
+        """(pair tensor, count tensor) to pass through the reference-shaped op signatures: the Native lists when
+        they exist, else EMPTY placeholders [2, kv, 0] / [0] that carry the rulebook (ops.attach_rulebook) -- the
+        ops resolve what they need from it and derive the lists only if a kernel asks for them."""
+        from spconv_amd.pytorch import ops
+        if self._pair_native is not None:
+            return ops.attach_rulebook(self._pair_native, self), self._num_per_loc
+        dev = self.pair_fwd.device
+        return (ops.attach_rulebook(torch.empty((2, self.kv, 0), dtype=torch.int32, device=dev), self),
+                torch.empty((0,), dtype=torch.int32, device=dev))
+
+    @property
     def pair_native(self) -> torch.Tensor:
         self._ensure_native()
         return self._pair_native

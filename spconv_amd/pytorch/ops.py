@@ -661,10 +661,12 @@ def igemm_bwd(features: torch.Tensor, out_bp: torch.Tensor, filters: torch.Tenso
               table: torch.Tensor, mask: Optional[torch.Tensor], argsort: Optional[torch.Tensor],
               native: torch.Tensor, num_per_loc: torch.Tensor, subm: bool,
               plan: Optional[torch.Tensor] = None, need_din: bool = True,
-              tile_order: int = 0, dense_rows: bool = False):
+              tile_order: int = 0, dense_rows: bool = False, lists=None):
     """(din, dW) of one layer from one launch (+ the wgrad second stage).  need_din=False (the
     input does not require grad: a network's first layer) computes dW only and returns None.
-    `table` / `mask` are row-order tables unless tile_order == 1 (see tables_of)."""
+    `table` / `mask` are row-order tables unless tile_order == 1 (see tables_of).  `native` may be None
+    when `lists` is given: a callable returning (native, num_per_loc, plan), asked only if the pair-list
+    weight gradient runs (the rows walk of narrow layers needs none of the three)."""
     _check_feat(out_bp, filters)
     K0, C0 = filters.shape[0], filters.shape[-1]
     m = _lane_mult(out_bp.dtype)
@@ -675,6 +677,8 @@ def igemm_bwd(features: torch.Tensor, out_bp: torch.Tensor, filters: torch.Tenso
             and (argsort is None or tile_order == _ROWS_LAYOUT) and tile_order != 1):
         # (the rows walk reads the row-order tables: a rows layout does not concern it)
         return _igemm_bwd_rows(features, out_bp, filters, table, mask, subm, need_din, K0, C0, kvf)
+    if native is None:
+        native, num_per_loc, plan = lists()
     if not need_din or K0 % m or C0 not in _MFMA_COUT or kvf > 32:      # (kv > 32: dgrad in groups of 32 offsets)
         din = igemm_dgrad(out_bp, filters, table, mask, argsort, features.shape[0], subm,
                           tile_order=tile_order) if need_din else None
@@ -706,6 +710,24 @@ def igemm_bwd(features: torch.Tensor, out_bp: torch.Tensor, filters: torch.Tenso
 # SPCONV_AMD_BWD_ROWS: "auto" (default: occupancy >= _BWD_ROWS_OCC), "1" always, "0" never.
 _BWD_ROWS = {"0": False, "1": True}.get(os.environ.get("SPCONV_AMD_BWD_ROWS", "auto"), "auto")
 _BWD_ROWS_OCC = float(os.environ.get("SPCONV_AMD_BWD_ROWS_OCC", "0.003"))
+
+
+def rows_backward_expected(dtype: torch.dtype, cin: int, cout: int, kv: int, n_rows: int, batch_size: int,
+                           dims) -> bool:
+    """Will the backward of a layer with these shapes take the rows walk (igemm_bwdn.hip), which reads the dense
+    table and needs neither the Native lists nor the range plan?  The same rule as igemm_bwd / _dense_rows, usable
+    BEFORE the rulebook exists: a module asks it to decide whether its build has to produce the lists at all (a
+    layer that shares the rulebook and does need them derives them from the table on first use)."""
+    if _BWD_ROWS is False or dtype not in (torch.float16, torch.bfloat16):
+        return False
+    if cin not in (16, 32) or cout not in (16, 32) or kv > 27:
+        return False
+    if _BWD_ROWS is True:
+        return True
+    cells = float(batch_size)
+    for d in dims:
+        cells *= float(d)
+    return n_rows >= _BWD_ROWS_OCC * cells
 
 
 def _dense_rows(rb: Optional[Rulebook], n_rows: int, which: str) -> bool:
@@ -843,7 +865,15 @@ def indice_conv_backward(features: torch.Tensor, filters: torch.Tensor, out_bp: 
         table, mask, argsort, tile_order = tables_of(rb, which, filters.shape[-1])
     else:
         table, mask = _table_from_native(indice_pairs, indice_pair_num, n_in, subm, (not subm) and (not inverse))
-    native = indice_pairs
+    if rb is not None and not inverse and not rb.has_native:
+        # the build left the lists out (conv.py: _needs_native_lists): they -- and the range plan -- are derived
+        # only if the launch below turns out to need them
+        return igemm_bwd(features, out_bp, filters, table, mask, argsort, None, None, subm, None, need_din,
+                         tile_order=tile_order, dense_rows=_dense_rows(rb, n_in, which),
+                         lists=lambda: (rb.pair_native, rb.num_per_loc, _plan_of(rb)))
+    native = indice_pairs if (rb is None or indice_pairs.shape[2] > 0 or rb.n_in == 0) else rb.pair_native
+    if rb is not None and indice_pair_num.numel() != rb.kv:
+        indice_pair_num = rb.num_per_loc
     if inverse:
         native = rb.native_swapped() if rb is not None else torch.stack(
             [indice_pairs[1], indice_pairs[0]]).contiguous()

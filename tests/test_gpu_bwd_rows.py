@@ -170,3 +170,45 @@ def test_padded_rows_of_a_static_tensor(cuda):
     torch.cuda.synchronize()
     assert torch.equal(dinp[:n], din) and not bool(dinp[n:].any())
     assert rel_err(dwp.float().cpu().numpy(), dw.float().cpu().numpy()) <= 1e-3      # (another tile partition: summation order)
+
+
+def test_module_leaves_the_native_lists_out_when_the_rows_walk_runs(cuda):
+    """A 32-channel SubM layer on a dense level takes the rows walk in its backward pass: its rulebook build leaves
+    the ConvAlgo.Native lists (and the range plan) out, nothing derives them, and the gradients equal those of the
+    pair-list backward over lists built the usual way."""
+    import spconv_amd.pytorch as spconv
+    from spconv_amd.pytorch import ops
+    shape = [16, 40, 40]
+    idx = dense_scene(shape, 9000, 1, 4)
+    n = idx.shape[0]
+    assert n >= ops._BWD_ROWS_OCC * np.prod(shape)
+    torch.manual_seed(2)
+    net = spconv.SparseSequential(spconv.SubMConv3d(32, 32, 3, bias=False, indice_key="r"),
+                                  spconv.SubMConv3d(32, 32, 3, bias=False, indice_key="r")).to(cuda).half()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    f = (torch.rand((n, 32), generator=g) * 2 - 1).to(cuda).half()
+    dout = ((torch.rand((n, 32), generator=g) * 2 - 1) * 0.2).to(cuda).half()
+
+    def run():
+        net.zero_grad(set_to_none=True)
+        fe = f.clone().requires_grad_(True)
+        y = net(spconv.SparseConvTensor(fe, torch.from_numpy(idx).to(cuda), shape, 1))
+        y.features.backward(dout)
+        torch.cuda.synchronize()
+        return y.indice_dict["r"].rulebook, fe.grad.clone(), [p.grad.clone() for p in net.parameters()]
+    rb, din, dws = run()
+    assert not rb.has_native and rb.wgrad_plan is None, "the lists were built although nothing reads them"
+    saved = ops._BWD_ROWS
+    try:
+        ops._BWD_ROWS = False                      # pair-list backward: lists built inside the rulebook build
+        rb2, din2, dws2 = run()
+    finally:
+        ops._BWD_ROWS = saved
+    assert rb2.has_native
+    np.testing.assert_array_equal(rb.pair_fwd.cpu().numpy(), rb2.pair_fwd.cpu().numpy())
+    assert float((din.float() - din2.float()).abs().max()) <= 2e-3 * float(din2.float().abs().max())
+    for a, b in zip(dws, dws2):
+        assert float((a.float() - b.float()).abs().max()) <= 3e-3 * float(b.float().abs().max())
+    # asked for afterwards (reference-shaped API), the lists are derived from the table and equal the built ones
+    np.testing.assert_array_equal(rb.pair_native.cpu().numpy(), rb2.pair_native.cpu().numpy())
+    np.testing.assert_array_equal(rb.num_per_loc.cpu().numpy(), rb2.num_per_loc.cpu().numpy())

@@ -250,6 +250,35 @@ def test_static_training_step_with_subm_and_batchnorm(cuda):
     assert rel < 2e-2, rel
 
 
+def test_static_training_step_fp32_is_a_bound_not_a_noise_floor(cuda):
+    """The captured step against the eager step in fp32 (at fp16 the check through 12 BatchNorm
+    layers is a noise-floor argument).  In fp32 only summation orders differ (statistics over padded blocks, weight-
+    gradient ranges cut by a different row count): every parameter gradient within 2e-4, the output within 1e-5."""
+    import spconv_amd.pytorch as spconv
+    from spconv_amd.pytorch.static import StaticTrainingStep, strided_layers
+    shape, bs, C = [32, 40, 40], 2, 8
+    net = _backbone(spconv, C, cuda, torch.float32).train()
+    eager = copy.deepcopy(net)
+    names = list(strided_layers(net))
+    g = (torch.rand((1_700, 64), device=cuda) - 0.5) * 0.2
+    f, idx = _scene_tensors(shape, 4000, bs, C, 1, cuda, torch.float32)
+    step = StaticTrainingStep(net, 9_000, C, shape, bs, torch.float32, bounds={names[0]: 13_000, names[1]: 1_700},
+                              out_grad=g, input_grad=True, example=(f, idx))
+    out = step(f, idx)
+    fe = f.clone().requires_grad_(True)
+    ye = eager(spconv.SparseConvTensor(fe, idx, shape, bs))
+    n_out = ye.features.shape[0]
+    ye.features.backward(g[:n_out])
+    assert int(out.n_live_dev) == n_out and torch.equal(out.indices[:n_out], ye.indices)
+    err = float((out.features[:n_out] - ye.features).abs().max() / ye.features.abs().max())
+    assert err < 1e-5, err
+    for (name, pa), pb in zip(net.named_parameters(), eager.parameters()):
+        rel = float((pa.grad - pb.grad).norm() / pb.grad.norm().clamp_min(1e-20))
+        assert rel < 2e-4, (name, rel)
+    rel = float((step.features.grad[:f.shape[0]] - fe.grad).norm() / fe.grad.norm())
+    assert rel < 2e-4, rel
+
+
 @pytest.mark.parametrize("pool", [False, True])
 def test_static_training_step_runner(cuda, pool):
     """StaticTrainingStep: one graph, several scenes; parameter gradients of every replay against the eager step.
