@@ -854,7 +854,7 @@ def run_int8(args, D: Dist):
         pair, mask, order, to = ops.tables_of(rb, "fwd", K)
         return ops.igemm_fwd_int8(f, w, pair, mask, order, n, 13, scale, bias, None, 0.0,
                                   torch.int8, ops.Activation.ReLU, 0.0, tile_order=to,
-                                  sparse_hint=rb.sparse_class is True)
+                                  sparse_hint=rb.sparse_class is True, hint_rows=getattr(rb, "heavy_rows", 0))
     graphs = None
     if not args.no_graph:
         try:

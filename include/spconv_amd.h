@@ -229,25 +229,31 @@ int spx_permute_tables(const int32_t *pair, const uint32_t *mask, const int32_t 
  * implicit-GEMM tiles skip the offsets none of their rows has.  spx_subm_layout does that job INSIDE
  * the rulebook build -- no sort, nothing read back: the masks of the finished tables are classified
  * on the device and, for a SPARSE rulebook (fewer than a quarter of the rows have any neighbour), the
- * rows are regrouped by a stable counting partition (wave ballots + prefix sums): rows that only
- * have their centre pair first, in their order, then the rows with neighbours grouped by their lowest
- * neighbour offset.  A DENSE rulebook (LiDAR) keeps its row order (regrouping loses there).
- * The result is ONE int32 blob the gather-GEMM reads (pass it as `argsort` with tile_order =
- * SPX_ROWS_LAYOUT; spx_igemm_fwd_int8: OR SPX_ROWS_LAYOUT_ACT into `act`):
- *   [0] class: 1 = regrouped, 0 = identity order     [1] rows with a neighbour   [2] n   [3] kv
- *   [64, 64 + npad)            order:  tile position t -> row            (npad = n rounded up to 64)
- *   [64 + npad, 64 + 2 npad)   mask words in tile order
- *   [64 + 2 npad, ... + kv n)  pair table in tile order -- class 1 only, and only the columns of the
- *                              rows with a neighbour (+ the 256 positions ahead of them) are written:
- *                              a tile of centre-only rows never reads its table.  Class 0: the
- *                              kernels read the caller's row-order `pair` (selected on the device).
- * The class word stays on the device: a launch is the same for both classes (hipGraph-safe). */
+ * rows WITH a neighbour are taken out of the row-order walk into a compact appendix, grouped by their
+ * lowest neighbour offset (a stable counting partition: wave ballots + prefix sums).  The gather-GEMM
+ * then runs the rows in their own order with the CENTRE pair only -- a plain streaming GEMM: no row
+ * order to fetch, no pair word, one step per tile -- and a handful of appendix tiles with all their
+ * offsets.  A DENSE rulebook (LiDAR) keeps everything in the row-order walk (regrouping loses there).
+ * The result is ONE int32 blob (pass it as `argsort` with tile_order = SPX_ROWS_LAYOUT;
+ * spx_igemm_fwd_int8: OR SPX_ROWS_LAYOUT_ACT into `act`; `pair` / `mask` stay the row-order tables):
+ *   [0] class: 1 = appendix in use, 0 = none   [1] M = rows with a neighbour   [2] n   [3] kv   [4] mcap
+ *   main mask  [npad]       row-order mask words; class 1: ZERO for the rows that moved to the appendix
+ *                           (a zero mask word means: not this tile's row, nothing stored)
+ *   order      [mcap]       appendix position -> row       (first M entries; class 1 only)
+ *   mask       [mcap]       mask words of those rows
+ *   pair       [kv, mcap]   their pair words
+ *   npad = n rounded up to 64, mcap = spx_subm_layout_mcap(n) >= n / 4 + 256.
+ * The launch is the same for both classes (hipGraph-safe): ceil(n / 4 / tile rows) appendix workgroups
+ * lead the grid, read {class, M} and leave at once when there is nothing for them. */
+size_t spx_subm_layout_mcap(int n);
 #define SPX_ROWS_LAYOUT 2
 #define SPX_ROWS_LAYOUT_ACT 0x400
 /* OR-ed into `act` of spx_igemm_fwd_int8 next to SPX_ROWS_LAYOUT_ACT: the HOST knows the class word is 1 (it may
  * read it once per rulebook, outside any timed or captured region) -- a launch-shape hint only: 64-row instead
  * of 128-row tiles at 128 output channels (the role of the reference's per-problem tuner cache,
- * csrc/sparse/convops.py:1150,1283-1297).  Results never depend on it. */
+ * csrc/sparse/convops.py:1150,1283-1297).  Bits 16..31 of `act` may then carry ceil(M / 64), M = the blob's
+ * word [1]: only that many appendix rows get workgroups (instead of the n / 4 the class rule allows).
+ * Results never depend on either. */
 #define SPX_SPARSE_HINT 0x800
 #define SPX_LAYOUT_HEADER 64
 size_t spx_subm_layout_bytes(int n, int kv);

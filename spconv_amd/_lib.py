@@ -42,6 +42,7 @@ SIGNATURES = {
     "spx_conv_rulebook_static": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
                                  + [c_int_p] * 6 + [ctypes.c_int, ctypes.c_int] + [vp] * 8
                                  + [vp, ctypes.c_size_t, vp]),
+    "spx_subm_layout_mcap": (ctypes.c_size_t, [ctypes.c_int]),
     "spx_subm_layout_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "spx_subm_layout_ws_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "spx_subm_layout": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_size_t, vp]),

@@ -122,15 +122,13 @@ __device__ __forceinline__ void unpack_gemm_args(GemmParams &p, const void *argA
   p.out_dtype = rest.out_dtype;
   p.dbg = rest.dbg;
   p.xcd_rot = 0;
-  // rows layout (bit 12): everything derives from the preloaded arguments -- `argsort` points at the blob's order
-  // array (64 words behind its class word, 2 * npad ahead of its tile-order pair table), `pair` is the row-order table
+  p.app_rows = rest.napp;      // (the body reads it as a workgroup count)
+  // rows layout (bit 12): `mask` = the blob's main mask words, `argsort` = the appendix' row list (its mask words and
+  // pair table lie behind it, the class word and M npad + 64 words ahead of it), `pair` = the row-order table
   p.cls = nullptr;
-  p.pair_rows = nullptr;
   if ((b_reverse >> 12) & 1) {
     const size_t npad = (static_cast<size_t>(n_dst) + 63) & ~static_cast<size_t>(63);
-    p.cls = arg_argsort - SPX_LAYOUT_HEADER;
-    p.pair_rows = arg_pair;
-    p.pair = arg_argsort + 2 * npad;
+    p.cls = arg_argsort - npad - SPX_LAYOUT_HEADER;
   }
 }
 
@@ -160,12 +158,6 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   SPX_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntiles = (p.n_dst + TM - 1) / TM;
-  // Rows layout (spx_subm_layout): the class of the rulebook is a DEVICE word -- 1: rows regrouped, tables in tile
-  // order; 0: identity order, the pair table is the row-order one.  It rides at the head of the vector-memory queue
-  // (loads return in order: the wait for the mask words below covers it, no trip of its own) and is consumed where
-  // the first pair words are requested; `order` and the mask words come from the blob in both classes.  Unconditional
-  // (a launch without a layout reads a zero-sized resource) so that the counted waits stay exact.
-  const uint32_t cls_raw = __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(p.cls, p.cls ? 4u : 0u), 0, 0, 0);
   // Tables in tile order = rows sorted by mask word: the tiles at the END hold the rows with the most
   // offsets (the identity-only rows sort first), and a launch lasts as long as its slowest workgroup.
   // Those tiles are handed to the FIRST blocks (longest work first), one after the other to different
@@ -174,15 +166,32 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   // Only when the launch has more tiles than resident workgroups (the host sets `lpt`): a single-round
   // launch keeps the XCD mapping, which lets the dgrad tiles and the wgrad ranges of one row eighth share
   // the gradient rows in one L2 (config 2 backward: 57 vs 67 MB of HBM traffic).
-  // (a launch of that size over a layout blob waits for the class word here: identity order keeps the XCD ranges)
+  // Rows layout (spx_subm_layout): the first `napp` workgroups of the launch are APPENDIX tiles -- the rows of a sparse
+  // rulebook that have a neighbour, grouped by offset, with their own compact tables; they read {class, M} and leave at
+  // once when there is nothing for them (a dense rulebook, or fewer rows than reserved).  They lead the grid because
+  // they are the long tiles.  Every other workgroup is a MAIN tile: rows in their own order, masks from the blob -- on a
+  // sparse rulebook those only carry the centre bit (a zero word = the row moved to the appendix: nothing stored), so a
+  // main tile is ONE step with no row order and no pair word to fetch; on a dense one they are the rulebook's masks.
+  const int napp = p.cls ? (p.app_rows >= 0 ? p.app_rows : layout_app_tiles(p.n_dst, TM)) : 0;
+  const bool app = block < napp;                                   // (uniform)
+  int app_m = 0;
   int tile;
-  if (p.tile_order && p.lpt) {
-    typedef const int32_t __attribute__((address_space(4))) *cls_ptr_t;
-    const int big_cls = p.cls ? *(cls_ptr_t)(p.cls) : 1;           // (a blocking scalar load, multi-round launches only)
-    tile = big_cls ? ntiles - 1 - block : xcd_tile(block, ntiles);
+  if (app) {
+    typedef const int32_t __attribute__((address_space(4))) *cptr_t;
+    const int cls = *(cptr_t)(p.cls);
+    app_m = *(cptr_t)(p.cls + 1);
+    if (!cls || block * TM >= app_m) return;
+    tile = block;
   } else {
-    tile = p.xcd_rot ? xcd_tile_rot(block, ntiles, p.xcd_rot) : xcd_tile(block, ntiles);
+    const int bid = block - napp;
+    const int rot = (p.xcd_rot + napp) & 7;                        // workgroup bid runs on XCD (bid + rot) % 8
+    tile = (p.tile_order && p.lpt) ? ntiles - 1 - bid : (rot ? xcd_tile_rot(bid, ntiles, rot) : xcd_tile(bid, ntiles));
   }
+  const int mcap = layout_mcap(p.n_dst);
+  const int32_t *order_app = p.argsort;                            // (layout launches only)
+  const uint32_t *maskp = app ? reinterpret_cast<const uint32_t *>(order_app + mcap) : p.mask;
+  const int32_t *pairp = app ? order_app + 2 * static_cast<size_t>(mcap) : p.pair;
+  const int tbl_rows = app ? mcap : p.n_dst;                       // row stride of the pair table in use
   const int lrow = lane & 15, lgrp = lane >> 4;
   const int slot = tid & 7, r0 = tid >> 3;
   // Output-channel permutation: MFMA row (g = i >> 2, e = i & 3) of channel block nb carries
@@ -200,8 +209,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
 
   const uint32_t a_bytes = static_cast<uint32_t>(p.n_src) * rowB;
   const uint32_t w_bytes = static_cast<uint32_t>(p.COUT) * p.kv * rowB;
-  const uint32_t pair_bytes = static_cast<uint32_t>(p.n_dst) * 4u;
-  const int32_t *pairp = p.pair;     // (rows layout: the class picks the table once the mask words are in, below)
+  const uint32_t pair_bytes = static_cast<uint32_t>(tbl_rows) * 4u;
 
   // rows of this lane: tile rows wave*16*MB + mb*16 + lrow
   int grow[MB];
@@ -210,9 +218,14 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   for (int mb = 0; mb < MB; ++mb) {
     const int t = tile * TM + (wave * MB + mb) * 16 + lrow;
     int g = -1;
-    if (t < p.n_dst) g = p.argsort ? p.argsort[t] : t;
+    if (app) {
+      if (t < app_m) g = order_app[t];                              // appendix position -> row
+      goff[mb] = g < 0 ? kOob : static_cast<uint32_t>(t) * 4u;
+    } else {
+      if (t < p.n_dst) g = (p.argsort && !p.cls) ? p.argsort[t] : t;
+      goff[mb] = g < 0 ? kOob : static_cast<uint32_t>(p.tile_order ? t : g) * 4u;
+    }
     grow[mb] = g;
-    goff[mb] = g < 0 ? kOob : static_cast<uint32_t>(p.tile_order ? t : g) * 4u;
   }
 
   // per-thread constant offsets.  *_tail is the out-of-range bit to OR in for the last
@@ -265,7 +278,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   auto load_idx = [&](const StepIt &it, auto SET) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
     const int k = it.k < 0 ? 0 : it.k;
-    const __amdgpu_buffer_rsrc_t rP = make_rsrc(pairp + static_cast<size_t>(k) * p.n_dst,
+    const __amdgpu_buffer_rsrc_t rP = make_rsrc(pairp + static_cast<size_t>(k) * tbl_rows,
                                                 (pairp && it.k >= 0) ? pair_bytes : 0u);
     // the identity select happens where the words are consumed (load_a): selecting here would
     // make the loop-carried value depend on the load and park the wave on it at the loop end
@@ -353,7 +366,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   it0.rest = 0;
   // the mask words head the longest dependency chain of the tile (mask -> pair words -> rows):
   // request them first, so they are not queued behind the 24 KB of identity-step loads
-  const __amdgpu_buffer_rsrc_t rM = make_rsrc(p.mask, p.mask ? pair_bytes * p.mask_words : 0u);
+  const __amdgpu_buffer_rsrc_t rM = make_rsrc(maskp, maskp ? pair_bytes * p.mask_words : 0u);
   uint32_t mraw[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
@@ -372,7 +385,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   uint32_t wm = 0;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) wm |= mraw[mb];         // rows past the end read 0
-  if (!p.mask) wm = 0xffffffffu;
+  if (!maskp) wm = 0xffffffffu;
   wm |= __shfl_xor(wm, 1, 64);
   wm |= __shfl_xor(wm, 2, 64);
   wm |= __shfl_xor(wm, 4, 64);
@@ -391,8 +404,13 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   }
   __syncthreads();
   SPX_STAMP(2);   // mask words arrived, tile mask exchanged
-  // first use of the class word (it arrived ahead of the mask words)
-  if (p.cls && __builtin_amdgcn_readfirstlane(cls_raw) == 0) pairp = p.pair_rows;
+  // rows layout, main tile: a zero mask word marks a row that lives in the appendix -- its (centre-step) result is not
+  // this tile's to store
+  if (p.cls && !app) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+      if (mraw[mb] == 0u) grow[mb] = -1;
+  }
   uint32_t tilemask = lds_mask[0] | lds_mask[1] | lds_mask[2] | lds_mask[3];
   tilemask = __builtin_amdgcn_readfirstlane(tilemask);
   if (p.kv - p.kbase < 32) tilemask &= (1u << (p.kv - p.kbase)) - 1u;
@@ -685,15 +703,19 @@ GemmRest rest_of(const GemmParams &p);
 template <int COUT, int MB, int DT>
 int launch_v4(const GemmParams &p, hipStream_t s) {
   const int ntiles = div_up(p.n_dst, 64 * MB);
+  // rows layout: appendix workgroups lead the grid -- as many as the class rule allows rows (n / 4), or as many as the
+  // host says there are (app_rows, SPX_SPARSE_HINT)
+  const int napp = p.cls ? (p.app_rows > 0 ? div_up(p.app_rows, 64 * MB) : layout_app_tiles(p.n_dst, 64 * MB)) : 0;
   GemmParams q = p;
   // more tiles than workgroups the chip holds at once (4 per CU up to 64 output channels, fewer beyond)
   q.lpt = p.tile_order && ntiles > ((DT == 2 || COUT > 64) ? 512 : 1024);
-  const GemmRest r = rest_of(p);
+  GemmRest r = rest_of(p);
+  r.napp = (p.cls && p.app_rows > 0) ? napp : -1;
   constexpr int es = DT == 2 ? 1 : (DT == 3 ? 4 : 2);
   const bool half = p.CIN * es <= 64;        // narrow rows: only the first 64 bytes of a piece exist
 #define SPX_LAUNCH_V4(BTV, NKSV)                                                                     \
-  hipLaunchKernelGGL((igemm_v4_kernel<COUT, MB, DT, BTV, NKSV>), dim3(ntiles), dim3(kThreads),          \
-                     (v4_smem_bytes<COUT, MB, DT>()), s, p.A, p.B, p.mask, p.argsort, (p.cls ? p.pair_rows : p.pair), p.n_dst,  \
+  hipLaunchKernelGGL((igemm_v4_kernel<COUT, MB, DT, BTV, NKSV>), dim3(napp + ntiles), dim3(kThreads),   \
+                     (v4_smem_bytes<COUT, MB, DT>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,  \
                      p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(q), r)
   if (DT == 2 || p.strideD == 1) {
     if (half) SPX_LAUNCH_V4(false, 1);
@@ -1887,6 +1909,7 @@ GemmRest rest_of(const GemmParams &p) {
   r.dbg = dbg | p.dbg;
   r.acc = p.acc;
   r.acc_mode = p.acc_mode;
+  r.napp = -1;
   return r;
 }
 
@@ -1901,18 +1924,18 @@ constexpr size_t bwd_smem_bytes() {
 
 template <int COUT, int MB, int DT>
 int launch_bwd(const GemmParams &p, const Wgrad2Params &q, int n_wgrad_blocks, hipStream_t s) {
-  const int n_dgrad = div_up(p.n_dst, 64 * MB);
+  const int n_dgrad = div_up(p.n_dst, 64 * MB) + (p.cls ? layout_app_tiles(p.n_dst, 64 * MB) : 0);
   constexpr int wgrad_first = 1;           // (the longer chains are dispatched first: settled A/B)
   GemmParams pl = p;
   pl.lpt = p.tile_order && n_dgrad + n_wgrad_blocks > 1024;           // (see launch_v4)
   if (p.CIN * (DT == 3 ? 4 : 2) <= 64)     // dgrad's reduction rows (dout channels) fit half a piece
     hipLaunchKernelGGL((igemm_bwd_kernel<COUT, MB, DT, 1>), dim3(n_dgrad + n_wgrad_blocks), dim3(kThreads),
-                       (bwd_smem_bytes<COUT, MB, DT>()), s, p.A, p.B, p.mask, p.argsort, (p.cls ? p.pair_rows : p.pair), p.n_dst,
+                       (bwd_smem_bytes<COUT, MB, DT>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,
                        p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(pl), rest_of(p),
                        wgrad_first ? ~n_wgrad_blocks : n_dgrad, q);
   else
     hipLaunchKernelGGL((igemm_bwd_kernel<COUT, MB, DT, 2>), dim3(n_dgrad + n_wgrad_blocks), dim3(kThreads),
-                       (bwd_smem_bytes<COUT, MB, DT>()), s, p.A, p.B, p.mask, p.argsort, (p.cls ? p.pair_rows : p.pair), p.n_dst,
+                       (bwd_smem_bytes<COUT, MB, DT>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,
                        p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(pl), rest_of(p),
                        wgrad_first ? ~n_wgrad_blocks : n_dgrad, q);
   SPX_LAUNCH_CHECK();
@@ -2010,8 +2033,8 @@ int spx_igemm_fwd_int8(const void *feat, const void *weight, void *out, const in
   p.identity_k = identity_k;
   p.b_reverse = 0;
   apply_rows_layout(p, (act & SPX_ROWS_LAYOUT_ACT) ? SPX_ROWS_LAYOUT : ((act & SPX_TILE_ORDER) ? 1 : 0));
-  const bool hinted = p.cls && (act & SPX_SPARSE_HINT);
-  if (hinted) p.cls = nullptr;     // the host has seen class word 1: the blob's tables ARE tables in tile order, no device read
+  const bool hinted = p.cls && (act & SPX_SPARSE_HINT);   // the host has seen class word 1: a launch-shape hint
+  if (hinted) p.app_rows = ((act >> 16) & 0xffff) * 64;   // ... and M (in units of 64 rows, 0 = not told)
   p.act = act & 0xff;
   p.act_alpha = act_alpha;
   p.scale = scale;
@@ -2032,7 +2055,7 @@ int spx_igemm_fwd_int8(const void *feat, const void *weight, void *out, const in
       // instead of three: 27.3 -> 25.7 us at BASELINE config 5); dense neighbourhoods keep 128 rows (LiDAR-like
       // 200 k: 104 vs 113 us, fixture 74 vs 83 us).  SPX_I8_MB = 1 / 2 forces one.
       constexpr int forced = 0;
-      if (forced == 1 || (forced == 0 && p.tile_order && !p.cls)) return launch_v4<128, 1, 2>(p, s);
+      if (forced == 1 || (forced == 0 && (p.tile_order || hinted))) return launch_v4<128, 1, 2>(p, s);
       return launch_v4<128, 2, 2>(p, s);
     }
     case 256: return launch_v4<256, 1, 2>(p, s);

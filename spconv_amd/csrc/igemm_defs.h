@@ -55,30 +55,35 @@ struct GemmParams {
   int dbg;                // ablation builds only (-DSPX_ABLATE, tools/dense_probe.py)
   int xcd_rot;            // blocks of the launch ahead of this kernel body's first one, mod 8 (fused backward)
   int lpt;                // tables in tile order AND more tiles than resident workgroups: longest tiles first
-  // rows layout of a SubM rulebook (spx_subm_layout, tile_order = SPX_ROWS_LAYOUT): `argsort`, `mask`, `pair` point into
-  // the layout blob, `cls` at its class word -- 1: the rows are regrouped, tables in tile order; 0: identity order,
-  // the pair table is the caller's row-order one (`pair_rows`).  `mask_rows`: the caller's row-order mask words,
-  // for the paths that read their tables by row (generic kernels).
+  // rows layout of a SubM rulebook (spx_subm_layout, tile_order = SPX_ROWS_LAYOUT): the launch walks the rows in their
+  // own order with `mask` = the blob's MAIN mask words (zero for the rows that moved to the appendix) and `pair` = the
+  // caller's row-order table; `cls` points at the blob (class word, M), `argsort` at the appendix' row list, behind
+  // which its mask words and pair table lie.  `mask_rows`: the caller's row-order mask words, for the paths that
+  // take no layout (generic kernels).
   const int32_t *cls;
-  const int32_t *pair_rows;
   const uint32_t *mask_rows;
+  int app_rows;           // > 0: the HOST knows an upper bound of M (SPX_SPARSE_HINT): only that many appendix rows get
+                          // workgroups instead of the n / 4 the class rule allows
 };
+
+// appendix geometry (the same arithmetic in spx_subm_layout_mcap, rulebook.hip)
+__host__ __device__ inline int layout_mcap(int n) { return ((n / 4 + 63) & ~63) + 256; }
+// appendix workgroups that lead a launch of TM-row tiles: the class rule (4 M < n) bounds M by n / 4
+__host__ __device__ inline int layout_app_tiles(int n, int tm) { return (n / 4 + tm - 1) / tm; }
 
 // tile_order = SPX_ROWS_LAYOUT: the caller passed a layout blob as `argsort` (include/spconv_amd.h)
 inline void apply_rows_layout(GemmParams &p, int tile_order) {
   p.cls = nullptr;
-  p.pair_rows = nullptr;
   p.mask_rows = nullptr;
+  p.app_rows = 0;
   if (tile_order == SPX_ROWS_LAYOUT && p.argsort && p.pair && p.mask) {
     const int32_t *blob = p.argsort;
     const size_t npad = (static_cast<size_t>(p.n_dst) + 63) & ~static_cast<size_t>(63);
     p.cls = blob;
-    p.pair_rows = p.pair;
     p.mask_rows = p.mask;
-    p.argsort = blob + SPX_LAYOUT_HEADER;
-    p.mask = reinterpret_cast<const uint32_t *>(blob + SPX_LAYOUT_HEADER + npad);
-    p.pair = blob + SPX_LAYOUT_HEADER + 2 * npad;
-    p.tile_order = 1;
+    p.mask = reinterpret_cast<const uint32_t *>(blob + SPX_LAYOUT_HEADER);
+    p.argsort = blob + SPX_LAYOUT_HEADER + npad;
+    p.tile_order = 0;
   } else {
     p.tile_order = (tile_order == 1 && p.argsort) ? 1 : 0;
     if (tile_order == SPX_ROWS_LAYOUT) p.argsort = nullptr;       // (a blob without tables: row order)
@@ -88,7 +93,6 @@ inline void apply_rows_layout(GemmParams &p, int tile_order) {
 // back to the row-order tables (paths that do not read tables by tile position)
 inline void drop_rows_layout(GemmParams &p) {
   if (!p.cls) return;
-  p.pair = p.pair_rows;
   p.mask = p.mask_rows;
   p.argsort = nullptr;
   p.tile_order = 0;
@@ -116,6 +120,7 @@ struct GemmRest {
   int dbg;
   float *acc;
   int acc_mode;
+  int napp;               // rows layout: appendix workgroups at the head of the grid, or -1 = the n / 4 rule
 };
 
 // igemm_gen1.hip: first-generation gather-GEMM (tensors beyond 32-bit buffer offsets)

@@ -1757,15 +1757,13 @@ namespace {
 // ---------------------------------------------------------------- SubM row layout
 // The default row order of a SubM rulebook (include/spconv_amd.h, spx_subm_layout): the reference sorts the rows of
 // every rulebook by mask (SPCONV_DO_SORT, constants.py:121; ops.py:763-785 -> all.py:935-991); here the finished
-// masks are classified and, for a sparse rulebook, regrouped by a stable counting partition -- bucket 0 = rows
-// that only have their centre pair (they keep their order and lead), bucket 1 + j = rows whose lowest neighbour
-// offset is j.  count -> scan (one block per bucket) -> scatter; ranks inside a block come from wave ballots,
-// every position is a function of the masks alone (no order-dependent atomics).  Nothing is read back: the
-// class lands in the blob, the gather-GEMM picks its tables by it.
+// masks are classified and, for a sparse rulebook, the rows WITH a neighbour move into a compact appendix -- bucket
+// 1 + j = rows whose lowest neighbour offset is j, a stable counting partition -- while the row-order walk keeps the
+// rows that only have their centre pair.  count -> scan (one block per bucket) -> scatter; ranks inside a block
+// come from wave ballots, every position is a function of the masks alone (no order-dependent atomics).  Nothing is
+// read back: class and count land in the blob, the gather-GEMM's appendix workgroups read them.
 constexpr int kLayBuckets = 33;       // centre-only + lowest neighbour offset 0 .. 31
 constexpr int kLayItems = 256;        // rows per block: one round (a 100 k-row rulebook must fill 256 CUs: 391 blocks)
-constexpr int kLayGuard = 256;        // positions ahead of the regrouped rows whose table columns are written too
-                                      // (the tile that holds the first regrouped row starts at most that far back)
 
 __device__ __forceinline__ int lay_bucket(uint32_t m, int centre) {
   m &= ~(1u << centre);
@@ -1790,76 +1788,57 @@ layout_count_kernel(const uint32_t *__restrict__ mask, int n, int kv, int nblk, 
 __global__ void __launch_bounds__(kBlock)
 layout_scatter_kernel(const int32_t *__restrict__ pair, const uint32_t *__restrict__ mask, int n, int kv, int nblk,
                       const int32_t *__restrict__ off, const int32_t *__restrict__ totals,
-                      int32_t *__restrict__ blob, int npad) {
-  __shared__ int base[kLayBuckets];              // first position of (bucket, this block)
-  __shared__ int wcnt[kBlock / 64][kLayBuckets]; // rows of a bucket per wave, this round
-  const int centre = kv / 2, begin = blockIdx.x * kLayItems;
+                      int32_t *__restrict__ blob, int npad, int mcap) {
+  __shared__ int base[kLayBuckets];              // first appendix position of (bucket, this block); bucket 0 unused
+  __shared__ int wcnt[kBlock / 64][kLayBuckets]; // rows of a bucket per wave
+  const int centre = kv / 2;
   const int heavy = n - totals[0];
   const int cls = (heavy > 0 && 4ll * heavy < n) ? 1 : 0;
-  int32_t *order = blob + SPX_LAYOUT_HEADER;
-  uint32_t *mask_t = reinterpret_cast<uint32_t *>(blob + SPX_LAYOUT_HEADER + npad);
-  int32_t *pair_t = blob + SPX_LAYOUT_HEADER + 2 * static_cast<size_t>(npad);
+  uint32_t *mask_main = reinterpret_cast<uint32_t *>(blob + SPX_LAYOUT_HEADER);
+  int32_t *order = blob + SPX_LAYOUT_HEADER + npad;
+  uint32_t *mask_app = reinterpret_cast<uint32_t *>(order + mcap);
+  int32_t *pair_app = order + 2 * static_cast<size_t>(mcap);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     blob[0] = cls;
     blob[1] = heavy;
     blob[2] = n;
     blob[3] = kv;
+    blob[4] = mcap;
   }
-  if (!cls) {                                    // identity order: the kernels read the row-order pair table
-#pragma unroll
-    for (int it = 0; it < kLayItems / kBlock; ++it) {
-      const int i = begin + it * kBlock + threadIdx.x;
-      if (i < n) {
-        order[i] = i;
-        mask_t[i] = mask[i];
-      }
-    }
-    return;
-  }
+  const int i = blockIdx.x * kLayItems + threadIdx.x;
+  const bool ok = i < n;
+  const uint32_t m = ok ? mask[i] : 0u;
+  const int b = ok ? lay_bucket(m, centre) : -1;
+  // the row-order walk keeps every row of a dense rulebook, and the centre-only rows of a sparse one
+  if (ok) mask_main[i] = (cls && b > 0) ? 0u : m;
+  if (!cls) return;
   if (threadIdx.x < kLayBuckets) {
-    int b = 0;
-    for (int j = 0; j < static_cast<int>(threadIdx.x); ++j) b += totals[j];
-    base[threadIdx.x] = b + off[static_cast<size_t>(threadIdx.x) * nblk + blockIdx.x];
+    int s = 0;
+    for (int j = 1; j < static_cast<int>(threadIdx.x); ++j) s += totals[j];
+    base[threadIdx.x] = s + off[static_cast<size_t>(threadIdx.x) * nblk + blockIdx.x];
   }
+  for (int j = threadIdx.x; j < (kBlock / 64) * kLayBuckets; j += kBlock) (&wcnt[0][0])[j] = 0;
+  __syncthreads();
+  // rank of a row with a neighbour among the rows of its bucket in this wave: one ballot per DISTINCT bucket present
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int first_col = n - heavy - kLayGuard;   // table columns from here on are read by some tile
-  for (int it = 0; it < kLayItems / kBlock; ++it) {
-    for (int j = threadIdx.x; j < (kBlock / 64) * kLayBuckets; j += kBlock) (&wcnt[0][0])[j] = 0;
-    __syncthreads();                             // (also publishes `base` in the first round)
-    const int i = begin + it * kBlock + threadIdx.x;
-    const bool ok = i < n;
-    const uint32_t m = ok ? mask[i] : 0u;
-    const int b = ok ? lay_bucket(m, centre) : -1;
-    // rank among the rows of the same bucket in this wave: one ballot per DISTINCT bucket present (1-3 on a
-    // sparse rulebook)
-    int rank = 0;
-    unsigned long long todo = __ballot(ok);
-    while (todo) {
-      const int leader = __builtin_ctzll(todo);
-      const int lb = __builtin_amdgcn_readlane(b, leader);
-      const unsigned long long same = __ballot(ok && b == lb);
-      if (b == lb) rank = __popcll(same & ((1ull << lane) - 1ull));
-      if (lane == leader) wcnt[wave][lb] = __popcll(same);
-      todo &= ~same;
-    }
-    __syncthreads();
-    if (ok) {
-      int pos = base[b] + rank;
-      for (int w = 0; w < wave; ++w) pos += wcnt[w][b];
-      order[pos] = i;
-      mask_t[pos] = m;
-      if (pos >= first_col)
-        for (int k = 0; k < kv; ++k)
-          pair_t[static_cast<size_t>(k) * n + pos] = pair[static_cast<size_t>(k) * n + i];
-    }
-    __syncthreads();
-    if (threadIdx.x < kLayBuckets) {
-      int add = 0;
-#pragma unroll
-      for (int w = 0; w < kBlock / 64; ++w) add += wcnt[w][threadIdx.x];
-      base[threadIdx.x] += add;
-    }
-    __syncthreads();                             // wcnt is cleared by the next round
+  const bool hv = ok && b > 0;
+  int rank = 0;
+  unsigned long long todo = __ballot(hv);
+  while (todo) {
+    const int leader = __builtin_ctzll(todo);
+    const int lb = __builtin_amdgcn_readlane(b, leader);
+    const unsigned long long same = __ballot(hv && b == lb);
+    if (b == lb) rank = __popcll(same & ((1ull << lane) - 1ull));
+    if (lane == leader) wcnt[wave][lb] = __popcll(same);
+    todo &= ~same;
+  }
+  __syncthreads();
+  if (hv) {
+    int pos = base[b] + rank;
+    for (int w = 0; w < wave; ++w) pos += wcnt[w][b];
+    order[pos] = i;
+    mask_app[pos] = m;
+    for (int k = 0; k < kv; ++k) pair_app[static_cast<size_t>(k) * mcap + pos] = pair[static_cast<size_t>(k) * n + i];
   }
 }
 }  // namespace
@@ -1867,9 +1846,14 @@ layout_scatter_kernel(const int32_t *__restrict__ pair, const uint32_t *__restri
 
 extern "C" {
 
+size_t spx_subm_layout_mcap(int n) {
+  const size_t nn = n > 0 ? n : 1;
+  return ((nn / 4 + 63) & ~static_cast<size_t>(63)) + 256;
+}
+
 size_t spx_subm_layout_bytes(int n, int kv) {
-  const size_t nn = n > 0 ? n : 1, npad = (nn + 63) & ~static_cast<size_t>(63);
-  return (SPX_LAYOUT_HEADER + 2 * npad + static_cast<size_t>(kv) * nn) * sizeof(int32_t);
+  const size_t nn = n > 0 ? n : 1, npad = (nn + 63) & ~static_cast<size_t>(63), mcap = spx_subm_layout_mcap(n);
+  return (SPX_LAYOUT_HEADER + npad + (2 + static_cast<size_t>(kv)) * mcap) * sizeof(int32_t);
 }
 
 size_t spx_subm_layout_ws_bytes(int n) {
@@ -1893,7 +1877,7 @@ int spx_subm_layout(const int32_t *pair_fwd, const uint32_t *mask, int n, int kv
   hipLaunchKernelGGL(layout_count_kernel, dim3(nblk), dim3(kBlock), 0, s, mask, n, kv, nblk, cnt);
   hipLaunchKernelGGL(scan_kernel, dim3(kLayBuckets), dim3(kBlock), 0, s, cnt, off, nblk, totals);
   hipLaunchKernelGGL(layout_scatter_kernel, dim3(nblk), dim3(kBlock), 0, s, pair_fwd, mask, n, kv, nblk, off,
-                     totals, layout, npad);
+                     totals, layout, npad, static_cast<int>(spx_subm_layout_mcap(n)));
   SPX_LAUNCH_CHECK();
   return 0;
 }

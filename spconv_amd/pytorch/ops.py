@@ -270,12 +270,12 @@ def build_rulebook(indices: torch.Tensor, batch_size: int, spatial_shape: List[i
 # Density-aware row order = the DEFAULT of the layer modules (the reference sorts every rulebook by mask:
 # SPCONV_DO_SORT = "1", constants.py:121, ops.py:346,550,763-785).  spx_subm_layout classifies the finished
 # masks on the device and, for a SPARSE rulebook (fewer than a quarter of the rows have any neighbour),
-# regroups the rows by a stable counting partition -- centre-only rows first, then the rows with
-# neighbours grouped by offset -- which turns "every 128-row tile walks ~4 extra offsets" into "97 % of
-# the tiles walk none, the last tiles 2-3 each" (forward 13.3 -> 11.1 us, dgrad 13.9 -> 11.7 us at
-# BASELINE config 2); a dense (LiDAR) rulebook keeps its row order (regrouping loses 19 % there).  No
-# sort, no read-back: the class is a word in the blob that the gather-GEMM launch reads, so the same
-# launch serves both classes and the whole thing sits in a hipGraph.
+# moves the rows with a neighbour into a compact appendix grouped by offset (a stable counting partition),
+# which turns "every 128-row tile walks ~4 extra offsets" into "97 % of the rows run as a plain streaming
+# GEMM on their centre pair -- no row order, no pair word to fetch -- and ~25 appendix tiles walk 2-3
+# offsets each"; a dense (LiDAR) rulebook keeps everything in the row-order walk (regrouping loses 19 %
+# there).  No sort, no read-back: class and count are words in the blob that the appendix workgroups of
+# the gather-GEMM launch read, so the same launch serves both classes and the whole thing sits in a hipGraph.
 _LAYOUT_MIN_ROWS = 32768
 _ROWS_LAYOUT = 2              # SPX_ROWS_LAYOUT: `argsort` of a gather-GEMM call is a layout blob
 
@@ -295,13 +295,15 @@ def rows_layout(rb: Rulebook) -> None:
 
 
 def layout_views(rb: Rulebook):
-    """(class word [1], order [n], mask words in tile order [n], pair table in tile order [kv, n]) of
-    rb.layout -- views for tests and tools; the pair table is only defined for a regrouped rulebook, and
-    there only for the columns of rows with a neighbour."""
+    """(header [5]: class, M, n, kv, mcap; main mask words [n]; appendix row list [mcap]; appendix mask words [mcap];
+    appendix pair table [kv, mcap]) of rb.layout -- views for tests and tools; only the first M appendix entries are
+    defined, and only for a class-1 rulebook."""
     n, kv, blob = rb.n_out, rb.kv, rb.layout
     npad = (n + 63) // 64 * 64
-    return (blob[:4], blob[64:64 + n], blob[64 + npad:64 + npad + n],
-            blob[64 + 2 * npad:64 + 2 * npad + kv * n].view(kv, n))
+    mcap = int(_lib.load().spx_subm_layout_mcap(n))
+    o = 64 + npad
+    return (blob[:5], blob[64:64 + n], blob[o:o + mcap], blob[o + mcap:o + 2 * mcap],
+            blob[o + 2 * mcap:o + (2 + kv) * mcap].view(kv, mcap))
 
 
 def sparse_neighbourhoods(rb: Rulebook) -> bool:
@@ -313,7 +315,8 @@ def sparse_neighbourhoods(rb: Rulebook) -> bool:
         return cached
     ok = False
     if rb.layout is not None:
-        ok = bool(int(rb.layout[0].item()))
+        head = rb.layout[:2].tolist()
+        ok, rb.heavy_rows = bool(head[0]), int(head[1])
     elif rb.subm and 1 < rb.kv <= 32 and rb.n_out >= _LAYOUT_MIN_ROWS and rb.mask_fwd is not None:
         centre = 1 << (rb.kv // 2)
         ok = float((rb.mask_fwd.view(-1) != centre).float().mean().item()) < 0.25
@@ -461,7 +464,7 @@ def igemm_fwd_int8(features: torch.Tensor, filters: torch.Tensor, pair: torch.Te
                    bias: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None,
                    add_scale: float = 0.0, out_dtype: torch.dtype = torch.int8,
                    act_type: int = Activation.None_, act_alpha: float = 0.0,
-                   tile_order: int = 0, sparse_hint: bool = False) -> torch.Tensor:
+                   tile_order: int = 0, sparse_hint: bool = False, hint_rows: int = 0) -> torch.Tensor:
     """int8 inference forward (i32 accumulate on v_mfma_i32_16x16x64_i8):
     ``v = acc * scale[k] + bias[k] + add * add_scale; v = act(v)``; int8 output =
     ``clip(round_half_even(v), -128, 127)`` (reference numerics test/test_all_algo.py:272-287)."""
@@ -495,7 +498,7 @@ def igemm_fwd_int8(features: torch.Tensor, filters: torch.Tensor, pair: torch.Te
                                     _OUT_CODES[out_dtype],
                                     int(act_type) | (0 if argsort is None else
                                                      {0: 0, 1: _TILE_ORDER, 2: _ROWS_LAYOUT_ACT}[int(tile_order)])
-                                    | (_SPARSE_HINT if sparse_hint else 0),
+                                    | ((_SPARSE_HINT | (min(65535, -(-int(hint_rows) // 64)) << 16)) if sparse_hint else 0),
                                     float(act_alpha), _stream(features)))
     return out if K == K0 else out[:, :K0].contiguous()
 
@@ -912,7 +915,8 @@ def implicit_gemm(features: torch.Tensor, filters: torch.Tensor, pair_fwd: torch
         out = igemm_fwd_int8(features, filters, pair_fwd, mask, argsort, num_activate_out,
                              kv // 2 if is_subm else -1, scale, bias, output_add, beta, out_dt,
                              act_type, act_alpha, tile_order=tile_order,
-                             sparse_hint=rb is not None and rb.sparse_class is True)
+                             sparse_hint=rb is not None and rb.sparse_class is True,
+                             hint_rows=getattr(rb, "heavy_rows", 0) if rb is not None else 0)
         if out_dt == torch.int8 and features.is_quantized:
             out = torch._make_per_tensor_quantized_tensor(out, float(output_scale), 0)
         return out, None, -1

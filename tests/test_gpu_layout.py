@@ -2,8 +2,9 @@
 order of the layer modules, the job of the reference's default mask sort (SPCONV_DO_SORT = "1",
 spconv/constants.py:121; pytorch/ops.py:346,550,763-785 -> all.py:935-991).
 
-* the blob is a pure function of the mask words: restated in numpy here (class rule, stable counting
-  partition by lowest neighbour offset, mask words / pair columns in tile order) and compared bit for bit;
+* the blob is a pure function of the mask words: restated in numpy here (class rule; main mask words with the
+  appendix' rows zeroed; the appendix = rows with a neighbour in a stable order by lowest neighbour offset, with
+  their mask words and pair columns) and compared bit for bit;
 * a layout never changes a result: forward, dgrad, the fused backward and the int8 forward are bit-identical
   to the same launches over the row-order tables, for a regrouped (sparse) and an identity (dense) rulebook;
 * it is what `net(x)` builds with a default environment, also inside a captured graph (nothing is read back).
@@ -17,38 +18,40 @@ from util import dense_scene, gpu_rulebook, scene
 pytestmark = pytest.mark.gpu
 
 K3, ONE = [3] * 3, [1] * 3
-GUARD = 256
 
 
 def layout_ref(mask: np.ndarray, kv: int):
-    """numpy restatement: (class, heavy, order, bucket of every row)."""
+    """numpy restatement: (class, M, main mask words, appendix row list) -- the appendix holds the rows with a neighbour
+    in a stable order by their LOWEST neighbour offset."""
     m = mask.astype(np.uint32).reshape(-1)
     n = m.shape[0]
     centre = np.uint32(1 << (kv // 2))
     rest = m & ~centre
     low = np.zeros(n, dtype=np.int64)
     nz = rest != 0
-    # index of the lowest set bit
-    low[nz] = np.log2((rest[nz] & (~rest[nz] + np.uint32(1))).astype(np.float64)).astype(np.int64) + 1
+    low[nz] = np.log2((rest[nz] & (~rest[nz] + np.uint32(1))).astype(np.float64)).astype(np.int64) + 1   # lowest set bit
     heavy = int(nz.sum())
     cls = 1 if (heavy > 0 and 4 * heavy < n) else 0
-    order = np.argsort(low, kind="stable").astype(np.int32) if cls else np.arange(n, dtype=np.int32)
-    return cls, heavy, order, low
+    rows = np.nonzero(nz)[0]
+    order = rows[np.argsort(low[rows], kind="stable")].astype(np.int32) if cls else np.zeros(0, dtype=np.int32)
+    main = np.where(nz, np.uint32(0), m) if cls else m
+    return cls, heavy, main, order
 
 
 def check_blob(rb):
     from spconv_amd.pytorch import ops
-    head, order, mask_t, pair_t = (t.cpu().numpy() for t in ops.layout_views(rb))
+    head, main, order, mask_a, pair_a = (t.cpu().numpy() for t in ops.layout_views(rb))
     mask = rb.mask_fwd.cpu().numpy().view(np.uint32).reshape(-1)
     pair = rb.pair_fwd.cpu().numpy()
     n, kv = rb.n_out, rb.kv
-    cls, heavy, order_ref, _ = layout_ref(mask, kv)
+    cls, heavy, main_ref, order_ref = layout_ref(mask, kv)
     assert head[0] == cls and head[1] == heavy and head[2] == n and head[3] == kv, (head, cls, heavy)
-    np.testing.assert_array_equal(order, order_ref)
-    np.testing.assert_array_equal(mask_t.view(np.uint32), mask[order_ref])
+    assert head[4] == order.shape[0] >= n // 4 + 256
+    np.testing.assert_array_equal(main.view(np.uint32), main_ref)
     if cls:
-        first = max(0, n - heavy - GUARD)
-        np.testing.assert_array_equal(pair_t[:, first:], pair[:, order_ref[first:]])
+        np.testing.assert_array_equal(order[:heavy], order_ref)
+        np.testing.assert_array_equal(mask_a[:heavy].view(np.uint32), mask[order_ref])
+        np.testing.assert_array_equal(pair_a[:, :heavy], pair[:, order_ref])
     return cls, heavy
 
 
@@ -93,16 +96,19 @@ def _tensors(rb, C, K, dtype, seed, cuda):
     return f, w, d
 
 
-@pytest.mark.parametrize("sparse", [True, False])
+@pytest.mark.parametrize("sparse", [True, False, "small"])
 @pytest.mark.parametrize("C,K,dtype", [(64, 64, torch.float16), (32, 64, torch.bfloat16), (16, 16, torch.float16),
                                        (64, 128, torch.float16), (32, 32, torch.float32)])
 def test_layout_launches_are_bit_identical_to_row_order(cuda, sparse, C, K, dtype):
     from spconv_amd.pytorch import ops
-    if sparse:
-        shape, idx = [40, 1280, 1600], scene([40, 1280, 1600], 150_000, 1, 3)     # 1172 tiles: the longest-first path
+    if sparse == "small":          # 32 768 rows: the smallest rulebook that gets a layout, 64-row tiles
+        shape, idx = [40, 1280, 1600], scene([40, 1280, 1600], 32_768, 1, 3)
+    elif sparse:                   # 1172 main tiles + 293 appendix workgroups, ~70 of them with rows
+        shape, idx = [40, 1280, 1600], scene([40, 1280, 1600], 150_000, 1, 3)
     else:
         shape, idx = [24, 300, 300], scene([24, 300, 300], 150_000, 1, 3)
-    rb, _ = gpu_rulebook(idx, 1, shape, K3, ONE, ONE, ONE, True, do_sort="layout")
+    bs = 1
+    rb, _ = gpu_rulebook(idx, bs, shape, K3, ONE, ONE, ONE, True, do_sort="layout")
     cls, _ = check_blob(rb)
     assert cls == (1 if sparse else 0)
     f, w, d = _tensors(rb, C, K, dtype, 5, cuda)
@@ -141,6 +147,10 @@ def test_layout_int8_forward_is_bit_identical(cuda, sparse):
                                  ops.Activation.ReLU, 0.0, tile_order=to, sparse_hint=hint)
         assert torch.equal(ref, got)
     assert ops.sparse_neighbourhoods(rb) == sparse
+    if sparse:                            # ... and with the row count the host read next to the class word
+        got = ops.igemm_fwd_int8(f, w, pair, mask, blob, rb.n_out, 13, sc, bias, None, 0.0, torch.int8,
+                                 ops.Activation.ReLU, 0.0, tile_order=to, sparse_hint=True, hint_rows=rb.heavy_rows)
+        assert torch.equal(ref, got) and rb.heavy_rows > 0
 
 
 def test_module_default_builds_the_layout_and_reuses_it(cuda):
