@@ -176,11 +176,37 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   const bool app = block < napp;                                   // (uniform)
   int app_m = 0;
   int tile;
+  int gspec[MB];                                                   // appendix: rows and mask words of this lane,
+  uint32_t mspec[MB];                                              // requested before M is known
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    gspec[mb] = -1;
+    mspec[mb] = 0u;
+  }
   if (app) {
+    // the row list is read SPECULATIVELY next to {class, M} (positions below mcap exist in the blob whatever M is;
+    // what lies past M is never used): one trip instead of two at the head of the launch's longest tiles
+    const int32_t *ord = p.argsort;
+#if SPX_APP_SPEC
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const int q = block * TM + (threadIdx.x >> 6) * (16 * MB) + mb * 16 + (threadIdx.x & 15);
+      gspec[mb] = ord[q];
+      mspec[mb] = static_cast<uint32_t>(ord[layout_mcap(p.n_dst) + q]);
+    }
+#endif
     typedef const int32_t __attribute__((address_space(4))) *cptr_t;
     const int cls = *(cptr_t)(p.cls);
     app_m = *(cptr_t)(p.cls + 1);
     if (!cls || block * TM >= app_m) return;
+#if !SPX_APP_SPEC
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const int q = block * TM + (threadIdx.x >> 6) * (16 * MB) + mb * 16 + (threadIdx.x & 15);
+      gspec[mb] = ord[q];
+      mspec[mb] = static_cast<uint32_t>(ord[layout_mcap(p.n_dst) + q]);
+    }
+#endif
     tile = block;
   } else {
     const int bid = block - napp;
@@ -219,7 +245,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
     const int t = tile * TM + (wave * MB + mb) * 16 + lrow;
     int g = -1;
     if (app) {
-      if (t < app_m) g = order_app[t];                              // appendix position -> row
+      if (t < app_m) g = gspec[mb];                                 // appendix position -> row
       goff[mb] = g < 0 ? kOob : static_cast<uint32_t>(t) * 4u;
     } else {
       if (t < p.n_dst) g = (p.argsort && !p.cls) ? p.argsort[t] : t;
@@ -369,8 +395,10 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   const __amdgpu_buffer_rsrc_t rM = make_rsrc(maskp, maskp ? pair_bytes * p.mask_words : 0u);
   uint32_t mraw[MB];
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
-    mraw[mb] = __builtin_amdgcn_raw_buffer_load_b32(rM, goff[mb] == kOob ? kOob : goff[mb] * p.mask_words, 0, SPX_AUX_TABLE);
+  for (int mb = 0; mb < MB; ++mb) {
+    if (app) mraw[mb] = goff[mb] == kOob ? 0u : mspec[mb];
+    else mraw[mb] = __builtin_amdgcn_raw_buffer_load_b32(rM, goff[mb] == kOob ? kOob : goff[mb] * p.mask_words, 0, SPX_AUX_TABLE);
+  }
   __builtin_amdgcn_sched_barrier(0);
   // identity step: start its loads before the mask words arrive.  Unconditional (a regular
   // conv has it0.k == -1 here and reads zero-sized resources) so that the wait for the mask

@@ -21,6 +21,10 @@
 #ifndef SPX_AUX_OUT
 #define SPX_AUX_OUT 2
 #endif
+// rows layout, appendix tiles: 1 = their row list / mask words are requested next to {class, M}, 0 = after (A/B builds)
+#ifndef SPX_APP_SPEC
+#define SPX_APP_SPEC 1
+#endif
 
 namespace spx {
 

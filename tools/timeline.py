@@ -61,12 +61,26 @@ def main():
     ntiles = (n + 64 * mb - 1) // (64 * mb)
     if i8:
         ntiles = (n + 127) // 128
-    t = buf[:ntiles].astype(np.int64)
-    t0 = t[:, 0].min()
+    napp = 0
+    if srt:                       # rows layout: the appendix workgroups lead the grid (csrc/igemm.hip)
+        napp = (n // 4 + 64 * mb - 1) // (64 * mb)
+    allt = buf[:napp + ntiles].astype(np.int64)
+    app = allt[:napp]
+    real_app = app[app[:, 7] > 0]
+    t = allt[napp:]
+    t0 = allt[:, 0].min()
     rel = (t - t0) / float(os.environ.get("SPX_TICK_MHZ", "2200"))       # s_memtime: shader clock under load
     names = ["entry", "ident_issued", "mask_known", "prologue_done", "loop_done", "staged",
              "stores_issued", "stores_retired"]
-    out = {"scene": scene, "centre_only": centre, "tiles": int(ntiles), "stamps_us": {}, "phases_us": {}}
+    out = {"scene": scene, "centre_only": centre, "tiles": int(ntiles), "appendix_workgroups": int(napp),
+           "appendix_with_rows": int(real_app.shape[0]), "stamps_us": {}, "phases_us": {}}
+    if real_app.shape[0]:
+        ra = (real_app - t0) / float(os.environ.get("SPX_TICK_MHZ", "2200"))
+        out["appendix_stamps_us"] = {nm: [round(float(v), 2) for v in np.percentile(ra[:, i], [0, 50, 100])]
+                                     for i, nm in enumerate(["entry", "ident_issued", "mask_known", "prologue_done",
+                                                             "loop_done", "staged", "stores_issued", "stores_retired"])}
+        out["appendix_lifetime_us"] = [round(float(v), 2) for v in np.percentile(ra[:, 7] - ra[:, 0], [10, 50, 90, 100])]
+        out["launch_entry_to_last_retire_us"] = round(float((allt[:, 7].max() - t0) / float(os.environ.get("SPX_TICK_MHZ", "2200"))), 2)
     for i, nm in enumerate(names):
         q = np.percentile(rel[:, i], [0, 10, 50, 90, 100])
         out["stamps_us"][nm] = [round(float(v), 2) for v in q]
@@ -79,7 +93,8 @@ def main():
     tick = 1.0 / float(os.environ.get("SPX_TICK_MHZ", "2200"))
     spans, ramps = [], []
     for x in range(8):
-        g = t[x::8]
+        g = allt[x::8]
+        g = g[g[:, 7] > 0]
         spans.append((g[:, 7].max() - g[:, 0].min()) * tick)
         ramps.append((g[:, 0].max() - g[:, 0].min()) * tick)
     out["xcd_span_us"] = [round(float(v), 2) for v in spans]
