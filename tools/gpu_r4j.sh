@@ -1,0 +1,15 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 1200 python -m pytest tests/test_gpu_conv.py tests/test_gpu_layout.py tests/test_gpu_fused_bwd.py tests/test_gpu_int8.py tests/test_gpu_modules.py -x -q > gpurun_out/r4j_pytest.txt 2>&1; echo "pytest rc $?"
+tail -3 gpurun_out/r4j_pytest.txt
+for cfg in 2 2b 5; do
+timeout 600 python bench.py --config $cfg --no-also --no-cpu-baseline --steps 400 --warmup 50 > gpurun_out/r4j_bench_$cfg.json 2> gpurun_out/r4j_bench_$cfg.err; echo "bench $cfg rc $?"
+done
+python - <<'PY'
+import json
+for c in ("2", "2b", "5"):
+    r = json.loads(open(f"gpurun_out/r4j_bench_{c}.json").read().strip().splitlines()[-1])
+    print(c, round(r["value"] / 1e9, 4), r["ms_per_step"], {k: v["ms"] for k, v in r.get("kernels", {}).items()})
+PY
