@@ -123,6 +123,7 @@ __device__ __forceinline__ void unpack_gemm_args(GemmParams &p, const void *argA
   p.dbg = rest.dbg;
   p.xcd_rot = 0;
   p.app_rows = rest.napp;      // (the body reads it as a workgroup count)
+  p.app_budget = 0;
   // rows layout (bit 12): `mask` = the blob's main mask words, `argsort` = the appendix' row list (its mask words and
   // pair table lie behind it, the class word and M npad + 64 words ahead of it), `pair` = the row-order table
   p.cls = nullptr;
@@ -175,43 +176,39 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   const int napp = p.cls ? (p.app_rows >= 0 ? p.app_rows : layout_app_tiles(p.n_dst, TM)) : 0;
   const bool app = block < napp;                                   // (uniform)
   int app_m = 0;
-  int tile;
-  int gspec[MB];                                                   // appendix: rows and mask words of this lane,
-  uint32_t mspec[MB];                                              // requested before M is known
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-    gspec[mb] = -1;
-    mspec[mb] = 0u;
-  }
+  int tile = 0;
+  int pos[MB];                                                     // position of this lane's rows in the tables the
+                                                                   // workgroup walks (-1: no row)
   if (app) {
-    // the row list is read SPECULATIVELY next to {class, M} (positions below mcap exist in the blob whatever M is;
-    // what lies past M is never used): one trip instead of two at the head of the launch's longest tiles
-    const int32_t *ord = p.argsort;
-#if SPX_APP_SPEC
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      const int q = block * TM + (threadIdx.x >> 6) * (16 * MB) + mb * 16 + (threadIdx.x & 15);
-      gspec[mb] = ord[q];
-      mspec[mb] = static_cast<uint32_t>(ord[layout_mcap(p.n_dst) + q]);
-    }
-#endif
     typedef const int32_t __attribute__((address_space(4))) *cptr_t;
     const int cls = *(cptr_t)(p.cls);
     app_m = *(cptr_t)(p.cls + 1);
-    if (!cls || block * TM >= app_m) return;
-#if !SPX_APP_SPEC
+    if (!cls) return;
+    // The M rows of the appendix are dealt to the launch's napp appendix workgroups in whole 16-row blocks, h rows
+    // each: the appendix tiles are the launch's critical path (a walk over every offset any of their rows has, after
+    // the main tiles have long finished), and the workgroups reserved for it (n / 4 rows' worth) are there anyway --
+    // config 2: 3 165 rows, 25 tiles of 128 rows walk 4.6 offsets on average and 10 at most, 99 tiles of 32 rows
+    // 2.7 and 7 (forward 11.2 -> 9.5 us).  A full appendix (M = n / 4) keeps whole tiles.  The fused backward shares
+    // the chip's 1024 workgroup slots with the wgrad ranges and deals to at most kAppBudget workgroups (app_budget).
+    const int groups = p.app_budget > 0 ? min(napp, p.app_budget) : napp;
+    const int h = min(TM, (((app_m + groups - 1) / groups) + 15) & ~15);
+    if (block * h >= app_m) return;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
-      const int q = block * TM + (threadIdx.x >> 6) * (16 * MB) + mb * 16 + (threadIdx.x & 15);
-      gspec[mb] = ord[q];
-      mspec[mb] = static_cast<uint32_t>(ord[layout_mcap(p.n_dst) + q]);
+      const int blk = mb * (kThreads / 64) + (threadIdx.x >> 6);  // 16-row blocks go to the waves round-robin
+      const int q = block * h + blk * 16 + (threadIdx.x & 15);
+      pos[mb] = (blk * 16 < h && q < app_m) ? q : -1;
     }
-#endif
     tile = block;
   } else {
     const int bid = block - napp;
     const int rot = (p.xcd_rot + napp) & 7;                        // workgroup bid runs on XCD (bid + rot) % 8
     tile = (p.tile_order && p.lpt) ? ntiles - 1 - bid : (rot ? xcd_tile_rot(bid, ntiles, rot) : xcd_tile(bid, ntiles));
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const int t = tile * TM + ((threadIdx.x >> 6) * MB + mb) * 16 + (threadIdx.x & 15);
+      pos[mb] = t < p.n_dst ? t : -1;
+    }
   }
   const int mcap = layout_mcap(p.n_dst);
   const int32_t *order_app = p.argsort;                            // (layout launches only)
@@ -237,22 +234,37 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   const uint32_t w_bytes = static_cast<uint32_t>(p.COUT) * p.kv * rowB;
   const uint32_t pair_bytes = static_cast<uint32_t>(tbl_rows) * 4u;
 
-  // rows of this lane: tile rows wave*16*MB + mb*16 + lrow
-  int grow[MB];
+  // Rows of this lane.  Their numbers come from a list (the appendix' row list; an explicit mask argsort) or are the
+  // positions themselves.  ONE load instruction for every kind of workgroup, through a zero-sized resource where there
+  // is no list (nothing is fetched, the words come back at once): a load inside a branch makes the compiler's wait
+  // counts inexact at the join, and the main tiles then waited for their mask words BEFORE requesting the centre
+  // step's rows and weights (two dependent trips at the head of every tile of the launch instead of one).
+  const int32_t *olist = (app || !p.cls) ? p.argsort : nullptr;
+  const bool by_row = olist && !app && !p.tile_order;               // listed rows, tables in row order
+  const __amdgpu_buffer_rsrc_t rO = make_rsrc(olist, olist ? pair_bytes : 0u);
+  int glist[MB];
   uint32_t goff[MB];      // byte offset of the row's entry inside one pair-table row
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
-    const int t = tile * TM + (wave * MB + mb) * 16 + lrow;
-    int g = -1;
-    if (app) {
-      if (t < app_m) g = gspec[mb];                                 // appendix position -> row
-      goff[mb] = g < 0 ? kOob : static_cast<uint32_t>(t) * 4u;
-    } else {
-      if (t < p.n_dst) g = (p.argsort && !p.cls) ? p.argsort[t] : t;
-      goff[mb] = g < 0 ? kOob : static_cast<uint32_t>(p.tile_order ? t : g) * 4u;
-    }
-    grow[mb] = g;
+    goff[mb] = pos[mb] < 0 ? kOob : static_cast<uint32_t>(pos[mb]) * 4u;
+    glist[mb] = static_cast<int>(__builtin_amdgcn_raw_buffer_load_b32(rO, goff[mb], 0, SPX_AUX_TABLE));
   }
+  if (by_row) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) goff[mb] = pos[mb] < 0 ? kOob : static_cast<uint32_t>(glist[mb]) * 4u;
+    asm volatile("" ::: "memory");                                  // (stays a branch: a select would wait for the list)
+  }
+  // the mask words head the longest dependency chain of the tile (mask -> pair words -> rows): requested before the
+  // centre step's 24 KB of loads, not queued behind them
+  const __amdgpu_buffer_rsrc_t rM = make_rsrc(maskp, maskp ? pair_bytes * p.mask_words : 0u);
+  uint32_t mraw[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+    mraw[mb] = __builtin_amdgcn_raw_buffer_load_b32(rM, goff[mb] == kOob ? kOob : goff[mb] * p.mask_words, 0, SPX_AUX_TABLE);
+  __builtin_amdgcn_sched_barrier(0);      // (the list words are waited for AFTER the mask words are requested)
+  int grow[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) grow[mb] = pos[mb] < 0 ? -1 : (olist ? glist[mb] : pos[mb]);
 
   // per-thread constant offsets.  *_tail is the out-of-range bit to OR in for the last
   // reduction chunk when CIN is not a multiple of 64 (reduction elements >= CIN must read as
@@ -390,15 +402,6 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   it0.k = p.identity_k;
   it0.chunk = 0;
   it0.rest = 0;
-  // the mask words head the longest dependency chain of the tile (mask -> pair words -> rows):
-  // request them first, so they are not queued behind the 24 KB of identity-step loads
-  const __amdgpu_buffer_rsrc_t rM = make_rsrc(maskp, maskp ? pair_bytes * p.mask_words : 0u);
-  uint32_t mraw[MB];
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-    if (app) mraw[mb] = goff[mb] == kOob ? 0u : mspec[mb];
-    else mraw[mb] = __builtin_amdgcn_raw_buffer_load_b32(rM, goff[mb] == kOob ? kOob : goff[mb] * p.mask_words, 0, SPX_AUX_TABLE);
-  }
   __builtin_amdgcn_sched_barrier(0);
   // identity step: start its loads before the mask words arrive.  Unconditional (a regular
   // conv has it0.k == -1 here and reads zero-sized resources) so that the wait for the mask
@@ -733,12 +736,12 @@ int launch_v4(const GemmParams &p, hipStream_t s) {
   const int ntiles = div_up(p.n_dst, 64 * MB);
   // rows layout: appendix workgroups lead the grid -- as many as the class rule allows rows (n / 4), or as many as the
   // host says there are (app_rows, SPX_SPARSE_HINT)
-  const int napp = p.cls ? (p.app_rows > 0 ? div_up(p.app_rows, 64 * MB) : layout_app_tiles(p.n_dst, 64 * MB)) : 0;
+  const int napp = p.cls ? (p.app_rows > 0 ? div_up(p.app_rows, (option_int("SPX_HINT_ROWS", 64)) * MB) : layout_app_tiles(p.n_dst, 64 * MB)) : 0;
   GemmParams q = p;
   // more tiles than workgroups the chip holds at once (4 per CU up to 64 output channels, fewer beyond)
   q.lpt = p.tile_order && ntiles > ((DT == 2 || COUT > 64) ? 512 : 1024);
   GemmRest r = rest_of(p);
-  r.napp = (p.cls && p.app_rows > 0) ? napp : -1;
+  r.napp = p.cls ? napp : -1;
   constexpr int es = DT == 2 ? 1 : (DT == 3 ? 4 : 2);
   const bool half = p.CIN * es <= 64;        // narrow rows: only the first 64 bytes of a piece exist
 #define SPX_LAUNCH_V4(BTV, NKSV)                                                                     \
@@ -1619,6 +1622,7 @@ igemm_bwd_kernel(const void *argA, const void *argB, const uint32_t *arg_mask,
     unpack_gemm_args(p, argA, argB, arg_mask, arg_argsort, arg_pair, n_dst, n_src, CIN, kv,
                      identity_k, b_reverse, rest);
     p.xcd_rot = (rest.dbg & 0x100) ? 0 : (nw & 7);      // (SPX_V4_DBG=256: A/B switch)
+    p.app_budget = kAppBudget;
     igemm_v4_body<COUT, MB, DT, true, NKS>(p, n_dgrad < 0 ? b - nw : b);
   } else {
     if constexpr (DT == 3) wgrad_f32_body(wp, n_dgrad < 0 ? b : b - n_dgrad);
@@ -1857,7 +1861,7 @@ size_t wgrad_plan_ints(int n_in, int kv) {
 // workgroups of the balanced wgrad: 1.5 per CU once there is enough work (more workgroups
 // mean more partials for the second stage: 384 measured best at 100k voxels), never more
 // ranges than twice the 128-pair chunks of the identity list
-int wgrad_groups(int n_in) {
+int wgrad_groups(int n_in, int subm) {
   constexpr int forced = 0;
   int g = forced > 0 ? forced : 384;
   if (forced <= 0) {
@@ -1868,7 +1872,9 @@ int wgrad_groups(int n_in) {
     // chains of > 100 chunks and double the launch time of 16 / 32-channel layers, which is what
     // the large levels of a backbone are (igemm_bwd_kernel<32>: 158 -> 294 us at 450 k voxels);
     // the plan is built per rulebook, without knowing the layer widths that will use it
-    const int room = 1024 - div_up(n_in > 0 ? n_in : 1, 128);
+    // SubM rulebooks of that size carry a rows layout (spx_subm_layout): its appendix tiles lead the dgrad half of the
+    // launch, kAppBudget of them at most (config 2: 50 tiles of 64 rows; step 25.7 -> 24.2-24.9 us with the room left)
+    const int room = 1024 - div_up(n_in > 0 ? n_in : 1, 128) - ((subm && n_in >= kLayoutMinRows) ? kAppBudget : 0);
     if (room >= 128 && room < g) g = room;
   }
   const int chunks = div_up(n_in > 0 ? n_in : 1, 128);
@@ -1889,7 +1895,7 @@ int wgrad_xcd_order() {
 }
 
 size_t wgrad_plan2_ints(int n_in, int kv) {
-  const size_t G = wgrad_groups(n_in);
+  const size_t G = wgrad_groups(n_in, 0);   // (an upper bound: the SubM rule never asks for more)
   return 8 + kW2Rec * G + kv + 1 + 3 * (G + kv) + 4 + 4 + 4 * static_cast<size_t>(kv) * 256 + 8;
 }
 
@@ -1952,19 +1958,22 @@ constexpr size_t bwd_smem_bytes() {
 
 template <int COUT, int MB, int DT>
 int launch_bwd(const GemmParams &p, const Wgrad2Params &q, int n_wgrad_blocks, hipStream_t s) {
-  const int n_dgrad = div_up(p.n_dst, 64 * MB) + (p.cls ? layout_app_tiles(p.n_dst, 64 * MB) : 0);
+  const int napp = p.cls ? layout_app_tiles(p.n_dst, 64 * MB) : 0;
+  const int n_dgrad = div_up(p.n_dst, 64 * MB) + napp;
+  GemmRest rr = rest_of(p);
+  rr.napp = p.cls ? napp : -1;
   constexpr int wgrad_first = 1;           // (the longer chains are dispatched first: settled A/B)
   GemmParams pl = p;
   pl.lpt = p.tile_order && n_dgrad + n_wgrad_blocks > 1024;           // (see launch_v4)
   if (p.CIN * (DT == 3 ? 4 : 2) <= 64)     // dgrad's reduction rows (dout channels) fit half a piece
     hipLaunchKernelGGL((igemm_bwd_kernel<COUT, MB, DT, 1>), dim3(n_dgrad + n_wgrad_blocks), dim3(kThreads),
                        (bwd_smem_bytes<COUT, MB, DT>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,
-                       p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(pl), rest_of(p),
+                       p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(pl), rr,
                        wgrad_first ? ~n_wgrad_blocks : n_dgrad, q);
   else
     hipLaunchKernelGGL((igemm_bwd_kernel<COUT, MB, DT, 2>), dim3(n_dgrad + n_wgrad_blocks), dim3(kThreads),
                        (bwd_smem_bytes<COUT, MB, DT>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,
-                       p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(pl), rest_of(p),
+                       p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(pl), rr,
                        wgrad_first ? ~n_wgrad_blocks : n_dgrad, q);
   SPX_LAUNCH_CHECK();
   return 0;
@@ -2127,7 +2136,7 @@ int spx_wgrad_plan(const int32_t *num_per_loc, int n_in, int kv, int subm, int32
   // spx_igemm_wgrad, which build it themselves when they run: one launch less per rulebook
   int32_t *plan2 = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(plan) + plan1_bytes(n_in, kv));
   hipLaunchKernelGGL(wgrad_plan2_kernel, dim3(1), dim3(kW2MaxG), 0, static_cast<hipStream_t>(stream),
-                     num_per_loc, n_in, kv, subm, wgrad_groups(n_in), plan2);
+                     num_per_loc, n_in, kv, subm, wgrad_groups(n_in, subm), plan2);
   SPX_LAUNCH_CHECK();
   return 0;
 }
@@ -2137,7 +2146,7 @@ size_t spx_igemm_wgrad_ws_bytes(int n_in, int C, int K, int kv) {
   const size_t nchunks = div_up(n_in > 0 ? n_in : 1, chunk);
   const size_t tiles = static_cast<size_t>(div_up(C, kWT)) * div_up(K, kWT);
   size_t parts = nchunks * kv;                                   // item list (generic kernels)
-  const size_t segs = static_cast<size_t>(wgrad_groups(n_in)) + kv;   // balanced segments
+  const size_t segs = static_cast<size_t>(wgrad_groups(n_in, 0)) + kv;   // balanced segments
   if (segs > parts) parts = segs;
   return align_up(parts * tiles * kWT * kWT * sizeof(float), 256) + spx_wgrad_plan_bytes(n_in, kv);
 }
@@ -2206,7 +2215,7 @@ int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t 
     q.subm = subm;
     q.tiles_c = p.tiles_c;
     q.tiles_k = p.tiles_k;
-    q.G = wgrad_groups(n_in);
+    q.G = wgrad_groups(n_in, subm);
     q.xcd_order = wgrad_xcd_order();
     const dim3 grid(static_cast<unsigned>(q.G) * ntile);
     const size_t lds = 2 * 2 * kW2J * 128;    // two stages x two operand tiles
@@ -2340,7 +2349,7 @@ int spx_igemm_bwd(const void *feat, const void *dout, const void *weight, void *
   q.subm = subm;
   q.tiles_c = div_up(C, kWT);
   q.tiles_k = div_up(K, kWT);
-  q.G = wgrad_groups(n_in);
+  q.G = wgrad_groups(n_in, subm);
   q.xcd_order = wgrad_xcd_order();
   const int ntile = q.tiles_c * q.tiles_k;
   const int rc = dtype == SPX_F32 ? dispatch_bwd<3>(p, q, q.G * ntile, s)

@@ -21,10 +21,6 @@
 #ifndef SPX_AUX_OUT
 #define SPX_AUX_OUT 2
 #endif
-// rows layout, appendix tiles: 1 = their row list / mask words are requested next to {class, M}, 0 = after (A/B builds)
-#ifndef SPX_APP_SPEC
-#define SPX_APP_SPEC 1
-#endif
 
 namespace spx {
 
@@ -68,8 +64,14 @@ struct GemmParams {
   const uint32_t *mask_rows;
   int app_rows;           // > 0: the HOST knows an upper bound of M (SPX_SPARSE_HINT): only that many appendix rows get
                           // workgroups instead of the n / 4 the class rule allows
+  int app_budget;         // (device side) > 0: the appendix' rows are dealt to at most this many workgroups
 };
 
+// appendix workgroups of a fused backward launch, whose dgrad half shares the chip's 1024 workgroup slots with the
+// wgrad ranges (wgrad_groups leaves that room); SubM rulebooks from kLayoutMinRows rows on carry a layout (the host
+// rule: ops._LAYOUT_MIN_ROWS)
+constexpr int kAppBudget = 64;
+constexpr int kLayoutMinRows = 32768;
 // appendix geometry (the same arithmetic in spx_subm_layout_mcap, rulebook.hip)
 __host__ __device__ inline int layout_mcap(int n) { return ((n / 4 + 63) & ~63) + 256; }
 // appendix workgroups that lead a launch of TM-row tiles: the class rule (4 M < n) bounds M by n / 4
@@ -80,6 +82,7 @@ inline void apply_rows_layout(GemmParams &p, int tile_order) {
   p.cls = nullptr;
   p.mask_rows = nullptr;
   p.app_rows = 0;
+  p.app_budget = 0;
   if (tile_order == SPX_ROWS_LAYOUT && p.argsort && p.pair && p.mask) {
     const int32_t *blob = p.argsort;
     const size_t npad = (static_cast<size_t>(p.n_dst) + 63) & ~static_cast<size_t>(63);

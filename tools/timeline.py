@@ -22,6 +22,67 @@ from spconv_amd.pytorch import ops  # noqa: E402
 from spconv_amd.utils import synthetic  # noqa: E402
 
 
+def bwd_timeline(scene, idx, f, w, n, C):
+    """The fused backward launch (igemm_bwd_kernel): [wgrad ranges | appendix workgroups | main dgrad tiles] under the
+    modules' default rows layout.  wgrad workgroups stamp 0 entry, 1 first rows issued, 4 last chunk loop done,
+    6 partials issued, 7 retired; dgrad tiles as in the forward."""
+    rb, _ = ops.build_rulebook(idx, 1, SHAPE, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True, do_sort="layout")
+    dout = (torch.rand(n, C, device=f.device) * 2 - 1).half()
+    pair, mask, order, to = ops.tables_of(rb, "fwd", C)
+    plan = ops._plan_of(rb)
+    L = _lib.load()
+    getter = L.spx_debug_timeline
+    getter.restype = ctypes.c_int
+    getter.argtypes = [ctypes.c_void_p]
+    for _ in range(20):
+        ops.igemm_bwd(f, dout, w, pair, mask, order, rb.pair_native, rb.num_per_loc, True, plan, tile_order=to)
+    torch.cuda.synchronize()
+    buf = np.zeros((8192, 8), dtype=np.uint64)
+    _lib.check(getter(buf.ctypes.data))
+    tick = 1.0 / float(os.environ.get("SPX_TICK_MHZ", "2200"))
+    if os.environ.get("TL_RAW"):
+        np.save(os.environ["TL_RAW"], buf)
+    a = buf.astype(np.int64)
+    live = a[:, 0] > 0
+    last = int(np.nonzero(live)[0].max()) + 1
+    a = a[:last]
+    ntiles = (n + 127) // 128
+    napp = last - ntiles
+    # wgrad workgroups never stamp 2 (tile mask known); the appendix workgroups that left at once stamp 0 only
+    nw = 0
+    while nw < last and a[nw, 2] == 0 and a[nw, 7] > 0:
+        nw += 1
+    napp -= nw
+    wg, ap, mt = a[:nw], a[nw:nw + napp], a[nw + napp:]
+    ap_live = ap[ap[:, 7] > 0]
+    out = {"scene": scene, "mode": "fused backward", "workgroups": last, "wgrad": nw, "appendix": int(napp),
+           "appendix_with_rows": int(ap_live.shape[0]), "main_tiles": int(mt.shape[0])}
+    # s_memtime is per XCD: every figure is a difference taken inside one XCD (workgroup b runs on XCD b % 8)
+    t0x = np.zeros(8)
+    for x in range(8):
+        g = a[x::8]
+        g = g[g[:, 7] > 0]
+        t0x[x] = g[:, 0].min()
+    def rel(block_rows, first_index):
+        idxs = first_index + np.arange(block_rows.shape[0])
+        return (block_rows - t0x[idxs % 8][:, None]) * tick
+    for nm, rows, first in (("wgrad", wg, 0), ("appendix", ap, nw), ("main", mt, nw + napp)):
+        keep = rows[:, 7] > 0
+        if not keep.any():
+            continue
+        r = rel(rows, first)[keep]
+        out[nm] = {"entry_us": [round(float(v), 2) for v in np.percentile(r[:, 0], [0, 50, 100])],
+                   "retire_us": [round(float(v), 2) for v in np.percentile(r[:, 7], [0, 50, 90, 100])],
+                   "lifetime_us": [round(float(v), 2) for v in np.percentile(r[:, 7] - r[:, 0], [10, 50, 90, 100])]}
+    spans = []
+    for x in range(8):
+        g = a[x::8]
+        g = g[g[:, 7] > 0]
+        spans.append((g[:, 7].max() - g[:, 0].min()) * tick)
+    out["xcd_span_us"] = [round(float(v), 2) for v in spans]
+    print(json.dumps(out))
+
+
 def main():
     scene = sys.argv[1] if len(sys.argv) > 1 else "uniform"
     centre = len(sys.argv) > 2 and sys.argv[2] == "centre"
@@ -45,6 +106,8 @@ def main():
         w = torch.randint(-127, 128, (C, 3, 3, 3, C), dtype=torch.int8, device=dev)
         sc = torch.rand(C, device=dev) * 1e-2
         bi = torch.rand(C, device=dev)
+    if len(sys.argv) > 2 and sys.argv[2] == "bwd":
+        return bwd_timeline(scene, idx, f, w, n, C)
     L = _lib.load()
     getter = L.spx_debug_timeline
     getter.restype = ctypes.c_int
