@@ -736,7 +736,7 @@ int launch_v4(const GemmParams &p, hipStream_t s) {
   const int ntiles = div_up(p.n_dst, 64 * MB);
   // rows layout: appendix workgroups lead the grid -- as many as the class rule allows rows (n / 4), or as many as the
   // host says there are (app_rows, SPX_SPARSE_HINT)
-  const int napp = p.cls ? (p.app_rows > 0 ? div_up(p.app_rows, (option_int("SPX_HINT_ROWS", 64)) * MB) : layout_app_tiles(p.n_dst, 64 * MB)) : 0;
+  const int napp = p.cls ? (p.app_rows > 0 ? div_up(p.app_rows, 64 * MB) : layout_app_tiles(p.n_dst, 64 * MB)) : 0;
   GemmParams q = p;
   // more tiles than workgroups the chip holds at once (4 per CU up to 64 output channels, fewer beyond)
   q.lpt = p.tile_order && ntiles > ((DT == 2 || COUT > 64) ? 512 : 1024);

@@ -48,9 +48,24 @@ def from_csv(path, pmc):
     return stats, counters
 
 
+def from_stats_csv(path):
+    """*_kernel_stats.csv (rocprofv3 --stats): one aggregated row per kernel."""
+    rows = []
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            rows.append((short(row["Name"]), int(row["Calls"]), float(row["TotalDurationNs"]), float(row["MinNs"]),
+                         float(row["MaxNs"])))
+    total = sum(r[2] for r in rows) or 1
+    print(f"{'kernel':70s} {'calls':>6s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'share%':>7s}")
+    for name, calls, tot, mn, mx in sorted(rows, key=lambda r: -r[2]):
+        print(f"{name:70s} {calls:6d} {tot / calls / 1e3:9.2f} {mn / 1e3:9.2f} {mx / 1e3:9.2f} {100 * tot / total:7.1f}")
+
+
 def main():
     path = sys.argv[1]
     pmc = "--pmc" in sys.argv
+    if path.endswith("kernel_stats.csv"):
+        return from_stats_csv(path)
     stats, counters = (from_db if path.endswith(".db") else from_csv)(path, pmc)
     total = sum(sum(v) for v in stats.values()) or 1
     print(f"{'kernel':70s} {'calls':>6s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'share%':>7s}")
