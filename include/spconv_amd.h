@@ -244,7 +244,9 @@ int spx_permute_tables(const int32_t *pair, const uint32_t *mask, const int32_t 
  *   pair       [kv, mcap]   their pair words
  *   npad = n rounded up to 64, mcap = spx_subm_layout_mcap(n) >= n / 4 + 256.
  * The launch is the same for both classes (hipGraph-safe): ceil(n / 4 / tile rows) appendix workgroups
- * lead the grid, read {class, M} and leave at once when there is nothing for them. */
+ * lead the grid, read {class, M} and leave at once when there is nothing for them; the M rows are dealt to
+ * them in whole 16-row blocks (ceil(M / workgroups) rows each, rounded up to 16), so that a short appendix
+ * becomes many short tiles instead of a few long ones. */
 size_t spx_subm_layout_mcap(int n);
 #define SPX_ROWS_LAYOUT 2
 #define SPX_ROWS_LAYOUT_ACT 0x400
