@@ -127,6 +127,32 @@ def test_layout_launches_are_bit_identical_to_row_order(cuda, sparse, C, K, dtyp
     assert torch.equal(b1[0], din1)
 
 
+@pytest.mark.parametrize("n,shape,lo,hi", [
+    (60_000, [40, 380, 380], 0.20, 0.25),      # appendix nearly full: whole 128-row tiles, more tiles than the backward's budget
+    (60_000, [40, 552, 552], 0.09, 0.15),      # 64- / 80-row appendix tiles
+    (40_000, [40, 1280, 1600], 0.0, 0.02),     # a few hundred rows: 16-row tiles, most reserved workgroups leave at once
+])
+def test_layout_appendix_dealing_is_bit_identical_for_every_fill(cuda, n, shape, lo, hi):
+    """The appendix' M rows are dealt to the reserved workgroups in 16-row blocks (csrc/igemm.hip): every fill of the
+    appendix -- a handful of rows up to n / 4 -- gives the row-order results, forward, dgrad and fused backward (which
+    deals to at most kAppBudget workgroups)."""
+    from spconv_amd.pytorch import ops
+    idx = scene(shape, n, 1, 21)
+    rb, _ = gpu_rulebook(idx, 1, shape, K3, ONE, ONE, ONE, True, do_sort="layout")
+    cls, heavy = check_blob(rb)
+    assert cls == 1 and lo * rb.n_out <= heavy <= hi * rb.n_out, (heavy, rb.n_out)
+    f, w, d = _tensors(rb, 64, 64, torch.float16, 6, cuda)
+    pair, mask, blob, to = ops.tables_of(rb, "fwd", 64)
+    plan = ops._plan_of(rb)
+    assert torch.equal(ops.igemm_fwd(f, w, rb.pair_fwd, rb.mask_fwd, None, rb.n_out, 13),
+                       ops.igemm_fwd(f, w, pair, mask, blob, rb.n_out, 13, tile_order=to))
+    din0 = ops.igemm_dgrad(d, w, rb.pair_fwd, rb.mask_fwd, None, rb.n_in, True)
+    assert torch.equal(din0, ops.igemm_dgrad(d, w, pair, mask, blob, rb.n_in, True, tile_order=to))
+    b0 = ops.igemm_bwd(f, d, w, rb.pair_fwd, rb.mask_fwd, None, rb.pair_native, rb.num_per_loc, True, plan)
+    b1 = ops.igemm_bwd(f, d, w, pair, mask, blob, rb.pair_native, rb.num_per_loc, True, plan, tile_order=to)
+    assert torch.equal(b0[0], b1[0]) and torch.equal(b0[1], b1[1]) and torch.equal(b1[0], din0)
+
+
 @pytest.mark.parametrize("sparse", [True, False])
 def test_layout_int8_forward_is_bit_identical(cuda, sparse):
     from spconv_amd.pytorch import ops
