@@ -267,7 +267,7 @@ def test_xcd_aware_mappings_are_bijective():
 
     import random
     rnd = random.Random(0)
-    for G in (1, 8, 242, 384, 1023):
+    for G in (1, 8, 178, 242, 384, 1023):
         xs = [min(7, (t * 8) // G) if rnd.random() < 0.9 else rnd.randrange(8) for t in range(G)]
         take = hand_out(xs)
         assert sorted(take) == list(range(G))
@@ -324,6 +324,7 @@ def test_wgrad_plan_cost_space_cut_covers_every_pair_once():
         return segs, kc
 
     cases = [([121] * 13 + [100000] + [121] * 13, 242),            # BASELINE config 2 (SubM, uniform scene)
+             ([121] * 13 + [100000] + [121] * 13, 178),            # ... with room for the rows layout's appendix
              ([30000 + 997 * k for k in range(27)], 384),          # dense scene
              ([0, 5, 0, 1, 0, 0, 700, 0, 3], 7), ([1], 1), ([0, 0, 4096], 64)]
     for lens, G in cases:

@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """Per-workgroup timeline of igemm_v4_kernel (debug build, spconv_amd/csrc/build_debug.sh).
 
-    SPX_LIB=spconv_amd/lib/libspconv_amd_dbg.so python tools/timeline.py [uniform|lidar] [centre]
+    SPX_LIB=spconv_amd/lib/libspconv_amd_dbg.so python tools/timeline.py [uniform|lidar] [centre|sort|i8|i8sort|bwd]
+
+(sort = the modules' default rows layout; i8 = the int8 layer of config 5; bwd = the fused backward launch, wgrad ranges |
+appendix workgroups | dgrad tiles, under the rows layout; TL_RAW=<file.npy> keeps the raw stamp table.)
 
 Every workgroup stamps s_memtime (100 MHz constant clock on gfx950: 10 ns ticks) at
 0 entry, 1 identity loads issued, 2 tile mask known, 3 prologue done, 4 main loop done,
