@@ -143,17 +143,17 @@ def main():
     if real_app.shape[0]:
         ra = (real_app - t0) / float(os.environ.get("SPX_TICK_MHZ", "2200"))
         out["appendix_stamps_us"] = {nm: [round(float(v), 2) for v in np.percentile(ra[:, i], [0, 50, 100])]
-                                     for i, nm in enumerate(["entry", "ident_issued", "mask_known", "prologue_done",
-                                                             "loop_done", "staged", "stores_issued", "stores_retired"])}
+                                     for i, nm in enumerate(names) if i != 5}
         out["appendix_lifetime_us"] = [round(float(v), 2) for v in np.percentile(ra[:, 7] - ra[:, 0], [10, 50, 90, 100])]
         out["launch_entry_to_last_retire_us"] = round(float((allt[:, 7].max() - t0) / float(os.environ.get("SPX_TICK_MHZ", "2200"))), 2)
-    for i, nm in enumerate(names):
+    used = [0, 1, 2, 3, 4, 6, 7]                    # (stamp 5 is not taken by the current kernel)
+    for i in used:
         q = np.percentile(rel[:, i], [0, 10, 50, 90, 100])
-        out["stamps_us"][nm] = [round(float(v), 2) for v in q]
-    for i in range(1, 8):
-        d = rel[:, i] - rel[:, i - 1]
+        out["stamps_us"][names[i]] = [round(float(v), 2) for v in q]
+    for a, b in zip(used[:-1], used[1:]):
+        d = rel[:, b] - rel[:, a]
         q = np.percentile(d, [10, 50, 90, 100])
-        out["phases_us"][f"{names[i - 1]}->{names[i]}"] = [round(float(v), 2) for v in q]
+        out["phases_us"][f"{names[a]}->{names[b]}"] = [round(float(v), 2) for v in q]
     # s_memtime is per XCD (not synchronised across dies): spans are taken inside each XCD
     # (workgroup b runs on XCD b % 8) and the stamps above are only meaningful as differences
     tick = 1.0 / float(os.environ.get("SPX_TICK_MHZ", "2200"))
