@@ -33,7 +33,6 @@ if sel.startswith("node:"):
 elif sel != "none":
     os.sched_setaffinity(0, parse_cpus(sel))
 
-import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
