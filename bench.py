@@ -1087,8 +1087,8 @@ def static_training_steps(net, data, bs, cin, shape, steps, warm, D: Dist, input
         d = float((pa.grad.float() - pb.grad.float()).norm() / pb.grad.float().norm().clamp_min(1e-20))
         per_param.append((round(d, 6), name))
         worst = max(worst, d)
-    out_diff = float((y_static[:ye.features.shape[0]].float() - ye.features.float()).norm()
-                     / ye.features.float().norm().clamp_min(1e-20))
+    ye_f = ye.features.detach().float()
+    out_diff = float((y_static[:ye_f.shape[0]].detach().float() - ye_f).norm() / ye_f.norm().clamp_min(1e-20))
     # noise floor of that comparison: the eager step on the SAME scene with its rows permuted -- mathematically
     # the same gradients, another summation order (with BatchNorm layers and a zero-mean synthetic output
     # gradient the sums are small against their terms, so fp16 rounding flips show up at the percent level)
