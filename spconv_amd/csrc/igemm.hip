@@ -1894,8 +1894,16 @@ int wgrad_xcd_order() {
   return v;
 }
 
+// what the *_bytes functions size for: the larger of the two rules.  (They used to take wgrad_groups(n, 0) as "an
+// upper bound of the SubM value", which the appendix budget broke for n in (106 496, 114 688]: 164 vs 384 ranges at
+// n = 110 000 -- at small kernel volumes the plan kernel then wrote past the buffer; round-4 ADVICE.)
+int wgrad_groups_max(int n_in) {
+  const int a = wgrad_groups(n_in, 0), b = wgrad_groups(n_in, 1);
+  return a > b ? a : b;
+}
+
 size_t wgrad_plan2_ints(int n_in, int kv) {
-  const size_t G = wgrad_groups(n_in, 0);   // (an upper bound: the SubM rule never asks for more)
+  const size_t G = wgrad_groups_max(n_in);
   return 8 + kW2Rec * G + kv + 1 + 3 * (G + kv) + 4 + 4 + 4 * static_cast<size_t>(kv) * 256 + 8;
 }
 
@@ -2135,8 +2143,11 @@ int spx_wgrad_plan(const int32_t *num_per_loc, int n_in, int kv, int subm, int32
   // the first-generation item list (front of the buffer) is only read by the fallback kernels of
   // spx_igemm_wgrad, which build it themselves when they run: one launch less per rulebook
   int32_t *plan2 = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(plan) + plan1_bytes(n_in, kv));
+  const int G = wgrad_groups(n_in, subm);
+  SPX_CHECK(G <= wgrad_groups_max(n_in), "wgrad plan: %d ranges exceed the %d the plan buffer is sized for", G,
+            wgrad_groups_max(n_in));
   hipLaunchKernelGGL(wgrad_plan2_kernel, dim3(1), dim3(kW2MaxG), 0, static_cast<hipStream_t>(stream),
-                     num_per_loc, n_in, kv, subm, wgrad_groups(n_in, subm), plan2);
+                     num_per_loc, n_in, kv, subm, G, plan2);
   SPX_LAUNCH_CHECK();
   return 0;
 }
@@ -2146,7 +2157,7 @@ size_t spx_igemm_wgrad_ws_bytes(int n_in, int C, int K, int kv) {
   const size_t nchunks = div_up(n_in > 0 ? n_in : 1, chunk);
   const size_t tiles = static_cast<size_t>(div_up(C, kWT)) * div_up(K, kWT);
   size_t parts = nchunks * kv;                                   // item list (generic kernels)
-  const size_t segs = static_cast<size_t>(wgrad_groups(n_in, 0)) + kv;   // balanced segments
+  const size_t segs = static_cast<size_t>(wgrad_groups_max(n_in)) + kv;   // balanced segments
   if (segs > parts) parts = segs;
   return align_up(parts * tiles * kWT * kWT * sizeof(float), 256) + spx_wgrad_plan_bytes(n_in, kv);
 }

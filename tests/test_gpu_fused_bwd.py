@@ -234,3 +234,41 @@ def test_cfg4_backbone_step_fused_bwd_vs_oracle(cuda):
     assert len(tap.layers) == 12
     _check_layers_vs_oracle(tap, 3e-3)
     tap.close()
+
+
+@pytest.mark.parametrize("ksize", [(3, 1, 1), (3, 3, 1)])
+def test_wgrad_plan_fits_its_buffer_at_small_kernel_volumes(cuda, ksize):
+    """Round-4 ADVICE (medium): for n in (106 496, 114 688] the SubM rule asks for 384 wgrad ranges while the plan
+    buffer was sized with the non-SubM rule's 164 -- at kv = 3 / 9 the plan kernel then wrote ~10 KB past the buffer
+    (into whatever the caching allocator handed out next).  A guard tensor allocated right behind the plan must stay
+    untouched and the gradients must equal the oracle."""
+    import spconv_amd.pytorch as spconv
+    shape, n, C = [40, 1280, 1600], 110_000, 64
+    idx = scene(shape, n, 1, 3)
+    rng = np.random.default_rng(7)
+    dtype = torch.float16
+    f = _rounded(rng.uniform(-1, 1, (n, C)).astype(np.float32), dtype)
+    w = _rounded(rng.uniform(-1, 1, (C, *ksize, C)).astype(np.float32), dtype)
+    dout = _rounded(rng.uniform(-0.2, 0.2, (n, C)).astype(np.float32), dtype)
+    net = spconv.SubMConv3d(C, C, ksize, bias=False, indice_key="t").to(cuda, dtype)
+    with torch.no_grad():
+        net.weight.copy_(w.to(cuda, dtype))
+    feats = f.to(cuda, dtype).requires_grad_(True)
+    x = spconv.SparseConvTensor(feats, torch.from_numpy(idx).to(cuda), shape, 1)
+    y = net(x)
+    # guards the allocator may place right behind the plan, which the backward derives on demand
+    torch.cuda.synchronize()
+    guards = [torch.full((4096,), 0x5A5A5A5A, dtype=torch.int32, device=cuda) for _ in range(8)]
+    y.features.backward(dout.to(cuda, dtype))
+    torch.cuda.synchronize()
+    for g in guards:
+        assert bool((g == 0x5A5A5A5A).all())
+    ref = oracle_rulebook(idx, 1, shape, list(ksize), ONE, ONE, ONE, True)
+    din_ref, dw_ref = oracle.indice_conv_backward(f, w, dout, ref["pair"], ref["num"], subm=True)
+    assert rel_err(feats.grad.float().cpu().numpy(), din_ref.numpy()) <= TOL[dtype]
+    assert rel_err(net.weight.grad.float().cpu().numpy(), dw_ref.numpy()) <= TOL[dtype]
+    # the sizing rule itself: the byte count covers the larger of the two range counts
+    from spconv_amd import _lib
+    L = _lib.load()
+    kv = int(np.prod(ksize))
+    assert L.spx_wgrad_plan_bytes(n, kv) >= 4 * (8 + 8 * 384 + kv + 1 + 3 * (384 + kv))

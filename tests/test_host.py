@@ -506,3 +506,15 @@ def test_static_shape_bookkeeping_on_the_host():
     rb.in_shape = rb.out_shape = [21, 800, 704]
     assert ops._dense_rows(rb, 313_127, "fwd") and ops._dense_rows(rb, 313_127, "bwd")   # 0.66 %: the tile walk
     assert not ops._dense_rows(None, 10, "fwd")
+
+
+def test_committed_pmc_traffic_answers_every_key_bench_asks_for():
+    """profiles/traffic.json is KEYED by workload (a per-key fragment copied over it made every
+    lookup return None and the driver's line carry `traffic: null`)."""
+    import bench
+    for key, group in bench.TRAFFIC_KEYS:
+        v = bench.pmc_traffic(key, group)
+        assert isinstance(v, int) and v > 1_000_000, (key, group, v)
+    r = bench.roofline_obj("fwd", 36.6e6, 0.0095, "k", bench.pmc_traffic("uniform-f16-c64-n100000", "fwd"))
+    assert r["traffic"] and 0.3 < r["traffic_over_algorithmic"] < 3.0
+    assert bench.roofline_obj("fwd", 1e6, 1.0, "k")["traffic_over_algorithmic"] is None

@@ -20,6 +20,6 @@ echo "## SQ counters, average per dispatch (quad-cycles)"; f=$(find gpurun_out/p
 echo "## FETCH_SIZE [KiB, x2 for wide reads on gfx950]"; f1=$(find gpurun_out/prof_${TAG}_fetch -name "*counter_collection.csv" | head -1); python tools/rocprof_summary.py "$f1" --pmc | sed -n '/^$/,$p'
 echo "## WRITE_SIZE [KiB], TCC hit/miss"; f2=$(find gpurun_out/prof_${TAG}_write -name "*counter_collection.csv" | head -1); python tools/rocprof_summary.py "$f2" --pmc | sed -n '/^$/,$p'
 } > $S 2>&1
-python tools/pmc_traffic.py "$f1" "$f2" uniform-f16-c64-n100000 | tee gpurun_out/traffic_$TAG.json
+python tools/pmc_traffic.py "$f1" "$f2" uniform-f16-c64-n100000 | tee gpurun_out/traffic_fragment_$TAG.json   # ONE key's entry; the keyed file is profiles/traffic.json
 cp profiles/traffic.json gpurun_out/traffic.json
 tail -5 gpurun_out/bench_$TAG.err
