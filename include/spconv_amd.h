@@ -249,6 +249,13 @@ int spx_permute_tables(const int32_t *pair, const uint32_t *mask, const int32_t 
  * becomes many short tiles instead of a few long ones. */
 size_t spx_subm_layout_mcap(int n);
 #define SPX_ROWS_LAYOUT 2
+/* OR-ed into `tile_order` of spx_igemm_fwd / spx_igemm_dgrad: the HOST knows that the rulebook's neighbourhoods are
+ * dense (it has seen class word 0 of the rows layout, or knows its data).  C = K = 64 16-bit layers then take the
+ * weight-stationary gather-GEMM (csrc/igemm_ws.hip: one 512-row workgroup per CU, weights staged nine offsets at a time
+ * through LDS-DMA) instead of the 128-row tiles -- a launch SHAPE, which is why it cannot be read on the device.  Results
+ * are bit-identical with and without the hint; a wrong hint only costs time.  Stands in for the reference's tuner choice
+ * between implicit-GEMM tile shapes (spconv/csrc/sparse/convops.py:1150-1297). */
+#define SPX_DENSE_HINT 0x100
 #define SPX_ROWS_LAYOUT_ACT 0x400
 /* OR-ed into `act` of spx_igemm_fwd_int8 next to SPX_ROWS_LAYOUT_ACT: the HOST knows the class word is 1 (it may
  * read it once per rulebook, outside any timed or captured region) -- a launch-shape hint only: 64-row instead

@@ -1737,6 +1737,14 @@ bool mfma_ok(int dtype, int cin, int cout, int kv, const uint32_t *mask) {
 template <bool BF16>
 int dispatch_gather_gemm(const GemmParams &p, hipStream_t s) {
   constexpr int mb_forced = 0;              // (tile height: rule below)
+  // dense neighbourhoods (the caller's hint; SPX_WS = 1 / 0 forces / forbids): the weight-stationary kernel --
+  // bit-identical results, so the choice never shows in an output
+  const int wsv = option_int("SPX_WS", -1);
+  if ((wsv > 0 || (wsv < 0 && p.dense_hint)) && ws_ok(p, BF16 ? SPX_BF16 : SPX_F16)) {
+    GemmParams q = p;
+    drop_rows_layout(q);
+    return launch_gather_gemm_ws(q, BF16 ? SPX_BF16 : SPX_F16, s);
+  }
   if (v4_ok(p)) {
     // 64-row tiles while the grid would otherwise leave CUs idle, 128-row tiles beyond -- except
     // for 128 output channels, whose 128-row variant holds 64 accumulator registers per lane and
@@ -2035,7 +2043,8 @@ int spx_igemm_fwd(const void *feat, const void *weight, void *out, const int32_t
   p.kv = kv;
   p.identity_k = identity_k;
   p.b_reverse = 0;
-  apply_rows_layout(p, tile_order);
+  p.dense_hint = (tile_order & SPX_DENSE_HINT) ? 1 : 0;
+  apply_rows_layout(p, tile_order & ~SPX_DENSE_HINT);
   p.act = act & 0xff;
   if (act & SPX_OUT_CACHED) p.dbg = 0x400;       // plain result stores: the next launch reads the rows
   p.act_alpha = act_alpha;
@@ -2121,7 +2130,8 @@ int spx_igemm_dgrad(const void *dout, const void *weight, void *din, const int32
   SPX_CHECK((dout || n_out == 0) && weight && din, "null tensor pointer");
   SPX_CHECK(pair || kv == 1, "pair table required");
   GemmParams p = dgrad_params(dout, weight, din, pair, mask, argsort, n_out, n_in, C, K, kv, subm);
-  apply_rows_layout(p, tile_order);
+  p.dense_hint = (tile_order & SPX_DENSE_HINT) ? 1 : 0;
+  apply_rows_layout(p, tile_order & ~SPX_DENSE_HINT);
   if (ws && ws_bytes >= spx_igemm_acc_bytes(n_in, C, kv) && kv > 32) p.acc = static_cast<float *>(ws);
   return run_gather_gemm(p, dtype, static_cast<hipStream_t>(stream));
 }
@@ -2321,7 +2331,8 @@ int spx_igemm_bwd(const void *feat, const void *dout, const void *weight, void *
   SPX_CHECK(ws_bytes >= spx_igemm_wgrad_ws_bytes(n_in, C, K, kv), "workspace too small");
   constexpr int fuse = 1;                  // (dgrad + wgrad in one launch: settled A/B)
   GemmParams p = dgrad_params(dout, weight, din, pair, mask, argsort, n_out, n_in, C, K, kv, subm);
-  apply_rows_layout(p, tile_order);
+  p.dense_hint = (tile_order & SPX_DENSE_HINT) ? 1 : 0;
+  apply_rows_layout(p, tile_order & ~SPX_DENSE_HINT);
   const bool small_offsets = static_cast<unsigned long long>(n_out) * K * 2ull < 0x7fff0000ull &&
                              static_cast<unsigned long long>(n_in) * C * 2ull < 0x7fff0000ull &&
                              static_cast<unsigned long long>(n_in) * 4ull * (kv + 1) < 0x7fff0000ull;   // both lists of an offset through one resource

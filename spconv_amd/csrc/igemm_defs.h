@@ -65,6 +65,8 @@ struct GemmParams {
   int app_rows;           // > 0: the HOST knows an upper bound of M (SPX_SPARSE_HINT): only that many appendix rows get
                           // workgroups instead of the n / 4 the class rule allows
   int app_budget;         // (device side) > 0: the appendix' rows are dealt to at most this many workgroups
+  int dense_hint;         // the caller knows the neighbourhoods are dense (SPX_DENSE_HINT in tile_order): forward and
+                          // dgrad take the weight-stationary kernel (igemm_ws.hip) where its shape limits allow
 };
 
 // appendix workgroups of a fused backward launch, whose dgrad half shares the chip's 1024 workgroup slots with the
@@ -132,6 +134,9 @@ struct GemmRest {
 
 // igemm_gen1.hip: first-generation gather-GEMM (tensors beyond 32-bit buffer offsets)
 int launch_gather_gemm_gen1(const GemmParams &p, bool bf16, hipStream_t s);
+// igemm_ws.hip: weight-stationary gather-GEMM for dense neighbourhoods (forward and dgrad)
+bool ws_ok(const GemmParams &p, int dtype);
+int launch_gather_gemm_ws(const GemmParams &p, int dtype, hipStream_t s);
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

@@ -342,7 +342,7 @@ class SparseConvolution(SparseModule):
                                                do_sort=False if static else MODULE_DO_SORT,
                                                need_native=self._needs_native_lists(features, indices, batch_size,
                                                                                       spatial_shape),
-                                               static_num_out=static)
+                                               static_num_out=static, pred_key=id(self))
                 self._static_n_out_dev = rb.n_out_dev
                 rb.in_n_live_dev = getattr(input, "n_live_dev", None)
                 if rb.n_out_dev is not None:      # live output rows: the count found, at most the bound

@@ -69,6 +69,10 @@ class Rulebook:
         self.sort_decided = False
         # density class (ops.sparse_neighbourhoods): None = not measured yet
         self.sparse_class = None
+        self.heavy_rows = 0
+        # asynchronous read of the class word (ops.poll_class): the pending request, and whose rulebook this is
+        self._class_req = None
+        self.pred_key = None
         # static-shape build (ops.build_rulebook(static_num_out=...)): device int32 [2] =
         # {distinct outputs found, hash-table overflow}; rows >= the count are dead.  None otherwise.
         self.n_out_dev = None

@@ -154,7 +154,8 @@ def build_rulebook(indices: torch.Tensor, batch_size: int, spatial_shape: List[i
                    dilation: List[int], out_padding: List[int], subm: bool = False,
                    transpose: bool = False, need_bwd_table: bool = False,
                    do_sort=False, need_native: bool = True,
-                   num_out_act_bound: int = -1, static_num_out: int = 0) -> Tuple[Rulebook, List[int]]:
+                   num_out_act_bound: int = -1, static_num_out: int = 0,
+                   pred_key=None) -> Tuple[Rulebook, List[int]]:
     """One call builds every artefact (dense tables, masks, Native lists).  need_native=False
     (inference) leaves the ConvAlgo.Native lists out -- three launches and two thirds of the
     fill traffic -- and the Rulebook derives them from the tables if they are asked for later.
@@ -256,6 +257,7 @@ def build_rulebook(indices: torch.Tensor, batch_size: int, spatial_shape: List[i
         rb = Rulebook(out_indices, pair_fwd, pair_bwd, mask_fwd, mask_bwd, native, num, n_in,
                       n_out, kv, False)
     rb.in_indices, rb.in_shape, rb.out_shape, rb.batch_size = indices, list(spatial_shape), list(out_shape), batch_size
+    rb.pred_key = pred_key        # whose rulebook this is, for the density-class prediction (poll_class)
     if do_sort in ("layout", "auto"):
         # the default row order: classified and regrouped on the device inside the build (SubM; nothing
         # read back).  Strided layers keep their row order (dense by construction: every output has
@@ -292,6 +294,74 @@ def rows_layout(rb: Rulebook) -> None:
                                  ws.data_ptr(), ws.numel(), _stream(rb.pair_fwd)))
     rb.layout = blob
     rb.sort_decided = True
+    _request_class(rb)
+
+
+# ---- the density class on the HOST, without a synchronisation ------------------------------------------------------
+# A launch SHAPE cannot be picked on the device: the weight-stationary gather-GEMM of dense C = K = 64 layers
+# (csrc/igemm_ws.hip, 512-row workgroups) and the int8 tile height are host choices.  The class word of a rows layout
+# is therefore copied to pinned host memory asynchronously when the layout is built and looked at (never waited for)
+# when a launch is prepared: until it has arrived -- the host usually runs ahead of the device on the first layer that
+# uses a new rulebook -- the launch goes by what the same layer's previous rulebook turned out to be (`_class_pred`,
+# keyed by the owning module), and inside a stream capture, where nothing can be polled, by that prediction alone.
+# Both kernels give bit-identical results, so neither a late answer nor a wrong prediction shows in an output.
+_DENSE_HINT = 0x100           # SPX_DENSE_HINT (include/spconv_amd.h)
+_WS_MIN_ROWS = 98304          # one 512-row workgroup per CU: below ~3/4 of 256 x 512 rows the 128-row tiles fill the chip better
+_CLASS_SLOTS = 1024
+_class_ring = {}              # device index -> [pinned int32 [_CLASS_SLOTS, 2], next slot, owner tokens]
+_class_pred = {}              # prediction key (module id) -> the rulebook built for it last time was dense
+
+
+def _request_class(rb: Rulebook) -> None:
+    blob = rb.layout
+    rb._class_req = None
+    if blob is None:
+        return
+    blob._spx_dense = bool(_class_pred.get(getattr(rb, "pred_key", None), False))
+    if torch.cuda.is_current_stream_capturing():
+        return
+    ring = _class_ring.get(blob.device.index)
+    if ring is None:
+        ring = [torch.zeros((_CLASS_SLOTS, 2), dtype=torch.int32).pin_memory(), 0, [None] * _CLASS_SLOTS]
+        _class_ring[blob.device.index] = ring
+    host, slot = ring[0], ring[1]
+    ring[1] = (slot + 1) % _CLASS_SLOTS
+    token = object()
+    ring[2][slot] = token
+    host[slot].copy_(blob[:2], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    rb._class_req = (ring, slot, token, ev)
+
+
+def poll_class(rb: Optional[Rulebook]) -> None:
+    """Non-blocking: takes the class word of rb's rows layout if its copy has arrived (see above)."""
+    if rb is None or rb.layout is None:
+        return
+    if rb.sparse_class is not None or getattr(rb, "_class_req", None) is None:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return
+    ring, slot, token, ev = rb._class_req
+    if ring[2][slot] is not token:          # (the ring wrapped before anybody looked: stay with the prediction)
+        rb._class_req = None
+        return
+    if not ev.query():
+        return
+    cls, heavy = (int(v) for v in ring[0][slot])
+    rb._class_req = None
+    rb.sparse_class, rb.heavy_rows = bool(cls), heavy
+    dense = (not cls) and rb.n_out >= _WS_MIN_ROWS and 4 * heavy >= 3 * rb.n_out
+    rb.layout._spx_dense = dense
+    key = getattr(rb, "pred_key", None)
+    if key is not None:
+        _class_pred[key] = dense
+
+
+def _with_dense_hint(tile_order: int, argsort) -> int:
+    if tile_order == _ROWS_LAYOUT and getattr(argsort, "_spx_dense", False):
+        return tile_order | _DENSE_HINT
+    return tile_order
 
 
 def layout_views(rb: Rulebook):
@@ -317,6 +387,8 @@ def sparse_neighbourhoods(rb: Rulebook) -> bool:
     if rb.layout is not None:
         head = rb.layout[:2].tolist()
         ok, rb.heavy_rows = bool(head[0]), int(head[1])
+        rb.layout._spx_dense = (not ok) and rb.n_out >= _WS_MIN_ROWS and 4 * rb.heavy_rows >= 3 * rb.n_out
+        rb._class_req = None
     elif rb.subm and 1 < rb.kv <= 32 and rb.n_out >= _LAYOUT_MIN_ROWS and rb.mask_fwd is not None:
         centre = 1 << (rb.kv // 2)
         ok = float((rb.mask_fwd.view(-1) != centre).float().mean().item()) < 0.25
@@ -367,6 +439,7 @@ def tables_of(rb: Rulebook, which: str, cout: int = 64):
     if order is not None and st is not None:
         return st[0], st[1], order, 1
     if order is None and which == "fwd" and rb.subm and rb.layout is not None:
+        poll_class(rb)
         return pair, mask, rb.layout, _ROWS_LAYOUT
     return pair, mask, order, 0
 
@@ -562,8 +635,8 @@ def igemm_fwd(features: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
         bias = bias.to(features.dtype).contiguous()
     ws = _ws(L.spx_igemm_acc_bytes(n_out, K, kv), features.device) if kv > 32 else None   # fp32 partial sums
     _lib.check(L.spx_igemm_fwd(features.data_ptr(), filters.data_ptr(), out.data_ptr(),
-                               _ptr(pair), _ptr(mask), _ptr(argsort), int(tile_order), features.shape[0], n_out,
-                               C, K, kv, _dtype_code(features), identity_k, _ptr(bias),
+                               _ptr(pair), _ptr(mask), _ptr(argsort), _with_dense_hint(int(tile_order), argsort),
+                               features.shape[0], n_out, C, K, kv, _dtype_code(features), identity_k, _ptr(bias),
                                int(act_type) | (_OUT_CACHED if getattr(_out_policy, "cached", False) else 0),
                                float(act_alpha), _ptr(ws), 0 if ws is None else ws.numel(),
                                _stream(features)))
@@ -593,7 +666,8 @@ def igemm_dgrad(out_bp: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
     code = _dtype_code(out_bp)
     ws = _ws(max(L.spx_igemm_dgrad_ws_bytes(C, K, kv, code), L.spx_igemm_acc_bytes(n_in, C, kv)), out_bp.device)
     _lib.check(L.spx_igemm_dgrad(out_bp.data_ptr(), filters.data_ptr(), din.data_ptr(), _ptr(pair),
-                                 _ptr(mask), _ptr(argsort), int(tile_order), out_bp.shape[0], n_in, C, K, kv, code,
+                                 _ptr(mask), _ptr(argsort), _with_dense_hint(int(tile_order), argsort), out_bp.shape[0],
+                                 n_in, C, K, kv, code,
                                  int(subm), ws.data_ptr(), ws.numel(), _stream(out_bp)))
     return din if C == C0 else din[:, :C0].contiguous()
 
