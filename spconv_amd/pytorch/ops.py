@@ -16,6 +16,7 @@ this implementation has no CPU path.
 """
 from __future__ import annotations
 
+import collections
 import contextlib
 import ctypes
 import functools
@@ -312,13 +313,49 @@ _class_ring = {}              # device index -> [pinned int32 [_CLASS_SLOTS, 2],
 _class_pred = {}              # prediction key (module id) -> the rulebook built for it last time was dense
 
 
+class _ClassRequest:
+    """One asynchronous read of a rows layout's class word (see above)."""
+    __slots__ = ("ring", "slot", "token", "event", "key", "n", "rb", "done")
+
+    def resolve(self) -> bool:
+        """Non-blocking; True once the request is settled (answer taken, or lost to a wrapped ring)."""
+        if self.done:
+            return True
+        if self.ring[2][self.slot] is not self.token:     # the ring wrapped before anybody looked: stay with the prediction
+            self.done = True
+            return True
+        if not self.event.query():
+            return False
+        cls, heavy = (int(v) for v in self.ring[0][self.slot])
+        self.done = True
+        dense = (not cls) and self.n >= _WS_MIN_ROWS and 4 * heavy >= 3 * self.n
+        if self.key is not None:
+            _class_pred[self.key] = dense
+        rb = self.rb()
+        if rb is not None and rb.layout is not None:
+            rb.sparse_class, rb.heavy_rows = bool(cls), heavy
+            rb.layout._spx_dense = dense
+        return True
+
+
+_class_pending = collections.deque()
+
+
 def _request_class(rb: Rulebook) -> None:
     blob = rb.layout
     rb._class_req = None
     if blob is None:
         return
+    capturing = torch.cuda.is_current_stream_capturing()
+    if not capturing:
+        # answers to earlier requests (a layer that uses every rulebook once, right behind its build, never comes back
+        # to ask: the next build does it for it)
+        while _class_pending and _class_pending[0].resolve():
+            _class_pending.popleft()
+        if len(_class_pending) > 64:
+            _class_pending.popleft()
     blob._spx_dense = bool(_class_pred.get(getattr(rb, "pred_key", None), False))
-    if torch.cuda.is_current_stream_capturing():
+    if capturing:
         return
     ring = _class_ring.get(blob.device.index)
     if ring is None:
@@ -326,36 +363,26 @@ def _request_class(rb: Rulebook) -> None:
         _class_ring[blob.device.index] = ring
     host, slot = ring[0], ring[1]
     ring[1] = (slot + 1) % _CLASS_SLOTS
-    token = object()
-    ring[2][slot] = token
+    req = _ClassRequest()
+    req.ring, req.slot, req.token, req.done = ring, slot, object(), False
+    req.key, req.n, req.rb = getattr(rb, "pred_key", None), rb.n_out, weakref.ref(rb)
+    ring[2][slot] = req.token
     host[slot].copy_(blob[:2], non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record()
-    rb._class_req = (ring, slot, token, ev)
+    req.event = torch.cuda.Event()
+    req.event.record()
+    rb._class_req = req
+    _class_pending.append(req)
 
 
 def poll_class(rb: Optional[Rulebook]) -> None:
     """Non-blocking: takes the class word of rb's rows layout if its copy has arrived (see above)."""
-    if rb is None or rb.layout is None:
+    if rb is None or rb.layout is None or rb.sparse_class is not None:
         return
-    if rb.sparse_class is not None or getattr(rb, "_class_req", None) is None:
+    req = getattr(rb, "_class_req", None)
+    if req is None or torch.cuda.is_current_stream_capturing():
         return
-    if torch.cuda.is_current_stream_capturing():
-        return
-    ring, slot, token, ev = rb._class_req
-    if ring[2][slot] is not token:          # (the ring wrapped before anybody looked: stay with the prediction)
+    if req.resolve():
         rb._class_req = None
-        return
-    if not ev.query():
-        return
-    cls, heavy = (int(v) for v in ring[0][slot])
-    rb._class_req = None
-    rb.sparse_class, rb.heavy_rows = bool(cls), heavy
-    dense = (not cls) and rb.n_out >= _WS_MIN_ROWS and 4 * heavy >= 3 * rb.n_out
-    rb.layout._spx_dense = dense
-    key = getattr(rb, "pred_key", None)
-    if key is not None:
-        _class_pred[key] = dense
 
 
 def _with_dense_hint(tile_order: int, argsort) -> int:

@@ -22,8 +22,13 @@ def _run(args, extra_env=None, timeout=420):
 
 
 def test_bench_single_gpu_contract(cuda):
-    r = _run(["--steps", "16", "--warmup", "8", "--no-cpu-baseline", "--scenes", "4"])
-    assert r["n_gpus"] == 1 and r["steps"] == 16 and r["warmup"] == 8
+    r = _run(["--steps", "20", "--warmup", "8", "--no-cpu-baseline", "--scenes", "4"])
+    assert r["n_gpus"] == 1 and r["steps"] == 20 and r["warmup"] == 8
+    # the same replay structure at every N: 8 steps per graph, no untimed steps beyond --warmup; round
+    # 4's schedule (one K-step graph behind 400 pre-warm steps) rides along as a side figure
+    assert r["config"]["steps_per_replay"] == 8 and r["config"]["prewarm_steps"] == 0
+    assert r["round4_protocol"]["steps_per_replay"] == 20 and r["round4_protocol"]["value"] > 0
+    assert r["roofline"]["traffic"] and r["roofline"]["traffic_over_algorithmic"] > 0
     assert r["unit"] == "voxels/s" and r["value"] > 0 and r["scaling"] == "weak"
     for key in ("roofline", "roofline_cold", "roofline_warm"):
         assert r[key]["bound"] == "hbm" and 0 < r[key]["frac"] < 1.0
@@ -47,6 +52,19 @@ def test_bench_gpus_2_spawns_two_ranks(cuda):
     assert r["config"]["steps_per_replay"] == 8 and "side stream" in r["config"]["gradient_exchange"]
     assert r["config"]["ranks_seen"] == 2 and r["config"]["parallelism"] == "dp2"
     assert r["config"]["dist_backend"] == "gloo"
+
+
+def test_bench_gpus_8_dry_run_on_one_device(cuda):
+    """What the driver launches on an 8-GPU node (`--gpus 8`), as far as one device can take it: eight ranks over gloo
+    share cuda:0 -- launcher, per-rank scenes, the two alternating 8-step graphs, eight-way flat-bucket averages, the
+    max-over-ranks timing -- for the headline layer and for the backbone (VERDICT r4 next #6)."""
+    env = {"BENCH_DIST_BACKEND": "gloo", "BENCH_ONE_DEVICE": "1"}
+    r = _run(["--gpus", "8", "--steps", "16", "--warmup", "8", "--scenes", "1", "--voxels", "30000"], env, timeout=900)
+    assert r["n_gpus"] == 8 and r["config"]["ranks_seen"] == 8 and r["config"]["parallelism"] == "dp8"
+    assert r["config"]["steps_per_replay"] == 8 and r["value"] > 0
+    r = _run(["--gpus", "8", "--config", "4", "--steps", "2", "--warmup", "1", "--voxels", "8000", "--scenes", "1"],
+             env, timeout=900)
+    assert r["n_gpus"] == 8 and r["config"]["ranks_seen"] == 8 and len(r["config"]["layer_voxels"]) == 12
 
 
 def test_bench_config4_two_ranks(cuda):
