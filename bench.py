@@ -368,10 +368,49 @@ def cpu_baseline_layer(idx, shape, C, K, seed):
                 while len(times) < 10 and (time.perf_counter() < budget or not times):
                     times.append(one_pass(omp))
             results[f"{variant}@{threads}"] = statistics.median(times)
+    # The same step on the reference's OWN code where it compiles here: rulebook = SparseConvIndicesCPU (indices.py:1639-1708),
+    # row gather / scatter-add = GatherCPU (gather.py:30-86), both rendered from /root/reference by oracle/refbuild and
+    # compiled into oracle/_ref; torch.mm in between, as the reference's cppcore.py:232-348 callbacks do.  Serial gather /
+    # scatter (the published CPU wheel has no OpenMP, README.md:133) + MKL threads.
+    reference = None
+    try:
+        from oracle import ref as oref
+        if oref.available():
+            t0 = time.perf_counter()
+            _, rpair, rnum, _ = oref.get_indice_pairs(idx, 1, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, subm=True)
+            t_rrule = time.perf_counter() - t0
+            same = bool(np.array_equal(rpair, pair) and np.array_equal(rnum, num))
+            threads = min(16, cores)
+            torch.set_num_threads(threads)
+            oracle.use_reference_gather(True)
+            try:
+                def ref_pass():
+                    t0 = time.perf_counter()
+                    oracle.indice_conv(f, w, rpair, rnum, n, subm=True, omp=False)
+                    oracle.indice_conv_backward(f, w, dout, rpair, rnum, subm=True, omp=False)
+                    return time.perf_counter() - t0
+                first = ref_pass()
+                rtimes = [first] if first > 3.0 else []
+                budget = time.perf_counter() + 5.0
+                while not rtimes or (first <= 3.0 and len(rtimes) < 10 and time.perf_counter() < budget):
+                    rtimes.append(ref_pass())
+            finally:
+                oracle.use_reference_gather(False)
+            rmed = statistics.median(rtimes)
+            reference = {"value": n / rmed, "unit": "voxels/s", "cores": threads, "kind": "reference-rendered",
+                         "ms_per_step": rmed * 1e3, "rulebook_ms": t_rrule * 1e3,
+                         "rulebook_equals_port": same,
+                         "sample": f"{len(rtimes)} fwd+bwd passes of the same {n}-voxel scene: rulebook by the reference's "
+                                   f"SparseConvIndicesCPU ({t_rrule * 1e3:.1f} ms, single thread), rows moved by its GatherCPU "
+                                   f"(serial), torch.mm on {threads} threads; compiled from /root/reference by "
+                                   f"oracle/refbuild (oracle/_ref/libspconv_ref.so)"}
+    except Exception as e:                                   # the checker library is optional on a box without it
+        reference = {"error": f"{type(e).__name__}: {e}"[:200], "kind": "reference-rendered"}
     best = min(results, key=results.get)
     med = results[best]
     others = ", ".join(f"{k}: {v * 1e3:.0f} ms/step" for k, v in results.items())
     return {"value": n / med, "unit": "voxels/s", "cores": int(best.split("@")[1]), "kind": "port",
+            "reference_rendered": reference,
             "sample": f"fwd+bwd passes (1 warm-up, <= 10 timed, ~5 s budget per setting) of one "
                       f"{n}-voxel scene of this workload, fp32, per-offset gather -> torch.mm -> scatter-add "
                       f"(BASELINE.md) on a {cores}-thread host; fastest = {best}; all settings: {others}; "
