@@ -132,6 +132,26 @@ struct GemmRest {
   int napp;               // rows layout: appendix workgroups at the head of the grid, or -1 = the n / 4 rule
 };
 
+// balanced-segment weight gradient (igemm_bwd.h: wgrad_tr_body / wgrad_f32_body; plan: wgrad_plan2_kernel in igemm.hip)
+struct Wgrad2Params {
+  const void *feat;        // [n_in, C]
+  const void *dout;        // [n_out, K]
+  float *partial;          // [segment][tile][64*64]
+  const int32_t *native;   // [2, kv, n_in]
+  const int32_t *num;      // [kv]
+  const int32_t *plan2;    // see wgrad_plan2_kernel
+  int n_in, n_out, C, K, kv, subm, tiles_c, tiles_k, G;
+  int xcd_order;           // ranges are handed out in the plan's XCD-aware order
+};
+
+// One translation unit per operand type (the template bodies live in igemm_v4.h / igemm_bwd.h; igemm.hip holds the f16
+// instantiations, the generic kernels, the plans and the C ABI): a full rebuild compiles them side by side.
+int dispatch_gather_gemm_bf16(const GemmParams &p, hipStream_t s);                                   // igemm_bf16.hip
+int dispatch_bwd_bf16(const GemmParams &p, const Wgrad2Params &q, int n_wgrad_blocks, hipStream_t s);
+int dispatch_gather_gemm_f32(const GemmParams &p, hipStream_t s);                                    // igemm_f32.hip
+int dispatch_bwd_f32(const GemmParams &p, const Wgrad2Params &q, int n_wgrad_blocks, hipStream_t s);
+int launch_gather_gemm_int8(const GemmParams &p, bool rows64, hipStream_t s);                        // igemm_i8.hip
+
 // igemm_gen1.hip: first-generation gather-GEMM (tensors beyond 32-bit buffer offsets)
 int launch_gather_gemm_gen1(const GemmParams &p, bool bf16, hipStream_t s);
 // igemm_ws.hip: weight-stationary gather-GEMM for dense neighbourhoods (forward and dgrad)

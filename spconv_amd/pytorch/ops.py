@@ -295,6 +295,7 @@ def rows_layout(rb: Rulebook) -> None:
                                  ws.data_ptr(), ws.numel(), _stream(rb.pair_fwd)))
     rb.layout = blob
     rb.sort_decided = True
+    rb.sparse_class, rb.heavy_rows = None, 0      # (what was known belongs to the blob this one replaces)
     _request_class(rb)
 
 

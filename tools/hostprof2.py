@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Host-side cost of one single-scene backbone training step, split into forward (autograd on),
 loss and backward, with a cumulative cProfile of the forward and torch's own profiler for the
-backward thread.  Companion of tools/hostprof.py."""
+backward thread.  Companion of tools/experiments/hostprof.py."""
 import cProfile, io, os, pstats, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
