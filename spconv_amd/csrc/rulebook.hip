@@ -127,13 +127,18 @@ __device__ __forceinline__ int table_insert_min(const Table &t, hkey_t key, int3
   return -1;
 }
 
-// Value of key, or -1 when absent (values are row indices / positions, never negative).
-__device__ __forceinline__ int32_t table_find(const Table &t, hkey_t key) {
+// Home slot of a key.
+__device__ __forceinline__ uint32_t table_home(const Table &t, hkey_t key) {
+  return (t.packed ? hash_key32(static_cast<uint32_t>(key), t.gbits) : hash_key(key, t.gbits)) & t.mask;
+}
+
+// Value of key, or -1 when absent (values are row indices / positions, never negative): the walk from `slot`,
+// `probe` slots into it.
+__device__ __forceinline__ int32_t table_find_from(const Table &t, hkey_t key, uint32_t slot, uint32_t probe) {
   if (t.packed) {
     const unsigned long long *slots = reinterpret_cast<const unsigned long long *>(t.keys);
     const uint32_t k32 = static_cast<uint32_t>(key);
-    uint32_t slot = hash_key32(k32, t.gbits) & t.mask;
-    for (uint32_t probe = 0; probe <= t.max_probe; ++probe) {
+    for (; probe <= t.max_probe; ++probe) {
       const unsigned long long v = slots[slot];
       if (static_cast<uint32_t>(v >> 32) == k32 && v != kEmptySlot) return static_cast<int32_t>(v);
       if (v == kEmptySlot) return -1;
@@ -141,14 +146,17 @@ __device__ __forceinline__ int32_t table_find(const Table &t, hkey_t key) {
     }
     return -1;
   }
-  uint32_t slot = hash_key(key, t.gbits) & t.mask;
-  for (uint32_t probe = 0; probe <= t.max_probe; ++probe) {
+  for (; probe <= t.max_probe; ++probe) {
     const hkey_t k = t.keys[slot];
     if (k == key) return t.vals[slot];
     if (k == -1LL) return -1;
     slot = (slot + (1u << t.gbits)) & t.mask;
   }
   return -1;
+}
+
+__device__ __forceinline__ int32_t table_find(const Table &t, hkey_t key) {
+  return table_find_from(t, key, table_home(t, key), 0u);
 }
 
 // Reads one index row (batch, coords...) into canonical 4-d form.
@@ -260,7 +268,8 @@ void table_fill(FillList &f, const Table &t);
 __global__ void __launch_bounds__(kBlock)
 subm_insert_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table t,
                    int32_t *__restrict__ slot_of, uint32_t *__restrict__ mask_zero = nullptr,
-                   int words = 0, int32_t *__restrict__ fill_fwd = nullptr, int32_t *__restrict__ fill_bwd = nullptr) {
+                   int words = 0, int32_t *__restrict__ fill_fwd = nullptr, int32_t *__restrict__ fill_bwd = nullptr,
+                   uint32_t *__restrict__ occupied = nullptr) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   if (mask_zero)      // the probe kernel ORs bits into the masks: clear them here (no fill launch)
@@ -279,6 +288,8 @@ subm_insert_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table t,
   if (b >= 0 && b < g.batch && in_range(c, g.in_dims))
     slot = table_insert_min(t, layout_key(b, c, g.in_dims), i);
   if (slot_of) slot_of[i] = slot;
+  // one occupancy bit per slot for subm_probe5_kernel (set again by a duplicate coordinate: idempotent)
+  if (occupied && slot >= 0) atomicOr(&occupied[slot >> 5], 1u << (slot & 31));
 }
 
 // One thread per (voxel, offset k < kv/2): every probe chain is independent and there are only
@@ -389,6 +400,123 @@ subm_probe4_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table t,
       for (int w = 0; w < kBlock / 64; ++w) sum += lds_wave[w];
       groupcount[static_cast<size_t>(list) * ngroups + blockIdx.x] = sum;
     }
+  }
+}
+
+// Fifth form of the probe pass: an OCCUPANCY BIT per table slot, staged in LDS, answers most probes.
+// A SubM probe asks for a neighbour that, on a sparse scene, is almost never there (config 2: 97 % misses), and
+// with linear probing and no deletions a key whose HOME slot is empty was never inserted.  The insert kernel sets
+// one bit per occupied slot (cap / 8 bytes: 64 KB at 100 k voxels and 4 N slots); a workgroup of 1024 threads copies
+// the bits into LDS once, takes 256 voxels x all their upper-half offsets (thread = voxel x one of four offset
+// groups), tests every home slot there, and only goes to the table -- random 8-byte reads, the operation the fourth
+// form was rate-bound on (84 G/s device-wide, tools/probes/atomic_probe.hip) -- where the bit is set: the table's
+// load factor (0.19-0.38) + the real hits.  The first table word of a thread's offsets is requested in one
+// straight-line batch (an inactive lane reads slot 0); walks past the home slot are rare and serial.  Offsets are
+// decoded once per workgroup (LDS).  Same entries, same masks, same group counts as subm_probe4_kernel.
+constexpr int kP5Chunk = 4, kP5Groups = 4, kP5Threads = kBlock * kP5Groups;
+__global__ void __launch_bounds__(kP5Threads, 8)   // two workgroups per CU (64 KB of bits each)
+subm_probe5_kernel(const int32_t *__restrict__ indices, int n, Geom g, Table t,
+                   const uint32_t *__restrict__ occupied, int fwords, const int32_t *__restrict__ slot_of,
+                   int32_t *__restrict__ pair_fwd, int32_t *__restrict__ pair_bwd, uint32_t *__restrict__ mask,
+                   int words, int32_t *__restrict__ groupcount, int ngroups, int mask_pass) {
+  // [fwords] occupancy bits | [half] int4 coordinate steps | [half] key steps | [half][4] hit counts
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_occ[];
+  const int tid = threadIdx.x;
+  const int kv = g.kv, center = kv / 2, half = kv / 2;
+  int4 *lds_delta = reinterpret_cast<int4 *>(lds_occ + fwords);
+  hkey_t *lds_dkey = reinterpret_cast<hkey_t *>(lds_delta + half);
+  int *lds_cnt = reinterpret_cast<int *>(lds_dkey + half);
+  for (int i = tid; i < fwords / 4; i += kP5Threads)
+    reinterpret_cast<uint4 *>(lds_occ)[i] = reinterpret_cast<const uint4 *>(occupied)[i];
+  for (int l = tid; l < half; l += kP5Threads) {         // neighbour of list l: offset k = kv - 1 - l (> centre)
+    int r[4], dq[4];
+    decode_offset(kv - 1 - l, g.ksize, r);
+    hkey_t dk = 0;                                       // the key is linear in the coordinates: key(c + dq) = key(c) + dk
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      dq[d] = r[d] * g.dilation[d] - g.padding[d];
+      dk = dk * g.in_dims[d] + dq[d];
+    }
+    lds_delta[l] = make_int4(dq[0], dq[1], dq[2], dq[3]);
+    lds_dkey[l] = dk;
+  }
+  const int o = blockIdx.x * kBlock + (tid & (kBlock - 1));
+  const int grp = tid / kBlock;                          // lists grp, grp + 4, ... (uniform per wave)
+  int b = -1, c[4] = {0, 0, 0, 0};
+  bool valid = false;
+  if (o < n) {
+    read_row(indices, o, g.ndim, b, c);
+    valid = b >= 0 && b < g.batch && in_range(c, g.in_dims);
+  }
+  __syncthreads();
+  auto set = [&](int kk, int row, int val) __attribute__((always_inline)) {
+    pair_fwd[static_cast<size_t>(kk) * n + row] = val;
+    if (pair_bwd) pair_bwd[static_cast<size_t>(kv - 1 - kk) * n + row] = val;
+  };
+  const unsigned long long *slots = reinterpret_cast<const unsigned long long *>(t.keys);   // packed slots / wide keys
+  const hkey_t key0 = layout_key(b, c, g.in_dims);
+  int first = -1;                               // row o is the first of its coordinate: looked up at its first hit
+  for (int l0 = grp; l0 < half; l0 += kP5Chunk * kP5Groups) {
+    hkey_t key[kP5Chunk];
+    uint32_t home[kP5Chunk];
+    unsigned long long cur[kP5Chunk];
+    bool act[kP5Chunk];
+#pragma unroll
+    for (int j = 0; j < kP5Chunk; ++j) {
+      const int lj = l0 + j * kP5Groups;
+      const int l = lj < half ? lj : half - 1;
+      const int4 dq = lds_delta[l];
+      const int q[4] = {c[0] + dq.x, c[1] + dq.y, c[2] + dq.z, c[3] + dq.w};
+      key[j] = key0 + lds_dkey[l];
+      home[j] = table_home(t, key[j]);
+      bool a = valid && lj < half && in_range(q, g.in_dims);
+      if (fwords) a = a && ((lds_occ[home[j] >> 5] >> (home[j] & 31)) & 1u);
+      act[j] = a;
+      cur[j] = slots[a ? home[j] : 0u];
+    }
+#pragma unroll
+    for (int j = 0; j < kP5Chunk; ++j) {
+      const int l = l0 + j * kP5Groups;
+      const bool live = l < half;                 // (uniform per wave)
+      const int k = kv - 1 - l;
+      int v = -1;
+      if (act[j]) {
+        const bool hit = t.packed ? (static_cast<uint32_t>(cur[j] >> 32) == static_cast<uint32_t>(key[j]) &&
+                                     cur[j] != kEmptySlot)
+                                  : cur[j] == static_cast<unsigned long long>(key[j]);
+        if (hit) v = t.packed ? static_cast<int32_t>(static_cast<uint32_t>(cur[j])) : t.vals[home[j]];
+        else if (cur[j] != kEmptySlot)
+          v = table_find_from(t, key[j], (home[j] + (1u << t.gbits)) & t.mask, 1u);
+      }
+      if (live && o < n) {
+        set(k, o, v);                             // own entry, hit or miss
+        if (v >= 0) {
+          if (!mask_pass) atomicOr(&mask[static_cast<size_t>(o) * words + (k >> 5)], 1u << (k & 31));
+          if (first < 0) {
+            const int self = slot_of[o];
+            first = (self >= 0 && table_val(t, self) == o) ? 1 : 0;
+          }
+          if (first) {                            // first row of its coordinate: mirror entry
+            set(l, v, o);
+            if (!mask_pass) atomicOr(&mask[static_cast<size_t>(v) * words + (l >> 5)], 1u << (l & 31));
+          }
+        }
+      }
+      if (groupcount && live) {
+        const unsigned long long bal = __ballot(v >= 0);
+        if ((tid & 63) == 0) lds_cnt[l * 4 + ((tid >> 6) & 3)] = __popcll(bal);
+      }
+    }
+  }
+  if (grp == 0 && o < n) {
+    set(center, o, o);
+    if (!mask_pass) atomicOr(&mask[static_cast<size_t>(o) * words + (center >> 5)], 1u << (center & 31));
+  }
+  if (groupcount) {                               // hits per (list, 256-voxel group), as the fourth form leaves them
+    __syncthreads();
+    for (int l = tid; l < half; l += kP5Threads)
+      groupcount[static_cast<size_t>(l) * ngroups + blockIdx.x] =
+          lds_cnt[l * 4] + lds_cnt[l * 4 + 1] + lds_cnt[l * 4 + 2] + lds_cnt[l * 4 + 3];
   }
 }
 
@@ -1892,6 +2020,7 @@ size_t spx_subm_rulebook_ws_bytes(int n, int kv) {
   b += align_up(static_cast<size_t>(n > 0 ? n : 1) * sizeof(int32_t), 256);   // hash slot of every row
   // second generation: hit counts per (list, 256-voxel group)
   b += align_up(static_cast<size_t>(kv / 2 + 1) * div_up(n > 0 ? n : 1, kBlock) * sizeof(int32_t), 256);
+  b += align_up(cap / 8, 256);                // occupancy bit per table slot (subm_probe5_kernel)
   return b;
 }
 
@@ -1939,6 +2068,14 @@ int spx_subm_rulebook(const int32_t *indices, int n, int ndim, int batch_size,
   int32_t *slot_of = cv.take<int32_t>(n);
   const int nblk256 = div_up(n, kBlock);
   int32_t *groupcount = cv.take<int32_t>(static_cast<size_t>(kv / 2 + 1) * nblk256);
+  uint32_t *occupied = cv.take<uint32_t>(cap / 32);
+  // probe pass, fifth form (subm_probe5_kernel): behind an occupancy bit per slot in LDS for tables up to 2^19 slots
+  // (64 KB of bits, two workgroups per CU); larger tables take the same kernel without the bits
+  // -- the north star's "LDS-staged open-address hashing".  Measured (profiles/r04_experiments.md 1f, r05 7): 35.4 vs
+  // 36.9 us at 100 k uniform voxels, level at 100-125 k LiDAR-density voxels; without the bits (tables beyond 2^19 slots:
+  // 128 KB of bits would leave one workgroup per CU) the fourth form is faster (150 vs 163 us at 400 k) and stays.
+  const bool probe5 = option_int("SPX_SUBM_PROBE", 5) >= 5 && cap >= 1024u && cap <= (1u << 19) && kv <= 128;
+  const bool occ_bits = probe5;
   const dim3 grid(div_up(n, kBlock));
   // second generation: 4 launches (table fill, insert, probe, lists), no table pre-fills; beyond
   // ~4 M voxels the lists kernel's in-block prefix over the group counts would dominate
@@ -1947,16 +2084,28 @@ int spx_subm_rulebook(const int32_t *indices, int n, int ndim, int batch_size,
   if (kv > 1 && kv <= 128 && nblk256 <= 16384) {
     FillList fills;                    // the hash table only: the -1 halves of the tables ride in the insert kernel
     table_fill(fills, t);              // (pair_fwd rows k < centre; pair_bwd[kv-1-kk] mirrors pair_fwd[kk]: its rows above)
+    if (occ_bits) fills.add(occupied, cap / 8, 0u);
     SPX_HIP(fills.launch(s));
     // masks from a pass over the finished table instead of one atomicOr per entry: the extra launch costs 5-10 us at
     // 100 k voxels, the saved atomics (20-25 G/s device-wide) win from ~250 k (400 k: 162 -> 151 us); -1 = by size
     const int mp_opt = option_int("SPX_SUBM_MASK_PASS", -1);
     const int mask_pass = mp_opt < 0 ? (n >= 250000 ? 1 : 0) : mp_opt;
     hipLaunchKernelGGL(subm_insert_kernel, grid, dim3(kBlock), 0, s, indices, n, g, t, slot_of,
-                       mask_pass ? static_cast<uint32_t *>(nullptr) : mask, words, pair_fwd, pair_bwd);
+                       mask_pass ? static_cast<uint32_t *>(nullptr) : mask, words, pair_fwd, pair_bwd,
+                       occ_bits ? occupied : static_cast<uint32_t *>(nullptr));
     const bool lists = pair_native || num_per_loc;
-    hipLaunchKernelGGL(subm_probe4_kernel, dim3(div_up(n, kBlock), kv / 2 + 1), dim3(kBlock), 0, s, indices, n,
-                       g, t, slot_of, pair_fwd, pair_bwd, mask, words, lists ? groupcount : nullptr, nblk256, mask_pass);
+    if (probe5) {
+      const int fwords = occ_bits ? static_cast<int>(cap / 32) : 0;
+      const size_t lds = static_cast<size_t>(fwords) * 4 + static_cast<size_t>(kv / 2) * (16 + 8 + 16);
+      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&subm_probe5_kernel),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)attr;
+      hipLaunchKernelGGL(subm_probe5_kernel, dim3(nblk256), dim3(kP5Threads), lds, s, indices, n, g, t, occupied, fwords,
+                         slot_of, pair_fwd, pair_bwd, mask, words, lists ? groupcount : nullptr, nblk256, mask_pass);
+    } else {
+      hipLaunchKernelGGL(subm_probe4_kernel, dim3(div_up(n, kBlock), kv / 2 + 1), dim3(kBlock), 0, s, indices, n,
+                         g, t, slot_of, pair_fwd, pair_bwd, mask, words, lists ? groupcount : nullptr, nblk256, mask_pass);
+    }
     if (mask_pass)
       hipLaunchKernelGGL(mask_from_table_kernel, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, pair_fwd, kv, n, words, mask);
     if (lists) {

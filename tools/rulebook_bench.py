@@ -40,6 +40,10 @@ def main():
             return lambda i: ops.build_rulebook(ind, bs, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True,
                                                 need_native=native, do_sort=sort)
         row["subm_tables_us"] = round(bench.event_time_ms(subm(False), iters=40, span=4) * 1e3, 1)
+        # the probe pass without the LDS-staged occupancy bits (its fourth form), for comparison
+        set_option("SPX_SUBM_PROBE", 4)
+        row["subm_tables_probe4_us"] = round(bench.event_time_ms(subm(False), iters=40, span=4) * 1e3, 1)
+        set_option("SPX_SUBM_PROBE", 5)
         row["subm_with_lists_us"] = round(bench.event_time_ms(subm(True), iters=40, span=4) * 1e3, 1)
         # what the layer modules build by default: + the rows layout (count -> scan -> scatter, nothing read back)
         row["subm_tables_layout_us"] = round(bench.event_time_ms(subm(False, "layout"), iters=40, span=4) * 1e3, 1)
