@@ -279,6 +279,47 @@ def test_static_training_step_fp32_is_a_bound_not_a_noise_floor(cuda):
     assert rel < 2e-4, rel
 
 
+def test_config4_network_captured_step_equals_eager_in_fp32(cuda):
+    """The BASELINE config-4 network itself (spconv_amd.utils.nets.second_backbone: 12 sparse convolutions, 12
+    BatchNorm1d + ReLU, the p = (0, 1, 1) and (3, 1, 1) / (2, 1, 1) layers) as ONE captured training step against the
+    eager, unbounded step -- in fp32, where the comparison is a bound and not a noise floor (bench.py
+    accepts the fp16 step against a self-permutation floor).  Output 1e-5, every parameter gradient 5e-4 (twelve
+    normalisation layers deep; summation orders of the statistics and of the weight-gradient ranges differ)."""
+    import spconv_amd.pytorch as spconv
+    from spconv_amd.pytorch.static import StaticTrainingStep, strided_layers
+    from spconv_amd.utils import nets
+    shape, bs, C = [41, 96, 88], 2, 4
+    torch.manual_seed(3)
+    net = nets.second_backbone(C).to(cuda).train()
+    eager = copy.deepcopy(net)
+    f, idx = _scene_tensors(shape, 9000, bs, C, 2, cuda, torch.float32)
+    with torch.no_grad():                                  # the layer bounds: what this scene produces, + 10 %
+        counts = {}
+        probe = copy.deepcopy(net)
+        hs = [m.register_forward_hook(lambda mod, inp, out, nm=nm: counts.__setitem__(nm, out.features.shape[0]))
+              for nm, m in strided_layers(probe).items()]
+        probe(spconv.SparseConvTensor(f, idx, shape, bs))
+        for h in hs:
+            h.remove()
+    bounds = {nm: int(c * 1.1) + 64 for nm, c in counts.items()}
+    assert len(bounds) == 4
+    n_last = counts[list(strided_layers(net))[-1]]
+    g = (torch.rand((bounds[list(strided_layers(net))[-1]], 128), device=cuda) - 0.5) * 0.2
+    step = StaticTrainingStep(net, f.shape[0] + 500, C, shape, bs, torch.float32, bounds=bounds, out_grad=g,
+                              input_grad=False, example=(f, idx))
+    out = step(f, idx)
+    assert step.overflowed() == {}
+    ye = eager(spconv.SparseConvTensor(f, idx, shape, bs))
+    n_out = ye.features.shape[0]
+    assert n_out == n_last and int(out.n_live_dev) == n_out and torch.equal(out.indices[:n_out], ye.indices)
+    ye.features.backward(g[:n_out])
+    err = float((out.features[:n_out] - ye.features).abs().max() / ye.features.abs().max())
+    assert err < 1e-5, err
+    for (name, pa), pb in zip(net.named_parameters(), eager.parameters()):
+        rel = float((pa.grad - pb.grad).norm() / pb.grad.norm().clamp_min(1e-20))
+        assert rel < 5e-4, (name, rel)
+
+
 @pytest.mark.parametrize("pool", [False, True])
 def test_static_training_step_runner(cuda, pool):
     """StaticTrainingStep: one graph, several scenes; parameter gradients of every replay against the eager step.
