@@ -818,10 +818,16 @@ def run_layer(args, D: Dist):
         net_e.weight.grad = None
         fe.grad = None
         net_e(xe).features.backward(do)
-    # host-paced (three launches per step enqueued from Python): the box's host decides, and it is bimodal from run to
-    # run (76 vs 157 us on the same tree, profiles/r04_experiments.md) -- the MEDIAN of three windows, all three reported
+    # host-paced (three launches per step enqueued from Python).  Round 5 pinned the bimodal figure of rounds 3-4 (76 vs
+    # 150-200 us on the same tree) to the autograd engine's DEVICE THREAD: backward runs on a worker thread the calling
+    # thread wakes every step, and when the scheduler parks that thread on a far / sleeping core the hand-over doubles the
+    # step.  With the engine single-threaded (torch.autograd.set_multithreading_enabled(False): backward on the calling
+    # thread) six of six processes ran 76-77 us; pinning the process to two cores does the same
+    # (profiles/r05_experiments.md section 8).  Both figures: the recipe's, and the default engine's (median of three).
+    with torch.autograd.set_multithreading_enabled(False):
+        eager_runs_st = [event_time_ms(compute_eager, iters=200, warm=30) for _ in range(3)]
     eager_runs = [event_time_ms(compute_eager, iters=200, warm=30) for _ in range(3)]
-    t_eager = sorted(eager_runs)[1]           # the median (the host is bimodal: all three runs are reported)
+    t_eager = sorted(eager_runs_st)[1]
     del net_e, eager
     t_sort_dev = None
     if scenes[0].rb.argsort_fwd is not None:      # mask sort + tile-order table copies: once per rulebook
@@ -894,7 +900,10 @@ def run_layer(args, D: Dist):
         "round4_protocol": round4,
         "step_GBps_algorithmic": round(total_bytes / (ms_per_step * 1e-3) / 1e9, 1),
         "eager_device_ms_per_step": round(t_eager, 5),
-        "eager_device_ms_per_step_runs": [round(v, 5) for v in eager_runs],
+        "eager_device_ms_per_step_note": "autograd engine single-threaded (torch.autograd.set_multithreading_enabled(False)): "
+                                         "median of three windows; default engine beside it",
+        "eager_device_ms_per_step_runs": [round(v, 5) for v in eager_runs_st],
+        "eager_device_ms_per_step_default_engine_runs": [round(v, 5) for v in eager_runs],
         "ms_per_step_one_step_per_replay": None if single_replay_ms is None else round(single_replay_ms, 5),
         "rulebook_ms": round(statistics.median(rule_ms), 4),
         "rulebook_device_ms": round(t_rule_dev, 4),
@@ -1043,6 +1052,10 @@ def run_net(args, D: Dist):
     warm = min(args.warmup, 20)
     steps = min(args.steps, 200)
     elapsed = timed_region(D, run_steps, warm, steps)
+    eager_st_ms = None
+    if not D.multi:          # the eager step with the autograd engine on the calling thread (run_layer: the recipe)
+        with torch.autograd.set_multithreading_enabled(False):
+            eager_st_ms = timed_region(D, run_steps, min(warm, 5), steps) / steps * 1e3
     eager_ms, static_info = None, None
     if not args.no_graph and not D.multi:
         # the same step with static shapes, captured (rulebooks included); `value` is from this loop when it
@@ -1107,6 +1120,8 @@ def run_net(args, D: Dist):
     res["roofline_cold"] = res["roofline"]
     if eager_ms is not None:
         res["eager_ms_per_step"] = eager_ms
+    if eager_st_ms is not None:
+        res["eager_ms_per_step_single_thread_autograd"] = eager_st_ms
     if world == 1 and not args.no_cpu_baseline:
         t, done = cpu_baseline_net(recs)
         frac_layers = done / len(recs)
@@ -1361,6 +1376,7 @@ def also_block(args, D: Dist):
         if "kernels" in r:
             c["kernels_ms"] = {k: v["ms"] for k, v in r["kernels"].items()}
         for k in ("rulebook_device_ms", "eager_device_ms_per_step", "graph_ms_per_step", "eager_ms_per_step",
+                  "eager_ms_per_step_single_thread_autograd", "eager_device_ms_per_step_default_engine_runs",
                   "live_rows_identical_to_eager", "bn_folded_graph_ms_per_step",
                   "bn_folded_live_rows_identical_to_its_eager_pass"):
             if k in r:
