@@ -336,6 +336,7 @@ class _ClassRequest:
         if rb is not None and rb.layout is not None:
             rb.sparse_class, rb.heavy_rows = bool(cls), heavy
             rb.layout._spx_dense = dense
+            rb.layout._spx_heavy = heavy
         return True
 
 
@@ -416,6 +417,7 @@ def sparse_neighbourhoods(rb: Rulebook) -> bool:
         head = rb.layout[:2].tolist()
         ok, rb.heavy_rows = bool(head[0]), int(head[1])
         rb.layout._spx_dense = (not ok) and rb.n_out >= _WS_MIN_ROWS and 4 * rb.heavy_rows >= 3 * rb.n_out
+        rb.layout._spx_heavy = rb.heavy_rows
         rb._class_req = None
     elif rb.subm and 1 < rb.kv <= 32 and rb.n_out >= _LAYOUT_MIN_ROWS and rb.mask_fwd is not None:
         centre = 1 << (rb.kv // 2)
@@ -593,6 +595,15 @@ def igemm_fwd_int8(features: torch.Tensor, filters: torch.Tensor, pair: torch.Te
         add = _int_repr(add).contiguous()
         assert add.dtype == torch.int8 and tuple(add.shape) == (n_out, K0)
         add = _pad_last(add, K)
+    if sparse_hint and int(tile_order) == _ROWS_LAYOUT:
+        # The hint sizes the appendix part of the grid: rows past it would never be computed (round-4 ADVICE).  It is
+        # therefore taken from what has been READ from this very blob (poll_class / sparse_neighbourhoods leave it on the
+        # tensor), never from a caller's number alone: unknown -> no hint (the launch reserves n / 4 rows' worth).
+        known = getattr(argsort, "_spx_heavy", None)
+        if known is None:
+            sparse_hint, hint_rows = False, 0
+        else:
+            hint_rows = max(int(hint_rows), int(known))
     _lib.check(L.spx_igemm_fwd_int8(features.data_ptr(), filters.data_ptr(), out.data_ptr(), _ptr(pair),
                                     _ptr(mask), _ptr(argsort), features.shape[0], n_out, C, K, kv,
                                     identity_k, _ptr(scale), _ptr(bias), _ptr(add), float(add_scale),

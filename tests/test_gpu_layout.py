@@ -177,6 +177,11 @@ def test_layout_int8_forward_is_bit_identical(cuda, sparse):
         got = ops.igemm_fwd_int8(f, w, pair, mask, blob, rb.n_out, 13, sc, bias, None, 0.0, torch.int8,
                                  ops.Activation.ReLU, 0.0, tile_order=to, sparse_hint=True, hint_rows=rb.heavy_rows)
         assert torch.equal(ref, got) and rb.heavy_rows > 0
+        # a caller's number that is too small (a stale hint: round-4 ADVICE) cannot shrink the appendix grid below what
+        # was read from this blob: every row is still computed
+        got = ops.igemm_fwd_int8(f, w, pair, mask, blob, rb.n_out, 13, sc, bias, None, 0.0, torch.int8,
+                                 ops.Activation.ReLU, 0.0, tile_order=to, sparse_hint=True, hint_rows=64)
+        assert torch.equal(ref, got) and rb.heavy_rows > 64
 
 
 def test_module_default_builds_the_layout_and_reuses_it(cuda):
