@@ -1150,8 +1150,13 @@ def indice_avgpool_implicit_gemm(features: torch.Tensor, indice_pairs: torch.Ten
 @_on_device
 def indice_avgpool_implicit_gemm_backward(out_bp: torch.Tensor, indice_pairs: torch.Tensor,
                                           count_out: torch.Tensor) -> torch.Tensor:
-    """din[i] = sum_o dout[o] / count[o] over pair_bwd [kv, n_in] (cf. ops.py:2059-2084)."""
+    """din[i] = sum_o dout[o] / count[o] over pair_bwd [kv, n_in] (cf. ops.py:2059-2084).  With
+    SPCONV_AMD_REFERENCE_QUIRKS=1 the reference's own arithmetic (it MULTIPLIES by the count, maxpool.py:262-300): the
+    Python constant is the single source of truth and is handed to the library with every call (round-4 ADVICE: the
+    native side used to re-read the environment by itself)."""
+    from spconv_amd import constants
     L = _lib.load()
+    _lib.check(L.spx_set_option(b"SPCONV_AMD_REFERENCE_QUIRKS", int(bool(constants.REFERENCE_QUIRKS))))
     out_bp = out_bp.contiguous()
     n_in = indice_pairs.shape[1]
     din = torch.empty((n_in, out_bp.shape[1]), dtype=out_bp.dtype, device=out_bp.device)
