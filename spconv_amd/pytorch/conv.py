@@ -326,6 +326,14 @@ class SparseConvolution(SparseModule):
             self._check_subm_reuse_valid(input, spatial_shape, datas)
             rb = datas.rulebook
             outids = datas.out_indices
+            # The layer that BUILT this rulebook decided from its own shapes whether the Native lists (and the wgrad range
+            # plan) are needed; a later layer under the same key can need them when the builder did not (other channel
+            # counts).  Derived here, in the forward, not inside this layer's first backward -- where the extra launches
+            # would land in a timed or captured backward pass (round-4 ADVICE).
+            if (not rb.has_native and torch.is_grad_enabled() and (features.requires_grad or self.weight.requires_grad)
+                    and self._needs_native_lists(features, indices, batch_size, spatial_shape)):
+                rb._ensure_native()
+                ops._plan_of(rb)
         else:
             if input.benchmark:
                 torch.cuda.synchronize()

@@ -140,7 +140,7 @@ def test_native_maxpool_equals_the_reference_code_executed(cuda):
 def test_reference_quirks_switch_avgpool_backward(cuda):
     """SPCONV_AMD_REFERENCE_QUIRKS=1: the average-pool backward multiplies by the window count, as the reference
     kernel does (maxpool.py:262-300); the default divides."""
-    from spconv_amd import _lib
+    from spconv_amd import constants
     from spconv_amd.pytorch import ops
     shape, bs, C = [24, 24, 24], 1, 16
     idx = dense_scene(shape, 2500, bs, 3)
@@ -152,12 +152,13 @@ def test_reference_quirks_switch_avgpool_backward(cuda):
     fg, dg = torch.from_numpy(f).to(cuda), torch.from_numpy(dout).to(cuda)
     _, cnt = ops.indice_avgpool_implicit_gemm(fg, ops.attach_rulebook(rb.pair_fwd, rb), rb.n_out, True)
     pb = ops.attach_rulebook(rb.pair_bwd, rb)
-    L = _lib.load()
+    # the Python constant is the single source of truth (it travels to the library with the call)
+    saved = constants.REFERENCE_QUIRKS
     try:
-        _lib.check(L.spx_set_option(b"SPCONV_AMD_REFERENCE_QUIRKS", 1))
+        constants.REFERENCE_QUIRKS = True
         quirk = to_np(ops.indice_avgpool_implicit_gemm_backward(dg, pb, cnt))
     finally:
-        _lib.check(L.spx_set_option(b"SPCONV_AMD_REFERENCE_QUIRKS", 0))
+        constants.REFERENCE_QUIRKS = saved
     plain = to_np(ops.indice_avgpool_implicit_gemm_backward(dg, pb, cnt))
     want_q = oracle.avgpool_bwd_ref(dout, to_np(cnt), ref["pair"], ref["num"], ref["n_in"], False, reference_quirks=True)
     want_p = oracle.avgpool_bwd_ref(dout, to_np(cnt), ref["pair"], ref["num"], ref["n_in"], False)
