@@ -155,6 +155,59 @@ int spx_conv_rulebook_static(const int32_t *indices, int n_in, int ndim, int bat
                              uint32_t *mask_bwd, int32_t *pair_native, int32_t *num_per_loc,
                              int32_t *n_out_dev, void *ws, size_t ws_bytes, spx_stream_t stream);
 
+/* ---- sorted-order levels ---------------------------------------------------------------------------
+ * The reference's GPU path does not fix the order of a strided convolution's outputs: they come out of a
+ * sort + unique of the linear coordinate keys (csrc/sparse/all.py:1533-1552 apply_thrust_unique_to_indice_pairs_uniq)
+ * or out of a hash table in slot order (csrc/sparse/indices.py:1380-1425); only the CPU path is first-seen
+ * (indices.py:1742-1771, what spx_conv_rulebook_fill reproduces).  The calls below produce the SORTED order
+ * (batch-major linear key, last spatial dimension fastest) without a sort and without a hash table, through the
+ * RANK MAP of the output level: one {occupancy bits, number of occupied cells before the word} pair per 32
+ * consecutive keys; row of a key = prefix + popcount of the bits below it.  The map is the caller's buffer
+ * (spx_rankmap_bytes; 0 = key space beyond 2^31 cells: keep the hash builder) and stays valid after the call:
+ * spx_subm_rulebook_ranked builds the SubM rulebook of a layer BEHIND the strided one from it -- no table fill,
+ * no insert, one 8-byte load per neighbour query.  Rows in key order put x-neighbours in adjacent rows, which is
+ * what the gather kernels of the level gain (tools/order_probe.py).
+ * Values per coordinate are those of the first-seen build; only the row numbering differs.
+ * spx_conv_sorted_ok: 1 when the geometry has compact candidates (at most 8 per input and at most half of the
+ * offsets: k3 s2, k2 s2, k3 s3, ...; not transposed, not stride 1, not (3,1,1)/(2,1,1)) and the key space fits. */
+size_t spx_rankmap_bytes(int ndim, int batch_size, const int *shape);
+int spx_conv_sorted_ok(int ndim, int batch_size, const int *in_shape, const int *out_shape, const int *ksize,
+                       const int *stride, const int *padding, const int *dilation, int transposed);
+size_t spx_conv_rulebook_sorted_ws_bytes(int n_in, int ndim, int batch_size, const int *out_shape,
+                                         const int *ksize);
+/* phase 1 (as spx_conv_rulebook_count: the one D->H read of the count), phase 2 (as spx_conv_rulebook_fill)
+ * and the static-shape form (as spx_conv_rulebook_static; n_out_dev[1] stays 0: a rank map cannot overflow).
+ * `rankmap` and `ws` must be passed unchanged from phase 1 to phase 2. */
+int spx_conv_rulebook_count_sorted(const int32_t *indices, int n_in, int ndim, int batch_size,
+                                   const int *in_shape, const int *out_shape, const int *ksize,
+                                   const int *stride, const int *padding, const int *dilation,
+                                   void *rankmap, size_t rankmap_bytes, void *ws, size_t ws_bytes,
+                                   int *n_out_h, spx_stream_t stream);
+int spx_conv_rulebook_fill_sorted(const int32_t *indices, int n_in, int ndim, int batch_size,
+                                  const int *in_shape, const int *out_shape, const int *ksize,
+                                  const int *stride, const int *padding, const int *dilation, int n_out,
+                                  int32_t *out_indices, int32_t *pair_fwd, int32_t *pair_bwd,
+                                  uint32_t *mask_fwd, uint32_t *mask_bwd, int32_t *pair_native,
+                                  int32_t *num_per_loc, void *rankmap, size_t rankmap_bytes, void *ws,
+                                  size_t ws_bytes, spx_stream_t stream);
+int spx_conv_rulebook_static_sorted(const int32_t *indices, int n_in, int ndim, int batch_size,
+                                    const int *in_shape, const int *out_shape, const int *ksize,
+                                    const int *stride, const int *padding, const int *dilation,
+                                    int n_out_cap, int32_t *out_indices, int32_t *pair_fwd,
+                                    int32_t *pair_bwd, uint32_t *mask_fwd, uint32_t *mask_bwd,
+                                    int32_t *pair_native, int32_t *num_per_loc, int32_t *n_out_dev,
+                                    void *rankmap, size_t rankmap_bytes, void *ws, size_t ws_bytes,
+                                    spx_stream_t stream);
+/* SubM rulebook (outputs as spx_subm_rulebook, bit for bit) of a level whose rows are in key order and whose
+ * rank map a sorted-order build left behind: `indices` must be that build's out_indices (rows past its count:
+ * batch -1). */
+size_t spx_subm_rulebook_ranked_ws_bytes(int n, int kv);
+int spx_subm_rulebook_ranked(const int32_t *indices, int n, int ndim, int batch_size,
+                             const int *spatial_shape, const int *ksize, const int *dilation,
+                             int32_t *pair_fwd, int32_t *pair_bwd, uint32_t *mask,
+                             int32_t *pair_native, int32_t *num_per_loc, const void *rankmap,
+                             size_t rankmap_bytes, void *ws, size_t ws_bytes, spx_stream_t stream);
+
 /* mask_argsort: permutation that groups rows with equal masks (stable, ascending
  * mask value).  Replaces SpconvOps.sort_1d_by_key_allocator (all.py:935-991). */
 size_t spx_mask_argsort_ws_bytes(int n);

@@ -42,6 +42,21 @@ SIGNATURES = {
     "spx_conv_rulebook_static": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
                                  + [c_int_p] * 6 + [ctypes.c_int, ctypes.c_int] + [vp] * 8
                                  + [vp, ctypes.c_size_t, vp]),
+    "spx_rankmap_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, c_int_p]),
+    "spx_conv_sorted_ok": (ctypes.c_int, [ctypes.c_int, ctypes.c_int] + [c_int_p] * 6 + [ctypes.c_int]),
+    "spx_conv_rulebook_sorted_ws_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_int_p, c_int_p]),
+    "spx_conv_rulebook_count_sorted": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+                                       + [c_int_p] * 6 + [vp, ctypes.c_size_t, vp, ctypes.c_size_t, c_int_p, vp]),
+    "spx_conv_rulebook_fill_sorted": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+                                      + [c_int_p] * 6 + [ctypes.c_int] + [vp] * 7
+                                      + [vp, ctypes.c_size_t, vp, ctypes.c_size_t, vp]),
+    "spx_conv_rulebook_static_sorted": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+                                        + [c_int_p] * 6 + [ctypes.c_int] + [vp] * 8
+                                        + [vp, ctypes.c_size_t, vp, ctypes.c_size_t, vp]),
+    "spx_subm_rulebook_ranked_ws_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "spx_subm_rulebook_ranked": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_int_p,
+                                                c_int_p, c_int_p, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp,
+                                                ctypes.c_size_t, vp]),
     "spx_subm_layout_mcap": (ctypes.c_size_t, [ctypes.c_int]),
     "spx_subm_layout_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "spx_subm_layout_ws_bytes": (ctypes.c_size_t, [ctypes.c_int]),

@@ -9,6 +9,12 @@ SPCONV_DO_SORT = os.getenv("SPCONV_DO_SORT", "1") == "1"
 # analogue of the reference's default); "1" = the reference's explicit mask sort of every rulebook
 # (radix argsort + tables copied into tile order: ~100 us per rulebook); "0" = rows stay in input order.
 MODULE_DO_SORT = {"1": True, "0": False}.get(os.getenv("SPCONV_DO_SORT", ""), "layout")
+# Row order of a strided layer's outputs in the layer modules.  The reference fixes none on the GPU (sort + unique of
+# the coordinate keys, all.py:1533-1552, or hash-slot order, indices.py:1380-1425); its CPU path is first-seen
+# (indices.py:1742-1771).  "sorted" (default) = ascending coordinate key through the level's rank map (a cheaper build,
+# SubM layers behind it without a hash table, x-neighbours in adjacent rows for every gather of the level);
+# "first_seen" = the CPU reference's numbering.  The functional API (ops.get_indice_pairs*) is first-seen always.
+CONV_OUTPUT_ORDER = os.getenv("SPCONV_AMD_CONV_ORDER", "sorted")
 # spconv/constants.py:36: layout of checkpoints produced by spconv 1.x / 2.1 ("KRSC", "RSKC", "RSCK").
 SAVED_WEIGHT_LAYOUT = os.getenv("SPCONV_SAVED_WEIGHT_LAYOUT", "")
 # spconv/constants.py:112: skip the constructor checks of SparseConvTensor while torch.fx traces a

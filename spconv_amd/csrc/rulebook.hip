@@ -1219,6 +1219,250 @@ conv3_pairs_kernel(const int32_t *__restrict__ indices, int n, Geom g,
   }
 }
 
+// ------------------------------------------ regular conv, fourth generation: outputs numbered by KEY RANK
+// The passes above number the outputs in the CPU reference's first-seen order (indices.py:1742-1771), which takes a
+// hash table, a first-seen bit map and a rank per (offset, input).  The reference's GPU path has no such order: its
+// outputs come out of a sort + unique of the linear coordinate keys (all.py:1533-1552) or out of a hash table in slot
+// order (indices.py:1380-1425).  This generation produces the SORTED order, without a sort and without a hash table:
+//   * the RANK MAP of a level: one {occupancy bits, prefix} pair per 32 consecutive linear keys (batch-major, x
+//     fastest) -- mark: one atomicOr per candidate (skipped when a plain read already shows the bit);
+//     prefix: popcount scan of the words (block-local, + block offsets from scan_kernel);
+//     row of key = prefix + popcount(bits below): ONE 8-byte load, no probing, no first-seen resolution;
+//   * out_indices are decoded from the set bits in key order, the pair tables are written per input as before;
+//   * the map stays with the level: a SubM layer behind the strided layer looks its neighbours up in it
+//     (subm_rank_probe_kernel below) -- no table fill, no insert, no slot walks -- and its rows, being in key
+//     order, put x-neighbours in adjacent rows (what the gather-GEMMs of the level gain: order_probe.py).
+// Memory: (batch x grid cells) / 4 bytes (47 M cells of a 21 x 800 x 704 x 4 level: 11.8 MB); key spaces beyond
+// 2^31 cells keep the hash builder.
+constexpr int kRankWords = 2048;      // words (65536 cells) per prefix block
+constexpr int kRankPer = kRankWords / kBlock;
+
+template <int MJ>
+__global__ void __launch_bounds__(kBlock)
+conv4_mark_kernel(const int32_t *__restrict__ indices, int n, Geom g, uint2 *__restrict__ cells) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  int b, c[4];
+  read_row(indices, i, g.ndim, b, c);
+  CandIter it;
+  it.init(g, c, b >= 0 && b < g.batch);
+  const int share = blockIdx.y, shares = gridDim.y - 1;      // (as conv3_insert_kernel)
+#pragma unroll
+  for (int j = 0; j < MJ; ++j) {
+    if (!it.live) break;
+    if ((j & shares) == share) {
+      int q[4];
+      it.offset(g, c, q);
+      const unsigned long long key = static_cast<unsigned long long>(layout_key(b, q, g.out_dims));
+      uint32_t *word = &cells[key >> 5].x;
+      const uint32_t bit = 1u << (key & 31);
+      // several inputs reach the same output: a (possibly stale) read that shows the bit is final
+      if (!(*word & bit)) atomicOr(word, bit);
+    }
+    it.next();
+  }
+}
+
+// block-local exclusive prefix of the words' popcounts -> cells[w].y, block total -> blockcount
+__global__ void __launch_bounds__(kBlock)
+conv4_prefix_kernel(uint2 *__restrict__ cells, unsigned W, int32_t *__restrict__ blockcount) {
+  __shared__ int lds_wave[kBlock / 64];
+  const unsigned base = blockIdx.x * kRankWords + threadIdx.x * kRankPer;
+  int cnt[kRankPer], sum = 0;
+#pragma unroll
+  for (int e = 0; e < kRankPer; ++e) {
+    cnt[e] = base + e < W ? __popc(cells[base + e].x) : 0;
+    sum += cnt[e];
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int u = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += u;
+  }
+  if (lane == 63) lds_wave[wave] = incl;
+  __syncthreads();
+  int prefix = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) {
+    const int x = lds_wave[w];
+    if (w < wave) prefix += x;
+    total += x;
+  }
+  int run = prefix + incl - sum;
+#pragma unroll
+  for (int e = 0; e < kRankPer; ++e) {
+    if (base + e < W) cells[base + e].y = static_cast<uint32_t>(run);
+    run += cnt[e];
+  }
+  if (threadIdx.x == 0) blockcount[blockIdx.x] = total;
+}
+
+// prefix made global (+ block offset), coordinates of the set bits -> out_indices in key order; outputs beyond the
+// caller's bound are dropped (their rank says so wherever it is looked up)
+__global__ void __launch_bounds__(kBlock)
+conv4_emit_kernel(uint2 *__restrict__ cells, unsigned W, const int32_t *__restrict__ blockoff, Geom g,
+                  int32_t *__restrict__ out_indices, int n_cap) {
+  const unsigned w = blockIdx.x * kBlock + threadIdx.x;
+  if (w >= W) return;
+  uint2 cell = cells[w];
+  const int p = blockoff[w / kRankWords] + static_cast<int>(cell.y);
+  cells[w].y = static_cast<uint32_t>(p);
+  uint32_t bits = cell.x;
+  const int lead = 4 - g.ndim;
+  int oid = p;
+  while (bits && oid < n_cap) {
+    const int bit = __builtin_ctz(bits);
+    bits &= bits - 1;
+    unsigned long long v = (static_cast<unsigned long long>(w) << 5) | static_cast<unsigned>(bit);
+    int c[4];
+#pragma unroll
+    for (int d = 3; d >= 0; --d) {
+      c[d] = static_cast<int>(v % static_cast<unsigned>(g.out_dims[d]));
+      v /= static_cast<unsigned>(g.out_dims[d]);
+    }
+    int32_t *dst = out_indices + static_cast<size_t>(oid) * (g.ndim + 1);
+    dst[0] = static_cast<int32_t>(v);
+    for (int d = lead; d < 4; ++d) dst[1 + d - lead] = c[d];
+    ++oid;
+  }
+}
+
+__device__ __forceinline__ int rank_of(const uint2 *__restrict__ cells, unsigned long long key) {
+  const uint2 cell = cells[key >> 5];
+  const uint32_t bit = 1u << (key & 31);
+  return (cell.x & bit) ? static_cast<int>(cell.y) + __popc(cell.x & (bit - 1u)) : -1;
+}
+
+// both tables, the input-side mask and the pair counts of the Native lists (as conv3_pairs_kernel; the output row
+// of a candidate is its key's rank)
+template <int MJ>
+__global__ void __launch_bounds__(kBlock)
+conv4_pairs_kernel(const int32_t *__restrict__ indices, int n, Geom g, const uint2 *__restrict__ cells, int n_out,
+                   int32_t *__restrict__ pair_fwd, int32_t *__restrict__ pair_bwd,
+                   uint32_t *__restrict__ mask_bwd, int words, int32_t *__restrict__ groupcount) {
+  __shared__ int lds_cnt[kMaxKv3];
+  const int i = blockIdx.x * kBlock + threadIdx.x, kv = g.kv;
+  if (groupcount) {
+    if (threadIdx.x < kMaxKv3) lds_cnt[threadIdx.x] = 0;
+    __syncthreads();
+  }
+  int kk[MJ], oid[MJ];
+#pragma unroll
+  for (int j = 0; j < MJ; ++j) {
+    kk[j] = -1;
+    oid[j] = -1;
+  }
+  if (i < n) {
+    int b, c[4];
+    read_row(indices, i, g.ndim, b, c);
+    CandIter it;
+    it.init(g, c, b >= 0 && b < g.batch);
+    unsigned long long key[MJ];
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) {
+      key[j] = 0;
+      if (it.live) {
+        int q[4];
+        kk[j] = it.offset(g, c, q);
+        key[j] = static_cast<unsigned long long>(layout_key(b, q, g.out_dims));
+        it.next();
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) {                 // (every map load of the row in flight together)
+      if (kk[j] >= 0) {
+        const int r = rank_of(cells, key[j]);
+        oid[j] = r < n_out ? r : -1;               // an output beyond the caller's bound
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < MJ; ++j)
+      if (oid[j] >= 0) pair_fwd[static_cast<size_t>(kk[j]) * n_out + oid[j]] = i;
+  }
+  uint32_t mword = 0;
+  for (int k = 0; k < kv; ++k) {
+    int val = -1;
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) val = kk[j] == k ? oid[j] : val;
+    if (i < n) pair_bwd[static_cast<size_t>(k) * n + i] = val;
+    if (val >= 0) mword |= 1u << (k & 31);
+    if (mask_bwd && i < n && ((k & 31) == 31 || k == kv - 1)) {
+      mask_bwd[static_cast<size_t>(i) * words + (k >> 5)] = mword;
+      mword = 0;
+    }
+    if (groupcount) {
+      const unsigned long long bal = __ballot(val >= 0);
+      if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&lds_cnt[k], __popcll(bal));
+    }
+  }
+  if (groupcount) {
+    __syncthreads();
+    if (threadIdx.x < kv) groupcount[static_cast<size_t>(threadIdx.x) * gridDim.x + blockIdx.x] = lds_cnt[threadIdx.x];
+  }
+}
+
+// SubM probe pass over the rank map of a level whose rows are in key order (row = rank of its key): as
+// subm_probe4_kernel -- same entries, masks and group counts --, the neighbour looked up by rank_of instead of a
+// hash walk; every row is the first (and only) row of its coordinate.
+__global__ void __launch_bounds__(kBlock)
+subm_rank_probe_kernel(const int32_t *__restrict__ indices, int n, Geom g, const uint2 *__restrict__ cells,
+                       int32_t *__restrict__ pair_fwd, int32_t *__restrict__ pair_bwd,
+                       uint32_t *__restrict__ mask, int words, int32_t *__restrict__ groupcount, int ngroups,
+                       int mask_pass) {
+  __shared__ int lds_wave[kBlock / 64];
+  const int o = blockIdx.x * kBlock + threadIdx.x;
+  const int kv = g.kv, center = kv / 2;
+  const int list = blockIdx.y;                // 0 .. kv/2 - 1, or kv/2 = the identity offset
+  const int k = kv - 1 - list;                // probed offset (> centre), or the centre itself
+  auto set = [&](int kk, int row, int val) __attribute__((always_inline)) {
+    pair_fwd[static_cast<size_t>(kk) * n + row] = val;
+    if (pair_bwd) pair_bwd[static_cast<size_t>(kv - 1 - kk) * n + row] = val;
+  };
+  if (list == center) {
+    if (o < n) {
+      set(center, o, o);
+      if (!mask_pass) atomicOr(&mask[static_cast<size_t>(o) * words + (center >> 5)], 1u << (center & 31));
+    }
+    return;
+  }
+  int v = -1;
+  if (o < n) {
+    int b, c[4];
+    read_row(indices, o, g.ndim, b, c);
+    if (b >= 0 && b < g.batch && in_range(c, g.in_dims)) {
+      int r[4], q[4];
+      decode_offset(k, g.ksize, r);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) q[d] = c[d] - g.padding[d] + r[d] * g.dilation[d];
+      if (in_range(q, g.in_dims)) {
+        v = rank_of(cells, static_cast<unsigned long long>(layout_key(b, q, g.in_dims)));
+        if (v >= n) v = -1;                   // (an output the producing layer's bound dropped)
+      }
+      set(k, o, v);                           // own entry, hit or miss
+      if (v >= 0) {
+        if (!mask_pass) atomicOr(&mask[static_cast<size_t>(o) * words + (k >> 5)], 1u << (k & 31));
+        set(list, v, o);                      // mirror entry
+        if (!mask_pass) atomicOr(&mask[static_cast<size_t>(v) * words + (list >> 5)], 1u << (list & 31));
+      }
+    } else {
+      set(k, o, -1);                          // a dead row (static shapes): no neighbours, and nobody's neighbour
+    }
+  }
+  if (groupcount) {
+    const unsigned long long bal = __ballot(v >= 0);
+    if ((threadIdx.x & 63) == 0) lds_wave[threadIdx.x >> 6] = __popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int sum = 0;
+#pragma unroll
+      for (int w = 0; w < kBlock / 64; ++w) sum += lds_wave[w];
+      groupcount[static_cast<size_t>(list) * ngroups + blockIdx.x] = sum;
+    }
+  }
+}
+
 // mask[row][w] bit k = (table[k][row] >= 0)  (indices.py:652-676)
 __global__ void __launch_bounds__(kBlock)
 mask_from_table_kernel(const int32_t *__restrict__ table, int kv, int n, int words,
@@ -2434,6 +2678,259 @@ int spx_conv_rulebook_static(const int32_t *indices, int n_in, int ndim, int bat
                              dilation, transposed, n_out_cap, out_indices, pair_fwd, pair_bwd, mask_fwd, mask_bwd,
                              pair_native, num_per_loc, ws, ws_bytes, stream, true);
 }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Sorted-order builds (conv4_* / subm_rank_probe_kernel above): the rank map is the caller's buffer -- it outlives
+// the call, the SubM layers of the level read it.
+namespace spx {
+namespace {
+// words of a level's rank map (0: the key space does not fit)
+size_t rank_words(int ndim, int batch_size, const int *shape) {
+  if (ndim < 1 || ndim > kMaxNdim || batch_size < 1) return 0;
+  unsigned long long cells = static_cast<unsigned long long>(batch_size);
+  for (int i = 0; i < ndim; ++i) {
+    if (shape[i] < 1) return 0;
+    cells *= static_cast<unsigned long long>(shape[i]);
+    if (cells > 0x7fffffe0ull) return 0;
+  }
+  return static_cast<size_t>((cells + 31) / 32);
+}
+
+struct Conv4Ws {
+  int32_t *blockcount, *blockoff, *d_nout, *groupcount;
+  int nblk;
+  size_t bytes;
+};
+Conv4Ws carve_conv4_ws(void *ws, int n_in, int kv, size_t W) {
+  Conv4Ws w;
+  w.nblk = static_cast<int>((W + kRankWords - 1) / kRankWords);
+  Carver cv(ws);
+  w.blockcount = cv.take<int32_t>(w.nblk > 0 ? w.nblk : 1);
+  w.blockoff = cv.take<int32_t>(w.nblk > 0 ? w.nblk : 1);
+  w.d_nout = cv.take<int32_t>(2);
+  w.groupcount = cv.take<int32_t>(static_cast<size_t>(kv) * div_up(n_in > 0 ? n_in : 1, kBlock));
+  w.bytes = cv.off;
+  return w;
+}
+
+int conv4_count_impl(const int32_t *indices, int n_in, int ndim, int batch_size, const int *in_shape,
+                     const int *out_shape, const int *ksize, const int *stride, const int *padding,
+                     const int *dilation, void *rankmap, size_t rankmap_bytes, void *ws, size_t ws_bytes,
+                     int *n_out_h, hipStream_t s, const FillList *more, int32_t *nout_dev) {
+  SPX_CHECK(ndim >= 1 && ndim <= kMaxNdim, "ndim must be in [1,4], got %d", ndim);
+  const Geom g = make_geom(ndim, batch_size, in_shape, out_shape, ksize, stride, padding, dilation);
+  if (check_geom(ndim, n_in, g.kv)) return -1;
+  const int mj = conv3_cands(ndim, in_shape, ksize, stride, padding, dilation, 0);
+  SPX_CHECK(mj > 0, "sorted-order build: this geometry takes the first-seen builder (spx_conv_sorted_ok)");
+  const size_t W = rank_words(ndim, batch_size, out_shape);
+  SPX_CHECK(W > 0 && rankmap && rankmap_bytes >= W * sizeof(uint2), "rank map missing or too small (%zu words)", W);
+  Conv4Ws w = carve_conv4_ws(ws, n_in, g.kv, W);
+  SPX_CHECK(ws && ws_bytes >= w.bytes, "workspace too small");
+  if (n_out_h) *n_out_h = 0;
+  uint2 *cells = static_cast<uint2 *>(rankmap);
+  if (nout_dev) w.d_nout = nout_dev;
+  {
+    FillList fills;
+    fills.add(cells, W * sizeof(uint2), 0u);
+    fills.add(w.d_nout, 2 * sizeof(int32_t), 0u);
+    if (more)
+      for (int j = 0; j < more->jobs.n; ++j)
+        fills.add(more->jobs.ptr[j], more->jobs.words[j] * 4, more->jobs.value[j]);
+    SPX_HIP(fills.launch(s));
+  }
+  if (n_in > 0) {
+    SPX_CONV3_LAUNCH(conv4_mark_kernel, mj, dim3(div_up(n_in, kBlock), conv3_shares(n_in, mj)), dim3(kBlock), 0, s,
+                     indices, n_in, g, cells);
+    hipLaunchKernelGGL(conv4_prefix_kernel, dim3(w.nblk), dim3(kBlock), 0, s, cells, static_cast<unsigned>(W),
+                       w.blockcount);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kBlock), 0, s, w.blockcount, w.blockoff, w.nblk, w.d_nout);
+    SPX_LAUNCH_CHECK();
+  }
+  if (!n_out_h) return 0;                // static-shape form: the count stays on the device
+  int32_t host_n[2] = {0, 0};
+  SPX_HIP(hipMemcpyAsync(host_n, w.d_nout, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  SPX_HIP(hipStreamSynchronize(s));
+  *n_out_h = host_n[0];
+  return 0;
+}
+
+int conv4_fill_impl(const int32_t *indices, int n_in, int ndim, int batch_size, const int *in_shape,
+                    const int *out_shape, const int *ksize, const int *stride, const int *padding,
+                    const int *dilation, int n_out, int32_t *out_indices, int32_t *pair_fwd, int32_t *pair_bwd,
+                    uint32_t *mask_fwd, uint32_t *mask_bwd, int32_t *pair_native, int32_t *num_per_loc,
+                    void *rankmap, size_t rankmap_bytes, void *ws, size_t ws_bytes, hipStream_t s, bool prefilled) {
+  const Geom g = make_geom(ndim, batch_size, in_shape, out_shape, ksize, stride, padding, dilation);
+  if (check_geom(ndim, n_in, g.kv)) return -1;
+  const int mj = conv3_cands(ndim, in_shape, ksize, stride, padding, dilation, 0);
+  SPX_CHECK(mj > 0, "sorted-order build: this geometry takes the first-seen builder (spx_conv_sorted_ok)");
+  const size_t W = rank_words(ndim, batch_size, out_shape);
+  SPX_CHECK(W > 0 && rankmap && rankmap_bytes >= W * sizeof(uint2), "rank map missing or too small (%zu words)", W);
+  Conv4Ws w = carve_conv4_ws(ws, n_in, g.kv, W);
+  SPX_CHECK(ws && ws_bytes >= w.bytes, "workspace too small");
+  SPX_CHECK(pair_fwd && pair_bwd && out_indices, "out_indices, pair_fwd and pair_bwd are required");
+  const int kv = g.kv, words = div_up(kv, 32);
+  const int ngroups = div_up(n_in > 0 ? n_in : 1, kBlock);
+  const bool lists = pair_native || num_per_loc;
+  SPX_CHECK(!lists || (ngroups <= 16384 && kv <= 128), "Native lists of a sorted-order build: too many rows / offsets");
+  SPX_CHECK(!pair_native || num_per_loc, "num_per_loc is required with pair_native");
+  uint2 *cells = static_cast<uint2 *>(rankmap);
+  {
+    FillList fills;
+    if (n_in > 0 && n_out > 0 && !prefilled)
+      fills.add(pair_fwd, sizeof(int32_t) * static_cast<size_t>(kv) * n_out, 0xFFFFFFFFu);
+    if (n_in == 0 && num_per_loc) fills.add(num_per_loc, sizeof(int32_t) * kv, 0u);
+    SPX_HIP(fills.launch(s));
+  }
+  if (n_in == 0) return 0;
+  hipLaunchKernelGGL(conv4_emit_kernel, dim3(div_up(static_cast<int>(W), kBlock)), dim3(kBlock), 0, s, cells,
+                     static_cast<unsigned>(W), static_cast<const int32_t *>(w.blockoff), g, out_indices, n_out);
+  SPX_CONV3_LAUNCH(conv4_pairs_kernel, mj, dim3(div_up(n_in, kBlock)), dim3(kBlock), 0, s, indices, n_in, g,
+                   static_cast<const uint2 *>(cells), n_out, pair_fwd, pair_bwd, mask_bwd, words,
+                   lists ? w.groupcount : nullptr);
+  if (mask_fwd && n_out > 0)
+    hipLaunchKernelGGL(mask_from_tables_kernel, dim3(div_up(n_out, kBlock)), dim3(kBlock), 0, s, pair_fwd, n_out, mask_fwd,
+                       pair_bwd, 0, mask_bwd, kv, words);
+  if (lists)
+    hipLaunchKernelGGL(subm_lists_kernel, dim3(div_up(n_in, kItems), kv), dim3(kBlock), 0, s, pair_bwd, kv, n_in, ngroups,
+                       w.groupcount, pair_native, num_per_loc, 0, 1);
+  SPX_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace
+}  // namespace spx
+
+extern "C" {
+
+size_t spx_rankmap_bytes(int ndim, int batch_size, const int *shape) {
+  return spx::rank_words(ndim, batch_size, shape) * sizeof(uint2);
+}
+
+int spx_conv_sorted_ok(int ndim, int batch_size, const int *in_shape, const int *out_shape, const int *ksize,
+                       const int *stride, const int *padding, const int *dilation, int transposed) {
+  if (ndim < 1 || ndim > spx::kMaxNdim || transposed) return 0;
+  return spx::conv3_cands(ndim, in_shape, ksize, stride, padding, dilation, 0) > 0 &&
+         spx::rank_words(ndim, batch_size, out_shape) > 0;
+}
+
+size_t spx_conv_rulebook_sorted_ws_bytes(int n_in, int ndim, int batch_size, const int *out_shape, const int *ksize) {
+  if (ndim < 1 || ndim > spx::kMaxNdim) return 0;
+  int kv = 1;
+  for (int i = 0; i < ndim; ++i) kv *= ksize[i];
+  return spx::carve_conv4_ws(nullptr, n_in, kv, spx::rank_words(ndim, batch_size, out_shape)).bytes + 256;
+}
+
+int spx_conv_rulebook_count_sorted(const int32_t *indices, int n_in, int ndim, int batch_size, const int *in_shape,
+                                   const int *out_shape, const int *ksize, const int *stride, const int *padding,
+                                   const int *dilation, void *rankmap, size_t rankmap_bytes, void *ws,
+                                   size_t ws_bytes, int *n_out_h, spx_stream_t stream) {
+  SPX_CHECK(n_out_h, "n_out_h is required");
+  return spx::conv4_count_impl(indices, n_in, ndim, batch_size, in_shape, out_shape, ksize, stride, padding, dilation,
+                               rankmap, rankmap_bytes, ws, ws_bytes, n_out_h, static_cast<hipStream_t>(stream),
+                               nullptr, nullptr);
+}
+
+int spx_conv_rulebook_fill_sorted(const int32_t *indices, int n_in, int ndim, int batch_size, const int *in_shape,
+                                  const int *out_shape, const int *ksize, const int *stride, const int *padding,
+                                  const int *dilation, int n_out, int32_t *out_indices, int32_t *pair_fwd,
+                                  int32_t *pair_bwd, uint32_t *mask_fwd, uint32_t *mask_bwd, int32_t *pair_native,
+                                  int32_t *num_per_loc, void *rankmap, size_t rankmap_bytes, void *ws,
+                                  size_t ws_bytes, spx_stream_t stream) {
+  return spx::conv4_fill_impl(indices, n_in, ndim, batch_size, in_shape, out_shape, ksize, stride, padding, dilation,
+                              n_out, out_indices, pair_fwd, pair_bwd, mask_fwd, mask_bwd, pair_native, num_per_loc,
+                              rankmap, rankmap_bytes, ws, ws_bytes, static_cast<hipStream_t>(stream), false);
+}
+
+int spx_conv_rulebook_static_sorted(const int32_t *indices, int n_in, int ndim, int batch_size, const int *in_shape,
+                                    const int *out_shape, const int *ksize, const int *stride, const int *padding,
+                                    const int *dilation, int n_out_cap, int32_t *out_indices, int32_t *pair_fwd,
+                                    int32_t *pair_bwd, uint32_t *mask_fwd, uint32_t *mask_bwd, int32_t *pair_native,
+                                    int32_t *num_per_loc, int32_t *n_out_dev, void *rankmap, size_t rankmap_bytes,
+                                    void *ws, size_t ws_bytes, spx_stream_t stream) {
+  SPX_CHECK(n_out_cap > 0 && n_out_dev && out_indices, "n_out_cap > 0, n_out_dev and out_indices are required");
+  SPX_CHECK(n_in > 0, "static-shape rulebook needs n_in > 0 (pad the input with batch = -1 rows)");
+  SPX_CHECK(pair_fwd && pair_bwd, "pair_fwd and pair_bwd are required");
+  int kv = 1;
+  for (int i = 0; i < ndim; ++i) kv *= ksize[i];
+  spx::FillList pre;         // (as spx_conv_rulebook_static: the -1 fills of the outputs ride in the first fill launch)
+  pre.add(out_indices, sizeof(int32_t) * static_cast<size_t>(n_out_cap) * (ndim + 1), 0xFFFFFFFFu);
+  pre.add(pair_fwd, sizeof(int32_t) * static_cast<size_t>(kv) * n_out_cap, 0xFFFFFFFFu);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = spx::conv4_count_impl(indices, n_in, ndim, batch_size, in_shape, out_shape, ksize, stride, padding,
+                                 dilation, rankmap, rankmap_bytes, ws, ws_bytes, nullptr, s, &pre, n_out_dev);
+  if (rc) return rc;
+  return spx::conv4_fill_impl(indices, n_in, ndim, batch_size, in_shape, out_shape, ksize, stride, padding, dilation,
+                              n_out_cap, out_indices, pair_fwd, pair_bwd, mask_fwd, mask_bwd, pair_native,
+                              num_per_loc, rankmap, rankmap_bytes, ws, ws_bytes, s, true);
+}
+
+size_t spx_subm_rulebook_ranked_ws_bytes(int n, int kv) {
+  const int nblk256 = spx::div_up(n > 0 ? n : 1, spx::kBlock);
+  return spx::align_up(static_cast<size_t>(kv / 2 + 1) * nblk256 * sizeof(int32_t), 256) + 512;
+}
+
+int spx_subm_rulebook_ranked(const int32_t *indices, int n, int ndim, int batch_size, const int *spatial_shape,
+                             const int *ksize, const int *dilation, int32_t *pair_fwd, int32_t *pair_bwd,
+                             uint32_t *mask, int32_t *pair_native, int32_t *num_per_loc, const void *rankmap,
+                             size_t rankmap_bytes, void *ws, size_t ws_bytes, spx_stream_t stream) {
+  using namespace spx;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int padding[4], stride[4] = {1, 1, 1, 1}, kv = 1;
+  SPX_CHECK(ndim >= 1 && ndim <= kMaxNdim, "ndim must be in [1,4], got %d", ndim);
+  for (int i = 0; i < ndim; ++i) {
+    SPX_CHECK(ksize[i] % 2 == 1, "subm only support odd ksize");  // indices.py:1650
+    padding[i] = (ksize[i] / 2) * dilation[i];                    // indices.py:1652
+    kv *= ksize[i];
+  }
+  if (check_geom(ndim, n, kv)) return -1;
+  if (n == 0) {
+    if (num_per_loc) SPX_HIP(hipMemsetAsync(num_per_loc, 0, sizeof(int32_t) * kv, s));
+    return 0;
+  }
+  SPX_CHECK(pair_fwd && mask, "pair_fwd and mask are required");
+  const int nblk256 = div_up(n, kBlock);
+  SPX_CHECK(kv > 1 && kv <= 128 && nblk256 <= 16384, "ranked SubM build: 1 < kernel volume <= 128, <= 4 M rows");
+  const size_t W = rank_words(ndim, batch_size, spatial_shape);
+  SPX_CHECK(W > 0 && rankmap && rankmap_bytes >= W * sizeof(uint2), "rank map missing or too small (%zu words)", W);
+  SPX_CHECK(ws && ws_bytes >= spx_subm_rulebook_ranked_ws_bytes(n, kv), "workspace too small");
+  const Geom g = make_geom(ndim, batch_size, spatial_shape, spatial_shape, ksize, stride, padding, dilation);
+  const int words = div_up(kv, 32);
+  Carver cv(ws);
+  int32_t *scratch_totals = cv.take<int32_t>(64);
+  int32_t *groupcount = cv.take<int32_t>(static_cast<size_t>(kv / 2 + 1) * nblk256);
+  const int mp_opt = option_int("SPX_SUBM_MASK_PASS", -1);
+  const int mask_pass = mp_opt < 0 ? (n >= 250000 ? 1 : 0) : mp_opt;
+  {
+    // what subm_insert_kernel writes on the hash path: the halves of the tables that only receive scattered mirror
+    // entries start as -1, the masks (atomicOr targets without the mask pass) as 0
+    FillList fills;
+    fills.add(pair_fwd, sizeof(int32_t) * static_cast<size_t>(kv / 2) * n, 0xFFFFFFFFu);
+    if (pair_bwd)
+      fills.add(pair_bwd + static_cast<size_t>(kv / 2 + 1) * n, sizeof(int32_t) * static_cast<size_t>(kv - kv / 2 - 1) * n,
+                0xFFFFFFFFu);
+    if (!mask_pass) fills.add(mask, sizeof(uint32_t) * static_cast<size_t>(n) * words, 0u);
+    SPX_HIP(fills.launch(s));
+  }
+  const bool lists = pair_native || num_per_loc;
+  hipLaunchKernelGGL(subm_rank_probe_kernel, dim3(nblk256, kv / 2 + 1), dim3(kBlock), 0, s, indices, n, g,
+                     static_cast<const uint2 *>(rankmap), pair_fwd, pair_bwd, mask, words,
+                     lists ? groupcount : nullptr, nblk256, mask_pass);
+  if (mask_pass)
+    hipLaunchKernelGGL(mask_from_table_kernel, dim3(nblk256), dim3(kBlock), 0, s, pair_fwd, kv, n, words, mask);
+  if (lists) {
+    SPX_CHECK(!pair_native || num_per_loc || kv / 2 <= 64, "num_per_loc required for kv > 128");
+    hipLaunchKernelGGL(subm_lists_kernel, dim3(div_up(n, kItems), kv / 2 + 1), dim3(kBlock), 0, s, pair_fwd, kv, n,
+                       nblk256, groupcount, pair_native, num_per_loc ? num_per_loc : scratch_totals,
+                       num_per_loc ? kv : 0);
+  }
+  SPX_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"
+
+extern "C" {
 
 size_t spx_mask_argsort_ws_bytes(int n) { return radix_argsort_ws_bytes(n) + 256; }
 

@@ -28,6 +28,7 @@ from torch.nn import init
 from torch.nn.init import calculate_gain
 from torch.nn.parameter import Parameter
 
+from spconv_amd import constants
 from spconv_amd.constants import MODULE_DO_SORT, SAVED_WEIGHT_LAYOUT
 from spconv_amd.tools import save_debug_data
 from spconv_amd.pytorch import functional as Fsp
@@ -350,7 +351,8 @@ class SparseConvolution(SparseModule):
                                                do_sort=False if static else MODULE_DO_SORT,
                                                need_native=self._needs_native_lists(features, indices, batch_size,
                                                                                       spatial_shape),
-                                               static_num_out=static, pred_key=id(self))
+                                               static_num_out=static, pred_key=id(self),
+                                               out_order=constants.CONV_OUTPUT_ORDER)
                 self._static_n_out_dev = rb.n_out_dev
                 rb.in_n_live_dev = getattr(input, "n_live_dev", None)
                 if rb.n_out_dev is not None:      # live output rows: the count found, at most the bound

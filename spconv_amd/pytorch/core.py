@@ -73,6 +73,8 @@ class Rulebook:
         # asynchronous read of the class word (ops.poll_class): the pending request, and whose rulebook this is
         self._class_req = None
         self.pred_key = None
+        # rank map of the OUTPUT level (a sorted-order strided build, ops._build_sorted), or None
+        self.rankmap = None
         # static-shape build (ops.build_rulebook(static_num_out=...)): device int32 [2] =
         # {distinct outputs found, hash-table overflow}; rows >= the count are dead.  None otherwise.
         self.n_out_dev = None

@@ -156,7 +156,7 @@ def build_rulebook(indices: torch.Tensor, batch_size: int, spatial_shape: List[i
                    transpose: bool = False, need_bwd_table: bool = False,
                    do_sort=False, need_native: bool = True,
                    num_out_act_bound: int = -1, static_num_out: int = 0,
-                   pred_key=None) -> Tuple[Rulebook, List[int]]:
+                   pred_key=None, out_order: str = "first_seen") -> Tuple[Rulebook, List[int]]:
     """One call builds every artefact (dense tables, masks, Native lists).  need_native=False
     (inference) leaves the ConvAlgo.Native lists out -- three launches and two thirds of the
     fill traffic -- and the Rulebook derives them from the tables if they are asked for later.
@@ -169,7 +169,13 @@ def build_rulebook(indices: torch.Tensor, batch_size: int, spatial_shape: List[i
 
     do_sort: False = rows stay in input order; "layout" (the modules' default; "auto" is an alias) =
     density-aware rows layout of a SubM rulebook, built on the device (rows_layout); True = the
-    reference's explicit mask sort (sort_rulebook)."""
+    reference's explicit mask sort (sort_rulebook).
+
+    out_order (regular convolution): "first_seen" = the CPU reference's numbering of the outputs (indices.py:1742-1771);
+    "sorted" = ascending linear coordinate key, the order of the reference's GPU sort + unique path
+    (all.py:1533-1552), built through the level's RANK MAP (include/spconv_amd.h, sorted-order levels) where the geometry
+    allows it (k3 s2, k2 s2, ...; otherwise first seen).  The map travels with rb.out_indices (`_spx_rankmap`): a SubM
+    build over exactly that tensor reads its neighbours from it instead of hashing the coordinates again."""
     _require_gpu(indices, "indices")
     assert indices.dtype == torch.int32 and indices.ndim == 2
     L = _lib.load()
@@ -198,16 +204,31 @@ def build_rulebook(indices: torch.Tensor, batch_size: int, spatial_shape: List[i
         pair_bwd = buf[(1 + nat) * tb:].view(kv, n_in) if need_bwd_table else None
         mask = torch.empty((n_in, words), **i32)
         num = torch.empty((kv,), **i32) if need_native else None
-        ws = _ws(L.spx_subm_rulebook_ws_bytes(n_in, kv), dev)
-        _lib.check(L.spx_subm_rulebook(indices.data_ptr(), n_in, ndim, batch_size,
-                                       _lib.ints(spatial_shape), _lib.ints(ksize),
-                                       _lib.ints(dilation), pair_fwd.data_ptr(), _ptr(pair_bwd),
-                                       mask.data_ptr(), _ptr(native), _ptr(num),
-                                       ws.data_ptr(), ws.numel(), stream))
+        rm = _rankmap_of(indices, batch_size, spatial_shape, n_in, kv)
+        if rm is not None:
+            # rows in key order with their level's rank map (a sorted-order strided layer built them): no table
+            ws = _ws(L.spx_subm_rulebook_ranked_ws_bytes(n_in, kv), dev)
+            _lib.check(L.spx_subm_rulebook_ranked(indices.data_ptr(), n_in, ndim, batch_size,
+                                                  _lib.ints(spatial_shape), _lib.ints(ksize),
+                                                  _lib.ints(dilation), pair_fwd.data_ptr(), _ptr(pair_bwd),
+                                                  mask.data_ptr(), _ptr(native), _ptr(num),
+                                                  rm.data_ptr(), rm.numel() * 4, ws.data_ptr(), ws.numel(), stream))
+        else:
+            ws = _ws(L.spx_subm_rulebook_ws_bytes(n_in, kv), dev)
+            _lib.check(L.spx_subm_rulebook(indices.data_ptr(), n_in, ndim, batch_size,
+                                           _lib.ints(spatial_shape), _lib.ints(ksize),
+                                           _lib.ints(dilation), pair_fwd.data_ptr(), _ptr(pair_bwd),
+                                           mask.data_ptr(), _ptr(native), _ptr(num),
+                                           ws.data_ptr(), ws.numel(), stream))
         rb = Rulebook(indices, pair_fwd, pair_bwd, mask, mask, native, num, n_in, n_in, kv, True)
     else:
         args = (_lib.ints(spatial_shape), _lib.ints(out_shape), _lib.ints(ksize), _lib.ints(stride),
                 _lib.ints(padding), _lib.ints(dilation), int(transpose))
+        if out_order not in ("first_seen", "sorted"):
+            raise ValueError(f"out_order must be 'first_seen' or 'sorted', got {out_order!r}")
+        if out_order == "sorted" and n_in > 0 and L.spx_conv_sorted_ok(ndim, batch_size, *args):
+            return _build_sorted(L, indices, batch_size, spatial_shape, out_shape, ksize, stride, padding, dilation,
+                                 args[:-1], need_native, num_out_act_bound, static_num_out, pred_key, stream)
         ws = _ws(L.spx_conv_rulebook_ws_bytes(n_in, ndim, _lib.ints(ksize), _lib.ints(stride),
                                               _lib.ints(dilation), int(transpose)), dev)
         if static_num_out > 0:
@@ -267,6 +288,67 @@ def build_rulebook(indices: torch.Tensor, batch_size: int, spatial_shape: List[i
             rows_layout(rb)
     elif do_sort and words == 1:
         sort_rulebook(rb)
+    return rb, out_shape
+
+
+def _rankmap_of(indices: torch.Tensor, batch_size: int, spatial_shape, n: int, kv: int):
+    """The rank map a sorted-order build attached to exactly this index tensor, if it describes this level."""
+    rm = getattr(indices, "_spx_rankmap", None)
+    if rm is None or not (1 < kv <= 128) or n > (4 << 20):
+        return None
+    cells, bs, shape, rows = rm
+    if bs != batch_size or shape != tuple(int(v) for v in spatial_shape) or rows != n or cells.device != indices.device:
+        return None
+    return cells
+
+
+def _build_sorted(L, indices, batch_size, spatial_shape, out_shape, ksize, stride, padding, dilation, args,
+                  need_native, num_out_act_bound, static_num_out, pred_key, stream):
+    """Regular-convolution rulebook with the outputs in key order (spx_conv_rulebook_*_sorted)."""
+    dev = indices.device
+    n_in, ndim = indices.shape[0], indices.shape[1] - 1
+    kv = _kv(ksize)
+    words = (kv + 31) // 32
+    i32 = dict(dtype=torch.int32, device=dev)
+    cells = torch.empty((L.spx_rankmap_bytes(ndim, batch_size, _lib.ints(out_shape)) // 4,), **i32)
+    ws = _ws(L.spx_conv_rulebook_sorted_ws_bytes(n_in, ndim, batch_size, _lib.ints(out_shape), _lib.ints(ksize)), dev)
+    n_out_dev = None
+    if static_num_out > 0:
+        n_out = int(static_num_out)
+        n_out_dev = torch.empty((2,), **i32)
+    else:
+        n_out_c = ctypes.c_int(0)
+        _lib.check(L.spx_conv_rulebook_count_sorted(indices.data_ptr(), n_in, ndim, batch_size, *args,
+                                                    cells.data_ptr(), cells.numel() * 4, ws.data_ptr(), ws.numel(),
+                                                    ctypes.byref(n_out_c), stream))
+        n_out = int(n_out_c.value)
+        if n_out == 0:
+            raise ValueError(_POINT_VANISH_MSG.format(spatial_shape, ksize, stride, padding, dilation))
+        if 0 < num_out_act_bound < n_out:
+            n_out = int(num_out_act_bound)        # (the outputs with the smallest keys survive)
+    out_indices = torch.empty((n_out, ndim + 1), **i32)
+    pair_fwd = torch.empty((kv, n_out), **i32)
+    pair_bwd = torch.empty((kv, n_in), **i32)
+    mask_fwd = torch.empty((n_out, words), **i32)
+    mask_bwd = torch.empty((n_in, words), **i32)
+    native = torch.empty((2, kv, n_in), **i32) if need_native else None
+    num = torch.empty((kv,), **i32) if need_native else None
+    outs = (out_indices.data_ptr(), pair_fwd.data_ptr(), pair_bwd.data_ptr(), mask_fwd.data_ptr(),
+            mask_bwd.data_ptr(), _ptr(native), _ptr(num))
+    if static_num_out > 0:
+        _lib.check(L.spx_conv_rulebook_static_sorted(indices.data_ptr(), n_in, ndim, batch_size, *args, n_out, *outs,
+                                                     n_out_dev.data_ptr(), cells.data_ptr(), cells.numel() * 4,
+                                                     ws.data_ptr(), ws.numel(), stream))
+    else:
+        _lib.check(L.spx_conv_rulebook_fill_sorted(indices.data_ptr(), n_in, ndim, batch_size, *args, n_out, *outs,
+                                                   cells.data_ptr(), cells.numel() * 4, ws.data_ptr(), ws.numel(),
+                                                   stream))
+    rb = Rulebook(out_indices, pair_fwd, pair_bwd, mask_fwd, mask_bwd, native, num, n_in, n_out, kv, False)
+    rb.n_out_dev = n_out_dev
+    rb.in_indices, rb.in_shape, rb.out_shape, rb.batch_size = indices, list(spatial_shape), list(out_shape), batch_size
+    rb.pred_key = pred_key
+    rb.rankmap = cells
+    out_indices._spx_rankmap = (cells, batch_size, tuple(int(v) for v in out_shape), n_out)
     return rb, out_shape
 
 

@@ -1,0 +1,191 @@
+"""GPU: sorted-order levels (include/spconv_amd.h "sorted-order levels"; csrc/rulebook.hip conv4_* /
+subm_rank_probe_kernel).
+
+The reference's GPU path fixes no order for the outputs of a strided convolution (sort + unique of the coordinate keys,
+spconv/csrc/sparse/all.py:1533-1552, or hash-slot order, csrc/sparse/indices.py:1380-1425); the CPU path numbers them
+first-seen (indices.py:1742-1771), and that build is pinned bit for bit against the oracle and the reference-executed
+vectors in tests/test_gpu_rulebook.py.  The sorted build is pinned HERE as exactly that build with the rows renumbered
+by ascending coordinate key: every artefact (coordinates, both pair tables, both masks, Native lists and counts) is
+compared under the permutation, bit for bit.  The SubM build over a level's rank map is compared with the hash build of
+the same rows, bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+from util import gpu_rulebook, scene, to_np
+
+pytestmark = pytest.mark.gpu
+
+SORTED_CASES = [
+    # (shape, n, bs, ksize, stride, padding, dilation)
+    ([19, 18, 17], 1500, 2, [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1]),
+    ([19, 18, 17], 1500, 2, [2, 2, 2], [2, 2, 2], [0, 0, 0], [1, 1, 1]),
+    ([19, 18, 17], 1500, 1, [3, 3, 3], [3, 3, 3], [2, 2, 2], [1, 1, 1]),
+    ([41, 64, 64], 6000, 2, [3, 3, 3], [2, 2, 2], [0, 1, 1], [1, 1, 1]),
+    ([60, 50], 900, 2, [3, 3], [2, 2], [1, 1], [1, 1]),                         # 2-d
+    ([41, 400, 352], 60000, 4, [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1]),    # several prefix blocks (24 M cells)
+]
+
+
+def _keys(ind, shape):
+    key = ind[:, 0].astype(np.int64)
+    for d, s in enumerate(shape):
+        key = key * int(s) + ind[:, 1 + d]
+    return key
+
+
+def _check_renumbered(rs, rf, out_shape, n_keep=None):
+    """rs (sorted build) == rf (first-seen build) with the output rows renumbered by ascending key."""
+    of, os_ = to_np(rf.out_indices), to_np(rs.out_indices)
+    kf = _keys(of, out_shape)
+    order = np.argsort(kf, kind="stable")               # sorted position -> first-seen row
+    if n_keep is None:
+        n_keep = of.shape[0]
+    assert rs.n_out == n_keep
+    np.testing.assert_array_equal(os_[:n_keep], of[order][:n_keep])
+    assert np.all(np.diff(_keys(os_[:n_keep], out_shape)) > 0)
+    newrow = np.full(of.shape[0], -1, np.int64)          # first-seen row -> sorted row (or dropped)
+    newrow[order[:n_keep]] = np.arange(n_keep)
+    ren = lambda t: np.where(t >= 0, newrow[np.maximum(t, 0)], -1)
+    pf_f, pf_s = to_np(rf.pair_fwd), to_np(rs.pair_fwd)
+    np.testing.assert_array_equal(pf_s, pf_f[:, order[:n_keep]])
+    pb_f, pb_s = to_np(rf.pair_bwd), to_np(rs.pair_bwd)
+    np.testing.assert_array_equal(pb_s, ren(pb_f))
+    np.testing.assert_array_equal(to_np(rs.mask_fwd), to_np(rf.mask_fwd)[order[:n_keep]])
+    kv = pb_f.shape[0]
+    want_mb = np.zeros_like(to_np(rf.mask_bwd)).view(np.uint32)
+    for k in range(kv):
+        want_mb[:, k // 32] |= ((pb_s[k] >= 0).astype(np.uint32) << np.uint32(k % 32))
+    np.testing.assert_array_equal(to_np(rs.mask_bwd).view(np.uint32), want_mb)
+    # Native lists: list k = the pairs of offset k in input order (indices.py:1767-1768)
+    num_s, nat_s = to_np(rs.num_per_loc), to_np(rs.pair_native)
+    for k in range(kv):
+        ins = np.nonzero(pb_s[k] >= 0)[0]
+        assert num_s[k] == ins.shape[0]
+        np.testing.assert_array_equal(nat_s[0, k, :num_s[k]], ins)
+        np.testing.assert_array_equal(nat_s[1, k, :num_s[k]], pb_s[k][ins])
+    if n_keep == of.shape[0]:
+        np.testing.assert_array_equal(num_s, to_np(rf.num_per_loc))
+
+
+@pytest.mark.parametrize("shape,n,bs,ksize,stride,pad,dil", SORTED_CASES)
+def test_sorted_build_is_the_first_seen_build_renumbered(cuda, shape, n, bs, ksize, stride, pad, dil):
+    idx = scene(shape, n, bs, seed=11)
+    rf, out_shape = gpu_rulebook(idx, bs, shape, ksize, stride, pad, dil, False)
+    rs, out_shape_s = gpu_rulebook(idx, bs, shape, ksize, stride, pad, dil, False, out_order="sorted")
+    assert list(out_shape) == list(out_shape_s) and rs.rankmap is not None
+    _check_renumbered(rs, rf, out_shape)
+
+
+def test_sorted_build_with_an_output_bound_keeps_the_smallest_keys(cuda):
+    shape, n, bs = [19, 18, 17], 1500, 2
+    idx = scene(shape, n, bs, seed=3)
+    args = ([3] * 3, [2] * 3, [1] * 3, [1] * 3)
+    rf, out_shape = gpu_rulebook(idx, bs, shape, *args, False)
+    bound = rf.n_out * 2 // 3
+    rs, _ = gpu_rulebook(idx, bs, shape, *args, False, out_order="sorted", num_out_act_bound=bound)
+    _check_renumbered(rs, rf, out_shape, n_keep=bound)
+
+
+def test_geometries_without_compact_candidates_keep_the_first_seen_builder(cuda):
+    """Stride 1, transposed convolutions and the (3,1,1) / (2,1,1) tail of VoxelBackBone8x (two of three offsets are
+    candidates): `sorted` is a request, the hash builder answers (documented)."""
+    shape, n = [19, 18, 17], 800
+    idx = scene(shape, n, 1, seed=5)
+    for ks, st, pd, tr in (([3] * 3, [1] * 3, [1] * 3, False), ([3] * 3, [2] * 3, [1] * 3, True),
+                           ([3, 1, 1], [2, 1, 1], [0] * 3, False)):
+        rf, _ = gpu_rulebook(idx, 1, shape, ks, st, pd, [1] * 3, False, tr)
+        rs, _ = gpu_rulebook(idx, 1, shape, ks, st, pd, [1] * 3, False, tr, out_order="sorted")
+        assert rs.rankmap is None
+        np.testing.assert_array_equal(to_np(rs.out_indices), to_np(rf.out_indices))
+        np.testing.assert_array_equal(to_np(rs.pair_fwd), to_np(rf.pair_fwd))
+
+
+@pytest.mark.parametrize("n_in,need_bwd", [(60000, True), (300000, False)])       # (the second: masks by the pass form)
+def test_subm_over_the_rank_map_equals_the_hash_build(cuda, n_in, need_bwd):
+    from spconv_amd.pytorch import ops
+    shape, bs = [41, 400, 352], 4
+    idx = scene(shape, n_in, bs, seed=21)
+    rs, out_shape = gpu_rulebook(idx, bs, shape, [3] * 3, [2] * 3, [1] * 3, [1] * 3, False, out_order="sorted")
+    ind = rs.out_indices
+    assert getattr(ind, "_spx_rankmap", None) is not None
+    plain = ind.clone()                                   # the same rows without the map: the hash build
+    kw = dict(need_bwd_table=need_bwd)
+    a = ops.build_rulebook(ind, bs, out_shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True, **kw)[0]
+    b = ops.build_rulebook(plain, bs, out_shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True, **kw)[0]
+    torch.cuda.synchronize()
+    for name in ("pair_fwd", "pair_bwd", "mask_fwd", "num_per_loc", "pair_native"):
+        x, y = getattr(a, name), getattr(b, name)
+        assert (x is None) == (y is None), name
+        if x is not None:
+            assert torch.equal(x, y), name
+    # dilated SubM over the same map
+    a = ops.build_rulebook(ind, bs, out_shape, [3] * 3, [1] * 3, [2] * 3, [2] * 3, [0] * 3, True)[0]
+    b = ops.build_rulebook(plain, bs, out_shape, [3] * 3, [1] * 3, [2] * 3, [2] * 3, [0] * 3, True)[0]
+    assert torch.equal(a.pair_fwd, b.pair_fwd) and torch.equal(a.pair_native, b.pair_native)
+    # a map that does not describe the rows (other tensor, other shape) is not used
+    assert ops._rankmap_of(plain, bs, out_shape, plain.shape[0], 27) is None
+    assert ops._rankmap_of(ind, bs, [s + 1 for s in out_shape], ind.shape[0], 27) is None
+
+
+def test_static_sorted_build_equals_the_two_call_build(cuda):
+    """Static-shape form: padded inputs (dead rows), room for more outputs than exist, a bound below the count."""
+    from spconv_amd.pytorch import ops
+    shape, bs = [41, 200, 176], 2
+    idx = scene(shape, 20000, bs, seed=9)
+    n = idx.shape[0]
+    pad = np.full((n + 777, 4), -1, np.int32)
+    pad[:n] = idx
+    args = ([3] * 3, [2] * 3, [1] * 3, [1] * 3, [0] * 3)
+    dev = torch.device("cuda:0")
+    ref, out_shape = ops.build_rulebook(torch.from_numpy(idx).to(dev), bs, shape, *args, out_order="sorted")
+    for cap in (ref.n_out + 1000, ref.n_out - 1234):
+        rb, _ = ops.build_rulebook(torch.from_numpy(pad).to(dev), bs, shape, *args, out_order="sorted",
+                                   static_num_out=cap)
+        torch.cuda.synchronize()
+        found, overflow = (int(v) for v in rb.n_out_dev.tolist())
+        assert found == ref.n_out and overflow == 0
+        live = min(cap, ref.n_out)
+        np.testing.assert_array_equal(to_np(rb.out_indices)[:live], to_np(ref.out_indices)[:live])
+        assert np.all(to_np(rb.out_indices)[live:] == -1)
+        pf, pf_ref = to_np(rb.pair_fwd), to_np(ref.pair_fwd)
+        np.testing.assert_array_equal(pf[:, :live], pf_ref[:, :live])
+        assert np.all(pf[:, live:] == -1)
+        pb, pb_ref = to_np(rb.pair_bwd), to_np(ref.pair_bwd)
+        np.testing.assert_array_equal(pb[:, :n], np.where(pb_ref < live, pb_ref, -1))
+        assert np.all(pb[:, n:] == -1)
+        np.testing.assert_array_equal(to_np(rb.mask_fwd)[:live], to_np(ref.mask_fwd)[:live])
+        # the SubM layer behind it, over the padded level: live rows as the unpadded build, dead rows without pairs
+        sub, _ = ops.build_rulebook(rb.out_indices, bs, out_shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True)
+        want, _ = ops.build_rulebook(ref.out_indices[:live].clone(), bs, out_shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3,
+                                     [0] * 3, True)
+        sp, wp = to_np(sub.pair_fwd), to_np(want.pair_fwd)
+        np.testing.assert_array_equal(sp[:, :live], wp)
+        centre = 13
+        assert np.all(np.delete(sp[:, live:], centre, axis=0) == -1)
+
+
+def test_backbone_in_sorted_order_equals_first_seen_order(cuda, monkeypatch):
+    """The config-4 backbone: the two output orders give the same network function -- dense outputs and every weight
+    gradient agree (fp32; only the summation order inside the weight gradients differs)."""
+    import spconv_amd.pytorch as spconv
+    from spconv_amd import constants
+    from spconv_amd.utils import nets, synthetic
+    shape, bs = [41, 160, 144], 2
+    idx = torch.from_numpy(synthetic.lidar_like_scene(shape, 9000, bs, seed=4)).cuda()
+    feat = torch.randn(idx.shape[0], 4, device="cuda")
+    torch.manual_seed(1)
+    net = nets.second_backbone(4, norm=False).cuda()
+    res = {}
+    for order in ("first_seen", "sorted"):
+        monkeypatch.setattr(constants, "CONV_OUTPUT_ORDER", order)
+        net.zero_grad(set_to_none=True)
+        y = net(spconv.SparseConvTensor(feat, idx, shape, bs))
+        d = y.dense()
+        (d * torch.linspace(-1, 1, d.numel(), device="cuda").view_as(d)).sum().backward()
+        res[order] = (d.detach().clone(), [p.grad.clone() for p in net.parameters()], y.indices.clone())
+    a, b = res["first_seen"], res["sorted"]
+    assert not torch.equal(a[2], b[2])                      # (the orders do differ)
+    assert float((a[0] - b[0]).abs().max()) <= 1e-5 * float(a[0].abs().max())
+    for ga, gb in zip(a[1], b[1]):
+        assert float((ga - gb).abs().max()) <= 2e-4 * float(ga.abs().max())
