@@ -451,390 +451,6 @@ bn_bwd_apply_kernel(const u32x4 *__restrict__ x, const u32x4 *__restrict__ dy, u
   }
 }
 
-
-// --------------------------------------------------------------------------------------------------------------
-// Two-launch forms (piece counts that divide 64, i.e. power-of-two channel counts): statistics | apply.
-// The finalize launch between the two (one tiny workgroup per channel: 5-6 us at its launch floor, 24 of them
-// per step of a 12-layer backbone) is gone: every workgroup of the APPLY launch merges the block partials itself,
-// in the same fixed order, before it touches its rows -- the partials are few (G * C <= kMergeGC floats per
-// plane: fat 1024-thread statistics blocks, one per CU) and L2-resident, and the first rows of the workgroup are
-// already requested when the merge starts.  Workgroup 0 also writes what the finalize launch wrote (saved mean /
-// 1 / std, running estimates, batch counter; dweight / dbias in the backward).
-// --------------------------------------------------------------------------------------------------------------
-constexpr int kTP = 1024;             // threads of a statistics block
-constexpr int kMU = 16;               // partial blocks one merging thread folds
-constexpr int kMergeGC = kMU * kT;    // G * C at most
-
-// block statistics: as bn_partial_kernel, NT threads, U rows of loads in flight per thread
-template <int VPL, int NT>
-__device__ __forceinline__ void wave_piece_reduce(float (&a)[VPL], float (&b)[VPL], int P, int C,
-                                                  float (*lds)[(NT / 64) * (kT / VPL)][VPL + 1], float &ra, float &rb) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int i = 0; i < VPL; ++i) {
-    for (int d = P; d < 64; d <<= 1) {
-      a[i] += __shfl_xor(a[i], d, 64);
-      b[i] += __shfl_xor(b[i], d, 64);
-    }
-  }
-  if (lane < P) {
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-      lds[0][wave * P + lane][i] = a[i];
-      lds[1][wave * P + lane][i] = b[i];
-    }
-  }
-  __syncthreads();
-  ra = rb = 0.f;
-  if (threadIdx.x < C) {
-    const int piece = threadIdx.x / VPL, e = threadIdx.x % VPL;
-    for (int w = 0; w < NT / 64; ++w) {
-      ra += lds[0][w * P + piece][e];
-      rb += lds[1][w * P + piece][e];
-    }
-  }
-}
-
-struct RowSplitN {
-  int r0, r1, piece, lane_row, rows_per_sweep;
-};
-template <int NT>
-__device__ __forceinline__ RowSplitN row_split_n(int n, int P, int nblocks) {
-  RowSplitN s;
-  const long long per = (static_cast<long long>(n) + nblocks - 1) / nblocks;
-  s.r0 = static_cast<int>(min(static_cast<long long>(n), per * blockIdx.x));
-  s.r1 = static_cast<int>(min(static_cast<long long>(n), per * (blockIdx.x + 1)));
-  s.rows_per_sweep = NT / P;          // P divides 64: every thread has a piece
-  s.piece = threadIdx.x % P;
-  s.lane_row = threadIdx.x / P;
-  return s;
-}
-
-template <int DT>
-__global__ void __launch_bounds__(kTP)
-bn_stats_kernel(const u32x4 *__restrict__ x, int n, int C, float *__restrict__ partial,
-                const int32_t *__restrict__ n_live) {
-  constexpr int VPL = Vec<DT>::VPL, U = 8;
-  __shared__ float lds[2][(kTP / 64) * (kT / VPL)][VPL + 1];      // P <= 256 / VPL pieces per wave
-  const int P = C / VPL;
-  const RowSplitN s = row_split_n<kTP>(live_rows(n_live, n), P, gridDim.x);
-  float shift[VPL], sum[VPL], sq[VPL];
-#pragma unroll
-  for (int i = 0; i < VPL; ++i) shift[i] = sum[i] = sq[i] = 0.f;
-  if (s.r0 < s.r1) Vec<DT>::unpack(x[static_cast<size_t>(s.r0) * P + s.piece], shift);
-  for (int r = s.r0 + s.lane_row; r < s.r1; r += U * s.rows_per_sweep) {
-    u32x4 v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int ru = r + u * s.rows_per_sweep;
-      v[u] = ru < s.r1 ? x[static_cast<size_t>(ru) * P + s.piece] : u32x4{0u, 0u, 0u, 0u};
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (r + u * s.rows_per_sweep < s.r1) {
-        float f[VPL];
-        Vec<DT>::unpack(v[u], f);
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-          const float d = f[i] - shift[i];
-          sum[i] += d;
-          sq[i] += d * d;
-        }
-      }
-    }
-  }
-  float a, b;
-  wave_piece_reduce<VPL, kTP>(sum, sq, P, C, lds, a, b);
-  if (threadIdx.x < C) {
-    const int piece = threadIdx.x / VPL, e = threadIdx.x % VPL;
-    const float cnt = static_cast<float>(s.r1 - s.r0);
-    float sh = 0.f;
-    if (s.r0 < s.r1) {
-      float f[VPL];
-      Vec<DT>::unpack(x[static_cast<size_t>(s.r0) * P + piece], f);
-      sh = f[e];
-    }
-    float *dst = partial + static_cast<size_t>(blockIdx.x) * 3 * C;
-    dst[threadIdx.x] = cnt;
-    dst[C + threadIdx.x] = cnt > 0.f ? sh + a / cnt : 0.f;
-    dst[2 * C + threadIdx.x] = cnt > 0.f ? b - a * a / cnt : 0.f;
-  }
-}
-
-__device__ __forceinline__ void chan_merge(float &n, float &m, float &M2, float nb, float mb, float Mb) {
-  if (nb > 0.f) {
-    const float tot = n + nb, d = mb - m;
-    m += d * (nb / tot);
-    M2 += Mb + d * d * (n * nb / tot);
-    n = tot;
-  }
-}
-
-// (count, mean, M2) of channel threadIdx.x (threads < C) out of the G block partials; kT threads, G * C <= kMergeGC,
-// C a power of two: thread (j, c) = (tid / C, tid % C) folds blocks j, j + R, ... (R = kT / C), all of its loads in
-// flight at once; thread c then folds the R rows.  Every workgroup of a launch computes the same bits.
-__device__ __forceinline__ void merge_moments(const float *__restrict__ partial, int G, int C, float (*red)[kT],
-                                              float &cnt, float &mean, float &M2) {
-  const int R = kT / C, c = threadIdx.x % C, j = threadIdx.x / C;
-  float nb[kMU], mb[kMU], qb[kMU];
-#pragma unroll
-  for (int u = 0; u < kMU; ++u) {
-    const int b = j + u * R;
-    const bool ok = b < G;
-    const float *src = partial + static_cast<size_t>(ok ? b : 0) * 3 * C + c;
-    nb[u] = ok ? src[0] : 0.f;
-    mb[u] = ok ? src[C] : 0.f;
-    qb[u] = ok ? src[2 * C] : 0.f;
-  }
-  float n = 0.f, m = 0.f, q = 0.f;
-#pragma unroll
-  for (int u = 0; u < kMU; ++u) chan_merge(n, m, q, nb[u], mb[u], qb[u]);
-  red[0][threadIdx.x] = n;
-  red[1][threadIdx.x] = m;
-  red[2][threadIdx.x] = q;
-  __syncthreads();
-  if (threadIdx.x < C) {
-    for (int jj = 1; jj < R; ++jj) chan_merge(n, m, q, red[0][jj * C + c], red[1][jj * C + c], red[2][jj * C + c]);
-  }
-  cnt = n;
-  mean = m;
-  M2 = q;
-}
-
-// y = relu?(x * scale + shift) with the batch statistics merged in the prologue (training forward)
-template <int DT>
-__global__ void __launch_bounds__(kT)
-bn_apply2_kernel(const u32x4 *__restrict__ x, u32x4 *__restrict__ y, long long pieces, int C,
-                 const float *__restrict__ partial, int G, const void *__restrict__ weight,
-                 const void *__restrict__ bias, int pdt, float eps, float momentum, int relu,
-                 float *__restrict__ mean_out, float *__restrict__ invstd_out, void *__restrict__ running_mean,
-                 void *__restrict__ running_var, long long *__restrict__ num_batches_tracked,
-                 const int32_t *__restrict__ n_live, int n) {
-  constexpr int VPL = Vec<DT>::VPL, U = 4;
-  __shared__ __attribute__((aligned(16))) float l_sc[kT], l_sh[kT];
-  __shared__ float red[3][kT];
-  const int P = C / VPL;
-  const long long live = static_cast<long long>(live_rows(n_live, n)) * P;
-  const long long stride = static_cast<long long>(gridDim.x) * kT;
-  long long i0 = static_cast<long long>(blockIdx.x) * kT + threadIdx.x;
-  // the first rows are requested before the merge: they do not depend on it
-  u32x4 v[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) v[u] = i0 + u * stride < pieces ? x[i0 + u * stride] : u32x4{0u, 0u, 0u, 0u};
-  float cnt, mean, M2;
-  merge_moments(partial, G, C, red, cnt, mean, M2);
-  if (threadIdx.x < C) {
-    const int c = threadIdx.x;
-    const float var = cnt > 0.f ? M2 / cnt : 0.f;
-    const float is = rsqrtf(var + eps);
-    const float sc = is * (weight ? ldp(weight, pdt, c) : 1.f);
-    l_sc[c] = sc;
-    l_sh[c] = (bias ? ldp(bias, pdt, c) : 0.f) - mean * sc;
-    if (blockIdx.x == 0) {
-      mean_out[c] = mean;
-      invstd_out[c] = is;
-      if (running_mean) stp(running_mean, pdt, c, (1.f - momentum) * ldp(running_mean, pdt, c) + momentum * mean);
-      if (running_var) {
-        const float unbiased = cnt > 1.f ? M2 / (cnt - 1.f) : var;
-        stp(running_var, pdt, c, (1.f - momentum) * ldp(running_var, pdt, c) + momentum * unbiased);
-      }
-      if (num_batches_tracked && c == 0) *num_batches_tracked += 1;
-    }
-  }
-  __syncthreads();
-  const int c0 = static_cast<int>(i0 % P) * VPL;      // stride is a multiple of P (kT is): one channel group per thread
-  float sc[VPL], sh[VPL];
-#pragma unroll
-  for (int e = 0; e < VPL; ++e) {
-    sc[e] = l_sc[c0 + e];
-    sh[e] = l_sh[c0 + e];
-  }
-  for (;;) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long long i = i0 + u * stride;
-      if (i < pieces) {
-        float f[VPL];
-        Vec<DT>::unpack(v[u], f);
-#pragma unroll
-        for (int e = 0; e < VPL; ++e) {
-          float t = f[e] * sc[e] + sh[e];
-          if (relu) t = t > 0.f ? t : 0.f;
-          f[e] = i < live ? t : 0.f;
-        }
-        __builtin_nontemporal_store(Vec<DT>::pack(f), &y[i]);
-      }
-    }
-    i0 += U * stride;
-    if (i0 >= pieces) break;
-#pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = i0 + u * stride < pieces ? x[i0 + u * stride] : u32x4{0u, 0u, 0u, 0u};
-  }
-}
-
-// block sums of the backward: as bn_bwd_partial_kernel, kTP threads
-template <int DT>
-__global__ void __launch_bounds__(kTP)
-bn_bwd_stats_kernel(const u32x4 *__restrict__ x, const u32x4 *__restrict__ dy, int n, int C,
-                    const float *__restrict__ mean, const float *__restrict__ invstd,
-                    const void *__restrict__ weight, const void *__restrict__ bias, int pdt, int relu,
-                    float *__restrict__ partial, const int32_t *__restrict__ n_live) {
-  constexpr int VPL = Vec<DT>::VPL, U = 4;
-  __shared__ float lds[2][(kTP / 64) * (kT / VPL)][VPL + 1];      // P <= 256 / VPL pieces per wave
-  const int P = C / VPL;
-  const RowSplitN s = row_split_n<kTP>(live_rows(n_live, n), P, gridDim.x);
-  float s1[VPL], s2[VPL], ka[VPL], kb[VPL], w[VPL], bb[VPL];     // xhat = x * ka + kb
-#pragma unroll
-  for (int i = 0; i < VPL; ++i) {
-    s1[i] = s2[i] = 0.f;
-    const int c = s.piece * VPL + i;
-    const float is = invstd[c];
-    ka[i] = is;
-    kb[i] = -mean[c] * is;
-    w[i] = weight ? ldp(weight, pdt, c) : 1.f;
-    bb[i] = bias ? ldp(bias, pdt, c) : 0.f;
-  }
-  for (int r = s.r0 + s.lane_row; r < s.r1; r += U * s.rows_per_sweep) {
-    u32x4 vx[U], vg[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int ru = r + u * s.rows_per_sweep;
-      const bool ok = ru < s.r1;
-      vx[u] = ok ? x[static_cast<size_t>(ru) * P + s.piece] : u32x4{0u, 0u, 0u, 0u};
-      vg[u] = ok ? dy[static_cast<size_t>(ru) * P + s.piece] : u32x4{0u, 0u, 0u, 0u};
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (r + u * s.rows_per_sweep < s.r1) {
-        float f[VPL], g[VPL];
-        Vec<DT>::unpack(vx[u], f);
-        Vec<DT>::unpack(vg[u], g);
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-          const float xh = f[i] * ka[i] + kb[i];
-          const float gg = (relu && xh * w[i] + bb[i] <= 0.f) ? 0.f : g[i];
-          s1[i] += gg;
-          s2[i] += gg * xh;
-        }
-      }
-    }
-  }
-  float a, b;
-  wave_piece_reduce<VPL, kTP>(s1, s2, P, C, lds, a, b);
-  if (threadIdx.x < C) {
-    partial[static_cast<size_t>(blockIdx.x) * 2 * C + threadIdx.x] = a;
-    partial[static_cast<size_t>(blockIdx.x) * 2 * C + C + threadIdx.x] = b;
-  }
-}
-
-// sums[0][c] = sum dy, sums[1][c] = sum dy * xhat of channel threadIdx.x (threads < C) out of the G block sums
-__device__ __forceinline__ void merge_sums(const float *__restrict__ partial, int G, int C, float (*red)[kT],
-                                           float &sa, float &sb) {
-  const int R = kT / C, c = threadIdx.x % C, j = threadIdx.x / C;
-  float a[kMU], b[kMU];
-#pragma unroll
-  for (int u = 0; u < kMU; ++u) {
-    const int blk = j + u * R;
-    const bool ok = blk < G;
-    const float *src = partial + static_cast<size_t>(ok ? blk : 0) * 2 * C + c;
-    a[u] = ok ? src[0] : 0.f;
-    b[u] = ok ? src[C] : 0.f;
-  }
-  float ta = 0.f, tb = 0.f;
-#pragma unroll
-  for (int u = 0; u < kMU; ++u) {
-    ta += a[u];
-    tb += b[u];
-  }
-  red[0][threadIdx.x] = ta;
-  red[1][threadIdx.x] = tb;
-  __syncthreads();
-  if (threadIdx.x < C) {
-    for (int jj = 1; jj < R; ++jj) {
-      ta += red[0][jj * C + c];
-      tb += red[1][jj * C + c];
-    }
-  }
-  sa = ta;
-  sb = tb;
-}
-
-// dx of the training backward with the block sums merged in the prologue; workgroup 0 writes dweight / dbias
-template <int DT>
-__global__ void __launch_bounds__(kT)
-bn_bwd_apply2_kernel(const u32x4 *__restrict__ x, const u32x4 *__restrict__ dy, u32x4 *__restrict__ dx,
-                     long long pieces, int n, int C, const float *__restrict__ mean,
-                     const float *__restrict__ invstd, const void *__restrict__ weight,
-                     const void *__restrict__ bias, int pdt, const float *__restrict__ partial, int G, int relu,
-                     int use_batch_stats, void *__restrict__ dweight, void *__restrict__ dbias,
-                     const int32_t *__restrict__ n_live) {
-  constexpr int VPL = Vec<DT>::VPL, U = 2;
-  // xhat = x * l_a + l_b;  relu mask: xhat * l_w + l_bias <= 0;  dx = l_g * (dy' - l_c1 - xhat * l_c2)
-  __shared__ __attribute__((aligned(16))) float l_a[kT], l_b[kT], l_w[kT], l_bias[kT], l_g[kT], l_c1[kT], l_c2[kT];
-  __shared__ float red[2][kT];
-  const int P = C / VPL;
-  const int n_eff = live_rows(n_live, n);
-  const long long live = static_cast<long long>(n_eff) * P;
-  const long long stride = static_cast<long long>(gridDim.x) * kT;
-  long long i0 = static_cast<long long>(blockIdx.x) * kT + threadIdx.x;
-  u32x4 vx[U], vg[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const bool ok = i0 + u * stride < pieces;
-    vx[u] = ok ? x[i0 + u * stride] : u32x4{0u, 0u, 0u, 0u};
-    vg[u] = ok ? dy[i0 + u * stride] : u32x4{0u, 0u, 0u, 0u};
-  }
-  float sa, sb;
-  merge_sums(partial, G, C, red, sa, sb);
-  if (threadIdx.x < C) {
-    const int c = threadIdx.x;
-    const float inv_n = (use_batch_stats && n_eff > 0) ? 1.f / static_cast<float>(n_eff) : 0.f;
-    const float w = weight ? ldp(weight, pdt, c) : 1.f;
-    const float is = invstd[c];
-    l_a[c] = is;
-    l_b[c] = -mean[c] * is;
-    l_w[c] = w;
-    l_bias[c] = bias ? ldp(bias, pdt, c) : 0.f;
-    l_g[c] = w * is;
-    l_c1[c] = sa * inv_n;
-    l_c2[c] = sb * inv_n;
-    if (blockIdx.x == 0) {
-      if (dbias) stp(dbias, pdt, c, sa);
-      if (dweight) stp(dweight, pdt, c, sb);
-    }
-  }
-  __syncthreads();
-  const int c0 = static_cast<int>(i0 % P) * VPL;      // (stride is a multiple of P)
-  for (;;) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long long i = i0 + u * stride;
-      if (i < pieces) {
-        float f[VPL], g[VPL];
-        Vec<DT>::unpack(vx[u], f);
-        Vec<DT>::unpack(vg[u], g);
-#pragma unroll
-        for (int e = 0; e < VPL; ++e) {
-          const int c = c0 + e;
-          const float xh = f[e] * l_a[c] + l_b[c];
-          float gg = g[e];
-          if (relu && xh * l_w[c] + l_bias[c] <= 0.f) gg = 0.f;
-          f[e] = i < live ? l_g[c] * (gg - l_c1[c] - xh * l_c2[c]) : 0.f;
-        }
-        __builtin_nontemporal_store(Vec<DT>::pack(f), &dx[i]);
-      }
-    }
-    i0 += U * stride;
-    if (i0 >= pieces) break;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const bool ok = i0 + u * stride < pieces;
-      vx[u] = ok ? x[i0 + u * stride] : u32x4{0u, 0u, 0u, 0u};
-      vg[u] = ok ? dy[i0 + u * stride] : u32x4{0u, 0u, 0u, 0u};
-    }
-  }
-}
-
 int bn_blocks(int n) {
   int g = div_up(n > 0 ? n : 1, 384);      // ~384 rows per block, at most 1024 blocks
   return g < 1 ? 1 : (g > 1024 ? 1024 : g);
@@ -844,29 +460,6 @@ bool bn_shape_ok(int C, int dtype) {
   const int vpl = dtype == SPX_F32 ? 4 : 8;
   return (dtype == SPX_F32 || dtype == SPX_F16 || dtype == SPX_BF16) && C > 0 && C % vpl == 0 && C <= kT &&
          C / vpl <= kT;
-}
-
-// two-launch forms: piece count of a row divides 64 (power-of-two channel counts); SPX_BN_MERGE=0 keeps the
-// three-launch forms (A/B)
-bool bn_merge_ok(int C, int dtype) {
-  const int vpl = dtype == SPX_F32 ? 4 : 8;
-  const int P = C / vpl;
-  return P >= 1 && 64 % P == 0 && kT % C == 0 && option_int("SPX_BN_MERGE", 1) != 0;
-}
-
-// statistics blocks of the two-launch forms: ~4 pieces per thread, G * C <= kMergeGC
-int bn_blocks2(int n, int C, int dtype) {
-  const int vpl = dtype == SPX_F32 ? 4 : 8;
-  const long long pieces = static_cast<long long>(n > 0 ? n : 1) * (C / vpl);
-  long long g = (pieces + kTP * 4 - 1) / (kTP * 4);
-  const int cap = kMergeGC / C;
-  return static_cast<int>(g < 1 ? 1 : (g > cap ? cap : g));
-}
-
-// apply launches of the two-launch forms: every workgroup pays the merge, so they are few and fat (two per CU)
-unsigned stream_grid2(long long pieces, int per_thread) {
-  long long b = (pieces + static_cast<long long>(kT) * per_thread - 1) / (static_cast<long long>(kT) * per_thread);
-  return static_cast<unsigned>(b < 1 ? 1 : (b > 512 ? 512 : b));
 }
 
 unsigned stream_grid(long long pieces) {
@@ -890,12 +483,7 @@ extern "C" {
 
 size_t spx_batchnorm_ws_bytes(int n, int C) {
   // per-block partials (3 floats per channel) + the [2][C] sums of the backward pass
-  // (the larger of the two block counts: three-launch forms bn_blocks, two-launch forms bn_blocks2 at their widest
-  // piece count, fp32 rows)
-  const int c = C > 0 ? C : 1;
-  const int g2 = (c % 4 == 0 && c <= kT) ? bn_blocks2(n, c, SPX_F32) : 1;
-  const int g = bn_blocks(n) > g2 ? bn_blocks(n) : g2;
-  return align_up((static_cast<size_t>(g) * 3 + 2) * c * sizeof(float), 256) + 256;
+  return align_up((static_cast<size_t>(bn_blocks(n)) * 3 + 2) * (C > 0 ? C : 1) * sizeof(float), 256) + 256;
 }
 
 int spx_batchnorm_fwd(const void *x, void *y, int n, int C, int dtype, const void *weight,
@@ -916,22 +504,8 @@ int spx_batchnorm_fwd(const void *x, void *y, int n, int C, int dtype, const voi
   if (training) {
     SPX_CHECK(save_mean && save_invstd && ws && ws_bytes >= spx_batchnorm_ws_bytes(n, C),
               "training needs save_mean / save_invstd and the workspace");
-    float *partial = static_cast<float *>(ws);
-    if (bn_merge_ok(C, dtype)) {
-      const int G = bn_blocks2(n, C, dtype);
-#define SPX_BN_STATS(D) hipLaunchKernelGGL(bn_stats_kernel<D>, dim3(G), dim3(kTP), 0, s, xv, n, C, partial, n_live)
-      SPX_BN_DISPATCH(dtype, SPX_BN_STATS);
-#undef SPX_BN_STATS
-#define SPX_BN_APPLY2(D)                                                                                     \
-  hipLaunchKernelGGL(bn_apply2_kernel<D>, dim3(stream_grid2(pieces, 4)), dim3(kT), 0, s, xv, yv, pieces, C,   \
-                     static_cast<const float *>(partial), G, weight, bias, param_dtype, eps, momentum, relu,  \
-                     save_mean, save_invstd, running_mean, running_var, num_batches_tracked, n_live, n)
-      SPX_BN_DISPATCH(dtype, SPX_BN_APPLY2);
-#undef SPX_BN_APPLY2
-      SPX_LAUNCH_CHECK();
-      return 0;
-    }
     const int G = bn_blocks(n);
+    float *partial = static_cast<float *>(ws);
 #define SPX_BN_PARTIAL(D) hipLaunchKernelGGL(bn_partial_kernel<D>, dim3(G), dim3(kT), 0, s, xv, n, C, partial, n_live)
     SPX_BN_DISPATCH(dtype, SPX_BN_PARTIAL);
 #undef SPX_BN_PARTIAL
@@ -973,26 +547,10 @@ int spx_batchnorm_bwd(const void *x, const void *dy, void *dx, int n, int C, int
   SPX_CHECK(x && dy && dx && ws && ws_bytes >= spx_batchnorm_ws_bytes(n, C), "null pointer / workspace too small");
   const int vpl = dtype == SPX_F32 ? 4 : 8;
   const long long pieces = static_cast<long long>(n) * (C / vpl);
-  float *partial = static_cast<float *>(ws);
-  const u32x4 *xv = static_cast<const u32x4 *>(x), *gv = static_cast<const u32x4 *>(dy);
-  if (bn_merge_ok(C, dtype)) {
-    const int G = bn_blocks2(n, C, dtype);
-#define SPX_BN_BS(D)                                                                                         \
-  hipLaunchKernelGGL(bn_bwd_stats_kernel<D>, dim3(G), dim3(kTP), 0, s, xv, gv, n, C, mean, invstd, weight,   \
-                     bias, param_dtype, relu, partial, n_live)
-    SPX_BN_DISPATCH(dtype, SPX_BN_BS);
-#undef SPX_BN_BS
-#define SPX_BN_BA2(D)                                                                                        \
-  hipLaunchKernelGGL(bn_bwd_apply2_kernel<D>, dim3(stream_grid2(pieces, 2)), dim3(kT), 0, s, xv, gv,         \
-                     static_cast<u32x4 *>(dx), pieces, n, C, mean, invstd, weight, bias, param_dtype,         \
-                     static_cast<const float *>(partial), G, relu, use_batch_stats, dweight, dbias, n_live)
-    SPX_BN_DISPATCH(dtype, SPX_BN_BA2);
-#undef SPX_BN_BA2
-    SPX_LAUNCH_CHECK();
-    return 0;
-  }
   const int G = bn_blocks(n);
+  float *partial = static_cast<float *>(ws);
   float *sums = partial + static_cast<size_t>(G) * 2 * C;      // [2][C] behind the partials
+  const u32x4 *xv = static_cast<const u32x4 *>(x), *gv = static_cast<const u32x4 *>(dy);
 #define SPX_BN_BP(D)                                                                                        \
   hipLaunchKernelGGL(bn_bwd_partial_kernel<D>, dim3(G), dim3(kT), 0, s, xv, gv, n, C, mean, invstd, weight, \
                      bias, param_dtype, relu, partial, n_live)

@@ -22,7 +22,7 @@ import pytest
 import torch
 
 import oracle
-from util import (assert_close_abs_sum, assert_close_elementwise, assert_rulebook_equal, gpu_rulebook,
+from util import (assert_close_abs_sum, assert_close_elementwise, assert_rulebook_equal, gpu_rulebook, match_rows,
                   oracle_rulebook, rel_err, scene)
 
 pytestmark = pytest.mark.gpu
@@ -168,7 +168,7 @@ class _Tap:
             h.remove()
 
 
-def _check_layers_vs_oracle(tap, tol, first_has_din=False):
+def _check_layers_vs_oracle(tap, tol, first_has_din=False, exact_order=True):
     """Every conv layer of the step: coordinates bit-exact, forward / dgrad / wgrad within tol of
     the oracle evaluated on the layer's own inputs."""
     for li, m in enumerate(tap.layers):
@@ -176,13 +176,19 @@ def _check_layers_vs_oracle(tap, tol, first_has_din=False):
         idx = r["idx"].cpu().numpy()
         ref = oracle_rulebook(idx, r["bs"], r["shape"], m.kernel_size, m.stride, m.padding, m.dilation,
                               m.subm)
-        np.testing.assert_array_equal(r["out_idx"].cpu().numpy(), ref["out_inds"])
         assert r["out_shape"] == list(ref["out_shape"])
+        # rows of the layer's output in the oracle's (first-seen) numbering: the identity unless a strided layer
+        # numbers its outputs by coordinate key (constants.CONV_OUTPUT_ORDER = "sorted")
+        perm = match_rows(r["out_idx"].cpu().numpy(), ref["out_inds"], r["out_shape"])
+        if exact_order:
+            np.testing.assert_array_equal(r["out_idx"].cpu().numpy(), ref["out_inds"])
         f = r["fin"].detach().float().cpu()
         w = m.weight.detach().float().cpu()
-        dout = r["fout"].grad.detach().float().cpu()
-        assert torch.isfinite(dout).all() and float(dout.abs().max()) > 0, f"layer {li}: degenerate gradient"
-        out_ref = oracle.indice_conv(f, w, ref["pair"], ref["num"], ref["n_out"], subm=m.subm)
+        dout_got = r["fout"].grad.detach().float().cpu()
+        assert torch.isfinite(dout_got).all() and float(dout_got.abs().max()) > 0, f"layer {li}: degenerate gradient"
+        dout = torch.empty_like(dout_got)
+        dout[torch.from_numpy(perm)] = dout_got
+        out_ref = oracle.indice_conv(f, w, ref["pair"], ref["num"], ref["n_out"], subm=m.subm)[torch.from_numpy(perm)]
         din_ref, dw_ref = oracle.indice_conv_backward(f, w, dout, ref["pair"], ref["num"], subm=m.subm)
         tag = f"layer {li} ({m.in_channels}->{m.out_channels}, {'subm' if m.subm else 'conv'}, n={idx.shape[0]})"
         e = rel_err(r["fout"].detach().float().cpu().numpy(), out_ref.numpy())
@@ -194,12 +200,17 @@ def _check_layers_vs_oracle(tap, tol, first_has_din=False):
             assert e <= tol, f"{tag} din: {e:.3e}"
 
 
-def test_cfg3_chain_backward_on_lidar_fixture_vs_oracle(cuda):
+@pytest.mark.parametrize("order", ["first_seen", "sorted"])
+def test_cfg3_chain_backward_on_lidar_fixture_vs_oracle(cuda, monkeypatch, order):
     """Backward of BASELINE config 3 (regular-conv rulebooks, fused dgrad + wgrad on pair_bwd and the
-    Native lists) on the reference fixture; forward-only coverage lives in test_gpu_modules.py."""
+    Native lists) on the reference fixture; forward-only coverage lives in test_gpu_modules.py.  Both row orders of
+    the strided layers' outputs: the CPU reference's (coordinates bit-exact, in order) and the sorted one (the same
+    coordinate sets; features and gradients compared row by row under the permutation)."""
     import spconv_amd.pytorch as spconv
     from golden import lidar_scene
+    from spconv_amd import constants
     from spconv_amd.utils.nets import downsample_chain
+    monkeypatch.setattr(constants, "CONV_OUTPUT_ORDER", order)
     idx, shape = lidar_scene()
     torch.manual_seed(3)
     net = downsample_chain().to(cuda).half().train()
@@ -209,16 +220,20 @@ def test_cfg3_chain_backward_on_lidar_fixture_vs_oracle(cuda):
     g = (torch.rand(y.features.shape, device=cuda) - 0.5).half() * 0.4
     y.features.backward(g)
     torch.cuda.synchronize()
-    _check_layers_vs_oracle(tap, 2e-3, first_has_din=True)
+    _check_layers_vs_oracle(tap, 2e-3, first_has_din=True, exact_order=order == "first_seen")
     tap.close()
 
 
 @pytest.mark.timeout(900)
-def test_cfg4_backbone_step_fused_bwd_vs_oracle(cuda):
+@pytest.mark.parametrize("order", ["first_seen", "sorted"])
+def test_cfg4_backbone_step_fused_bwd_vs_oracle(cuda, monkeypatch, order):
     """One training step of the SECOND-style backbone (BatchNorm + ReLU, fp16) over a batch of 4
-    LiDAR-density scenes of 100 k voxels: all 12 sparse conv layers against the oracle."""
+    LiDAR-density scenes of 100 k voxels: all 12 sparse conv layers against the oracle, in both row orders of the
+    strided layers' outputs (sorted: SubM rulebooks of levels 2-4 come from the rank maps)."""
     import spconv_amd.pytorch as spconv
+    from spconv_amd import constants
     from spconv_amd.utils import synthetic
+    monkeypatch.setattr(constants, "CONV_OUTPUT_ORDER", order)
     from spconv_amd.utils.nets import SECOND_SHAPE, second_backbone
     bs = 4
     idx = synthetic.lidar_like_scene(SECOND_SHAPE, 100_000, bs, seed=11)
@@ -232,7 +247,7 @@ def test_cfg4_backbone_step_fused_bwd_vs_oracle(cuda):
     y.features.backward(g)
     torch.cuda.synchronize()
     assert len(tap.layers) == 12
-    _check_layers_vs_oracle(tap, 3e-3)
+    _check_layers_vs_oracle(tap, 3e-3, exact_order=order == "first_seen")
     tap.close()
 
 

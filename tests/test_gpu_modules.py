@@ -165,7 +165,8 @@ def test_install_as_spconv_alias(cuda):
     assert spconv.SparseConvTensor is SparseConvTensor
 
 
-def test_cfg3_downsample_chain_on_reference_lidar_fixture(cuda):
+@pytest.mark.parametrize("order", ["first_seen", "sorted"])
+def test_cfg3_downsample_chain_on_reference_lidar_fixture(cuda, monkeypatch, order):
     """BASELINE config 3: SparseConv3d k3 s2 p1 chain 16 -> 32 -> 64 -> 128 (fp16) on the voxel
     coordinates of the reference's real-LiDAR fixture (test/data/test_spconv.pkl, 125 562 voxels
     in [80,1600,1600]; SURVEY.md 8d measured 125k -> 137k -> 66k -> 26k outputs).  Every layer's
@@ -174,6 +175,11 @@ def test_cfg3_downsample_chain_on_reference_lidar_fixture(cuda):
     import oracle
     import spconv_amd.pytorch as spconv
     from golden import lidar_scene
+    from spconv_amd import constants
+    from util import match_rows
+    # "sorted": the layers number their outputs by coordinate key -- the same coordinate sets, compared under the
+    # permutation; the oracle is fed the rows in ITS order
+    monkeypatch.setattr(constants, "CONV_OUTPUT_ORDER", order)
     idx, shape = lidar_scene()
     assert idx.shape[0] == 125562
     rng = np.random.default_rng(3)
@@ -189,10 +195,13 @@ def test_cfg3_downsample_chain_on_reference_lidar_fixture(cuda):
         w32 = conv.weight.detach().float().cpu()
         out_inds, pair, num, out_shape = oracle.get_indice_pairs(
             cur_idx, 1, cur_shape, [3] * 3, [2] * 3, [1] * 3, [1] * 3, None, False, False)
-        np.testing.assert_array_equal(x.indices.cpu().numpy(), out_inds)
+        if order == "first_seen":
+            np.testing.assert_array_equal(x.indices.cpu().numpy(), out_inds)
         assert x.spatial_shape == list(out_shape)
+        perm = torch.from_numpy(match_rows(x.indices.cpu().numpy(), out_inds, list(out_shape)))
         ref = oracle.indice_conv(cur_f, w32, pair, num, out_inds.shape[0], subm=False)
-        got = x.features.float().cpu()
+        got = torch.empty_like(ref)
+        got[perm] = x.features.float().cpu()            # the GPU rows, in the oracle's numbering
         assert rel_err(got.numpy(), ref.numpy()) < 3e-3, f"layer {li}"
         # continue from the GPU's fp16 output so that errors do not compound in the comparison
         cur_idx, cur_shape, cur_f = out_inds, list(out_shape), got

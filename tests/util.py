@@ -43,6 +43,23 @@ def to_np(t):
     return None if t is None else t.detach().cpu().numpy()
 
 
+def match_rows(got_idx, ref_idx, shape):
+    """perm with got_idx == ref_idx[perm]: the two hold the same coordinates (asserted), possibly in another row order
+    (a strided layer in sorted order against the oracle's first-seen numbering)."""
+    got_idx, ref_idx = np.asarray(got_idx), np.asarray(ref_idx)
+    assert got_idx.shape == ref_idx.shape, (got_idx.shape, ref_idx.shape)
+    if np.array_equal(got_idx, ref_idx):
+        return np.arange(got_idx.shape[0])
+    key = lambda a: np.ravel_multi_index(tuple(a[:, 1 + d].astype(np.int64) for d in range(len(shape))), shape) \
+        + a[:, 0].astype(np.int64) * int(np.prod(shape))
+    kg, kr = key(got_idx), key(ref_idx)
+    order = np.argsort(kr, kind="stable")
+    pos = np.searchsorted(kr[order], kg)
+    assert pos.max() < kr.shape[0] and np.array_equal(kr[order][pos], kg), "different coordinate sets"
+    assert np.unique(kg).shape[0] == kg.shape[0]
+    return order[pos]
+
+
 def assert_rulebook_equal(rb, ref, subm, check_bwd=True):
     """Bit-exact comparison of every artefact against the oracle."""
     assert rb.n_out == ref["n_out"], (rb.n_out, ref["n_out"])
