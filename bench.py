@@ -1110,6 +1110,7 @@ def run_net(args, D: Dist):
                       "launch": "eager" if eager_ms is None else "hipGraph replay of the whole step (static shapes: "
                                 "rulebook builds + forward + backward captured once, one graph for every scene)",
                       "static_shapes": static_info, "parallelism": f"dp{world}", "ranks_seen": ranks_seen,
+                      "conv_output_order": __import__("spconv_amd.constants", fromlist=["x"]).CONV_OUTPUT_ORDER,
                       "dist_backend": D.backend if D.multi else None},
            "roofline": roofline_obj("step", total, ms, "whole step: rulebook builders + igemm_v4 / igemm_bwd / "
                                     "wgrad_reduce2 of every layer (+ the bn_* BatchNorm+ReLU kernels at config 4)", None,
@@ -1342,6 +1343,7 @@ def run_infer(args, D: Dist):
                                    f"step INSIDE the graph, input padded to {runner.max_voxels} rows",
                        "bounds": bounds, "input_voxels_per_gpu": int(n_mean), "scenes_rotated": S,
                        "launch": "hipGraph replay (rulebooks + convolutions), one graph for every scene",
+                       "conv_output_order": __import__("spconv_amd.constants", fromlist=["x"]).CONV_OUTPUT_ORDER,
                        "parallelism": f"dp{world}", "ranks_seen": ranks_seen}}
 
 
@@ -1381,6 +1383,22 @@ def also_block(args, D: Dist):
                   "bn_folded_live_rows_identical_to_its_eager_pass"):
             if k in r:
                 c[k] = r[k]
+        if cfg in ("3", "4", "4i"):
+            # the same network with the strided layers' outputs in the CPU reference's first-seen order (the functional
+            # API's order; the modules default to ascending coordinate key: spconv_amd.constants.CONV_OUTPUT_ORDER)
+            from spconv_amd import constants as _c
+            c["conv_output_order"] = _c.CONV_OUTPUT_ORDER
+            if _c.CONV_OUTPUT_ORDER != "first_seen":
+                keep = _c.CONV_OUTPUT_ORDER
+                try:
+                    _c.CONV_OUTPUT_ORDER = "first_seen"
+                    r2 = run_infer(a, D) if cfg == "4i" else run_net(a, D)
+                    c["first_seen_order_ms_per_step"] = round(r2["ms_per_step"], 5)
+                    del r2
+                except Exception as e:
+                    c["first_seen_order_ms_per_step"] = f"{type(e).__name__}: {e}"[:200]
+                finally:
+                    _c.CONV_OUTPUT_ORDER = keep
         c["wall_s"] = round(time.perf_counter() - t0, 1)
         out[cfg] = c
         del r

@@ -12,7 +12,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value -mllvm -amdgpu-kernarg-preload-count=16"
 for v in ${@:-0 1 2 3 4 5}; do
   ( $HIPCC $FLAGS -DSPX_ABLATE=$v -c igemm.hip -o $OUT/abl/igemm$v.o &&
-    $HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT/libspconv_amd_abl$v.so $OUT/rulebook.o $OUT/abl/igemm$v.o $OUT/igemm_bf16.o $OUT/igemm_f32.o $OUT/igemm_i8.o $OUT/igemm_gen1.o $OUT/igemm_ws.o $OUT/igemm_wsl.o $OUT/igemm_bwdn.o $OUT/pool.o $OUT/rowsort.o $OUT/norm.o $OUT/common.o &&
+    $HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT/libspconv_amd_abl$v.so $OUT/rulebook.o $OUT/abl/igemm$v.o $OUT/igemm_bf16.o $OUT/igemm_f32.o $OUT/igemm_i8.o $OUT/igemm_gen1.o $OUT/igemm_ws.o $OUT/igemm_bwdn.o $OUT/pool.o $OUT/rowsort.o $OUT/norm.o $OUT/common.o &&
     echo built $OUT/libspconv_amd_abl$v.so ) &
 done
 wait

@@ -157,9 +157,6 @@ int launch_gather_gemm_gen1(const GemmParams &p, bool bf16, hipStream_t s);
 // igemm_ws.hip: weight-stationary gather-GEMM for dense neighbourhoods (forward and dgrad)
 bool ws_ok(const GemmParams &p, int dtype);
 int launch_gather_gemm_ws(const GemmParams &p, int dtype, hipStream_t s);
-// igemm_wsl.hip: weight-resident forward for 16 / 32 input channels on dense neighbourhoods
-bool wsl_ok(const GemmParams &p, int dtype);
-int launch_gather_gemm_wsl(const GemmParams &p, int dtype, hipStream_t s);
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

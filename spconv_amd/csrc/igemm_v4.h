@@ -773,14 +773,6 @@ int dispatch_gather_gemm(const GemmParams &p, hipStream_t s) {
     drop_rows_layout(q);
     return launch_gather_gemm_ws(q, BF16 ? SPX_BF16 : SPX_F16, s);
   }
-  // narrow rows (16 / 32 input channels) on dense neighbourhoods: every weight slice resident in LDS, waves on their
-  // own (igemm_wsl.hip; SPX_WSL = 1 / 0 forces / forbids) -- bit-identical as well
-  const int wslv = option_int("SPX_WSL", -1);
-  if ((wslv > 0 || (wslv < 0 && p.dense_hint)) && wsl_ok(p, BF16 ? SPX_BF16 : SPX_F16)) {
-    GemmParams q = p;
-    drop_rows_layout(q);
-    return launch_gather_gemm_wsl(q, BF16 ? SPX_BF16 : SPX_F16, s);
-  }
   if (v4_ok(p)) {
     // 64-row tiles while the grid would otherwise leave CUs idle, 128-row tiles beyond -- except
     // for 128 output channels, whose 128-row variant holds 64 accumulator registers per lane and

@@ -1310,20 +1310,36 @@ conv4_emit_kernel(uint2 *__restrict__ cells, unsigned W, const int32_t *__restri
   const int p = blockoff[w / kRankWords] + static_cast<int>(cell.y);
   cells[w].y = static_cast<uint32_t>(p);
   uint32_t bits = cell.x;
+  if (!bits || p >= n_cap) return;
   const int lead = 4 - g.ndim;
+  // coordinates of the word's first key, once (keys are below 2^31: 32-bit divisions); its other keys advance the
+  // last coordinate and carry
+  uint32_t v = w << 5;
+  int c0[4];
+#pragma unroll
+  for (int d = 3; d >= 0; --d) {
+    const uint32_t dim = static_cast<uint32_t>(g.out_dims[d]);
+    const uint32_t q = v / dim;
+    c0[d] = static_cast<int>(v - q * dim);
+    v = q;
+  }
+  const int b0 = static_cast<int>(v);
   int oid = p;
   while (bits && oid < n_cap) {
     const int bit = __builtin_ctz(bits);
     bits &= bits - 1;
-    unsigned long long v = (static_cast<unsigned long long>(w) << 5) | static_cast<unsigned>(bit);
-    int c[4];
+    int c[4] = {c0[0], c0[1], c0[2], c0[3] + bit};
+    int b = b0;
 #pragma unroll
-    for (int d = 3; d >= 0; --d) {
-      c[d] = static_cast<int>(v % static_cast<unsigned>(g.out_dims[d]));
-      v /= static_cast<unsigned>(g.out_dims[d]);
+    for (int d = 3; d >= 0; --d) {               // (at most a few carries: 32 keys span 32 cells of the last axis)
+      while (c[d] >= g.out_dims[d]) {
+        c[d] -= g.out_dims[d];
+        if (d > 0) ++c[d - 1];
+        else ++b;
+      }
     }
     int32_t *dst = out_indices + static_cast<size_t>(oid) * (g.ndim + 1);
-    dst[0] = static_cast<int32_t>(v);
+    dst[0] = b;
     for (int d = lead; d < 4; ++d) dst[1 + d - lead] = c[d];
     ++oid;
   }

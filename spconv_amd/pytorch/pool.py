@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from spconv_amd.pytorch import functional as Fsp
+from spconv_amd import constants
 from spconv_amd.pytorch import ops
 from spconv_amd.pytorch.core import (ConvAlgo, ImplicitGemmIndiceData, IndiceData, SparseConvTensor,
                                      expand_nd)
@@ -95,7 +96,7 @@ class _SparsePoolBase(SparseModule):
                                    self.padding, self.dilation, [0] * self.ndim, self.subm, False,
                                    need_bwd_table=True,
                                    need_native=(not static) or self.algo == ConvAlgo.Native,
-                                   static_num_out=static)
+                                   static_num_out=static, out_order=constants.CONV_OUTPUT_ORDER)
         self._static_n_out_dev = rb.n_out_dev
         rb.in_n_live_dev = getattr(input, "n_live_dev", None)
         if rb.n_out_dev is not None:
