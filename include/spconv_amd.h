@@ -176,7 +176,8 @@ int spx_conv_sorted_ok(int ndim, int batch_size, const int *in_shape, const int 
 size_t spx_conv_rulebook_sorted_ws_bytes(int n_in, int ndim, int batch_size, const int *out_shape,
                                          const int *ksize);
 /* phase 1 (as spx_conv_rulebook_count: the one D->H read of the count), phase 2 (as spx_conv_rulebook_fill)
- * and the static-shape form (as spx_conv_rulebook_static; n_out_dev[1] stays 0: a rank map cannot overflow).
+ * and the static-shape form (as spx_conv_rulebook_static, with n_out_dev [3]: {outputs found, 0 -- a rank map cannot
+ * overflow --, live output rows = min(found, n_out_cap)}).
  * `rankmap` and `ws` must be passed unchanged from phase 1 to phase 2. */
 int spx_conv_rulebook_count_sorted(const int32_t *indices, int n_in, int ndim, int batch_size,
                                    const int *in_shape, const int *out_shape, const int *ksize,

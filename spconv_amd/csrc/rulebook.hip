@@ -1303,8 +1303,10 @@ conv4_prefix_kernel(uint2 *__restrict__ cells, unsigned W, int32_t *__restrict__
 // caller's bound are dropped (their rank says so wherever it is looked up)
 __global__ void __launch_bounds__(kBlock)
 conv4_emit_kernel(uint2 *__restrict__ cells, unsigned W, const int32_t *__restrict__ blockoff, Geom g,
-                  int32_t *__restrict__ out_indices, int n_cap) {
+                  int32_t *__restrict__ out_indices, int n_cap, int32_t *__restrict__ live_out = nullptr) {
   const unsigned w = blockIdx.x * kBlock + threadIdx.x;
+  // static-shape form: the number of live output rows (outputs found, at most the bound) for the layers behind
+  if (live_out && w == 0) live_out[2] = live_out[0] < n_cap ? live_out[0] : n_cap;
   if (w >= W) return;
   uint2 cell = cells[w];
   const int p = blockoff[w / kRankWords] + static_cast<int>(cell.y);
@@ -2776,7 +2778,8 @@ int conv4_fill_impl(const int32_t *indices, int n_in, int ndim, int batch_size, 
                     const int *out_shape, const int *ksize, const int *stride, const int *padding,
                     const int *dilation, int n_out, int32_t *out_indices, int32_t *pair_fwd, int32_t *pair_bwd,
                     uint32_t *mask_fwd, uint32_t *mask_bwd, int32_t *pair_native, int32_t *num_per_loc,
-                    void *rankmap, size_t rankmap_bytes, void *ws, size_t ws_bytes, hipStream_t s, bool prefilled) {
+                    void *rankmap, size_t rankmap_bytes, void *ws, size_t ws_bytes, hipStream_t s, bool prefilled,
+                    int32_t *nout_dev = nullptr) {
   const Geom g = make_geom(ndim, batch_size, in_shape, out_shape, ksize, stride, padding, dilation);
   if (check_geom(ndim, n_in, g.kv)) return -1;
   const int mj = conv3_cands(ndim, in_shape, ksize, stride, padding, dilation, 0);
@@ -2801,7 +2804,7 @@ int conv4_fill_impl(const int32_t *indices, int n_in, int ndim, int batch_size, 
   }
   if (n_in == 0) return 0;
   hipLaunchKernelGGL(conv4_emit_kernel, dim3(div_up(static_cast<int>(W), kBlock)), dim3(kBlock), 0, s, cells,
-                     static_cast<unsigned>(W), static_cast<const int32_t *>(w.blockoff), g, out_indices, n_out);
+                     static_cast<unsigned>(W), static_cast<const int32_t *>(w.blockoff), g, out_indices, n_out, nout_dev);
   SPX_CONV3_LAUNCH(conv4_pairs_kernel, mj, dim3(div_up(n_in, kBlock)), dim3(kBlock), 0, s, indices, n_in, g,
                    static_cast<const uint2 *>(cells), n_out, pair_fwd, pair_bwd, mask_bwd, words,
                    lists ? w.groupcount : nullptr);
@@ -2878,7 +2881,7 @@ int spx_conv_rulebook_static_sorted(const int32_t *indices, int n_in, int ndim, 
   if (rc) return rc;
   return spx::conv4_fill_impl(indices, n_in, ndim, batch_size, in_shape, out_shape, ksize, stride, padding, dilation,
                               n_out_cap, out_indices, pair_fwd, pair_bwd, mask_fwd, mask_bwd, pair_native,
-                              num_per_loc, rankmap, rankmap_bytes, ws, ws_bytes, s, true);
+                              num_per_loc, rankmap, rankmap_bytes, ws, ws_bytes, s, true, n_out_dev);
 }
 
 size_t spx_subm_rulebook_ranked_ws_bytes(int n, int kv) {

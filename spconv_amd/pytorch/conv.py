@@ -355,8 +355,8 @@ class SparseConvolution(SparseModule):
                                                out_order=constants.CONV_OUTPUT_ORDER)
                 self._static_n_out_dev = rb.n_out_dev
                 rb.in_n_live_dev = getattr(input, "n_live_dev", None)
-                if rb.n_out_dev is not None:      # live output rows: the count found, at most the bound
-                    rb.out_n_live_dev = rb.n_out_dev[:1].clamp(max=rb.n_out)
+                if rb.n_out_dev is not None and getattr(rb, "out_n_live_dev", None) is None:
+                    rb.out_n_live_dev = rb.n_out_dev[:1].clamp(max=rb.n_out)      # live output rows: found, at most the bound
             except Exception:
                 # reference conv.py:289-297: say what was asked for and keep the inputs for a report
                 print(f"[Exception|rulebook] indices={tuple(indices.shape)},bs={batch_size},ss={spatial_shape},"

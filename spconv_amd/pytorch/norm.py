@@ -50,7 +50,10 @@ def _param_dtype(*tensors) -> Optional[torch.dtype]:
 class _BatchNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu, nbt=None,
-                n_live=None):
+                n_live=None, differentiable=True):
+        # differentiable: the caller's grad mode AND an input that requires grad (decided outside: inside forward the
+        # grad mode is always off, and ctx.needs_input_grad reports requires_grad whatever the mode -- an inference
+        # pass under no_grad over a model whose parameters still require grad must not pay for a snapshot)
         L = _lib.load()
         x = x.contiguous()
         n, C = x.shape
@@ -73,7 +76,7 @@ class _BatchNormFn(torch.autograd.Function):
         ctx.snap = False
         if training:
             ctx.save_for_backward(x, weight, bias, stats[0], stats[1])
-        elif any(ctx.needs_input_grad[:3]):
+        elif differentiable:
             ctx.snap = True
             ctx.save_for_backward(x, weight, bias, running_mean.float().clone(),
                                   torch.rsqrt(running_var.float() + float(eps)))
@@ -102,7 +105,7 @@ class _BatchNormFn(torch.autograd.Function):
                                            p(bias), _DT[ctx.pdt], mean.data_ptr(), invstd.data_ptr(),
                                            int(ctx.training), int(ctx.relu), p(dw), p(db), ws.data_ptr(), ws.numel(),
                                            p(ctx.n_live), torch._C._cuda_getCurrentRawStream(dev.index)))
-        return dx, dw, db, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
 def batch_norm(features: torch.Tensor, bn: nn.BatchNorm1d, relu: bool = False,
@@ -122,6 +125,8 @@ def batch_norm(features: torch.Tensor, bn: nn.BatchNorm1d, relu: bool = False,
             bn.num_batches_tracked.add_(1)
     use_batch = bn.training or (bn.running_mean is None and bn.running_var is None)
     update = bn.training and bn.track_running_stats
+    differentiable = torch.is_grad_enabled() and any(t is not None and t.requires_grad
+                                                     for t in (features, bn.weight, bn.bias))
     return _BatchNormFn.apply(features, bn.weight, bn.bias, bn.running_mean if (update or not use_batch) else None,
                               bn.running_var if (update or not use_batch) else None, use_batch, momentum, bn.eps,
-                              relu, nbt, n_live)
+                              relu, nbt, n_live, differentiable)

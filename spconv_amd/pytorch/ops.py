@@ -315,7 +315,7 @@ def _build_sorted(L, indices, batch_size, spatial_shape, out_shape, ksize, strid
     n_out_dev = None
     if static_num_out > 0:
         n_out = int(static_num_out)
-        n_out_dev = torch.empty((2,), **i32)
+        n_out_dev = torch.empty((4,), **i32)      # {found, 0, live rows = min(found, bound), -}
     else:
         n_out_c = ctypes.c_int(0)
         _lib.check(L.spx_conv_rulebook_count_sorted(indices.data_ptr(), n_in, ndim, batch_size, *args,
@@ -344,7 +344,9 @@ def _build_sorted(L, indices, batch_size, spatial_shape, out_shape, ksize, strid
                                                    cells.data_ptr(), cells.numel() * 4, ws.data_ptr(), ws.numel(),
                                                    stream))
     rb = Rulebook(out_indices, pair_fwd, pair_bwd, mask_fwd, mask_bwd, native, num, n_in, n_out, kv, False)
-    rb.n_out_dev = n_out_dev
+    if n_out_dev is not None:
+        rb.n_out_dev = n_out_dev[:2]
+        rb.out_n_live_dev = n_out_dev[2:3]        # written by the build itself: no clamp launch behind it
     rb.in_indices, rb.in_shape, rb.out_shape, rb.batch_size = indices, list(spatial_shape), list(out_shape), batch_size
     rb.pred_key = pred_key
     rb.rankmap = cells

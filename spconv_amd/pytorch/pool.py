@@ -99,7 +99,7 @@ class _SparsePoolBase(SparseModule):
                                    static_num_out=static, out_order=constants.CONV_OUTPUT_ORDER)
         self._static_n_out_dev = rb.n_out_dev
         rb.in_n_live_dev = getattr(input, "n_live_dev", None)
-        if rb.n_out_dev is not None:
+        if rb.n_out_dev is not None and getattr(rb, "out_n_live_dev", None) is None:
             rb.out_n_live_dev = rb.n_out_dev[:1].clamp(max=rb.n_out)
         outids = rb.out_indices
         if input.benchmark:
