@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Device time of one fused BatchNorm1d + ReLU forward and backward (csrc/norm.hip, through the C ABI on preallocated
-buffers, hipGraph replays of 20 calls) at the level shapes of the config-4 backbone: the two-launch forms (statistics
-merged by the apply launch) against the three-launch forms (SPX_BN_MERGE=0).
+buffers, hipGraph replays of 20 calls) at the level shapes of the config-4 backbone, next to the time the
+passes' bytes would take at 6 TB/s (tools/experiments/bn_two_launch.patch: the two-launch forms this tool compared).
     python tools/bn_probe.py            -> one JSON line per shape"""
 import json, os, sys
 import torch
@@ -58,13 +58,6 @@ for n, C in SHAPES:
 
     out = {"n": n, "C": C, "tensor_MB": round(n * C * 2 / 1e6, 1)}
     res = {}
-    for mode in (1, 0):
-        L.spx_set_option(b"SPX_BN_MERGE", mode)
-        tf = timed(fwd, s)
-        tb = timed(bwd, s)
-        res[mode] = (y.float().clone(), dx.float().clone(), dw.clone())
-        out["merge" if mode else "three_launch"] = {"fwd_us": round(tf, 2), "bwd_us": round(tb, 2)}
+    out["three_launches"] = {"fwd_us": round(timed(fwd, s), 2), "bwd_us": round(timed(bwd, s), 2)}
     out["ideal_us_at_6TBps"] = {"fwd": round(3 * n * C * 2 / 6e6, 2), "bwd": round(5 * n * C * 2 / 6e6, 2)}
-    out["maxdiff_y_dx_dw"] = [float((res[1][i] - res[0][i]).abs().max()) for i in range(3)]
     print(json.dumps(out), flush=True)
-L.spx_set_option(b"SPX_BN_MERGE", 1)
