@@ -80,6 +80,45 @@ def test_workspace_size_queries(lib):
     assert lib.spx_table_to_native_ws_bytes(100_000, 27) > 0
 
 
+def test_sorted_order_host_queries(lib):
+    """Rank-map sizing and the geometries that take the sorted-order builder (host-only entry points)."""
+    I = _lib.ints
+    # one {bits, prefix} pair (8 bytes) per 32 cells of batch x grid
+    assert lib.spx_rankmap_bytes(3, 4, I([21, 800, 704])) == (4 * 21 * 800 * 704 + 31) // 32 * 8
+    assert lib.spx_rankmap_bytes(2, 1, I([5, 7])) == 2 * 8
+    assert lib.spx_rankmap_bytes(3, 200, I([21, 800, 704])) == 0          # key space beyond 2^31 cells: hash builder
+    assert lib.spx_rankmap_bytes(3, 0, I([8, 8, 8])) == 0 and lib.spx_rankmap_bytes(3, 1, I([8, 0, 8])) == 0
+    ok = lambda shape, k, s, p, tr=0, bs=2: lib.spx_conv_sorted_ok(
+        3, bs, I(shape), I([(shape[i] + 2 * p[i] - (k[i] - 1) - 1) // s[i] + 1 for i in range(3)]), I(k), I(s), I(p),
+        I([1] * 3), tr)
+    assert ok([41, 1600, 1408], [3] * 3, [2] * 3, [1] * 3) == 1              # k3 s2
+    assert ok([41, 1600, 1408], [2] * 3, [2] * 3, [0] * 3) == 1              # k2 s2
+    assert ok([41, 1600, 1408], [3] * 3, [3] * 3, [1] * 3) == 1
+    assert ok([41, 1600, 1408], [3] * 3, [1] * 3, [1] * 3) == 0              # stride 1: every offset is a candidate
+    assert ok([5, 200, 176], [3, 1, 1], [2, 1, 1], [0] * 3) == 0             # two of three offsets
+    assert ok([41, 1600, 1408], [3] * 3, [2] * 3, [1] * 3, tr=1) == 0        # transposed
+    assert ok([41, 1600, 1408], [3] * 3, [2] * 3, [1] * 3, bs=400) == 0      # key space too large
+    ws = lib.spx_conv_rulebook_sorted_ws_bytes(400_000, 3, 4, I([21, 800, 704]), I([3] * 3))
+    assert 27 * (400_000 // 256) * 4 < ws < 1 << 20                           # group counts + block counts: no table
+    assert lib.spx_subm_rulebook_ranked_ws_bytes(313_000, 27) < lib.spx_subm_rulebook_ws_bytes(313_000, 27) // 8
+
+
+def test_rank_map_follows_its_index_tensor_only():
+    """ops._rankmap_of: the map a sorted-order build left on an index tensor is used for exactly that level."""
+    import torch
+    from spconv_amd.pytorch import ops
+    ind = torch.zeros((10, 4), dtype=torch.int32)
+    cells = torch.zeros((8,), dtype=torch.int32)
+    assert ops._rankmap_of(ind, 2, [4, 4, 4], 10, 27) is None
+    ind._spx_rankmap = (cells, 2, (4, 4, 4), 10)
+    assert ops._rankmap_of(ind, 2, [4, 4, 4], 10, 27) is cells
+    assert ops._rankmap_of(ind, 1, [4, 4, 4], 10, 27) is None          # other batch size
+    assert ops._rankmap_of(ind, 2, [4, 4, 5], 10, 27) is None          # other grid
+    assert ops._rankmap_of(ind, 2, [4, 4, 4], 9, 27) is None           # other row count
+    assert ops._rankmap_of(ind, 2, [4, 4, 4], 10, 1) is None           # 1 x 1 x 1: nothing to look up
+    assert ops._rankmap_of(ind.clone(), 2, [4, 4, 4], 10, 27) is None  # a copy does not carry it
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libspconv_amd.so")

@@ -3,7 +3,8 @@
 
     SubM k3 (inference tables only / with the Native lists), SparseConv k3 s2 p1 and k2 s2 in the
     static-shape form (spx_conv_rulebook_static: the same passes as the two-call form, nothing read
-    back, so it can sit in a graph), second- vs third-generation passes (SPX_CONV_V = 2 / 3).
+    back, so it can sit in a graph), second- vs third-generation passes (SPX_CONV_V = 2 / 3), the sorted-order
+    build of the same layer (rank map) and the SubM layer behind it, hash build vs rank-map build.
 
 Scenes: uniform 100 k (BASELINE config 2), LiDAR-like 100 k and 4 x 100 k (config 4 level 1), the
 reference fixture.  One JSON line.   python tools/rulebook_bench.py"""
@@ -69,6 +70,20 @@ def main():
                 else:
                     row[name + "_v3_equals_v2"] = all(torch.equal(a, b) for a, b in zip(ref, t))
             set_option("SPX_CONV_V", 3)
+            # sorted-order level (rank map instead of the hash table) and the SubM layer behind it:
+            # hash build of the same rows against the build over the level's rank map
+            fs = lambda i: ops.build_rulebook(ind, bs, shape, [k] * 3, [s] * 3, [p] * 3, [1] * 3, [0] * 3, False,
+                                              need_native=False, static_num_out=cap, out_order="sorted")
+            got = fs(0)[0]
+            if got.rankmap is not None:
+                row[name + "_sorted_us"] = round(bench.event_time_ms(fs, iters=40, span=4) * 1e3, 1)
+                lvl, oshape = got.out_indices, got.out_shape
+                plain = lvl.clone()
+                sub = lambda t: (lambda i: ops.build_rulebook(t, bs, oshape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3,
+                                                              True, need_native=False))
+                row[name + "_level_subm_hash_us"] = round(bench.event_time_ms(sub(plain), iters=40, span=4) * 1e3, 1)
+                row[name + "_level_subm_ranked_us"] = round(bench.event_time_ms(sub(lvl), iters=40, span=4) * 1e3, 1)
+                row[name + "_level_subm_equal"] = bool(torch.equal(sub(plain)(0)[0].pair_fwd, sub(lvl)(0)[0].pair_fwd))
         rows.append(row)
     print(json.dumps({"rulebook_device_us": rows}))
 
