@@ -1293,7 +1293,7 @@ conv4_prefix_kernel(uint2 *__restrict__ cells, unsigned W, int32_t *__restrict__
   int run = prefix + incl - sum;
 #pragma unroll
   for (int e = 0; e < kRankPer; ++e) {
-    if (base + e < W) cells[base + e].y = static_cast<uint32_t>(run);
+    if (cnt[e]) cells[base + e].y = static_cast<uint32_t>(run);      // (an empty word's prefix is never read)
     run += cnt[e];
   }
   if (threadIdx.x == 0) blockcount[blockIdx.x] = total;
@@ -1309,10 +1309,11 @@ conv4_emit_kernel(uint2 *__restrict__ cells, unsigned W, const int32_t *__restri
   if (live_out && w == 0) live_out[2] = live_out[0] < n_cap ? live_out[0] : n_cap;
   if (w >= W) return;
   uint2 cell = cells[w];
+  uint32_t bits = cell.x;
+  if (!bits) return;                           // most words of a sparse level: 8 bytes read, nothing written
   const int p = blockoff[w / kRankWords] + static_cast<int>(cell.y);
   cells[w].y = static_cast<uint32_t>(p);
-  uint32_t bits = cell.x;
-  if (!bits || p >= n_cap) return;
+  if (p >= n_cap) return;
   const int lead = 4 - g.ndim;
   // coordinates of the word's first key, once (keys are below 2^31: 32-bit divisions); its other keys advance the
   // last coordinate and carry

@@ -101,7 +101,7 @@ def test_geometries_without_compact_candidates_keep_the_first_seen_builder(cuda)
         np.testing.assert_array_equal(to_np(rs.pair_fwd), to_np(rf.pair_fwd))
 
 
-@pytest.mark.parametrize("n_in,need_bwd", [(60000, True), (300000, False)])       # (the second: masks by the pass form)
+@pytest.mark.parametrize("n_in,need_bwd", [(60000, True), (300000, False)])       # (the second: the hash build takes its mask-pass form)
 def test_subm_over_the_rank_map_equals_the_hash_build(cuda, n_in, need_bwd):
     from spconv_amd.pytorch import ops
     shape, bs = [41, 400, 352], 4
