@@ -99,7 +99,8 @@ def test_sorted_order_host_queries(lib):
     assert ok([41, 1600, 1408], [3] * 3, [2] * 3, [1] * 3, tr=1) == 0        # transposed
     assert ok([41, 1600, 1408], [3] * 3, [2] * 3, [1] * 3, bs=400) == 0      # key space too large
     ws = lib.spx_conv_rulebook_sorted_ws_bytes(400_000, 3, 4, I([21, 800, 704]), I([3] * 3))
-    assert 27 * (400_000 // 256) * 4 < ws < 1 << 20                           # group counts + block counts: no table
+    cells = 4 * 21 * 800 * 704
+    assert cells < ws < cells + (1 << 20)      # one byte per cell between the mark and the prefix pass + counts: no table
     assert lib.spx_subm_rulebook_ranked_ws_bytes(313_000, 27) < lib.spx_subm_rulebook_ws_bytes(313_000, 27) // 8
 
 
