@@ -162,8 +162,9 @@ int spx_conv_rulebook_static(const int32_t *indices, int n_in, int ndim, int bat
  * (indices.py:1742-1771, what spx_conv_rulebook_fill reproduces).  The calls below produce the SORTED order
  * (batch-major linear key, last spatial dimension fastest) without a sort and without a hash table, through the
  * RANK MAP of the output level: one {occupancy bits, number of occupied cells before the word} pair per 32
- * consecutive keys; row of a key = prefix + popcount of the bits below it.  (Built from a byte per cell in the
- * workspace -- plain idempotent stores, no atomics -- that a prefix pass packs into the words.)  The map is the caller's buffer
+ * consecutive keys (the prefix counted inside a block of 2048 words, the blocks' own offsets behind the words); row of a
+ * key = block offset + prefix + popcount of the bits below it.  (Built from a byte per cell in the workspace -- plain
+ * idempotent stores, no atomics -- that a prefix pass packs into the words.)  The map is the caller's buffer
  * (spx_rankmap_bytes; 0 = key space beyond 2^31 cells: keep the hash builder) and stays valid after the call:
  * spx_subm_rulebook_ranked builds the SubM rulebook of a layer BEHIND the strided one from it -- no table fill,
  * no insert, one 8-byte load per neighbour query.  Rows in key order put x-neighbours in adjacent rows, which is

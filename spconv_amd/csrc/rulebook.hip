@@ -1309,70 +1309,27 @@ conv4_prefix_kernel(const uint4 *__restrict__ occupied, uint2 *__restrict__ cell
   if (threadIdx.x == 0) blockcount[blockIdx.x] = total;
 }
 
-// prefix made global (+ block offset), coordinates of the set bits -> out_indices in key order; outputs beyond the
-// caller's bound are dropped (their rank says so wherever it is looked up)
-__global__ void __launch_bounds__(kBlock)
-conv4_emit_kernel(uint2 *__restrict__ cells, unsigned W, const int32_t *__restrict__ blockoff, Geom g,
-                  int32_t *__restrict__ out_indices, int n_cap, int32_t *__restrict__ live_out = nullptr) {
-  const unsigned w = blockIdx.x * kBlock + threadIdx.x;
-  // static-shape form: the number of live output rows (outputs found, at most the bound) for the layers behind
-  if (live_out && w == 0) live_out[2] = live_out[0] < n_cap ? live_out[0] : n_cap;
-  if (w >= W) return;
-  uint2 cell = cells[w];
-  uint32_t bits = cell.x;
-  if (!bits) return;                           // most words of a sparse level: 8 bytes read, nothing written
-  const int p = blockoff[w / kRankWords] + static_cast<int>(cell.y);
-  cells[w].y = static_cast<uint32_t>(p);
-  if (p >= n_cap) return;
-  const int lead = 4 - g.ndim;
-  // coordinates of the word's first key, once (keys are below 2^31: 32-bit divisions); its other keys advance the
-  // last coordinate and carry
-  uint32_t v = w << 5;
-  int c0[4];
-#pragma unroll
-  for (int d = 3; d >= 0; --d) {
-    const uint32_t dim = static_cast<uint32_t>(g.out_dims[d]);
-    const uint32_t q = v / dim;
-    c0[d] = static_cast<int>(v - q * dim);
-    v = q;
-  }
-  const int b0 = static_cast<int>(v);
-  int oid = p;
-  while (bits && oid < n_cap) {
-    const int bit = __builtin_ctz(bits);
-    bits &= bits - 1;
-    int c[4] = {c0[0], c0[1], c0[2], c0[3] + bit};
-    int b = b0;
-#pragma unroll
-    for (int d = 3; d >= 0; --d) {               // (at most a few carries: 32 keys span 32 cells of the last axis)
-      while (c[d] >= g.out_dims[d]) {
-        c[d] -= g.out_dims[d];
-        if (d > 0) ++c[d - 1];
-        else ++b;
-      }
-    }
-    int32_t *dst = out_indices + static_cast<size_t>(oid) * (g.ndim + 1);
-    dst[0] = b;
-    for (int d = lead; d < 4; ++d) dst[1 + d - lead] = c[d];
-    ++oid;
-  }
-}
-
-__device__ __forceinline__ int rank_of(const uint2 *__restrict__ cells, unsigned long long key) {
+// row of a key: occupied cells before its 65536-cell block + before its word inside the block + below it in the word
+__device__ __forceinline__ int rank_of(const uint2 *__restrict__ cells, const int32_t *__restrict__ blockoff,
+                                       unsigned long long key) {
   const uint2 cell = cells[key >> 5];
   const uint32_t bit = 1u << (key & 31);
-  return (cell.x & bit) ? static_cast<int>(cell.y) + __popc(cell.x & (bit - 1u)) : -1;
+  return (cell.x & bit) ? blockoff[key >> 16] + static_cast<int>(cell.y) + __popc(cell.x & (bit - 1u)) : -1;
 }
 
 // both tables, the input-side mask and the pair counts of the Native lists (as conv3_pairs_kernel; the output row
 // of a candidate is its key's rank)
 template <int MJ>
 __global__ void __launch_bounds__(kBlock)
-conv4_pairs_kernel(const int32_t *__restrict__ indices, int n, Geom g, const uint2 *__restrict__ cells, int n_out,
+conv4_pairs_kernel(const int32_t *__restrict__ indices, int n, Geom g, const uint2 *__restrict__ cells,
+                   const int32_t *__restrict__ blockoff, int n_out, int32_t *__restrict__ out_indices,
                    int32_t *__restrict__ pair_fwd, int32_t *__restrict__ pair_bwd,
-                   uint32_t *__restrict__ mask_bwd, int words, int32_t *__restrict__ groupcount) {
+                   uint32_t *__restrict__ mask_bwd, int words, int32_t *__restrict__ groupcount,
+                   int32_t *__restrict__ live_out) {
   __shared__ int lds_cnt[kMaxKv3];
   const int i = blockIdx.x * kBlock + threadIdx.x, kv = g.kv;
+  // static-shape form: the number of live output rows (outputs found, at most the bound) for the layers behind
+  if (live_out && i == 0) live_out[2] = live_out[0] < n_out ? live_out[0] : n_out;
   if (groupcount) {
     if (threadIdx.x < kMaxKv3) lds_cnt[threadIdx.x] = 0;
     __syncthreads();
@@ -1389,26 +1346,34 @@ conv4_pairs_kernel(const int32_t *__restrict__ indices, int n, Geom g, const uin
     CandIter it;
     it.init(g, c, b >= 0 && b < g.batch);
     unsigned long long key[MJ];
+    int qx[MJ][4];
 #pragma unroll
     for (int j = 0; j < MJ; ++j) {
       key[j] = 0;
       if (it.live) {
-        int q[4];
-        kk[j] = it.offset(g, c, q);
-        key[j] = static_cast<unsigned long long>(layout_key(b, q, g.out_dims));
+        kk[j] = it.offset(g, c, qx[j]);
+        key[j] = static_cast<unsigned long long>(layout_key(b, qx[j], g.out_dims));
         it.next();
       }
     }
 #pragma unroll
     for (int j = 0; j < MJ; ++j) {                 // (every map load of the row in flight together)
       if (kk[j] >= 0) {
-        const int r = rank_of(cells, key[j]);
+        const int r = rank_of(cells, blockoff, key[j]);
         oid[j] = r < n_out ? r : -1;               // an output beyond the caller's bound
       }
     }
+    const int lead = 4 - g.ndim;
 #pragma unroll
     for (int j = 0; j < MJ; ++j)
-      if (oid[j] >= 0) pair_fwd[static_cast<size_t>(kk[j]) * n_out + oid[j]] = i;
+      if (oid[j] >= 0) {
+        pair_fwd[static_cast<size_t>(kk[j]) * n_out + oid[j]] = i;
+        // the output's coordinates, by every input that reaches it (the same values: idempotent stores instead of a
+        // pass over the whole map that decodes the set bits)
+        int32_t *dst = out_indices + static_cast<size_t>(oid[j]) * (g.ndim + 1);
+        dst[0] = b;
+        for (int d = lead; d < 4; ++d) dst[1 + d - lead] = qx[j][d];
+      }
   }
   uint32_t mword = 0;
   for (int k = 0; k < kv; ++k) {
@@ -1437,7 +1402,7 @@ conv4_pairs_kernel(const int32_t *__restrict__ indices, int n, Geom g, const uin
 // hash walk; every row is the first (and only) row of its coordinate.
 __global__ void __launch_bounds__(kBlock)
 subm_rank_probe_kernel(const int32_t *__restrict__ indices, int n, Geom g, const uint2 *__restrict__ cells,
-                       int32_t *__restrict__ pair_fwd, int32_t *__restrict__ pair_bwd,
+                       const int32_t *__restrict__ blockoff, int32_t *__restrict__ pair_fwd, int32_t *__restrict__ pair_bwd,
                        uint32_t *__restrict__ mask, int words, int32_t *__restrict__ groupcount, int ngroups,
                        int mask_pass) {
   __shared__ int lds_wave[kBlock / 64];
@@ -1466,7 +1431,7 @@ subm_rank_probe_kernel(const int32_t *__restrict__ indices, int n, Geom g, const
 #pragma unroll
       for (int d = 0; d < 4; ++d) q[d] = c[d] - g.padding[d] + r[d] * g.dilation[d];
       if (in_range(q, g.in_dims)) {
-        v = rank_of(cells, static_cast<unsigned long long>(layout_key(b, q, g.in_dims)));
+        v = rank_of(cells, blockoff, static_cast<unsigned long long>(layout_key(b, q, g.in_dims)));
         if (v >= n) v = -1;                   // (an output the producing layer's bound dropped)
       }
       set(k, o, v);                           // own entry, hit or miss
@@ -2727,8 +2692,16 @@ size_t rank_words(int ndim, int batch_size, const int *shape) {
   return static_cast<size_t>((cells + 31) / 32);
 }
 
+// the caller's rank-map buffer: W {bits, prefix} words, then the occupied cells before each 2048-word block
+size_t rank_cells_bytes(size_t W) { return align_up(W * sizeof(uint2), 256); }
+size_t rank_blocks(size_t W) { return (W + kRankWords - 1) / kRankWords; }
+size_t rank_bytes(size_t W) { return W ? rank_cells_bytes(W) + align_up(rank_blocks(W) * sizeof(int32_t), 256) : 0; }
+int32_t *rank_blockoff(void *rankmap, size_t W) {
+  return reinterpret_cast<int32_t *>(static_cast<char *>(rankmap) + rank_cells_bytes(W));
+}
+
 struct Conv4Ws {
-  int32_t *blockcount, *blockoff, *d_nout, *groupcount;
+  int32_t *blockcount, *d_nout, *groupcount;
   uint8_t *occupied;                   // one byte per cell (32 per word of the rank map), alive between mark and prefix
   int nblk;
   size_t bytes;
@@ -2739,7 +2712,6 @@ Conv4Ws carve_conv4_ws(void *ws, int n_in, int kv, size_t W) {
   Carver cv(ws);
   w.occupied = cv.take<uint8_t>((W > 0 ? W : 1) * 32);
   w.blockcount = cv.take<int32_t>(w.nblk > 0 ? w.nblk : 1);
-  w.blockoff = cv.take<int32_t>(w.nblk > 0 ? w.nblk : 1);
   w.d_nout = cv.take<int32_t>(2);
   w.groupcount = cv.take<int32_t>(static_cast<size_t>(kv) * div_up(n_in > 0 ? n_in : 1, kBlock));
   w.bytes = cv.off;
@@ -2756,7 +2728,7 @@ int conv4_count_impl(const int32_t *indices, int n_in, int ndim, int batch_size,
   const int mj = conv3_cands(ndim, in_shape, ksize, stride, padding, dilation, 0);
   SPX_CHECK(mj > 0, "sorted-order build: this geometry takes the first-seen builder (spx_conv_sorted_ok)");
   const size_t W = rank_words(ndim, batch_size, out_shape);
-  SPX_CHECK(W > 0 && rankmap && rankmap_bytes >= W * sizeof(uint2), "rank map missing or too small (%zu words)", W);
+  SPX_CHECK(W > 0 && rankmap && rankmap_bytes >= rank_bytes(W), "rank map missing or too small (%zu words)", W);
   Conv4Ws w = carve_conv4_ws(ws, n_in, g.kv, W);
   SPX_CHECK(ws && ws_bytes >= w.bytes, "workspace too small");
   if (n_out_h) *n_out_h = 0;
@@ -2775,7 +2747,7 @@ int conv4_count_impl(const int32_t *indices, int n_in, int ndim, int batch_size,
     SPX_CONV3_LAUNCH(conv4_mark_kernel, mj, dim3(div_up(n_in, kBlock)), dim3(kBlock), 0, s, indices, n_in, g, w.occupied);
     hipLaunchKernelGGL(conv4_prefix_kernel, dim3(w.nblk), dim3(kBlock), 0, s,
                        reinterpret_cast<const uint4 *>(w.occupied), cells, static_cast<unsigned>(W), w.blockcount);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kBlock), 0, s, w.blockcount, w.blockoff, w.nblk, w.d_nout);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kBlock), 0, s, w.blockcount, rank_blockoff(rankmap, W), w.nblk, w.d_nout);
     SPX_LAUNCH_CHECK();
   }
   if (!n_out_h) return 0;                // static-shape form: the count stays on the device
@@ -2797,7 +2769,7 @@ int conv4_fill_impl(const int32_t *indices, int n_in, int ndim, int batch_size, 
   const int mj = conv3_cands(ndim, in_shape, ksize, stride, padding, dilation, 0);
   SPX_CHECK(mj > 0, "sorted-order build: this geometry takes the first-seen builder (spx_conv_sorted_ok)");
   const size_t W = rank_words(ndim, batch_size, out_shape);
-  SPX_CHECK(W > 0 && rankmap && rankmap_bytes >= W * sizeof(uint2), "rank map missing or too small (%zu words)", W);
+  SPX_CHECK(W > 0 && rankmap && rankmap_bytes >= rank_bytes(W), "rank map missing or too small (%zu words)", W);
   Conv4Ws w = carve_conv4_ws(ws, n_in, g.kv, W);
   SPX_CHECK(ws && ws_bytes >= w.bytes, "workspace too small");
   SPX_CHECK(pair_fwd && pair_bwd && out_indices, "out_indices, pair_fwd and pair_bwd are required");
@@ -2815,11 +2787,9 @@ int conv4_fill_impl(const int32_t *indices, int n_in, int ndim, int batch_size, 
     SPX_HIP(fills.launch(s));
   }
   if (n_in == 0) return 0;
-  hipLaunchKernelGGL(conv4_emit_kernel, dim3(div_up(static_cast<int>(W), kBlock)), dim3(kBlock), 0, s, cells,
-                     static_cast<unsigned>(W), static_cast<const int32_t *>(w.blockoff), g, out_indices, n_out, nout_dev);
   SPX_CONV3_LAUNCH(conv4_pairs_kernel, mj, dim3(div_up(n_in, kBlock)), dim3(kBlock), 0, s, indices, n_in, g,
-                   static_cast<const uint2 *>(cells), n_out, pair_fwd, pair_bwd, mask_bwd, words,
-                   lists ? w.groupcount : nullptr);
+                   static_cast<const uint2 *>(cells), static_cast<const int32_t *>(rank_blockoff(rankmap, W)), n_out,
+                   out_indices, pair_fwd, pair_bwd, mask_bwd, words, lists ? w.groupcount : nullptr, nout_dev);
   if (mask_fwd && n_out > 0)
     hipLaunchKernelGGL(mask_from_tables_kernel, dim3(div_up(n_out, kBlock)), dim3(kBlock), 0, s, pair_fwd, n_out, mask_fwd,
                        pair_bwd, 0, mask_bwd, kv, words);
@@ -2835,7 +2805,7 @@ int conv4_fill_impl(const int32_t *indices, int n_in, int ndim, int batch_size, 
 extern "C" {
 
 size_t spx_rankmap_bytes(int ndim, int batch_size, const int *shape) {
-  return spx::rank_words(ndim, batch_size, shape) * sizeof(uint2);
+  return spx::rank_bytes(spx::rank_words(ndim, batch_size, shape));
 }
 
 int spx_conv_sorted_ok(int ndim, int batch_size, const int *in_shape, const int *out_shape, const int *ksize,
@@ -2923,7 +2893,7 @@ int spx_subm_rulebook_ranked(const int32_t *indices, int n, int ndim, int batch_
   const int nblk256 = div_up(n, kBlock);
   SPX_CHECK(kv > 1 && kv <= 128 && nblk256 <= 16384, "ranked SubM build: 1 < kernel volume <= 128, <= 4 M rows");
   const size_t W = rank_words(ndim, batch_size, spatial_shape);
-  SPX_CHECK(W > 0 && rankmap && rankmap_bytes >= W * sizeof(uint2), "rank map missing or too small (%zu words)", W);
+  SPX_CHECK(W > 0 && rankmap && rankmap_bytes >= rank_bytes(W), "rank map missing or too small (%zu words)", W);
   SPX_CHECK(ws && ws_bytes >= spx_subm_rulebook_ranked_ws_bytes(n, kv), "workspace too small");
   const Geom g = make_geom(ndim, batch_size, spatial_shape, spatial_shape, ksize, stride, padding, dilation);
   const int words = div_up(kv, 32);
@@ -2947,7 +2917,8 @@ int spx_subm_rulebook_ranked(const int32_t *indices, int n, int ndim, int batch_
   }
   const bool lists = pair_native || num_per_loc;
   hipLaunchKernelGGL(subm_rank_probe_kernel, dim3(nblk256, kv / 2 + 1), dim3(kBlock), 0, s, indices, n, g,
-                     static_cast<const uint2 *>(rankmap), pair_fwd, pair_bwd, mask, words,
+                     static_cast<const uint2 *>(rankmap),
+                     static_cast<const int32_t *>(rank_blockoff(const_cast<void *>(rankmap), W)), pair_fwd, pair_bwd, mask, words,
                      lists ? groupcount : nullptr, nblk256, mask_pass);
   if (mask_pass)
     hipLaunchKernelGGL(mask_from_table_kernel, dim3(nblk256), dim3(kBlock), 0, s, pair_fwd, kv, n, words, mask);

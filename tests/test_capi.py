@@ -83,9 +83,11 @@ def test_workspace_size_queries(lib):
 def test_sorted_order_host_queries(lib):
     """Rank-map sizing and the geometries that take the sorted-order builder (host-only entry points)."""
     I = _lib.ints
-    # one {bits, prefix} pair (8 bytes) per 32 cells of batch x grid
-    assert lib.spx_rankmap_bytes(3, 4, I([21, 800, 704])) == (4 * 21 * 800 * 704 + 31) // 32 * 8
-    assert lib.spx_rankmap_bytes(2, 1, I([5, 7])) == 2 * 8
+    # one {bits, prefix} pair (8 bytes) per 32 cells of batch x grid + one count per 2048 words, both 256-byte aligned
+    al = lambda b: (b + 255) // 256 * 256
+    W = (4 * 21 * 800 * 704 + 31) // 32
+    assert lib.spx_rankmap_bytes(3, 4, I([21, 800, 704])) == al(W * 8) + al((W + 2047) // 2048 * 4)
+    assert lib.spx_rankmap_bytes(2, 1, I([5, 7])) == al(2 * 8) + al(4)
     assert lib.spx_rankmap_bytes(3, 200, I([21, 800, 704])) == 0          # key space beyond 2^31 cells: hash builder
     assert lib.spx_rankmap_bytes(3, 0, I([8, 8, 8])) == 0 and lib.spx_rankmap_bytes(3, 1, I([8, 0, 8])) == 0
     ok = lambda shape, k, s, p, tr=0, bs=2: lib.spx_conv_sorted_ok(
