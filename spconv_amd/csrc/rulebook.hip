@@ -1457,6 +1457,92 @@ subm_rank_probe_kernel(const int32_t *__restrict__ indices, int n, Geom g, const
   }
 }
 
+// SubM build over a rank map, ROW-OWNED: one thread per row looks up ALL its neighbours itself (a lookup is one 8-byte
+// load, and in key order the three x-offsets of a (dz, dy) pair share a word) and writes its whole column of the
+// table(s) and its mask word -- no mirror scatter, no atomicOr, no -1 pre-fill, one launch.  Same tables, masks and
+// list counts as subm_rank_probe_kernel / subm_probe4_kernel (tests/test_gpu_sorted.py: torch.equal to the hash build).
+constexpr int kRowsChunk = 9;
+__global__ void __launch_bounds__(kBlock)
+subm_rank_rows_kernel(const int32_t *__restrict__ indices, int n, Geom g, const uint2 *__restrict__ cells,
+                      const int32_t *__restrict__ blockoff, int32_t *__restrict__ pair_fwd,
+                      int32_t *__restrict__ pair_bwd, uint32_t *__restrict__ mask, int words,
+                      int32_t *__restrict__ groupcount, int ngroups) {
+  // [kv] coordinate steps | [kv] key steps | [kv] hits of the block per offset
+  extern __shared__ __attribute__((aligned(16))) int4 lds_delta[];
+  const int kv = g.kv, center = kv / 2;
+  hkey_t *lds_dkey = reinterpret_cast<hkey_t *>(lds_delta + kv);
+  int *lds_cnt = reinterpret_cast<int *>(lds_dkey + kv);
+  for (int k = threadIdx.x; k < kv; k += kBlock) {
+    int r[4], dq[4];
+    decode_offset(k, g.ksize, r);
+    hkey_t dk = 0;                                         // the key is linear in the coordinates
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      dq[d] = r[d] * g.dilation[d] - g.padding[d];
+      dk = dk * g.in_dims[d] + dq[d];
+    }
+    lds_delta[k] = make_int4(dq[0], dq[1], dq[2], dq[3]);
+    lds_dkey[k] = dk;
+    lds_cnt[k] = 0;
+  }
+  const int o = blockIdx.x * kBlock + threadIdx.x;
+  int b = -1, c[4] = {0, 0, 0, 0};
+  bool valid = false;
+  if (o < n) {
+    read_row(indices, o, g.ndim, b, c);
+    valid = b >= 0 && b < g.batch && in_range(c, g.in_dims);
+  }
+  __syncthreads();
+  const hkey_t key0 = layout_key(b, c, g.in_dims);
+  uint32_t mword = 0;
+  for (int k0 = 0; k0 < kv; k0 += kRowsChunk) {
+    uint2 cell[kRowsChunk];
+    hkey_t key[kRowsChunk];
+    bool act[kRowsChunk];
+#pragma unroll
+    for (int j = 0; j < kRowsChunk; ++j) {                 // the chunk's loads in one straight-line batch
+      const int k = k0 + j < kv ? k0 + j : kv - 1;
+      const int4 dq = lds_delta[k];
+      const int q[4] = {c[0] + dq.x, c[1] + dq.y, c[2] + dq.z, c[3] + dq.w};
+      key[j] = key0 + lds_dkey[k];
+      act[j] = valid && k0 + j < kv && k != center && in_range(q, g.in_dims);
+      cell[j] = cells[act[j] ? static_cast<unsigned long long>(key[j]) >> 5 : 0ull];
+    }
+#pragma unroll
+    for (int j = 0; j < kRowsChunk; ++j) {
+      const int k = k0 + j;
+      const bool live = k < kv;                            // (uniform; no break: the loop must unroll -- cell[] in registers)
+      int v = -1;
+      if (act[j]) {
+        const uint32_t bit = 1u << (static_cast<unsigned long long>(key[j]) & 31);
+        if (cell[j].x & bit)
+          v = blockoff[static_cast<unsigned long long>(key[j]) >> 16] + static_cast<int>(cell[j].y) +
+              __popc(cell[j].x & (bit - 1u));
+        if (v >= n) v = -1;                                // (an output the producing layer's bound dropped)
+      }
+      if (k == center && o < n) v = o;                     // (dead rows of a static level too: as the other forms)
+      if (live && o < n) {
+        pair_fwd[static_cast<size_t>(k) * n + o] = v;
+        if (pair_bwd) pair_bwd[static_cast<size_t>(kv - 1 - k) * n + o] = v;
+      }
+      if (live && v >= 0) mword |= 1u << (k & 31);
+      if (live && o < n && ((k & 31) == 31 || k == kv - 1)) {
+        mask[static_cast<size_t>(o) * words + (k >> 5)] = mword;
+        mword = 0;
+      }
+      if (groupcount && live && k > center) {              // list kv - 1 - k: the pairs found through offset k
+        const unsigned long long bal = __ballot(v >= 0);
+        if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&lds_cnt[k], __popcll(bal));
+      }
+    }
+  }
+  if (groupcount) {
+    __syncthreads();
+    for (int l = threadIdx.x; l < center; l += kBlock)
+      groupcount[static_cast<size_t>(l) * ngroups + blockIdx.x] = lds_cnt[kv - 1 - l];
+  }
+}
+
 // mask[row][w] bit k = (table[k][row] >= 0)  (indices.py:652-676)
 __global__ void __launch_bounds__(kBlock)
 mask_from_table_kernel(const int32_t *__restrict__ table, int kv, int n, int words,
@@ -2900,6 +2986,27 @@ int spx_subm_rulebook_ranked(const int32_t *indices, int n, int ndim, int batch_
   Carver cv(ws);
   int32_t *scratch_totals = cv.take<int32_t>(64);
   int32_t *groupcount = cv.take<int32_t>(static_cast<size_t>(kv / 2 + 1) * nblk256);
+  const bool lists = pair_native || num_per_loc;
+  // row-owned form from ~200 k rows (28 vs 35-37 us at 313-326 k rows); below, one thread per row is too few threads to
+  // hide its lookups (19 vs 14 us at 77 k) and the probe form stays.  SPX_SUBM_RANK_ROWS = 1 / 0 forces / forbids.
+  const int rows_opt = option_int("SPX_SUBM_RANK_ROWS", -1);
+  if (rows_opt > 0 || (rows_opt < 0 && n >= 196608)) {
+    // every entry of the tables and the masks is written by its row's thread -- no fill launch
+    const size_t lds = static_cast<size_t>(kv) * (sizeof(int4) + sizeof(hkey_t) + sizeof(int));
+    hipLaunchKernelGGL(subm_rank_rows_kernel, dim3(nblk256), dim3(kBlock), lds, s, indices, n, g,
+                       static_cast<const uint2 *>(rankmap),
+                       static_cast<const int32_t *>(rank_blockoff(const_cast<void *>(rankmap), W)), pair_fwd, pair_bwd,
+                       mask, words, lists ? groupcount : nullptr, nblk256);
+    if (lists) {
+      SPX_CHECK(!pair_native || num_per_loc || kv / 2 <= 64, "num_per_loc required for kv > 128");
+      hipLaunchKernelGGL(subm_lists_kernel, dim3(div_up(n, kItems), kv / 2 + 1), dim3(kBlock), 0, s, pair_fwd, kv, n,
+                         nblk256, groupcount, pair_native, num_per_loc ? num_per_loc : scratch_totals,
+                         num_per_loc ? kv : 0);
+    }
+    SPX_LAUNCH_CHECK();
+    return 0;
+  }
+  // probe form (SPX_SUBM_RANK_ROWS = 0, for A/B runs): thread per (row, upper offset), mirror entries scattered.
   // masks by atomicOr, at every size: rows in key order keep a wave's mask words in a few lines (measured 34.5 vs 45.0 us
   // with the table pass at 313 k rows, 36.9 vs 48.0 at 326 k; the hash build of shuffled rows switches at 250 k)
   const int mp_opt = option_int("SPX_SUBM_MASK_PASS", -1);
@@ -2915,7 +3022,6 @@ int spx_subm_rulebook_ranked(const int32_t *indices, int n, int ndim, int batch_
     if (!mask_pass) fills.add(mask, sizeof(uint32_t) * static_cast<size_t>(n) * words, 0u);
     SPX_HIP(fills.launch(s));
   }
-  const bool lists = pair_native || num_per_loc;
   hipLaunchKernelGGL(subm_rank_probe_kernel, dim3(nblk256, kv / 2 + 1), dim3(kBlock), 0, s, indices, n, g,
                      static_cast<const uint2 *>(rankmap),
                      static_cast<const int32_t *>(rank_blockoff(const_cast<void *>(rankmap), W)), pair_fwd, pair_bwd, mask, words,

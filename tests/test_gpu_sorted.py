@@ -111,14 +111,21 @@ def test_subm_over_the_rank_map_equals_the_hash_build(cuda, n_in, need_bwd):
     assert getattr(ind, "_spx_rankmap", None) is not None
     plain = ind.clone()                                   # the same rows without the map: the hash build
     kw = dict(need_bwd_table=need_bwd)
-    a = ops.build_rulebook(ind, bs, out_shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True, **kw)[0]
     b = ops.build_rulebook(plain, bs, out_shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True, **kw)[0]
-    torch.cuda.synchronize()
-    for name in ("pair_fwd", "pair_bwd", "mask_fwd", "num_per_loc", "pair_native"):
-        x, y = getattr(a, name), getattr(b, name)
-        assert (x is None) == (y is None), name
-        if x is not None:
-            assert torch.equal(x, y), name
+    from spconv_amd import _lib
+    L = _lib.load()
+    try:
+        for form in (1, 0, -1):       # row-owned kernel, probe kernel (mirror entries scattered), the size rule
+            L.spx_set_option(b"SPX_SUBM_RANK_ROWS", form)
+            a = ops.build_rulebook(ind, bs, out_shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True, **kw)[0]
+            torch.cuda.synchronize()
+            for name in ("pair_fwd", "pair_bwd", "mask_fwd", "num_per_loc", "pair_native"):
+                x, y = getattr(a, name), getattr(b, name)
+                assert (x is None) == (y is None), name
+                if x is not None:
+                    assert torch.equal(x, y), (name, form)
+    finally:
+        L.spx_set_option(b"SPX_SUBM_RANK_ROWS", -1)
     # dilated SubM over the same map
     a = ops.build_rulebook(ind, bs, out_shape, [3] * 3, [1] * 3, [2] * 3, [2] * 3, [0] * 3, True)[0]
     b = ops.build_rulebook(plain, bs, out_shape, [3] * 3, [1] * 3, [2] * 3, [2] * 3, [0] * 3, True)[0]
