@@ -24,6 +24,10 @@ SORTED_CASES = [
     ([41, 64, 64], 6000, 2, [3, 3, 3], [2, 2, 2], [0, 1, 1], [1, 1, 1]),
     ([60, 50], 900, 2, [3, 3], [2, 2], [1, 1], [1, 1]),                         # 2-d
     ([41, 400, 352], 60000, 4, [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1]),    # several prefix blocks (24 M cells)
+    ([19, 18, 17], 1500, 2, [3, 3, 1], [2, 2, 1], [1, 1, 0], [1, 1, 1]),       # a kernel that is flat along x
+    ([19, 18, 17], 1500, 2, [3, 3, 3], [2, 2, 2], [0, 0, 0], [1, 1, 1]),       # no padding
+    ([7, 6, 9, 8], 700, 2, [2, 2, 2, 2], [2, 2, 2, 2], [0] * 4, [1] * 4),      # 4-d
+    ([9000], 1200, 3, [2], [2], [0], [1]),                                     # 1-d (k3 s2 has 2 of 3 offsets: hash builder)
 ]
 
 
@@ -75,6 +79,21 @@ def test_sorted_build_is_the_first_seen_build_renumbered(cuda, shape, n, bs, ksi
     rs, out_shape_s = gpu_rulebook(idx, bs, shape, ksize, stride, pad, dil, False, out_order="sorted")
     assert list(out_shape) == list(out_shape_s) and rs.rankmap is not None
     _check_renumbered(rs, rf, out_shape)
+
+
+def test_sorted_build_skips_deleted_rows(cuda):
+    """Rows with a batch index outside [0, batch) ("deleted" points, docs/USAGE.md:150) create no output and no pair, as
+    in the first-seen build."""
+    shape, bs = [19, 18, 17], 2
+    idx = scene(shape, 1500, bs, seed=13).copy()
+    idx[::7, 0] = -1
+    idx[3::11, 0] = bs
+    args = ([3] * 3, [2] * 3, [1] * 3, [1] * 3)
+    rf, out_shape = gpu_rulebook(idx, bs, shape, *args, False)
+    rs, _ = gpu_rulebook(idx, bs, shape, *args, False, out_order="sorted")
+    _check_renumbered(rs, rf, out_shape)
+    dead = np.nonzero((idx[:, 0] < 0) | (idx[:, 0] >= bs))[0]
+    assert np.all(to_np(rs.pair_bwd)[:, dead] == -1)
 
 
 def test_sorted_build_with_an_output_bound_keeps_the_smallest_keys(cuda):
