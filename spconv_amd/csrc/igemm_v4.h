@@ -113,6 +113,97 @@ __device__ __forceinline__ void unpack_gemm_args(GemmParams &p, const void *argA
   }
 }
 
+// int8 inference epilogue of a tile whose accumulators lie in acc[nb][mb] (shared by igemm_v4_body and the streaming
+// main tiles of igemm_i8_sparse_kernel): lds_sb = [2][COUT] fp32 per-channel scale | bias
+template <int COUT, int MB>
+__device__ __forceinline__ void i8_epilogue(const GemmParams &p, i32x4 (&acc)[COUT / 16][MB], const int (&grow)[MB],
+                                            int lgrp, const float *lds_sb) {
+  constexpr int NB = COUT / 16, CPL = NB * 4;
+  // int8 inference epilogue (reference numerics: test/test_all_algo.py:272-287):
+  //   v = acc_i32 * scale[k] + bias[k] + add[o][k] * add_scale;  v = act(v)
+  //   int8 out: clip(round_half_even(v), -128, 127);  f16 / f32 out: v
+  const int oes = p.out_dtype == SPX_I8 ? 1 : (p.out_dtype == SPX_F32 ? 4 : 2);
+  const __amdgpu_buffer_rsrc_t rO =
+      make_rsrc(p.out, static_cast<uint32_t>(p.n_dst) * static_cast<uint32_t>(COUT * oes));
+  const __amdgpu_buffer_rsrc_t rAdd =
+      make_rsrc(p.add, p.add ? static_cast<uint32_t>(p.n_dst) * COUT : 0u);
+  uint32_t rowoff[MB];
+  uint32_t addw[MB][CPL / 4];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    rowoff[mb] = grow[mb] < 0 ? kOob : static_cast<uint32_t>(grow[mb]) * COUT + lgrp * CPL;
+    load_dwords<CPL / 4>(addw[mb], rAdd, rowoff[mb]);   // zeros when there is no residual input
+  }
+  // four channels (one output dword of an int8 row) at a time keeps the live set small
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const float4 sc4 = *reinterpret_cast<const float4 *>(lds_sb + lgrp * CPL + nb * 4);
+    const float4 bv4 = *reinterpret_cast<const float4 *>(lds_sb + COUT + lgrp * CPL + nb * 4);
+    const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, bv[4] = {bv4.x, bv4.y, bv4.z, bv4.w};
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      // (uniform conditions hoisted out of the per-value work: at 64 values per lane the epilogue of a
+      // tile was ~5.5 us of vector ALU time, more than an identity-only tile's loads and MFMAs)
+      float v[4];
+#pragma unroll
+      // every product and sum rounded on its own: the reference formula is numpy arithmetic,
+      // ((acc * scale) + bias) + (add * add_scale), and a fused multiply-add lands on the other side of a
+      // rounding tie for ~4 values in 10 million.  (HIP's __fmul_rn is a plain `*` that the compiler is
+      // free to contract; the empty asm pins the rounded product in a register.)
+      for (int e = 0; e < 4; ++e) {
+        float prod = static_cast<float>(acc[nb][mb][e]) * sc[e];
+        asm volatile("" : "+v"(prod));
+        v[e] = prod + bv[e];
+      }
+      if (p.add) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int a8 = static_cast<int>(static_cast<int8_t>((addw[mb][nb] >> (e * 8)) & 0xff));
+          float prod = static_cast<float>(a8) * p.add_scale;
+          asm volatile("" : "+v"(prod));
+          v[e] += prod;
+        }
+      }
+      if (p.act == SPX_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      } else if (p.act != SPX_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act, p.act_alpha);
+      }
+      if (p.out_dtype == SPX_I8) {
+        // round half to even, clamp, and pack the four low bytes: two v_cvt_pk_i16_i32 + one v_perm_b32
+        int q[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          q[e] = static_cast<int>(__builtin_amdgcn_fmed3f(__builtin_rintf(v[e]), -128.f, 127.f));
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        const uint32_t p01 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(q[0], q[1]));
+        const uint32_t p23 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(q[2], q[3]));
+        const uint32_t word = __builtin_amdgcn_perm(p23, p01, 0x06040200u);
+        addw[mb][nb] = word;                            // reuse: the residual word is consumed
+      } else if (p.out_dtype == SPX_F32) {
+        uint32_t d[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = __builtin_bit_cast(uint32_t, v[e]);
+        store_dwords<4, SPX_AUX_OUT>(d, rO, rowoff[mb] == kOob ? kOob : (rowoff[mb] + nb * 4) * 4u);
+      } else {
+        uint32_t d[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          d[q] = p.out_dtype == SPX_BF16 ? pack2<true>(v[2 * q], v[2 * q + 1])
+                                         : pack2<false>(v[2 * q], v[2 * q + 1]);
+        store_dwords<2, SPX_AUX_OUT>(d, rO, rowoff[mb] == kOob ? kOob : (rowoff[mb] + nb * 4) * 2u);
+      }
+    }
+  }
+  if (p.out_dtype == SPX_I8) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) store_dwords<CPL / 4, SPX_AUX_OUT>(addw[mb], rO, rowoff[mb]);
+  }
+
+}
+
 template <int COUT, int MB, int DT, bool BT, int NKS>
 __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   constexpr bool BF16 = DT == 1, I8 = DT == 2, F32 = DT == 3;
@@ -596,88 +687,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
       else store_dwords<(F32 ? CPL : CPL / 2), 2>(d, rO, vo);
     }
   } else {
-    // int8 inference epilogue (reference numerics: test/test_all_algo.py:272-287):
-    //   v = acc_i32 * scale[k] + bias[k] + add[o][k] * add_scale;  v = act(v)
-    //   int8 out: clip(round_half_even(v), -128, 127);  f16 / f32 out: v
-    const int oes = p.out_dtype == SPX_I8 ? 1 : (p.out_dtype == SPX_F32 ? 4 : 2);
-    const __amdgpu_buffer_rsrc_t rO =
-        make_rsrc(p.out, static_cast<uint32_t>(p.n_dst) * static_cast<uint32_t>(COUT * oes));
-    const __amdgpu_buffer_rsrc_t rAdd =
-        make_rsrc(p.add, p.add ? static_cast<uint32_t>(p.n_dst) * COUT : 0u);
-    uint32_t rowoff[MB];
-    uint32_t addw[MB][CPL / 4];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      rowoff[mb] = grow[mb] < 0 ? kOob : static_cast<uint32_t>(grow[mb]) * COUT + lgrp * CPL;
-      load_dwords<CPL / 4>(addw[mb], rAdd, rowoff[mb]);   // zeros when there is no residual input
-    }
-    // four channels (one output dword of an int8 row) at a time keeps the live set small
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const float4 sc4 = *reinterpret_cast<const float4 *>(lds_sb + lgrp * CPL + nb * 4);
-      const float4 bv4 = *reinterpret_cast<const float4 *>(lds_sb + COUT + lgrp * CPL + nb * 4);
-      const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, bv[4] = {bv4.x, bv4.y, bv4.z, bv4.w};
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        // (uniform conditions hoisted out of the per-value work: at 64 values per lane the epilogue of a
-        // tile was ~5.5 us of vector ALU time, more than an identity-only tile's loads and MFMAs)
-        float v[4];
-#pragma unroll
-        // every product and sum rounded on its own: the reference formula is numpy arithmetic,
-        // ((acc * scale) + bias) + (add * add_scale), and a fused multiply-add lands on the other side of a
-        // rounding tie for ~4 values in 10 million.  (HIP's __fmul_rn is a plain `*` that the compiler is
-        // free to contract; the empty asm pins the rounded product in a register.)
-        for (int e = 0; e < 4; ++e) {
-          float prod = static_cast<float>(acc[nb][mb][e]) * sc[e];
-          asm volatile("" : "+v"(prod));
-          v[e] = prod + bv[e];
-        }
-        if (p.add) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int a8 = static_cast<int>(static_cast<int8_t>((addw[mb][nb] >> (e * 8)) & 0xff));
-            float prod = static_cast<float>(a8) * p.add_scale;
-            asm volatile("" : "+v"(prod));
-            v[e] += prod;
-          }
-        }
-        if (p.act == SPX_ACT_RELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-        } else if (p.act != SPX_ACT_NONE) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act, p.act_alpha);
-        }
-        if (p.out_dtype == SPX_I8) {
-          // round half to even, clamp, and pack the four low bytes: two v_cvt_pk_i16_i32 + one v_perm_b32
-          int q[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            q[e] = static_cast<int>(__builtin_amdgcn_fmed3f(__builtin_rintf(v[e]), -128.f, 127.f));
-          typedef short s16x2 __attribute__((ext_vector_type(2)));
-          const uint32_t p01 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(q[0], q[1]));
-          const uint32_t p23 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(q[2], q[3]));
-          const uint32_t word = __builtin_amdgcn_perm(p23, p01, 0x06040200u);
-          addw[mb][nb] = word;                            // reuse: the residual word is consumed
-        } else if (p.out_dtype == SPX_F32) {
-          uint32_t d[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) d[e] = __builtin_bit_cast(uint32_t, v[e]);
-          store_dwords<4, SPX_AUX_OUT>(d, rO, rowoff[mb] == kOob ? kOob : (rowoff[mb] + nb * 4) * 4u);
-        } else {
-          uint32_t d[2];
-#pragma unroll
-          for (int q = 0; q < 2; ++q)
-            d[q] = p.out_dtype == SPX_BF16 ? pack2<true>(v[2 * q], v[2 * q + 1])
-                                           : pack2<false>(v[2 * q], v[2 * q + 1]);
-          store_dwords<2, SPX_AUX_OUT>(d, rO, rowoff[mb] == kOob ? kOob : (rowoff[mb] + nb * 4) * 2u);
-        }
-      }
-    }
-    if (p.out_dtype == SPX_I8) {
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) store_dwords<CPL / 4, SPX_AUX_OUT>(addw[mb], rO, rowoff[mb]);
-    }
+    i8_epilogue<COUT, MB>(p, acc, grow, lgrp, lds_sb);
   }
   SPX_STAMP(6);   // stores issued
 #ifdef SPX_TIMELINE
@@ -760,6 +770,148 @@ inline GemmRest rest_of(const GemmParams &p) {
   r.acc_mode = p.acc_mode;
   r.napp = -1;
   return r;
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// int8, SPARSE class (rows layout, class word 1): appendix tiles and STREAMING main tiles in one launch.
+// A main tile of a sparse rulebook is one step -- the centre pair: rows in their own order, no pair word -- and as a
+// workgroup of igemm_v4_kernel it pays for that step with a 16 KB weight slice through global -> registers -> LDS, a
+// barrier and a dispatch slot (3 125 tiles at BASELINE config 5: 51 MB of weight traffic for 51 MB of rows).  Here the
+// main tiles are a LOOP: a workgroup stages the centre slice once and streams 64-row tiles behind it (next tile's rows
+// and mask words in flight during the MFMAs and the quantised epilogue of the current one); the appendix tiles lead
+// the grid and run igemm_v4_body unchanged.  Same integer arithmetic, same epilogue function: bit-identical.  The class
+// word is read on the DEVICE as well: a dense rulebook behind a stale hint takes igemm_v4_body tile by tile.
+template <int COUT>
+__device__ __forceinline__ void i8_centre_stream(const GemmParams &p, int first, int stride) {
+  constexpr int NB = COUT / 16, CPL = NB * 4, B_BYTES = COUT * kRowBytes, TM = 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *lds_sb = reinterpret_cast<float *>(smem + 2 * B_BYTES + 64);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 15, lgrp = lane >> 4;
+  const int slot = tid & 7, r0 = tid >> 3;
+  auto swzB = [](int row, int sl) __attribute__((always_inline)) {
+    const int x = ((row >> 1) & 1) | (((row / CPL) & 3) << 1);
+    return row * kRowBytes + ((sl ^ x) << 4);
+  };
+  const uint32_t rowB = static_cast<uint32_t>(p.CIN);               // bytes of a row (int8)
+  {
+    // the centre slice -> stage 0 (pieces past the row's end: out of range -> zeros, as in igemm_v4_body)
+    const uint32_t w_bytes = static_cast<uint32_t>(p.COUT) * p.kv * rowB;
+    const __amdgpu_buffer_rsrc_t rW = make_rsrc(p.B, w_bytes);
+    const uint32_t so = static_cast<uint32_t>(p.identity_k) * static_cast<uint32_t>(p.strideK);
+#pragma unroll
+    for (int j = 0; j < (COUT + 31) / 32; ++j) {
+      const int n = r0 + 32 * j;
+      if (n < COUT) {
+        const uint32_t o = static_cast<uint32_t>(n) * static_cast<uint32_t>(p.strideN) + slot * 16u;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rW, slot * 16u < rowB ? o : kOob, so, 0);
+        *reinterpret_cast<u32x4 *>(smem + swzB(n, slot)) = v;
+      }
+    }
+    const float *bias_f = static_cast<const float *>(p.bias);
+    for (int c = tid; c < 2 * COUT; c += kThreads)
+      lds_sb[c] = c < COUT ? (p.scale ? p.scale[c] : 1.f) : (bias_f ? bias_f[c - COUT] : 0.f);
+  }
+  __syncthreads();
+  const int ntiles = (p.n_dst + TM - 1) / TM;
+  const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A, static_cast<uint32_t>(p.n_src) * rowB);
+  const __amdgpu_buffer_rsrc_t rM = make_rsrc(p.mask, static_cast<uint32_t>(p.n_dst) * 4u);
+  const int nks = rowB > 64u ? 2 : 1;
+  uint32_t aoff[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const uint32_t c = static_cast<uint32_t>(ks * 64 + lgrp * 16);
+    aoff[ks] = c < rowB ? c : kOob;
+  }
+  auto load_tile = [&](int t, u32x4 (&a)[2], uint32_t &m, int &row) __attribute__((always_inline)) {
+    row = t * TM + wave * 16 + lrow;
+    const bool ok = t < ntiles && row < p.n_dst;
+    m = __builtin_amdgcn_raw_buffer_load_b32(rM, ok ? static_cast<uint32_t>(row) * 4u : kOob, 0, SPX_AUX_TABLE);
+    const uint32_t base = ok ? static_cast<uint32_t>(row) * rowB : kOob;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      a[ks] = __builtin_amdgcn_raw_buffer_load_b128(rA, min(base + aoff[ks], kOob) | (aoff[ks] & kOob), 0, 0);
+  };
+  u32x4 a_cur[2], a_nxt[2];
+  uint32_t m_cur, m_nxt;
+  int row_cur, row_nxt;
+  int t = first;
+  load_tile(t, a_cur, m_cur, row_cur);
+  while (t < ntiles) {
+    const int tn = t + stride;
+    load_tile(tn, a_nxt, m_nxt, row_nxt);                 // (past the end: nothing is fetched)
+    i32x4 acc[NB][1];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb][0] = i32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (ks < nks) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const uint4 fa = *reinterpret_cast<const uint4 *>(
+              smem + swzB((lrow >> 2) * CPL + nb * 4 + (lrow & 3), ks * 4 + lgrp));
+          acc[nb][0] = mfma_step<2>(fa, __builtin_bit_cast(uint4, a_cur[ks]), acc[nb][0]);
+        }
+      }
+    }
+    // a zero mask word: the row lives in the appendix (its result is not this tile's to store); rows past the end
+    const int grow[1] = {(row_cur < p.n_dst && m_cur != 0u) ? row_cur : -1};
+    i8_epilogue<COUT, 1>(p, acc, grow, lgrp, lds_sb);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) a_cur[ks] = a_nxt[ks];
+    m_cur = m_nxt;
+    row_cur = row_nxt;
+    t = tn;
+  }
+}
+
+template <int COUT>
+__global__ void __launch_bounds__(kThreads, 4)
+igemm_i8_sparse_kernel(const void *argA, const void *argB, const uint32_t *arg_mask,
+                       const int32_t *arg_argsort, const int32_t *arg_pair, int n_dst, int n_src, int CIN,
+                       int kv, int identity_k, int b_reverse, GemmRest rest) {
+  GemmParams p;
+  unpack_gemm_args(p, argA, argB, arg_mask, arg_argsort, arg_pair, n_dst, n_src, CIN, kv, identity_k, b_reverse, rest);
+  const int napp = p.app_rows;                             // appendix workgroups at the head of the grid (the launcher's)
+  const int block = static_cast<int>(blockIdx.x), nmain = static_cast<int>(gridDim.x) - napp;
+  if (block < napp) {
+    igemm_v4_body<COUT, 1, 2, false, 2>(p, block);
+    return;
+  }
+  typedef const int32_t __attribute__((address_space(4))) *cptr_t;
+  if (*(cptr_t)(p.cls) == 1) {
+    i8_centre_stream<COUT>(p, block - napp, nmain);
+  } else {
+    const int ntiles = (n_dst + 63) / 64;                  // a dense rulebook (the hint was wrong): the general body
+    for (int b = block; b < napp + ntiles; b += nmain) {
+      igemm_v4_body<COUT, 1, 2, false, 2>(p, b);
+      __syncthreads();                                     // (the stages are reused by the next tile)
+    }
+  }
+}
+
+template <int COUT>
+int launch_i8_sparse(const GemmParams &p, hipStream_t s) {
+  const int ntiles = div_up(p.n_dst, 64);
+  const int napp = p.app_rows > 0 ? div_up(p.app_rows, 64) : layout_app_tiles(p.n_dst, 64);
+  const int resident = (COUT == 128 ? 4 : 5) * 256;        // workgroups the chip holds at once (113 / 83 registers per lane)
+  const int want = option_int("SPX_I8_NMAIN", 0);           // (A/B runs)
+  int nmain = want > 0 ? want : (resident - napp > 256 ? resident - napp : 256);
+  if (nmain > ntiles) nmain = ntiles;
+  GemmParams q = p;
+  q.lpt = false;
+  GemmRest r = rest_of(p);
+  r.napp = napp;
+  hipLaunchKernelGGL((igemm_i8_sparse_kernel<COUT>), dim3(napp + nmain), dim3(kThreads), (v4_smem_bytes<COUT, 1, 2>()), s,
+                     p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst, p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(q), r);
+  SPX_LAUNCH_CHECK();
+  return 0;
+}
+
+// shapes the streaming form is instantiated for (igemm_i8.hip)
+inline bool i8_sparse_ok(const GemmParams &p) {
+  return p.cls && p.identity_k >= 0 && p.identity_k < p.kv && (p.COUT == 64 || p.COUT == 128) && p.CIN <= 128 &&
+         p.kbase == 0 && p.mask_words <= 1 && !p.acc_mode && p.strideD == 1;
 }
 
 template <bool BF16>
