@@ -981,7 +981,8 @@ def run_int8(args, D: Dist):
     t_cold = event_time_ms(fwd, span=0 if args.no_graph else max(S, 8))
     t_warm = event_time_ms(lambda i: fwd(0), span=0 if args.no_graph else 8)
     ab = algorithmic_bytes(n, n, C, K, 27, 1)["fwd"]
-    r = roofline_obj("fwd", ab, t_cold, f"igemm_v4_kernel<{K},1,int8,fwd> (v_mfma_i32_16x16x64_i8)",
+    r = roofline_obj("fwd", ab, t_cold, f"igemm_i8_sparse_kernel<{K}> (appendix tiles + streaming main tiles; v_mfma_i32_16x16x64_i8)"
+                     if K in (64, 128) and C <= 128 else f"igemm_v4_kernel<{K},1,int8,fwd> (v_mfma_i32_16x16x64_i8)",
                      pmc_traffic(f"uniform-i8-c{C}-n{voxels}", "fwd"),
                      {"memory_level": f"HBM: {S} scenes rotated" if S >= 4 else "Infinity Cache (single scene)"})
     res = {"metric": "active-voxels/sec forward, int8 3x3x3 SubMConv3d C=128 (BASELINE config 5)",

@@ -36,7 +36,7 @@ def main():
     groups = {"fwd": [], "bwd": []}
     for name in set(fetch) | set(write):
         b = fetch.get(name, 0.0) * 1024 * 2 + write.get(name, 0.0) * 1024
-        m = re.search(r"(igemm_v4_kernel|igemm_ws_kernel|igemm_bwd_kernel|wgrad_reduce2_kernel)<([^>]*)>", name)
+        m = re.search(r"(igemm_v4_kernel|igemm_ws_kernel|igemm_i8_sparse_kernel|igemm_bwd_kernel|wgrad_reduce2_kernel)<([^>]*)>", name)
         if not m:
             continue
         short = f"{m.group(1)}<{m.group(2)}>"
@@ -44,6 +44,8 @@ def main():
         if m.group(1) == "igemm_v4_kernel" and len(targs) > 3 and targs[3] == "false":
             groups["fwd"].append((short, b))
         elif m.group(1) == "igemm_ws_kernel" and targs[-1] == "false":      # <NW, G, D, BF16, BT>: the forward launch
+            groups["fwd"].append((short, b))
+        elif m.group(1) == "igemm_i8_sparse_kernel":                        # int8 forward, sparse class (appendix + streaming tiles)
             groups["fwd"].append((short, b))
         elif m.group(1) in ("igemm_bwd_kernel", "wgrad_reduce2_kernel"):
             groups["bwd"].append((short, b))
