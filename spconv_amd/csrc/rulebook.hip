@@ -1225,15 +1225,18 @@ conv3_pairs_kernel(const int32_t *__restrict__ indices, int n, Geom g,
 // outputs come out of a sort + unique of the linear coordinate keys (all.py:1533-1552) or out of a hash table in slot
 // order (indices.py:1380-1425).  This generation produces the SORTED order, without a sort and without a hash table:
 //   * the RANK MAP of a level: one {occupancy bits, prefix} pair per 32 consecutive linear keys (batch-major, x
-//     fastest) -- mark: one atomicOr per candidate (skipped when a plain read already shows the bit);
-//     prefix: popcount scan of the words (block-local, + block offsets from scan_kernel);
-//     row of key = prefix + popcount(bits below): ONE 8-byte load, no probing, no first-seen resolution;
-//   * out_indices are decoded from the set bits in key order, the pair tables are written per input as before;
+//     fastest), and behind the words the occupied cells before each block of 2048 words.
+//     mark: one plain BYTE store per candidate into a byte-per-cell scratch map (idempotent: no atomics);
+//     prefix: bytes -> bits, popcount scan of the words inside a block; scan_kernel: the blocks' offsets;
+//     row of key = block offset + prefix + popcount(bits below): ONE 8-byte load, no probing, no first-seen resolution;
+//   * pairs: per input, the rank of every candidate's key -> both pair tables, the input-side mask, list counts, and
+//     the coordinates of the outputs it reaches (every input of an output stores the same values);
 //   * the map stays with the level: a SubM layer behind the strided layer looks its neighbours up in it
-//     (subm_rank_probe_kernel below) -- no table fill, no insert, no slot walks -- and its rows, being in key
-//     order, put x-neighbours in adjacent rows (what the gather-GEMMs of the level gain: order_probe.py).
-// Memory: (batch x grid cells) / 4 bytes (47 M cells of a 21 x 800 x 704 x 4 level: 11.8 MB); key spaces beyond
-// 2^31 cells keep the hash builder.
+//     (subm_rank_rows_kernel / subm_rank_probe_kernel below) -- no table fill, no insert, no slot walks -- and its
+//     rows, being in key order, put x-neighbours in adjacent rows (what the gather-GEMMs of the level gain:
+//     tools/order_probe.py).
+// Memory: the map (batch x grid cells) / 4 bytes (47 M cells of a 21 x 800 x 704 x 4 level: 11.8 MB) + one byte per
+// cell of scratch during the build; key spaces beyond 2^31 cells keep the hash builder.
 constexpr int kRankWords = 2048;      // words (65536 cells) per prefix block
 constexpr int kRankPer = kRankWords / kBlock;
 
