@@ -182,6 +182,22 @@ def test_layout_int8_forward_is_bit_identical(cuda, sparse):
         got = ops.igemm_fwd_int8(f, w, pair, mask, blob, rb.n_out, 13, sc, bias, None, 0.0, torch.int8,
                                  ops.Activation.ReLU, 0.0, tile_order=to, sparse_hint=True, hint_rows=64)
         assert torch.equal(ref, got) and rb.heavy_rows > 64
+        # ... on the streaming launch (appendix tiles + streaming main tiles, csrc/igemm_v4.h) and on one workgroup per tile
+        from spconv_amd import _lib
+        try:
+            _lib.load().spx_set_option(b"SPX_I8_STREAM", 0)
+            got = ops.igemm_fwd_int8(f, w, pair, mask, blob, rb.n_out, 13, sc, bias, None, 0.0, torch.int8,
+                                     ops.Activation.ReLU, 0.0, tile_order=to, sparse_hint=True, hint_rows=rb.heavy_rows)
+        finally:
+            _lib.load().spx_set_option(b"SPX_I8_STREAM", 1)
+        assert torch.equal(ref, got)
+    else:
+        # a WRONG hint (the host claims to have seen class 1 on a dense rulebook): the streaming launch reads the class
+        # word on the device and takes the general body tile by tile -- same bits
+        blob._spx_heavy = 4096
+        got = ops.igemm_fwd_int8(f, w, pair, mask, blob, rb.n_out, 13, sc, bias, None, 0.0, torch.int8,
+                                 ops.Activation.ReLU, 0.0, tile_order=to, sparse_hint=True, hint_rows=4096)
+        assert torch.equal(ref, got)
 
 
 def test_module_default_builds_the_layout_and_reuses_it(cuda):
