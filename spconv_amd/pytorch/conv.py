@@ -33,6 +33,7 @@ from spconv_amd.constants import MODULE_DO_SORT, SAVED_WEIGHT_LAYOUT
 from spconv_amd.tools import save_debug_data
 from spconv_amd.pytorch import functional as Fsp
 from spconv_amd.pytorch import ops
+from spconv_amd.pytorch import prefetch
 from spconv_amd.pytorch.core import (ConvAlgo, ImplicitGemmIndiceData, IndiceData, Rulebook,
                                      SparseConvTensor, expand_nd)
 from spconv_amd.pytorch.modules import SparseModule
@@ -332,7 +333,7 @@ class SparseConvolution(SparseModule):
             # counts).  Derived here, in the forward, not inside this layer's first backward -- where the extra launches
             # would land in a timed or captured backward pass (round-4 ADVICE).
             if (not rb.has_native and torch.is_grad_enabled() and (features.requires_grad or self.weight.requires_grad)
-                    and self._needs_native_lists(features, indices, batch_size, spatial_shape)):
+                    and self._needs_native_lists(features.dtype, indices, batch_size, spatial_shape)):
                 rb._ensure_native()
                 ops._plan_of(rb)
         else:
@@ -340,23 +341,13 @@ class SparseConvolution(SparseModule):
                 torch.cuda.synchronize()
                 t = time.time()
             try:
-                # static shapes (spconv_amd.pytorch.static): a strided layer with a frozen output bound
-                # builds its rulebook without the device -> host read of the output count -- in training
-                # mode too (the Native lists come out of the same build; dead rows are in no pair)
-                static = 0 if self.subm else int(getattr(self, "static_num_out", 0) or 0)
                 with _timed(input, sparse_unique_name or name, "gen_pairs"):
-                    rb, _ = ops.build_rulebook(indices, batch_size, spatial_shape, self.kernel_size,
-                                               self.stride, self.padding, self.dilation,
-                                               self.output_padding, self.subm, self.transposed,
-                                               do_sort=False if static else MODULE_DO_SORT,
-                                               need_native=self._needs_native_lists(features, indices, batch_size,
-                                                                                      spatial_shape),
-                                               static_num_out=static, pred_key=id(self),
-                                               out_order=constants.CONV_OUTPUT_ORDER)
+                    # (a rulebook the container built ahead of this layer on its side stream, or the build itself)
+                    rb = prefetch.take(self, indices, batch_size, spatial_shape)
+                    if rb is None:
+                        rb = self._build_rulebook(indices, batch_size, spatial_shape, features.dtype,
+                                                  getattr(input, "n_live_dev", None))
                 self._static_n_out_dev = rb.n_out_dev
-                rb.in_n_live_dev = getattr(input, "n_live_dev", None)
-                if rb.n_out_dev is not None and getattr(rb, "out_n_live_dev", None) is None:
-                    rb.out_n_live_dev = rb.n_out_dev[:1].clamp(max=rb.n_out)      # live output rows: found, at most the bound
             except Exception:
                 # reference conv.py:289-297: say what was asked for and keep the inputs for a report
                 print(f"[Exception|rulebook] indices={tuple(indices.shape)},bs={batch_size},ss={spatial_shape},"
@@ -395,7 +386,25 @@ class SparseConvolution(SparseModule):
                           getattr(input, "n_live_dev", None) if self.subm else rb.out_n_live_dev)
         return out
 
-    def _needs_native_lists(self, features, indices, batch_size, spatial_shape) -> bool:
+    def _build_rulebook(self, indices, batch_size, spatial_shape, feat_dtype, n_live_dev) -> Rulebook:
+        """The rulebook this layer builds when no layer before it left one under its `indice_key` (also called ahead of
+        the layer, on a side stream, by spconv_amd.pytorch.prefetch).  static shapes (spconv_amd.pytorch.static): a
+        strided layer with a frozen output bound builds its rulebook without the device -> host read of the output
+        count -- in training mode too (the Native lists come out of the same build; dead rows are in no pair)."""
+        static = 0 if self.subm else int(getattr(self, "static_num_out", 0) or 0)
+        rb, _ = ops.build_rulebook(indices, batch_size, spatial_shape, self.kernel_size,
+                                   self.stride, self.padding, self.dilation,
+                                   self.output_padding, self.subm, self.transposed,
+                                   do_sort=False if static else MODULE_DO_SORT,
+                                   need_native=self._needs_native_lists(feat_dtype, indices, batch_size, spatial_shape),
+                                   static_num_out=static, pred_key=self,
+                                   out_order=constants.CONV_OUTPUT_ORDER)
+        rb.in_n_live_dev = n_live_dev
+        if rb.n_out_dev is not None and getattr(rb, "out_n_live_dev", None) is None:
+            rb.out_n_live_dev = rb.n_out_dev[:1].clamp(max=rb.n_out)      # live output rows: found, at most the bound
+        return rb
+
+    def _needs_native_lists(self, feat_dtype, indices, batch_size, spatial_shape) -> bool:
         """The ConvAlgo.Native lists (and the range plan built from them) feed the pair-list weight gradient; an
         inference pass does not need them, and neither does a SubM layer whose backward takes the rows walk (16 / 32
         channels on a dense level: ops.rows_backward_expected).  Left out of the build, they are derived from the
@@ -406,7 +415,7 @@ class SparseConvolution(SparseModule):
             return False
         if self.subm and not self.inverse:
             kv = int(np.prod(self.kernel_size))
-            if ops.rows_backward_expected(features.dtype, self.in_channels, self.out_channels, kv, indices.shape[0],
+            if ops.rows_backward_expected(feat_dtype, self.in_channels, self.out_channels, kv, indices.shape[0],
                                           batch_size, spatial_shape):
                 return False
         return True

@@ -72,8 +72,20 @@ class SparseSequential(SparseModule):
         self._register(str(len(self._modules)) if name is None else name, module)
 
     def forward(self, input):
-        from spconv_amd.pytorch import norm, ops
+        from spconv_amd.pytorch import prefetch
         mods = list(self._modules.values())
+        # the chain's rulebooks depend on the coordinates alone: built ahead on a side stream where no build reads
+        # anything back (spconv_amd/pytorch/prefetch.py); the layers below pick them up, or build in line
+        chain = prefetch.start(mods, input) if isinstance(input, SparseConvTensor) else None
+        if chain is None:
+            return self._run(mods, input)
+        try:
+            return self._run(mods, input)
+        finally:
+            chain.finish()
+
+    def _run(self, mods, input):
+        from spconv_amd.pytorch import norm, ops
         i = 0
         while i < len(mods):
             module = mods[i]

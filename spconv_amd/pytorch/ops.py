@@ -388,14 +388,28 @@ def rows_layout(rb: Rulebook) -> None:
 # (csrc/igemm_ws.hip, 512-row workgroups) and the int8 tile height are host choices.  The class word of a rows layout
 # is therefore copied to pinned host memory asynchronously when the layout is built and looked at (never waited for)
 # when a launch is prepared: until it has arrived -- the host usually runs ahead of the device on the first layer that
-# uses a new rulebook -- the launch goes by what the same layer's previous rulebook turned out to be (`_class_pred`,
-# keyed by the owning module), and inside a stream capture, where nothing can be polled, by that prediction alone.
+# uses a new rulebook -- the launch goes by what the same layer's previous rulebook turned out to be (an attribute of
+# the owning module, `_pred_get`), and inside a stream capture, where nothing can be polled, by that prediction alone.
 # Both kernels give bit-identical results, so neither a late answer nor a wrong prediction shows in an output.
 _DENSE_HINT = 0x100           # SPX_DENSE_HINT (include/spconv_amd.h)
 _WS_MIN_ROWS = 98304          # one 512-row workgroup per CU: below ~3/4 of 256 x 512 rows the 128-row tiles fill the chip better
 _CLASS_SLOTS = 1024
 _class_ring = {}              # device index -> [pinned int32 [_CLASS_SLOTS, 2], next slot, owner tokens]
-_class_pred = {}              # prediction key (module id) -> the rulebook built for it last time was dense
+_PRED_ATTR = "_spx_dense_pred"     # on the owning module (rb.pred_key): the rulebook built for it last time was dense
+
+
+def _pred_get(key) -> bool:
+    """The prediction lives ON the module that owns the rulebooks (round-5 ADVICE: a dict keyed by id(module) outlives
+    the module and can be answered by another object that reuses the id)."""
+    return bool(getattr(key, _PRED_ATTR, False)) if key is not None else False
+
+
+def _pred_set(key, dense: bool) -> None:
+    if key is not None:
+        try:
+            object.__setattr__(key, _PRED_ATTR, bool(dense))
+        except (AttributeError, TypeError):       # (a key that cannot carry attributes: no prediction)
+            pass
 
 
 class _ClassRequest:
@@ -414,8 +428,7 @@ class _ClassRequest:
         cls, heavy = (int(v) for v in self.ring[0][self.slot])
         self.done = True
         dense = (not cls) and self.n >= _WS_MIN_ROWS and 4 * heavy >= 3 * self.n
-        if self.key is not None:
-            _class_pred[self.key] = dense
+        _pred_set(self.key, dense)
         rb = self.rb()
         if rb is not None and rb.layout is not None:
             rb.sparse_class, rb.heavy_rows = bool(cls), heavy
@@ -440,7 +453,7 @@ def _request_class(rb: Rulebook) -> None:
             _class_pending.popleft()
         if len(_class_pending) > 64:
             _class_pending.popleft()
-    blob._spx_dense = bool(_class_pred.get(getattr(rb, "pred_key", None), False))
+    blob._spx_dense = _pred_get(getattr(rb, "pred_key", None))
     if capturing:
         return
     ring = _class_ring.get(blob.device.index)

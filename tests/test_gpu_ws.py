@@ -139,7 +139,7 @@ def test_lidar_fixture_full_size(cuda, dtype):
         with torch.no_grad():
             outs.append(net(x).features)
         torch.cuda.synchronize()
-    assert ops._class_pred.get(id(net)) is True
+    assert ops._pred_get(net) is True
     assert torch.equal(outs[0], fwd_ref) and torch.equal(outs[2], fwd_ref)
 
 
