@@ -1408,6 +1408,24 @@ def also_block(args, D: Dist):
     return out
 
 
+def tree_stamp() -> str:
+    """Which tree this line measured: `git describe` where there is a repository, else the BUILD_STAMP file that
+    tools/grun.sh leaves at the root before a snapshot goes to a GPU box (the box has no .git)."""
+    root = os.path.dirname(os.path.abspath(__file__))
+    try:
+        import subprocess
+        h = subprocess.check_output(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], text=True,
+                                    stderr=subprocess.DEVNULL).strip()
+        dirty = subprocess.call(["git", "-C", root, "diff", "--quiet", "HEAD"], stderr=subprocess.DEVNULL) != 0
+        return h + ("+dirty" if dirty else "")
+    except Exception:
+        pass
+    try:
+        return open(os.path.join(root, "BUILD_STAMP")).read().split()[0]
+    except OSError:
+        return "unknown"
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse(argv)
@@ -1439,6 +1457,7 @@ def main(argv=None):
                    "group": c["roofline"].get("group")})
             for cfg, c in result["also"].items()}
     if D.rank == 0:
+        result["config"]["tree"] = tree_stamp()
         print(json.dumps(result), flush=True)
     D.finish()
 

@@ -119,15 +119,18 @@ ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_LEAKY_RELU = 0, 1, 2, 3
 _lib: Optional[ctypes.CDLL] = None
 
 
-def build(force: bool = False) -> str:
-    """Compile the HIP sources for gfx950 (no GPU needed)."""
+def linked_objects() -> list:
+    """Object files the library is linked from: csrc/build.sh holds the one list of translation units."""
     script = os.path.join(_HERE, "csrc", "build.sh")
-    if force:
-        for f in ("rulebook.o", "igemm.o", "igemm_gen1.o", "igemm_bwdn.o", "pool.o", "rowsort.o", "norm.o", "common.o", "libspconv_amd.so"):
-            p = os.path.join(_HERE, "lib", f)
-            if os.path.exists(p):
-                os.remove(p)
-    subprocess.check_call(["bash", script])
+    out = subprocess.check_output(["bash", script, "--list"], text=True)
+    return [os.path.join(_HERE, "lib", line.strip()) for line in out.splitlines() if line.strip()]
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP sources for gfx950 (no GPU needed).  force=True deletes EVERY object the library is linked from
+    (and the library) first -- the list is build.sh's own, so a translation unit added there cannot be forgotten here."""
+    script = os.path.join(_HERE, "csrc", "build.sh")
+    subprocess.check_call(["bash", script] + (["--force"] if force else []))
     return LIB_PATH
 
 

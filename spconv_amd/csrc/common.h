@@ -6,6 +6,8 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "../../include/spconv_amd.h"
 
 namespace spx {
@@ -59,6 +61,20 @@ struct Carver {
   } while (0)
 
 #define SPX_LAUNCH_CHECK() SPX_HIP(hipGetLastError())
+
+// A kernel that needs more than 64 KB of dynamic LDS raises hipFuncAttributeMaxDynamicSharedMemorySize first.  The
+// attribute belongs to (function, DEVICE): `done` keeps one bit per device index, so a process that drives several
+// GPUs sets it on each of them, from any thread (round-5 ADVICE: a plain static flag set it on the first device only).
+inline hipError_t ensure_dynamic_lds(const void *fn, int bytes, std::atomic<uint64_t> &done) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+  return e;
+}
 
 // Canonical 4-d description of a 1..4-d problem: leading dims are padded with
 // size-1 / ksize-1 entries so one kernel serves every ndim.  Column c of an

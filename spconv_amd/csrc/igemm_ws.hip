@@ -386,12 +386,8 @@ template <int NW, int G, int D, bool BF16, bool BT>
 int launch_ws_one(const WsArgs &a, hipStream_t s) {
   constexpr size_t lds = 2 * static_cast<size_t>(G) * 64 * kRowBytes;
   auto kern = igemm_ws_kernel<NW, G, D, BF16, BT>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    SPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(lds)));
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};      // one bit per device (common.h: ensure_dynamic_lds)
+  SPX_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), static_cast<int>(lds), attr_done));
   WsArgs q = a;
   q.ntiles = div_up(a.n_dst, NW * 32);
   hipLaunchKernelGGL(kern, dim3(q.ntiles), dim3(NW * 64), lds, s, q);

@@ -2424,9 +2424,8 @@ int spx_subm_rulebook(const int32_t *indices, int n, int ndim, int batch_size,
     if (probe5) {
       const int fwords = occ_bits ? static_cast<int>(cap / 32) : 0;
       const size_t lds = static_cast<size_t>(fwords) * 4 + static_cast<size_t>(kv / 2) * (16 + 8 + 16);
-      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&subm_probe5_kernel),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)attr;
+      static std::atomic<uint64_t> attr_done{0};      // one bit per device (common.h: ensure_dynamic_lds)
+      SPX_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(&subm_probe5_kernel), 160 * 1024, attr_done));
       hipLaunchKernelGGL(subm_probe5_kernel, dim3(nblk256), dim3(kP5Threads), lds, s, indices, n, g, t, occupied, fwords,
                          slot_of, pair_fwd, pair_bwd, mask, words, lists ? groupcount : nullptr, nblk256, mask_pass);
     } else {

@@ -226,9 +226,11 @@ def build_rulebook(indices: torch.Tensor, batch_size: int, spatial_shape: List[i
                 _lib.ints(padding), _lib.ints(dilation), int(transpose))
         if out_order not in ("first_seen", "sorted"):
             raise ValueError(f"out_order must be 'first_seen' or 'sorted', got {out_order!r}")
-        if out_order == "sorted" and n_in > 0 and L.spx_conv_sorted_ok(ndim, batch_size, *args):
+        if (out_order == "sorted" and n_in > 0 and L.spx_conv_sorted_ok(ndim, batch_size, *args)
+                and _sorted_pays(n_in, batch_size, out_shape)):
             return _build_sorted(L, indices, batch_size, spatial_shape, out_shape, ksize, stride, padding, dilation,
-                                 args[:-1], need_native, num_out_act_bound, static_num_out, pred_key, stream)
+                                 args[:-1], need_native, num_out_act_bound, static_num_out, pred_key, stream,
+                                 do_sort)
         ws = _ws(L.spx_conv_rulebook_ws_bytes(n_in, ndim, _lib.ints(ksize), _lib.ints(stride),
                                               _lib.ints(dilation), int(transpose)), dev)
         if static_num_out > 0:
@@ -291,19 +293,43 @@ def build_rulebook(indices: torch.Tensor, batch_size: int, spatial_shape: List[i
     return rb, out_shape
 
 
+# The rank-map builder's cost grows with the GRID (one byte per cell filled and scanned, cells / 4 bytes of map kept for
+# the level's SubM layers), the hash builder's with the INPUT rows (~0.45 us per 1000).  Measured break-even is a few
+# hundred cells per input row (config 4: 118 cells per row at level 1 -> 2, 20 at level 2 -> 3; 174 -> 118 us); beyond
+# `_SORTED_MAX_CELLS_PER_ROW` cells per row, or 1 GiB of scratch, the first-seen hash build is taken instead (round-5
+# ADVICE: a 500^3 x 2 grid with 50 k voxels would fill and scan 250 MB per build).  0 = no gate.
+_SORTED_MAX_CELLS_PER_ROW = float(os.environ.get("SPCONV_AMD_SORTED_MAX_CELLS_PER_ROW", "512"))
+_SORTED_MAX_SCRATCH = 1 << 30
+
+
+def _sorted_pays(n_in: int, batch_size: int, out_shape) -> bool:
+    cells = float(batch_size)
+    for d in out_shape:
+        cells *= float(d)
+    if _SORTED_MAX_CELLS_PER_ROW <= 0:
+        return True
+    return cells <= _SORTED_MAX_CELLS_PER_ROW * max(n_in, 1) and cells * 1.25 <= _SORTED_MAX_SCRATCH
+
+
 def _rankmap_of(indices: torch.Tensor, batch_size: int, spatial_shape, n: int, kv: int):
-    """The rank map a sorted-order build attached to exactly this index tensor, if it describes this level."""
+    """The rank map a sorted-order build attached to exactly this index tensor, if it describes this level -- and if
+    the tensor has not been written since (its version counter and storage are the ones recorded with the map: an
+    in-place edit of `out.indices` between the strided layer and the SubM layer behind it drops the map, round-5
+    ADVICE)."""
     rm = getattr(indices, "_spx_rankmap", None)
     if rm is None or not (1 < kv <= 128) or n > (4 << 20):
         return None
-    cells, bs, shape, rows = rm
+    cells, bs, shape, rows = rm[:4]
     if bs != batch_size or shape != tuple(int(v) for v in spatial_shape) or rows != n or cells.device != indices.device:
+        return None
+    if len(rm) >= 6 and (rm[4] != indices._version or rm[5] != indices.data_ptr()):
+        indices._spx_rankmap = None
         return None
     return cells
 
 
 def _build_sorted(L, indices, batch_size, spatial_shape, out_shape, ksize, stride, padding, dilation, args,
-                  need_native, num_out_act_bound, static_num_out, pred_key, stream):
+                  need_native, num_out_act_bound, static_num_out, pred_key, stream, do_sort=False):
     """Regular-convolution rulebook with the outputs in key order (spx_conv_rulebook_*_sorted)."""
     dev = indices.device
     n_in, ndim = indices.shape[0], indices.shape[1] - 1
@@ -350,7 +376,10 @@ def _build_sorted(L, indices, batch_size, spatial_shape, out_shape, ksize, strid
     rb.in_indices, rb.in_shape, rb.out_shape, rb.batch_size = indices, list(spatial_shape), list(out_shape), batch_size
     rb.pred_key = pred_key
     rb.rankmap = cells
-    out_indices._spx_rankmap = (cells, batch_size, tuple(int(v) for v in out_shape), n_out)
+    out_indices._spx_rankmap = (cells, batch_size, tuple(int(v) for v in out_shape), n_out,
+                                out_indices._version, out_indices.data_ptr())
+    if do_sort is True and words == 1:
+        sort_rulebook(rb)         # SPCONV_DO_SORT=1: "explicit mask sort of every rulebook" holds on this path too
     return rb, out_shape
 
 

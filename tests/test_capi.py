@@ -127,3 +127,21 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libspconv_amd.so")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_force_build_rebuilds_every_linked_object():
+    """`_lib.build(force=True)` (what `__graft_entry__.build()` runs) leaves no object older than the call: the list of
+    translation units is csrc/build.sh's own (`--list`), every HIP / C++ source of csrc/ is in it, and nothing else
+    sits in lib/ (four of twelve objects survived a 'forced' build because a second list had gone stale)."""
+    import time
+    objs = _lib.linked_objects()
+    units = {os.path.splitext(os.path.basename(o))[0] for o in objs}
+    csrc = os.path.join(ROOT, "spconv_amd", "csrc")
+    sources = {os.path.splitext(f)[0] for f in os.listdir(csrc) if f.endswith((".hip", ".cpp"))}
+    assert units == sources, (sorted(units ^ sources))
+    t0 = time.time() - 1.0
+    _lib.build(force=True)
+    stale = [o for o in objs + [_lib.LIB_PATH] if not os.path.exists(o) or os.path.getmtime(o) < t0]
+    assert not stale, stale
+    present = {f for f in os.listdir(os.path.join(ROOT, "spconv_amd", "lib")) if f.endswith(".o")}
+    assert present == {os.path.basename(o) for o in objs}, present

@@ -215,3 +215,55 @@ def test_backbone_in_sorted_order_equals_first_seen_order(cuda, monkeypatch):
     assert float((a[0] - b[0]).abs().max()) <= 1e-5 * float(a[0].abs().max())
     for ga, gb in zip(a[1], b[1]):
         assert float((ga - gb).abs().max()) <= 2e-4 * float(ga.abs().max())
+
+
+def test_rank_map_is_dropped_when_the_index_tensor_was_written(cuda):
+    """Round-5 ADVICE: the map is a Python attribute of the index tensor; an in-place edit of `out.indices` between the
+    strided layer and the SubM layer behind it must not leave a stale map in use.  The tensor's version counter and
+    storage are recorded with the map; after a write the SubM build takes the hash table (and is still right)."""
+    from spconv_amd.pytorch import ops
+    shape, bs = [41, 200, 176], 2
+    idx = scene(shape, 20000, bs, seed=4)
+    rs, out_shape = gpu_rulebook(idx, bs, shape, [3] * 3, [2] * 3, [1] * 3, [1] * 3, False, out_order="sorted")
+    ind = rs.out_indices
+    n = ind.shape[0]
+    assert ops._rankmap_of(ind, bs, out_shape, n, 27) is not None
+    want = ops.build_rulebook(ind.clone(), bs, out_shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True)[0]
+    # a user moves the first rows three cells along z, in place: other neighbourhoods, rows no longer in key order
+    ind[:300, 1] = (ind[:300, 1] + 3) % out_shape[0]
+    assert ops._rankmap_of(ind, bs, out_shape, n, 27) is None and getattr(ind, "_spx_rankmap", None) is None
+    got = ops.build_rulebook(ind, bs, out_shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True)[0]
+    ref = ops.build_rulebook(ind.clone(), bs, out_shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True)[0]
+    assert torch.equal(got.pair_fwd, ref.pair_fwd) and not torch.equal(got.pair_fwd, want.pair_fwd)
+
+
+def test_sorted_build_is_gated_by_grid_cells_per_input_row(cuda, monkeypatch):
+    """Round-5 ADVICE (medium): the rank-map build costs grid cells, not rows.  A large, very sparse grid -- more than
+    SPCONV_AMD_SORTED_MAX_CELLS_PER_ROW output cells per input row -- takes the first-seen hash build even when the
+    caller asks for `sorted`; no rank map is attached and the rulebook is the first-seen one bit for bit."""
+    from spconv_amd.pytorch import ops
+    shape, bs = [200, 200, 200], 1                        # 1 M output cells
+    idx = scene(shape, 1000, bs, seed=8)                  # ~1000 cells per input row > 512
+    assert not ops._sorted_pays(idx.shape[0], bs, [100, 100, 100])
+    rs, out_shape = gpu_rulebook(idx, bs, shape, [3] * 3, [2] * 3, [1] * 3, [1] * 3, False, out_order="sorted")
+    rf, _ = gpu_rulebook(idx, bs, shape, [3] * 3, [2] * 3, [1] * 3, [1] * 3, False, out_order="first_seen")
+    assert rs.rankmap is None and getattr(rs.out_indices, "_spx_rankmap", None) is None
+    assert torch.equal(rs.out_indices, rf.out_indices) and torch.equal(rs.pair_fwd, rf.pair_fwd)
+    monkeypatch.setattr(ops, "_SORTED_MAX_CELLS_PER_ROW", 0.0)       # the override: no gate
+    rs2, _ = gpu_rulebook(idx, bs, shape, [3] * 3, [2] * 3, [1] * 3, [1] * 3, False, out_order="sorted")
+    assert rs2.rankmap is not None
+    _check_renumbered(rs2, rf, out_shape)
+
+
+def test_explicit_mask_sort_also_applies_to_a_sorted_order_build(cuda):
+    """SPCONV_DO_SORT=1 (`do_sort=True`): "explicit mask sort of every rulebook" -- also behind the rank-map builder
+    (round-5 ADVICE: the sorted path returned before the sort)."""
+    from spconv_amd.pytorch import ops
+    shape, bs = [41, 200, 176], 2
+    idx = torch.from_numpy(scene(shape, 20000, bs, seed=6)).to("cuda:0")
+    args = ([3] * 3, [2] * 3, [1] * 3, [1] * 3, [0] * 3)
+    rb, _ = ops.build_rulebook(idx, bs, shape, *args, out_order="sorted", do_sort=True)
+    assert rb.rankmap is not None and rb.argsort_fwd is not None and rb.argsort_bwd is not None
+    m = rb.mask_fwd.view(-1).to(torch.int64) & 0xffffffff
+    assert bool((m[rb.argsort_fwd.long()].diff() >= 0).all())
+    assert "fwd" in rb.sorted_tables and "bwd" in rb.sorted_tables

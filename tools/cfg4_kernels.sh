@@ -11,7 +11,7 @@ for cfg in 4 4i; do
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_${T}_cfg$cfg -o bench -- python $R/bench.py --config $cfg --steps 40 --warmup 10 --no-cpu-baseline > $R/$O/${T}_cfg${cfg}_rocprof.log 2>&1)
   f=$(find $O/prof_${T}_cfg$cfg -name "*kernel_stats.csv" | head -1)
   out=$O/${T}_cfg${cfg}_step_kernels.txt
-  [ -n "$f" ] && python tools/rocprof_summary.py "$f" > $out 2>&1
+  [ -n "$f" ] && { echo "# tree: $(cat BUILD_STAMP 2>/dev/null || echo unknown: run through tools/grun.sh)   config $cfg, SPCONV_AMD_PREFETCH=${SPCONV_AMD_PREFETCH:-auto}"; python tools/rocprof_summary.py "$f"; } > $out 2>&1
   grep -o '"ms_per_step": [0-9.]*' $O/${T}_cfg${cfg}_rocprof.log | head -1
   find $O -name "*kernel_trace.csv" -delete
 done

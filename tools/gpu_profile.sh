@@ -15,6 +15,7 @@ echo "== rocprof pmc WRITE"; (cd /tmp && timeout 150 rocprofv3 --kernel-trace --
 S=gpurun_out/summary_$TAG.txt
 {
 echo "# rocprofv3 summaries of: $CMD   (tag $TAG)"
+echo "# tree: $(cat BUILD_STAMP 2>/dev/null || echo unknown: run through tools/grun.sh)"
 echo "## kernel stats (--kernel-trace --stats)"; f=$(find gpurun_out/prof_${TAG}_stats -name "*kernel_stats.csv" | head -1); cat "$f"
 echo "## SQ counters, average per dispatch (quad-cycles)"; f=$(find gpurun_out/prof_${TAG}_sq -name "*counter_collection.csv" | head -1); python tools/rocprof_summary.py "$f" --pmc | sed -n '/^$/,$p'
 echo "## FETCH_SIZE [KiB, x2 for wide reads on gfx950]"; f1=$(find gpurun_out/prof_${TAG}_fetch -name "*counter_collection.csv" | head -1); python tools/rocprof_summary.py "$f1" --pmc | sed -n '/^$/,$p'

@@ -15,6 +15,7 @@ f1=$(find gpurun_out/prof_${TAG}_fetch -name "*counter_collection.csv" | head -1
 f2=$(find gpurun_out/prof_${TAG}_write -name "*counter_collection.csv" | head -1)
 {
 echo "# rocprofv3 summaries of: $CMD   (tag $TAG)"
+echo "# tree: $(cat BUILD_STAMP 2>/dev/null || echo unknown: run through tools/grun.sh)"
 echo "## kernel stats (--kernel-trace --stats)"; f=$(find gpurun_out/prof_${TAG}_stats -name "*kernel_stats.csv" | head -1); head -12 "$f"
 echo "## SQ counters, average per dispatch"; f=$(find gpurun_out/prof_${TAG}_sq -name "*counter_collection.csv" | head -1); python tools/rocprof_summary.py "$f" --pmc | sed -n '/^$/,$p'
 echo "## FETCH_SIZE [KiB, x2 for wide reads on gfx950]"; python tools/rocprof_summary.py "$f1" --pmc | sed -n '/^$/,$p'
