@@ -67,6 +67,14 @@ int spx_version(void);
  * the benchmark use it to run two kernel generations against each other inside one process.  Host only. */
 int spx_set_option(const char *name_h, int value);
 
+/* Diagnostics: how many launches of a kernel family this process has enqueued (or captured) so far -- "igemm_v4" (128 /
+ * 64-row gather-GEMM tiles), "igemm_ws" (weight-stationary 512-row workgroups of dense C = K = 64 layers),
+ * "igemm_bwd" (fused dgrad + wgrad launch), "igemm_bwd_rows" (one-gather backward), "igemm_i8_stream", "generic";
+ * -1 for an unknown name.  The role of the reference's tuner record (which algorithm a layer was given:
+ * ConvTunerSimple, csrc/sparse/convops.py:919-1466): lets a test or a benchmark say which kernel a call REALLY took
+ * when the choice depends on an asynchronously read density class.  Host only. */
+long long spx_launch_count(const char *family_h);
+
 /* ops.get_conv_output_size / get_deconv_output_size (pytorch/ops.py:73-96). Host only. */
 int spx_conv_out_shape(int ndim, const int *in_shape, const int *ksize, const int *stride,
                        const int *padding, const int *dilation, const int *out_padding,

@@ -30,6 +30,8 @@ int g_noptions = 0;
 std::mutex g_option_mutex;
 }  // namespace
 
+std::atomic<long long> g_launches[kFamCount];
+
 int option_int(const char *name, int dflt) {
   {
     std::lock_guard<std::mutex> lock(g_option_mutex);
@@ -57,6 +59,15 @@ int spx_set_option(const char *name_h, int value) {
 }
 
 const char *spx_last_error(void) { return spx::g_error.c_str(); }
+
+long long spx_launch_count(const char *family_h) {
+  static const char *names[spx::kFamCount] = {"igemm_v4", "igemm_ws", "igemm_bwd", "igemm_bwd_rows", "igemm_i8_stream",
+                                              "generic"};
+  if (!family_h) return -1;
+  for (int i = 0; i < spx::kFamCount; ++i)
+    if (strcmp(names[i], family_h) == 0) return spx::g_launches[i].load(std::memory_order_relaxed);
+  return -1;
+}
 
 int spx_version(void) { return 1000; }
 

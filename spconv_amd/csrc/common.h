@@ -112,6 +112,13 @@ inline Geom make_geom(int ndim, int batch, const int *in_dims, const int *out_di
 
 }  // namespace spx
 
+// ---- launch counters (diagnostics: which kernel family a call dispatched; spx_launch_count) --------
+namespace spx {
+enum LaunchFamily { kFamV4 = 0, kFamWs, kFamBwdFused, kFamBwdRows, kFamI8Stream, kFamGeneric, kFamCount };
+extern std::atomic<long long> g_launches[kFamCount];
+inline void count_launch(LaunchFamily f) { g_launches[f].fetch_add(1, std::memory_order_relaxed); }
+}  // namespace spx
+
 // ---- row orders (rowsort.hip) ---------------------------------------------------------------------
 namespace spx {
 // stable LSD radix argsort behind spx_mask_argsort (rowsort.hip)

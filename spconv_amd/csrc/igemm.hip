@@ -692,6 +692,7 @@ int run_gather_gemm_single(const GemmParams &p, int dtype, hipStream_t s) {
   }
   const long long total = static_cast<long long>(p.n_dst) * p.COUT;
   const dim3 grid(static_cast<unsigned>((total + kThreads - 1) / kThreads));
+  count_launch(kFamGeneric);
   if (dtype == SPX_F32)
     hipLaunchKernelGGL(gather_gemm_generic_kernel<float>, grid, dim3(kThreads), 0, s, p);
   else if (dtype == SPX_F16)

@@ -382,6 +382,7 @@ int launch_bwd(const GemmParams &p, const Wgrad2Params &q, int n_wgrad_blocks, h
   constexpr int wgrad_first = 1;           // (the longer chains are dispatched first: settled A/B)
   GemmParams pl = p;
   pl.lpt = p.tile_order && n_dgrad + n_wgrad_blocks > 1024;           // (see launch_v4)
+  count_launch(kFamBwdFused);
   if (p.CIN * (DT == 3 ? 4 : 2) <= 64)     // dgrad's reduction rows (dout channels) fit half a piece
     hipLaunchKernelGGL((igemm_bwd_kernel<COUT, MB, DT, 1>), dim3(n_dgrad + n_wgrad_blocks), dim3(kThreads),
                        (bwd_smem_bytes<COUT, MB, DT>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,

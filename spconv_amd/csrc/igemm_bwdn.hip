@@ -425,6 +425,7 @@ int spx_igemm_bwd_rows(const void *feat, const void *dout, const void *weight_t,
   // occupancy nor a deeper ring, fewer barriers or fewer LDS reads moved them.
   // 8 waves at C = K = 16 only; the 8-wave forms of the 32-channel shapes spilled (12-16 bytes of scratch per lane)
   // and are no longer instantiated: every instantiation of this kernel runs without scratch
+  count_launch(kFamBwdRows);
 #define SPX_BWDN(BF, CC, KK, W8)                                                                                \
   hipLaunchKernelGGL((bwdn_kernel<BF, CC, KK, W8>), dim3(G), dim3(W8 ? 512 : 256), smem, s, p)
   const bool bf = dtype == SPX_BF16;

@@ -734,6 +734,7 @@ int launch_v4(const GemmParams &p, hipStream_t s) {
   r.napp = p.cls ? napp : -1;
   constexpr int es = DT == 2 ? 1 : (DT == 3 ? 4 : 2);
   const bool half = p.CIN * es <= 64;        // narrow rows: only the first 64 bytes of a piece exist
+  count_launch(kFamV4);
 #define SPX_LAUNCH_V4(BTV, NKSV)                                                                     \
   hipLaunchKernelGGL((igemm_v4_kernel<COUT, MB, DT, BTV, NKSV>), dim3(napp + ntiles), dim3(kThreads),   \
                      (v4_smem_bytes<COUT, MB, DT>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,  \
@@ -902,6 +903,7 @@ int launch_i8_sparse(const GemmParams &p, hipStream_t s) {
   q.lpt = false;
   GemmRest r = rest_of(p);
   r.napp = napp;
+  count_launch(kFamI8Stream);
   hipLaunchKernelGGL((igemm_i8_sparse_kernel<COUT>), dim3(napp + nmain), dim3(kThreads), (v4_smem_bytes<COUT, 1, 2>()), s,
                      p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst, p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(q), r);
   SPX_LAUNCH_CHECK();

@@ -390,6 +390,7 @@ int launch_ws_one(const WsArgs &a, hipStream_t s) {
   SPX_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), static_cast<int>(lds), attr_done));
   WsArgs q = a;
   q.ntiles = div_up(a.n_dst, NW * 32);
+  count_launch(kFamWs);
   hipLaunchKernelGGL(kern, dim3(q.ntiles), dim3(NW * 64), lds, s, q);
   SPX_LAUNCH_CHECK();
   return 0;

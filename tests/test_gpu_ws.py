@@ -153,3 +153,45 @@ def test_sparse_scene_keeps_the_row_tiles(cuda):
     ops.poll_class(rb)
     assert rb.sparse_class is True and rb.layout._spx_dense is False
     assert ops._with_dense_hint(2, rb.layout) == 2
+
+
+def test_captured_fixture_step_runs_the_weight_stationary_kernel(cuda):
+    """the CAPTURED training step of the reference's LiDAR fixture layer (what bench.py's
+    `also.2b` times) must take igemm_ws_kernel for its forward -- inside a capture nothing can be polled, the launch goes
+    by the prediction the eager warm-up passes left on the module.  `spx_launch_count` (the library's record of which
+    kernel family a call dispatched) is read around the capture; gradients of the replay equal the eager step's."""
+    import spconv_amd.pytorch as spconv
+    from golden import lidar_scene
+    from spconv_amd import _lib
+    from spconv_amd.pytorch.static import StaticTrainingStep
+    L = _lib.load()
+    idx, shape = lidar_scene()
+    n = idx.shape[0]
+    torch.manual_seed(1)
+    net = spconv.SparseSequential(spconv.SubMConv3d(64, 64, 3, bias=False, indice_key="k")).to(cuda).half()
+    f = (torch.rand((n, 64), device=cuda) - 0.5).half()
+    ind = torch.from_numpy(idx).to(cuda)
+    g = ((torch.rand((n, 64), device=cuda) - 0.5) * 0.2).half()
+    # eager passes first: the class word of the rows layout arrives, the module learns "dense"
+    for _ in range(3):
+        with torch.no_grad():
+            net(spconv.SparseConvTensor(f, ind, shape, 1))
+        torch.cuda.synchronize()
+    before = {k: L.spx_launch_count(k) for k in (b"igemm_ws", b"igemm_v4", b"igemm_bwd")}
+    step = StaticTrainingStep(net, n, 64, shape, 1, torch.float16, bounds={}, out_grad=g, input_grad=True,
+                              example=(f, ind), warmup=1)
+    after = {k: L.spx_launch_count(k) for k in before}
+    # one warm-up pass + the captured pass: both forwards on the weight-stationary kernel, none on the 128-row tiles;
+    # the backward is the fused launch (dgrad tiles + wgrad ranges: DESIGN.md 3.14 "the backward stays the fused launch")
+    assert after[b"igemm_ws"] - before[b"igemm_ws"] == 2, (before, after)
+    assert after[b"igemm_v4"] == before[b"igemm_v4"], (before, after)
+    assert after[b"igemm_bwd"] - before[b"igemm_bwd"] == 2, (before, after)
+    assert L.spx_launch_count(b"no_such_family") == -1
+    step(f, ind)
+    torch.cuda.synchronize()
+    dw_graph, din_graph = net[0].weight.grad.clone(), step.features.grad.clone()
+    net.zero_grad(set_to_none=True)
+    fe = f.clone().requires_grad_(True)
+    net(spconv.SparseConvTensor(fe, ind, shape, 1)).features.backward(g)
+    torch.cuda.synchronize()
+    assert torch.equal(net[0].weight.grad, dw_graph) and torch.equal(fe.grad, din_graph)
