@@ -88,6 +88,10 @@ def parse(argv=None):
                     help="untimed steps run BEFORE the contract's W warm-up steps (clock ramp, allocator and cache "
                          "state).  0 = none: `value` is W warm-up steps + K timed steps and nothing else; the "
                          "pre-warmed figure of round 4 is the side field `round4_protocol`")
+    ap.add_argument("--key-order", action="store_true",
+                    help="configs 3 / 4 / 4i: the scenes' voxels are handed over in ascending coordinate-key order (what "
+                         "spconv_amd.pytorch.utils.sort_voxels_by_coordinate gives a data loader) and the captured pass "
+                         "declares it (key_ordered_input=True): level 1 builds its rulebook from a rank map, not a hash table")
     ap.add_argument("--graph-steps", type=int, default=8,
                     help="steps captured per hipGraph (a replay boundary costs ~5 us): 8 at EVERY N, so that the first "
                          "step of a scaling curve measures the gradient exchange, not a change of graph shape")
@@ -325,6 +329,14 @@ def make_scene(kind, voxels, seed, batch=1, shape=None):
 
 
 # ------------------------------------------------------------------ CPU baselines
+def key_sorted(idx_np, shape):
+    """Rows of a scene in ascending coordinate-key order (batch-major, last axis fastest)."""
+    key = idx_np[:, 0].astype(np.int64)
+    for d, s in enumerate(shape):
+        key = key * int(s) + idx_np[:, 1 + d]
+    return np.ascontiguousarray(idx_np[np.argsort(key, kind="stable")])
+
+
 def cpu_baseline_layer(idx, shape, C, K, seed):
     """The oracle (port of the reference CPU path) on this host: rulebook once, then fwd+bwd.
 
@@ -537,6 +549,7 @@ def run_layer(args, D: Dist):
         y.features.backward(sc.dout)
 
     launch = "eager"
+    fwd_dispatched = {}   # forward launches per kernel family inside the timed graph's capture
     graphs = None         # one step per replay, one graph per scene
     graph_grads = []      # the gradient tensor each per-scene graph writes
     graph_u = None        # U steps per replay over consecutive scenes (N = 1 only)
@@ -564,10 +577,14 @@ def run_layer(args, D: Dist):
                 graph_grads.append(net.weight.grad)   # each graph writes dW into its own pool buffer
             if U > 1:
                 graph_u = torch.cuda.CUDAGraph()
+                lc0 = {k: _lib_count(k) for k in ("igemm_ws", "igemm_v4")}
                 with torch.cuda.graph(graph_u, capture_error_mode=CAPTURE_MODE):
                     for u in range(U):
                         compute(scenes[u % S])
                         dws_a.append(net.weight.grad)
+                # which forward kernel the TIMED graph holds (the library's own record of what it dispatched while
+                # the graph was captured -- not the class state seen afterwards: round-5 ADVICE)
+                fwd_dispatched.update({k: _lib_count(k) - v for k, v in lc0.items()})
                 if D.multi:
                     graph_b = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph_b, capture_error_mode=CAPTURE_MODE):
@@ -847,6 +864,8 @@ def run_layer(args, D: Dist):
     dt = args.dtype
     ops.poll_class(scenes[0].rb)
     dense_fwd = bool(getattr(scenes[0].rb.layout, "_spx_dense", False)) and C == 64 and K == 64
+    if fwd_dispatched:
+        dense_fwd = fwd_dispatched.get("igemm_ws", 0) > 0 and fwd_dispatched.get("igemm_v4", 0) == 0
     kname = {"fwd": (f"igemm_ws_kernel<16,9,2,{dt},fwd> (weight-stationary, dense class)" if dense_fwd
                      else f"igemm_v4_kernel<{K},2,{dt},fwd>"),
              "bwd": f"igemm_bwd_kernel<{C},2,{dt}> + wgrad_reduce2_kernel"}
@@ -880,6 +899,7 @@ def run_layer(args, D: Dist):
                    "rulebook_source": "net(x): the module's own build, default environment" if args.sort == "auto"
                                       else f"net(x) with SPCONV_DO_SORT={'1' if args.sort == 'on' else '0'}",
                    "rows_layout": layout_info, "mask_sort": scenes[0].rb.argsort_fwd is not None,
+                   "forward_launches_in_timed_graph": fwd_dispatched or None,
                    "prewarm_steps": args.prewarm, "gradient_exchange_check": exchange_check,
                    "parallelism": f"dp{world}",
                    "ranks_seen": ranks_seen,
@@ -1023,6 +1043,9 @@ def run_net(args, D: Dist):
         batches = [make_scene(kind, voxels, seed=rank * S + si, batch=bs, shape=nets.SECOND_SHAPE)
                    for si in range(S)]
         name = "SECOND-style VoxelBackBone8x (12 sparse convs + BatchNorm1d + ReLU)"
+    key_order = bool(getattr(args, "key_order", False))
+    if key_order:
+        batches = [(key_sorted(idx_np, shape), shape) for idx_np, shape in batches]
     data = []
     for idx_np, shape in batches:
         ind = torch.from_numpy(idx_np).to(dev)
@@ -1063,7 +1086,7 @@ def run_net(args, D: Dist):
         # ran clean, the eager loop's time rides along
         try:
             t_static, static_info = static_training_steps(net, data, bs, cin, data[0][2], steps, warm, D,
-                                                          input_grad=args.config == "3")
+                                                          input_grad=args.config == "3", key_ordered=key_order)
             # accepted when the gradients agree with the eager step as well as the eager step agrees with
             # itself under a permutation of the input rows (bit-identical for networks without BatchNorm)
             if (not static_info["overflowed"] and static_info["dw_rel_diff_vs_eager"]
@@ -1112,6 +1135,8 @@ def run_net(args, D: Dist):
                                 "rulebook builds + forward + backward captured once, one graph for every scene)",
                       "static_shapes": static_info, "parallelism": f"dp{world}", "ranks_seen": ranks_seen,
                       "conv_output_order": __import__("spconv_amd.constants", fromlist=["x"]).CONV_OUTPUT_ORDER,
+                      "input_row_order": "ascending coordinate key, declared (key_ordered_input)" if key_order
+                                         else "generator order (shuffled in space)",
                       "dist_backend": D.backend if D.multi else None},
            "roofline": roofline_obj("step", total, ms, "whole step: rulebook builders + igemm_v4 / igemm_bwd / "
                                     "wgrad_reduce2 of every layer (+ the bn_* BatchNorm+ReLU kernels at config 4)", None,
@@ -1137,7 +1162,7 @@ def run_net(args, D: Dist):
     return res
 
 
-def static_training_steps(net, data, bs, cin, shape, steps, warm, D: Dist, input_grad=True):
+def static_training_steps(net, data, bs, cin, shape, steps, warm, D: Dist, input_grad=True, key_ordered=False):
     """The training step of a network (BASELINE configs 3 and 4) with static shapes: input padded with dead
     rows, every strided layer's output bounded at 1.1 x the largest count over the scenes, rulebook builds +
     forward + backward of the whole step in ONE captured graph that serves every scene
@@ -1165,7 +1190,7 @@ def static_training_steps(net, data, bs, cin, shape, steps, warm, D: Dist, input
     gstat = ((torch.rand((bounds[list(layers)[-1]], k_last), device=dev) - 0.5) * 0.2).half()
     runner = StaticTrainingStep(net, n_max, cin, shape, bs, torch.float16, bounds=bounds, out_grad=gstat,
                                 input_grad=input_grad, device=dev, example=(data[0][1], data[0][0]),
-                                capture_error_mode=CAPTURE_MODE)
+                                capture_error_mode=CAPTURE_MODE, key_ordered_input=key_ordered)
     fbuf, g = runner.features, runner.graph
 
     def load(si):
@@ -1245,6 +1270,8 @@ def run_infer(args, D: Dist):
     data = []
     for si in range(S):
         idx_np, shape = make_scene(kind, voxels, seed=rank * S + si, batch=bs, shape=nets.SECOND_SHAPE)
+        if getattr(args, "key_order", False):
+            idx_np = key_sorted(idx_np, shape)
         data.append((torch.from_numpy(idx_np).to(dev), torch.randn(idx_np.shape[0], 4, device=dev).half(), shape))
     shape = data[0][2]
     D.init()
@@ -1277,7 +1304,7 @@ def run_infer(args, D: Dist):
     bounds = {k: int(v * 1.1) + 1 for k, v in seen.items()}
     n_max = max(d[0].shape[0] for d in data)
     runner = StaticInference(net, int(n_max * 1.05) + 1, 4, shape, bs, torch.float16, bounds=bounds,
-                             capture_error_mode=CAPTURE_MODE)
+                             capture_error_mode=CAPTURE_MODE, key_ordered_input=bool(getattr(args, "key_order", False)))
     identical = True
     for (ind, f, _), (wi, wf) in zip(data, want):
         got = runner(f, ind)
@@ -1306,7 +1333,8 @@ def run_infer(args, D: Dist):
             fwant = [(y.indices.clone(), y.features.clone()) for y in fwant]
         frunner = StaticInference(fnet, int(n_max * 1.05) + 1, 4, shape, bs, torch.float16,
                                   bounds={k2: bounds[k] for k, k2 in zip(strided_layers(net), strided_layers(fnet))},
-                                  capture_error_mode=CAPTURE_MODE)
+                                  capture_error_mode=CAPTURE_MODE,
+                                  key_ordered_input=bool(getattr(args, "key_order", False)))
         folded_ok = True
         for (ind, f, _), (wi, wf) in zip(data, fwant):
             got = frunner(f, ind)
@@ -1345,6 +1373,8 @@ def run_infer(args, D: Dist):
                        "bounds": bounds, "input_voxels_per_gpu": int(n_mean), "scenes_rotated": S,
                        "launch": "hipGraph replay (rulebooks + convolutions), one graph for every scene",
                        "conv_output_order": __import__("spconv_amd.constants", fromlist=["x"]).CONV_OUTPUT_ORDER,
+                       "input_row_order": "ascending coordinate key, declared (key_ordered_input)"
+                                          if getattr(args, "key_order", False) else "generator order (shuffled in space)",
                        "parallelism": f"dp{world}", "ranks_seen": ranks_seen}}
 
 
@@ -1400,12 +1430,28 @@ def also_block(args, D: Dist):
                     c["first_seen_order_ms_per_step"] = f"{type(e).__name__}: {e}"[:200]
                 finally:
                     _c.CONV_OUTPUT_ORDER = keep
+        if cfg in ("4", "4i") and not getattr(a, "key_order", False):
+            # the same network with the scenes handed over in coordinate-key order (a data loader that sorts once:
+            # utils.sort_voxels_by_coordinate) and the captured pass told so: level 1 without a hash table
+            try:
+                a2 = copy.copy(a)
+                a2.key_order = True
+                r3 = run_infer(a2, D) if cfg == "4i" else run_net(a2, D)
+                c["key_ordered_input_ms_per_step"] = round(r3["ms_per_step"], 5)
+                del r3
+            except Exception as e:
+                c["key_ordered_input_ms_per_step"] = f"{type(e).__name__}: {e}"[:200]
         c["wall_s"] = round(time.perf_counter() - t0, 1)
         out[cfg] = c
         del r
         gc.collect()
         torch.cuda.empty_cache()
     return out
+
+
+def _lib_count(family: str) -> int:
+    from spconv_amd import _lib
+    return int(_lib.load().spx_launch_count(family.encode()))
 
 
 def tree_stamp() -> str:

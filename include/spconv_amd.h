@@ -209,6 +209,16 @@ int spx_conv_rulebook_static_sorted(const int32_t *indices, int n_in, int ndim, 
                                     int32_t *pair_native, int32_t *num_per_loc, int32_t *n_out_dev,
                                     void *rankmap, size_t rankmap_bytes, void *ws, size_t ws_bytes,
                                     spx_stream_t stream);
+/* The rank map of a level whose rows ALREADY are in ascending, unique key order -- level 1 of a backbone whose data
+ * loader sorts the voxels it hands over (the reference's own GPU builders emit such rows for every strided level:
+ * csrc/sparse/all.py:1533-1552; its voxelisers emit point / hash-slot order, pytorch/utils.py:23-160).  Row = rank:
+ * two launches (a fill of the map, one pass over the rows), no marks, no scan, no atomics.  `violation` (device
+ * int32 [1], or NULL) is set to 1 when a live row's key is not above its predecessor's or a live row follows a dead
+ * one (batch -1 rows must trail); the caller decides when to read it.  With the map attached, the level's SubM layers
+ * take spx_subm_rulebook_ranked (no hash table) -- replaces, for such levels, the insert + probe passes of
+ * csrc/sparse/indices.py:723-741,806-874. */
+int spx_rankmap_from_sorted(const int32_t *indices, int n, int ndim, int batch_size, const int *spatial_shape,
+                            void *rankmap, size_t rankmap_bytes, int32_t *violation, spx_stream_t stream);
 /* SubM rulebook (outputs as spx_subm_rulebook, bit for bit) of a level whose rows are in key order and whose
  * rank map a sorted-order build left behind: `indices` must be that build's out_indices (rows past its count:
  * batch -1). */

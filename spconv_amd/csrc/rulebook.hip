@@ -1320,6 +1320,46 @@ __device__ __forceinline__ int rank_of(const uint2 *__restrict__ cells, const in
   return (cell.x & bit) ? blockoff[key >> 16] + static_cast<int>(cell.y) + __popc(cell.x & (bit - 1u)) : -1;
 }
 
+// The rank map of a level whose rows ALREADY are in ascending, unique key order (level 1 of a backbone when the data
+// loader sorts its voxels: spconv_amd.pytorch.utils.sort_voxels_by_coordinate): row = rank, so the word of a key holds
+// {bits of the level's rows that fall into it, index of the first of them} and every block offset is zero -- no marks,
+// no prefix pass, no scan, no atomics.  The first row of a word writes it (it looks ahead over the <= 31 rows that can
+// share the word).  Rows that break the contract (a key <= its predecessor's, a live row behind a dead one) raise
+// `violation`; dead rows (batch -1: static shapes) must trail.
+__global__ void __launch_bounds__(kBlock)
+rankmap_from_sorted_kernel(const int32_t *__restrict__ indices, int n, Geom g, uint2 *__restrict__ cells,
+                           int32_t *__restrict__ violation) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  auto key_of = [&](int row, bool &ok) __attribute__((always_inline)) {
+    int b, c[4];
+    read_row(indices, row, g.ndim, b, c);
+    ok = b >= 0 && b < g.batch && in_range(c, g.in_dims);
+    return ok ? static_cast<unsigned long long>(layout_key(b, c, g.in_dims)) : 0ull;
+  };
+  bool ok;
+  const unsigned long long key = key_of(i, ok);
+  if (!ok) return;
+  bool first = true;
+  if (i > 0) {
+    bool pok;
+    const unsigned long long prev = key_of(i - 1, pok);
+    if (!pok || prev >= key) {
+      if (violation) atomicOr(violation, 1);
+    }
+    first = !pok || (prev >> 5) != (key >> 5);
+  }
+  if (!first) return;
+  uint32_t bits = 1u << (key & 31);
+  for (int j = i + 1; j < n && j < i + 32; ++j) {
+    bool jok;
+    const unsigned long long kj = key_of(j, jok);
+    if (!jok || (kj >> 5) != (key >> 5)) break;
+    bits |= 1u << (kj & 31);
+  }
+  cells[key >> 5] = make_uint2(bits, static_cast<uint32_t>(i));
+}
+
 // both tables, the input-side mask and the pair counts of the Native lists (as conv3_pairs_kernel; the output row
 // of a candidate is its key's rank)
 template <int MJ>
@@ -2952,6 +2992,29 @@ int spx_conv_rulebook_static_sorted(const int32_t *indices, int n_in, int ndim, 
   return spx::conv4_fill_impl(indices, n_in, ndim, batch_size, in_shape, out_shape, ksize, stride, padding, dilation,
                               n_out_cap, out_indices, pair_fwd, pair_bwd, mask_fwd, mask_bwd, pair_native,
                               num_per_loc, rankmap, rankmap_bytes, ws, ws_bytes, s, true, n_out_dev);
+}
+
+int spx_rankmap_from_sorted(const int32_t *indices, int n, int ndim, int batch_size, const int *spatial_shape,
+                            void *rankmap, size_t rankmap_bytes, int32_t *violation, spx_stream_t stream) {
+  using namespace spx;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  SPX_CHECK(ndim >= 1 && ndim <= kMaxNdim, "ndim must be in [1,4], got %d", ndim);
+  const size_t W = rank_words(ndim, batch_size, spatial_shape);
+  SPX_CHECK(W > 0 && rankmap && rankmap_bytes >= rank_bytes(W), "rank map missing or too small (%zu words)", W);
+  SPX_CHECK(n >= 0 && (indices || n == 0), "indices required");
+  const int one[4] = {1, 1, 1, 1}, zero[4] = {0, 0, 0, 0};
+  const Geom g = make_geom(ndim, batch_size, spatial_shape, spatial_shape, one, one, zero, one);
+  {
+    FillList fills;                    // every word empty, every block offset zero (row = rank: the prefixes are global)
+    fills.add(rankmap, rank_bytes(W), 0u);
+    if (violation) fills.add(violation, sizeof(int32_t), 0u);
+    SPX_HIP(fills.launch(s));
+  }
+  if (n > 0)
+    hipLaunchKernelGGL(rankmap_from_sorted_kernel, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, indices, n, g,
+                       static_cast<uint2 *>(rankmap), violation);
+  SPX_LAUNCH_CHECK();
+  return 0;
 }
 
 size_t spx_subm_rulebook_ranked_ws_bytes(int n, int kv) {

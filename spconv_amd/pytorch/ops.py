@@ -328,6 +328,46 @@ def _rankmap_of(indices: torch.Tensor, batch_size: int, spatial_shape, n: int, k
     return cells
 
 
+# Level 1 in key order.  The levels behind a strided layer are numbered by THIS library (ascending key: _build_sorted);
+# the level a caller hands in is in the caller's order, and its SubM rulebook pays hash insert + probe (the largest
+# rulebook build of a backbone: 160 us at 4 x 100 k voxels).  When the caller's rows ARE in ascending, unique key order
+# (spconv_amd.pytorch.utils.sort_voxels_by_coordinate; a voxeliser that emits key order), `attach_rank_map` builds the
+# level's rank map from them directly (row = rank: a fill + one pass, spx_rankmap_from_sorted) and leaves it on the index
+# tensor exactly as a sorted-order strided build does: SubM layers over the tensor then take spx_subm_rulebook_ranked.
+# The map costs grid cells / 4 bytes of fill: taken up to `_RANKMAP_MAX_CELLS_PER_ROW` cells per row and 1 GiB.
+_RANKMAP_MAX_CELLS_PER_ROW = float(os.environ.get("SPCONV_AMD_RANKMAP_MAX_CELLS_PER_ROW", "4096"))
+
+
+@_on_device
+def attach_rank_map(indices: torch.Tensor, batch_size: int, spatial_shape, check: bool = True) -> bool:
+    """Declares `indices` [n, ndim + 1] (int32, batch index first) to be in ascending, unique coordinate-key order
+    (batch-major, last axis fastest; rows with batch index -1 -- static shapes -- trail) and attaches the level's rank
+    map to the tensor.  check=True reads the device-side verdict back (ONE synchronisation; a data loader's place): a
+    tensor that breaks the contract is left untouched and False is returned.  check=False (inside a stream capture;
+    the caller vouches for the order) never synchronises.  Returns whether a map was attached."""
+    _require_gpu(indices, "indices")
+    assert indices.dtype == torch.int32 and indices.ndim == 2 and indices.is_contiguous()
+    L = _lib.load()
+    n, ndim = indices.shape[0], indices.shape[1] - 1
+    nbytes = int(L.spx_rankmap_bytes(ndim, batch_size, _lib.ints(spatial_shape)))
+    cells = float(batch_size)
+    for d in spatial_shape:
+        cells *= float(d)
+    if (nbytes == 0 or n == 0 or nbytes > _SORTED_MAX_SCRATCH
+            or (_RANKMAP_MAX_CELLS_PER_ROW > 0 and cells > _RANKMAP_MAX_CELLS_PER_ROW * n)):
+        return False
+    i32 = dict(dtype=torch.int32, device=indices.device)
+    cells_t = torch.empty((nbytes // 4,), **i32)
+    bad = torch.empty((1,), **i32) if check else None
+    _lib.check(L.spx_rankmap_from_sorted(indices.data_ptr(), n, ndim, batch_size, _lib.ints(spatial_shape),
+                                         cells_t.data_ptr(), nbytes, _ptr(bad), _stream(indices)))
+    if check and int(bad.item()) != 0:
+        return False
+    indices._spx_rankmap = (cells_t, batch_size, tuple(int(v) for v in spatial_shape), n,
+                            indices._version, indices.data_ptr())
+    return True
+
+
 def _build_sorted(L, indices, batch_size, spatial_shape, out_shape, ksize, stride, padding, dilation, args,
                   need_native, num_out_act_bound, static_num_out, pred_key, stream, do_sort=False):
     """Regular-convolution rulebook with the outputs in key order (spx_conv_rulebook_*_sorted)."""

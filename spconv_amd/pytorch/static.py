@@ -90,6 +90,17 @@ def dense_static(t: SparseConvTensor, channels_first: bool = True) -> torch.Tens
     return res.permute(0, nd + 1, *range(1, nd + 1)).contiguous()
 
 
+def _declare_key_order(runner) -> None:
+    """`key_ordered_input=True`: the caller vouches that every scene it loads is in ascending, unique coordinate-key
+    order (spconv_amd.pytorch.utils.sort_voxels_by_coordinate).  The level's rank map is then rebuilt from the static
+    index buffer at the head of every pass -- inside the captured graph: a fill and one pass over the rows, no check,
+    nothing read back -- and the first level's SubM layers build their rulebooks from it instead of a hash table
+    (ops.attach_rank_map)."""
+    if getattr(runner, "key_ordered_input", False):
+        from spconv_amd.pytorch import ops
+        ops.attach_rank_map(runner.indices, runner.batch_size, runner.spatial_shape, check=False)
+
+
 class StaticInference:
     """`net` (eval mode, SparseConvTensor -> SparseConvTensor or tensor) captured for scenes of at
     most `max_voxels` voxels.
@@ -108,9 +119,11 @@ class StaticInference:
     def __init__(self, net: torch.nn.Module, max_voxels: int, in_channels: int,
                  spatial_shape: Sequence[int], batch_size: int, dtype: torch.dtype = torch.float16,
                  bounds: Optional[Dict[str, int]] = None, margin: float = 1.25,
-                 device: Optional[torch.device] = None, warmup: int = 2, capture_error_mode: str = "global"):
+                 device: Optional[torch.device] = None, warmup: int = 2, capture_error_mode: str = "global",
+                 key_ordered_input: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("StaticInference needs the GPU (there is no CPU path)")
+        self.key_ordered_input = bool(key_ordered_input)
         self.net = net.eval()
         self.device = torch.device(device if device is not None else "cuda")
         self.max_voxels = int(max_voxels)
@@ -144,6 +157,7 @@ class StaticInference:
                           if getattr(m, "_static_n_out_dev", None) is not None}
 
     def _forward(self):
+        _declare_key_order(self)
         x = SparseConvTensor(self.features, self.indices, self.spatial_shape, self.batch_size)
         x.n_live_dev = self.n_live          # (normalisation layers write zeros into the padding rows)
         return self.net(x)
@@ -209,9 +223,10 @@ class StaticTrainingStep:
                  batch_size: int, dtype: torch.dtype = torch.float16, bounds: Optional[Dict[str, int]] = None,
                  margin: float = 1.25, backward=None, out_grad: Optional[torch.Tensor] = None,
                  input_grad: bool = False, device: Optional[torch.device] = None, warmup: int = 2,
-                 example=None, capture_error_mode: str = "global"):
+                 example=None, capture_error_mode: str = "global", key_ordered_input: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("StaticTrainingStep needs the GPU (there is no CPU path)")
+        self.key_ordered_input = bool(key_ordered_input)
         if (backward is None) == (out_grad is None):
             raise ValueError("give exactly one of `backward` (callable on the output tensor) and `out_grad`")
         self.net = net.train()
@@ -251,6 +266,7 @@ class StaticTrainingStep:
     def _compute(self):
         self.net.zero_grad(set_to_none=True)
         self.features.grad = None
+        _declare_key_order(self)
         x = SparseConvTensor(self.features, self.indices, self.spatial_shape, self.batch_size)
         x.n_live_dev = self.n_live
         self.out = self.net(x)

@@ -106,7 +106,8 @@ def gather_features_by_pc_voxel_id(seg_res_features: torch.Tensor, pc_voxel_id: 
     return torch.where(inside.view(shape), rows, fill)
 
 
-def sort_voxels_by_coordinate(indices: torch.Tensor, spatial_shape: List[int], *row_tensors: torch.Tensor):
+def sort_voxels_by_coordinate(indices: torch.Tensor, spatial_shape: List[int], *row_tensors: torch.Tensor,
+                              batch_size: int = 0, rank_map: bool = True):
     """Rows in ascending coordinate-key order (batch-major, last axis fastest): ``(indices, *row_tensors, order)``.
 
     Not part of the reference's API.  The FIRST level of a backbone runs in the order the caller hands over; a
@@ -114,10 +115,19 @@ def sort_voxels_by_coordinate(indices: torch.Tensor, spatial_shape: List[int], *
     x-neighbours sit in adjacent rows (on the 4 x 100 k voxel level of BASELINE config 4 a SubM
     forward takes 40 instead of 49 us, its backward 84 instead of 96): a data loader that sorts once gives the first level
     what the layer modules give every level behind a strided layer.  ``order`` maps sorted rows to input rows
-    (``x_sorted = x[order]``) for carrying labels along."""
+    (``x_sorted = x[order]``) for carrying labels along.
+
+    ``rank_map=True`` with ``batch_size`` given (CUDA tensors): the sorted index tensor additionally carries the level's
+    rank map (``ops.attach_rank_map``: row = rank, built by one pass over the rows), so the SubM layers of the first
+    level build their rulebook without a hash table, like the levels behind a strided layer do.  Coordinates that occur
+    twice are detected on the device (one synchronisation, here in the data loader) and leave the tensor untagged."""
     assert indices.dim() == 2 and indices.shape[1] == len(spatial_shape) + 1
     key = indices[:, 0].to(torch.int64)
     for d, s in enumerate(spatial_shape):
         key = key * int(s) + indices[:, 1 + d].to(torch.int64)
     order = torch.argsort(key)
-    return (indices[order].contiguous(), *[t[order].contiguous() for t in row_tensors], order)
+    out = indices[order].contiguous()
+    if rank_map and batch_size > 0 and out.is_cuda and out.dtype == torch.int32:
+        from spconv_amd.pytorch import ops
+        ops.attach_rank_map(out, int(batch_size), [int(v) for v in spatial_shape], check=True)
+    return (out, *[t[order].contiguous() for t in row_tensors], order)

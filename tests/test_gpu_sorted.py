@@ -267,3 +267,98 @@ def test_explicit_mask_sort_also_applies_to_a_sorted_order_build(cuda):
     m = rb.mask_fwd.view(-1).to(torch.int64) & 0xffffffff
     assert bool((m[rb.argsort_fwd.long()].diff() >= 0).all())
     assert "fwd" in rb.sorted_tables and "bwd" in rb.sorted_tables
+
+
+def _sorted_scene(shape, n, bs, seed, dev="cuda:0"):
+    from spconv_amd.pytorch.utils import sort_voxels_by_coordinate
+    idx = torch.from_numpy(scene(shape, n, bs, seed)).to(dev)
+    return sort_voxels_by_coordinate(idx, shape, batch_size=bs)[0]
+
+
+@pytest.mark.parametrize("n_per,form", [(3000, -1), (30000, 0), (30000, 1), (80000, -1)])
+def test_level_one_in_key_order_builds_without_a_hash_table(cuda, n_per, form):
+    """rows the CALLER hands over in ascending unique key order carry a rank map built from the
+    rows themselves (spx_rankmap_from_sorted: row = rank); the SubM rulebook over it (spx_subm_rulebook_ranked) equals
+    the hash build of the same rows bit for bit -- tables, masks, Native lists, counts; also with trailing dead rows
+    (static shapes) and a dilated kernel."""
+    from spconv_amd import _lib
+    from spconv_amd.pytorch import ops
+    shape, bs = [41, 400, 352], 4
+    ind = _sorted_scene(shape, n_per, bs, seed=5)
+    n = ind.shape[0]
+    assert ops._rankmap_of(ind, bs, shape, n, 27) is not None            # (sort_voxels_by_coordinate attached it)
+    plain = ind.clone()
+    L = _lib.load()
+    L.spx_set_option(b"SPX_SUBM_RANK_ROWS", form)
+    try:
+        for dil in (1, 2):
+            args = ([3] * 3, [1] * 3, [dil] * 3, [dil] * 3, [0] * 3, True)
+            a = ops.build_rulebook(ind, bs, shape, *args, need_bwd_table=True)[0]
+            b = ops.build_rulebook(plain, bs, shape, *args, need_bwd_table=True)[0]
+            torch.cuda.synchronize()
+            for name in ("pair_fwd", "pair_bwd", "mask_fwd", "num_per_loc", "pair_native"):
+                assert torch.equal(getattr(a, name), getattr(b, name)), (name, dil)
+        # static shapes: the same rows padded with dead rows (batch -1) behind them
+        pad = torch.full((n + 555, 4), -1, dtype=torch.int32, device=ind.device)
+        pad[:n] = ind
+        assert ops.attach_rank_map(pad, bs, shape, check=True)
+        a = ops.build_rulebook(pad, bs, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True)[0]
+        b = ops.build_rulebook(pad.clone(), bs, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True)[0]
+        for name in ("pair_fwd", "mask_fwd", "num_per_loc", "pair_native"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), name
+    finally:
+        L.spx_set_option(b"SPX_SUBM_RANK_ROWS", -1)
+
+
+def test_rank_map_from_rows_refuses_rows_that_break_the_contract(cuda):
+    from spconv_amd.pytorch import ops
+    shape, bs = [41, 200, 176], 2
+    ind = _sorted_scene(shape, 8000, bs, seed=2)
+    n = ind.shape[0]
+    # unsorted
+    shuffled = ind[torch.randperm(n, device=ind.device)].contiguous()
+    assert not ops.attach_rank_map(shuffled, bs, shape, check=True)
+    assert getattr(shuffled, "_spx_rankmap", None) is None
+    # a coordinate twice (still non-decreasing: only uniqueness is broken)
+    dup = torch.cat([ind[:100], ind[99:100], ind[100:]]).contiguous()
+    assert not ops.attach_rank_map(dup, bs, shape, check=True)
+    # a live row behind a dead one
+    holes = ind.clone()
+    holes[50, 0] = -1
+    assert not ops.attach_rank_map(holes, bs, shape, check=True)
+    # a grid far too large for the rows: the map would cost more than the hash table it replaces
+    assert not ops.attach_rank_map(ind[:10].contiguous(), 1, [2000, 2000, 400], check=True)
+    # the untouched sorted rows pass, and the verdict is not cached anywhere: a second call passes too
+    assert ops.attach_rank_map(ind.clone(), bs, shape, check=True)
+
+
+def test_captured_pass_over_key_ordered_input_equals_eager(cuda):
+    """StaticInference(key_ordered_input=True): the level-1 rank map is rebuilt from the static index buffer inside the
+    graph for every scene; live rows equal the eager, unbounded pass (hash table at level 1) bit for bit."""
+    import copy
+    import spconv_amd.pytorch as spconv
+    from spconv_amd.pytorch.static import StaticInference, strided_layers
+    from spconv_amd.pytorch.utils import sort_voxels_by_coordinate
+    from torch import nn
+    shape, bs = [32, 40, 40], 2
+    torch.manual_seed(3)
+    net = spconv.SparseSequential(
+        spconv.SubMConv3d(8, 16, 3, bias=False, indice_key="s0"), nn.ReLU(),
+        spconv.SubMConv3d(16, 16, 3, bias=False, indice_key="s0"), nn.ReLU(),
+        spconv.SparseConv3d(16, 32, 3, 2, 1, bias=False, indice_key="d1"), nn.ReLU(),
+        spconv.SubMConv3d(32, 32, 3, bias=False, indice_key="s1")).to(cuda).half().eval()
+    eager = copy.deepcopy(net)
+    name = list(strided_layers(net))[0]
+    runner = StaticInference(net, max_voxels=12_000, in_channels=8, spatial_shape=shape, batch_size=bs,
+                             dtype=torch.float16, bounds={name: 13_000}, key_ordered_input=True)
+    for n, seed in ((4500, 1), (2001, 2), (5999, 3)):
+        idx = torch.from_numpy(scene(shape, n, bs, seed)).to(cuda)
+        f = (torch.rand((idx.shape[0], 8), device=cuda) - 0.5).half()
+        idx_s, f_s, _ = sort_voxels_by_coordinate(idx, shape, f, batch_size=bs, rank_map=False)
+        with torch.no_grad():
+            want = eager(spconv.SparseConvTensor(f_s, idx_s.clone(), shape, bs))     # (untagged: hash table at level 1)
+        got = runner(f_s, idx_s)
+        assert runner.overflowed() == {}
+        k = want.indices.shape[0]
+        assert torch.equal(got.indices[:k], want.indices) and torch.equal(got.features[:k], want.features)
+    runner.release_bounds()
