@@ -273,6 +273,22 @@ int spx_igemm_fwd(const void *feat, const void *weight, void *out, const int32_t
                   int act, float act_alpha, void *ws, size_t ws_bytes,
                   spx_stream_t stream);
 
+/* The same launch, and the BatchNorm statistics of the rows it stores on the way out: workgroup b of the launch leaves
+ * {rows, mean, M2 = sum of squared deviations} of every output channel at stats[b][3][K] (fp32; statistics of the
+ * ROUNDED output values, i.e. of what a normalisation layer behind the convolution reads), rows >= *n_live (device,
+ * static-shape tensors; NULL = every row) not counted.  *slots_used_h (host) = number of records written = the
+ * launch's workgroup count, or 0 when the kernel that was dispatched leaves none (bias / activation in the epilogue,
+ * kernel volumes > 32, generic kernels): spx_batchnorm_fwd_stats then starts at its merge step instead of reading the
+ * rows again for a statistics pass.  `stats` holds stats_slots >= spx_igemm_fwd_stats_slots(n_out) records.
+ * The reference leaves BatchNorm to torch on the feature matrix (spconv/pytorch/modules.py:127-168): two extra passes
+ * over every activation; this removes the first of them. */
+int spx_igemm_fwd_stats_slots(int n_out);
+int spx_igemm_fwd_stats(const void *feat, const void *weight, void *out, const int32_t *pair,
+                        const uint32_t *mask, const int32_t *argsort, int tile_order, int n_in, int n_out, int C,
+                        int K, int kv, int dtype, int identity_k, const void *bias, int act,
+                        float act_alpha, void *ws, size_t ws_bytes, float *stats, int stats_slots,
+                        const int32_t *n_live, int *slots_used_h, spx_stream_t stream);
+
 /* int8 inference forward.  Replaces the int8 branch of ConvGemmOps.implicit_gemm
  * (pytorch/ops.py:1540-1553,1631-1662, csrc/sparse/convops.py:2176-2205) as driven by the
  * quantised module (pytorch/quantization/quantized/conv.py:368-378).  Numerics pinned by the
@@ -511,6 +527,14 @@ int spx_batchnorm_fwd(const void *x, void *y, int n, int C, int dtype, const voi
                       long long *num_batches_tracked, int param_dtype, int training, float momentum,
                       float eps, int relu, float *save_mean, float *save_invstd, void *ws,
                       size_t ws_bytes, const int32_t *n_live, spx_stream_t stream);
+/* Training-mode forward whose statistics pass has already happened: `stats` = the {rows, mean, M2} records
+ * (stats_records of them, [3][C] fp32 each) that spx_igemm_fwd_stats left behind the convolution producing x.  Two
+ * launches (merge, apply) instead of three; semantics as spx_batchnorm_fwd with training = 1. */
+int spx_batchnorm_fwd_stats(const void *x, void *y, int n, int C, int dtype, const void *weight,
+                            const void *bias, void *running_mean, void *running_var,
+                            long long *num_batches_tracked, int param_dtype, float momentum, float eps,
+                            int relu, float *save_mean, float *save_invstd, const float *stats,
+                            int stats_records, const int32_t *n_live, spx_stream_t stream);
 /* use_batch_stats = 1: `mean` / `invstd` are the saved fp32 batch statistics (training);
  * 0: fp32 copies of running_mean and 1 / sqrt(running_var + eps) (evaluation mode with gradients).
  * dweight / dbias: [C] of `param_dtype`, or NULL. */

@@ -67,6 +67,9 @@ SIGNATURES = {
     "spx_batchnorm_fwd": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int,
                                          vp, vp, vp, ctypes.c_size_t, vp, vp]),
+    "spx_batchnorm_fwd_stats": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp,
+                                               ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int, vp, vp,
+                                               vp, ctypes.c_int, vp, vp]),
     "spx_batchnorm_bwd": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int,
                                          vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_size_t, vp, vp]),
     "spx_mask_argsort_ws_bytes": (ctypes.c_size_t, [ctypes.c_int]),
@@ -78,6 +81,10 @@ SIGNATURES = {
     "spx_igemm_acc_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "spx_igemm_fwd": (ctypes.c_int, [vp] * 6 + [ctypes.c_int] * 8 + [vp, ctypes.c_int, ctypes.c_float, vp,
                                                                      ctypes.c_size_t, vp]),
+    "spx_igemm_fwd_stats_slots": (ctypes.c_int, [ctypes.c_int]),
+    "spx_igemm_fwd_stats": (ctypes.c_int, [vp] * 6 + [ctypes.c_int] * 8 + [vp, ctypes.c_int, ctypes.c_float, vp,
+                                                                           ctypes.c_size_t, vp, ctypes.c_int, vp,
+                                                                           c_int_p, vp]),
     "spx_igemm_fwd_int8": (ctypes.c_int, [vp] * 6 + [ctypes.c_int] * 6 + [vp, vp, vp, ctypes.c_float,
                                                                        ctypes.c_int, ctypes.c_int,
                                                                        ctypes.c_float, vp]),

@@ -810,10 +810,12 @@ size_t spx_igemm_acc_bytes(int n_dst, int cout, int kv) {
   return kv > 32 ? align_up(static_cast<size_t>(n_dst > 0 ? n_dst : 1) * cout * sizeof(float), 256) : 0;
 }
 
-int spx_igemm_fwd(const void *feat, const void *weight, void *out, const int32_t *pair,
-                  const uint32_t *mask, const int32_t *argsort, int tile_order, int n_in, int n_out, int C,
-                  int K, int kv, int dtype, int identity_k, const void *bias, int act,
-                  float act_alpha, void *ws, size_t ws_bytes, spx_stream_t stream) {
+static int igemm_fwd_impl(const void *feat, const void *weight, void *out, const int32_t *pair,
+                          const uint32_t *mask, const int32_t *argsort, int tile_order, int n_in, int n_out, int C,
+                          int K, int kv, int dtype, int identity_k, const void *bias, int act,
+                          float act_alpha, void *ws, size_t ws_bytes, spx_stream_t stream, float *stats,
+                          const int32_t *n_live, int *slots_used_h) {
+  if (slots_used_h) *slots_used_h = 0;
   SPX_CHECK(C > 0 && K > 0 && kv > 0 && n_in >= 0 && n_out >= 0, "bad sizes");
   if (n_out == 0) return 0;                                   // empty scene: nothing to write
   SPX_CHECK((feat || n_in == 0) && weight && out, "null tensor pointer");
@@ -842,7 +844,38 @@ int spx_igemm_fwd(const void *feat, const void *weight, void *out, const int32_t
   if (act & SPX_OUT_CACHED) p.dbg = 0x400;       // plain result stores: the next launch reads the rows
   p.act_alpha = act_alpha;
   if (ws && ws_bytes >= spx_igemm_acc_bytes(n_out, K, kv) && kv > 32) p.acc = static_cast<float *>(ws);
+  if (stats && kv <= 32 && !bias && p.act == SPX_ACT_NONE) {   // (the training-mode call: plain rows)
+    p.stats = stats;
+    p.n_live = n_live;
+    p.grid_out = slots_used_h;
+  }
   return run_gather_gemm(p, dtype, static_cast<hipStream_t>(stream));
+}
+
+int spx_igemm_fwd(const void *feat, const void *weight, void *out, const int32_t *pair,
+                  const uint32_t *mask, const int32_t *argsort, int tile_order, int n_in, int n_out, int C,
+                  int K, int kv, int dtype, int identity_k, const void *bias, int act,
+                  float act_alpha, void *ws, size_t ws_bytes, spx_stream_t stream) {
+  return igemm_fwd_impl(feat, weight, out, pair, mask, argsort, tile_order, n_in, n_out, C, K, kv, dtype, identity_k,
+                        bias, act, act_alpha, ws, ws_bytes, stream, nullptr, nullptr, nullptr);
+}
+
+int spx_igemm_fwd_stats_slots(int n_out) {
+  // upper bound of the workgroups of a forward launch over n_out rows: 64-row tiles + the appendix workgroups the
+  // class rule allows (n / 4 rows) + slack
+  return n_out <= 0 ? 0 : div_up(n_out, 64) + div_up(n_out, 256) + 8;
+}
+
+int spx_igemm_fwd_stats(const void *feat, const void *weight, void *out, const int32_t *pair,
+                        const uint32_t *mask, const int32_t *argsort, int tile_order, int n_in, int n_out, int C,
+                        int K, int kv, int dtype, int identity_k, const void *bias, int act,
+                        float act_alpha, void *ws, size_t ws_bytes, float *stats, int stats_slots,
+                        const int32_t *n_live, int *slots_used_h, spx_stream_t stream) {
+  SPX_CHECK(slots_used_h, "slots_used_h is required");
+  SPX_CHECK(!stats || stats_slots >= spx_igemm_fwd_stats_slots(n_out), "statistics buffer too small: %d slots < %d",
+            stats_slots, spx_igemm_fwd_stats_slots(n_out));
+  return igemm_fwd_impl(feat, weight, out, pair, mask, argsort, tile_order, n_in, n_out, C, K, kv, dtype, identity_k,
+                        bias, act, act_alpha, ws, ws_bytes, stream, stats, n_live, slots_used_h);
 }
 
 int spx_igemm_fwd_int8(const void *feat, const void *weight, void *out, const int32_t *pair,

@@ -67,6 +67,14 @@ struct GemmParams {
   int app_budget;         // (device side) > 0: the appendix' rows are dealt to at most this many workgroups
   int dense_hint;         // the caller knows the neighbourhoods are dense (SPX_DENSE_HINT in tile_order): forward and
                           // dgrad take the weight-stationary kernel (igemm_ws.hip) where its shape limits allow
+  // BatchNorm statistics of the rows the launch stores (spx_igemm_fwd_stats): workgroup b leaves {rows, mean, M2} of
+  // every output channel at stats[b][3][COUT] -- the layout bn_partial_kernel writes (norm.hip), so the normalisation
+  // layer behind the convolution starts at its merge step.  n_live: device row count of a static-shape tensor (rows
+  // beyond it are padding: not counted), or null.  grid_out (host): receives the launch's workgroup count, 0 when the
+  // kernel that was dispatched leaves no statistics.
+  float *stats;
+  const int32_t *n_live;
+  int *grid_out;
 };
 
 // appendix workgroups of a fused backward launch, whose dgrad half shares the chip's 1024 workgroup slots with the
@@ -130,7 +138,106 @@ struct GemmRest {
   float *acc;
   int acc_mode;
   int napp;               // rows layout: appendix workgroups at the head of the grid, or -1 = the n / 4 rule
+  float *stats;           // per-workgroup BatchNorm statistics (GemmParams::stats), or null
+  const int32_t *n_live;
 };
+
+// ---- BatchNorm statistics out of a gather-GEMM epilogue ------------------------------------------------------------
+// A lane of the output-stationary kernels ends up with CPL consecutive channels (g * CPL + q, g = lane >> 4) of the rows
+// lane & 15 of its m-blocks.  s1 / s2: the lane's sums of the (rounded) output values and their squares over its valid
+// rows, nrows its valid rows (counted on g == 0 lanes only).  The 16 lanes of a group are reduced with DPP row
+// rotations, the waves of the workgroup through LDS (`lds`: NWAVES * (2 * COUT + 1) floats, free at this point -- the
+// caller has put a barrier behind its last read of the weight stages), and thread c < COUT writes channel c's
+// {rows, mean, M2} to dst[0 / COUT / 2 COUT + c]: bn_partial_kernel's record (norm.hip), merged by bn_finalize_kernel.
+__device__ __forceinline__ float row16_sum(float x) {
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xf, 0xf, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x122, 0xf, 0xf, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x121, 0xf, 0xf, false));
+  return x;
+}
+
+// ROUND: 0 = the values are stored as they are (fp32), 1 = rounded to f16, 2 = to bf16 (the statistics are those of the
+// rounded rows).  One channel at a time -- sum over the lane's m-blocks, rotate, store -- so that the epilogue's
+// register footprint stays what it was (arrays of 2 * CPL running sums cost igemm_v4_kernel<32, 2> half its waves).
+// Deviations are taken around the WAVE's own mean of the channel (two sweeps over the accumulators, no extra barrier)
+// and the waves are merged with Chan's update: no sum-of-squares cancellation however far a channel's mean is from
+// zero -- through twelve normalisation layers in fp32 a plain sum(x^2) - sum(x)^2 / n per tile showed as 0.8 % in the
+// first layer's weight gradient between two tilings of the same rows.
+template <int ROUND>
+__device__ __forceinline__ float bn_rounded(float v) {
+  if constexpr (ROUND == 1) v = static_cast<float>(static_cast<_Float16>(v));
+  if constexpr (ROUND == 2) {
+    uint32_t u = __builtin_bit_cast(uint32_t, v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    v = __builtin_bit_cast(float, u & 0xffff0000u);
+  }
+  return v;
+}
+
+template <int COUT, int CPL, int MB, int NWAVES, int ROUND, typename Acc>
+__device__ __forceinline__ void wg_bn_stats(const Acc (&acc)[CPL / 4][MB], const int (&grow)[MB], int n_live,
+                                            float *lds, float *__restrict__ dst) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 15, lgrp = lane >> 4;
+  constexpr int W = 2 * COUT + 1;
+  bool ok[MB];
+  int rows = 0;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    ok[mb] = grow[mb] >= 0 && grow[mb] < n_live;
+    rows += ok[mb] ? 1 : 0;
+  }
+  const float cnt = row16_sum(static_cast<float>(rows));      // rows of this wave (the same in each of its lane groups)
+  const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
+#pragma unroll
+  for (int nb = 0; nb < CPL / 4; ++nb)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a = 0.f;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) a += ok[mb] ? bn_rounded<ROUND>(acc[nb][mb][e]) : 0.f;
+      const float mean = row16_sum(a) * inv;
+      float b = 0.f;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const float d = bn_rounded<ROUND>(acc[nb][mb][e]) - mean;
+        b += ok[mb] ? d * d : 0.f;
+      }
+      b = row16_sum(b);
+      if (lrow == 0) {
+        lds[wave * W + lgrp * CPL + nb * 4 + e] = mean;
+        lds[wave * W + COUT + lgrp * CPL + nb * 4 + e] = b;
+      }
+    }
+  if (lane == 0) lds[wave * W + 2 * COUT] = cnt;
+  __syncthreads();
+  if (tid < COUT) {
+    float n = 0.f, m = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWAVES; ++w) {
+      const float nb = lds[w * W + 2 * COUT];
+      if (nb > 0.f) {
+        const float tot = n + nb, d = lds[w * W + tid] - m;
+        m += d * (nb / tot);
+        m2 += lds[w * W + COUT + tid] + d * d * (n * nb / tot);
+        n = tot;
+      }
+    }
+    dst[tid] = n;
+    dst[COUT + tid] = m;
+    dst[2 * COUT + tid] = m2;
+  }
+}
+
+// a workgroup that leaves without rows (appendix workgroups of a dense rulebook, ...): an empty record
+template <int COUT>
+__device__ __forceinline__ void wg_bn_stats_empty(float *__restrict__ dst) {
+  if (threadIdx.x < COUT) {
+    dst[threadIdx.x] = 0.f;
+    dst[COUT + threadIdx.x] = 0.f;
+    dst[2 * COUT + threadIdx.x] = 0.f;
+  }
+}
 
 // balanced-segment weight gradient (igemm_bwd.h: wgrad_tr_body / wgrad_f32_body; plan: wgrad_plan2_kernel in igemm.hip)
 struct Wgrad2Params {

@@ -102,6 +102,8 @@ __device__ __forceinline__ void unpack_gemm_args(GemmParams &p, const void *argA
   p.out_dtype = rest.out_dtype;
   p.dbg = rest.dbg;
   p.xcd_rot = 0;
+  p.stats = rest.stats;
+  p.n_live = rest.n_live;
   p.app_rows = rest.napp;      // (the body reads it as a workgroup count)
   p.app_budget = 0;
   // rows layout (bit 12): `mask` = the blob's main mask words, `argsort` = the appendix' row list (its mask words and
@@ -254,7 +256,10 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
     typedef const int32_t __attribute__((address_space(4))) *cptr_t;
     const int cls = *(cptr_t)(p.cls);
     app_m = *(cptr_t)(p.cls + 1);
-    if (!cls) return;
+    if (!cls) {
+      if constexpr (!I8 && !BT) if (p.stats) wg_bn_stats_empty<COUT>(p.stats + static_cast<size_t>(block) * 3 * COUT);
+      return;
+    }
     // The M rows of the appendix are dealt to the launch's napp appendix workgroups in whole 16-row blocks, h rows
     // each: the appendix tiles are the launch's critical path (a walk over every offset any of their rows has, after
     // the main tiles have long finished), and the workgroups reserved for it (n / 4 rows' worth) are there anyway --
@@ -263,7 +268,10 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
     // the chip's 1024 workgroup slots with the wgrad ranges and deals to at most kAppBudget workgroups (app_budget).
     const int groups = p.app_budget > 0 ? min(napp, p.app_budget) : napp;
     const int h = min(TM, (((app_m + groups - 1) / groups) + 15) & ~15);
-    if (block * h >= app_m) return;
+    if (block * h >= app_m) {
+      if constexpr (!I8 && !BT) if (p.stats) wg_bn_stats_empty<COUT>(p.stats + static_cast<size_t>(block) * 3 * COUT);
+      return;
+    }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
       const int blk = mb * (kThreads / 64) + (threadIdx.x >> 6);  // 16-row blocks go to the waves round-robin
@@ -686,6 +694,16 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
       if (p.dbg & 0x400) store_dwords<(F32 ? CPL : CPL / 2)>(d, rO, vo);          // (SPX_V4_DBG=1024: plain, A/B)
       else store_dwords<(F32 ? CPL : CPL / 2), 2>(d, rO, vo);
     }
+    // BatchNorm statistics of the rows this workgroup stores (spx_igemm_fwd_stats; the host asks for them on plain
+    // launches only: no bias, no activation) -- of the ROUNDED values, i.e. of what the normalisation layer will read
+    if constexpr (!BT) {
+      if (p.stats) {
+        const int st_live = p.n_live ? *p.n_live : 0x7fffffff;
+        __syncthreads();      // every wave is past its last read of the weight stages: the LDS is free
+        wg_bn_stats<COUT, CPL, MB, kThreads / 64, (F32 ? 0 : (BF16 ? 2 : 1))>(
+            acc, grow, st_live, reinterpret_cast<float *>(smem), p.stats + static_cast<size_t>(block) * 3 * COUT);
+      }
+    }
   } else {
     i8_epilogue<COUT, MB>(p, acc, grow, lgrp, lds_sb);
   }
@@ -739,6 +757,7 @@ int launch_v4(const GemmParams &p, hipStream_t s) {
   hipLaunchKernelGGL((igemm_v4_kernel<COUT, MB, DT, BTV, NKSV>), dim3(napp + ntiles), dim3(kThreads),   \
                      (v4_smem_bytes<COUT, MB, DT>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,  \
                      p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(q), r)
+  if (p.grid_out) *p.grid_out = (p.stats && DT != 2 && p.strideD == 1 && !p.acc_mode) ? napp + ntiles : 0;
   if (DT == 2 || p.strideD == 1) {
     if (half) SPX_LAUNCH_V4(false, 1);
     else SPX_LAUNCH_V4(false, 2);
@@ -770,6 +789,8 @@ inline GemmRest rest_of(const GemmParams &p) {
   r.acc = p.acc;
   r.acc_mode = p.acc_mode;
   r.napp = -1;
+  r.stats = p.stats;
+  r.n_live = p.n_live;
   return r;
 }
 

@@ -57,6 +57,8 @@ struct WsArgs {
   long long strideK, strideN, strideD;
   int n_dst, n_src, kv, identity_k, b_reverse, act, ntiles;
   float act_alpha;
+  float *stats;             // per-workgroup BatchNorm statistics of the stored rows (GemmParams::stats), or null
+  const int32_t *n_live;
   unsigned long long *tl;   // per-wave timeline (tools/ws_probe.py, WS_TL=1) or null: 8 s_memtime stamps per wave
 };
 
@@ -380,10 +382,18 @@ igemm_ws_kernel(WsArgs p) {
     }
   }
   stamp(7);                            // stores issued
+  if constexpr (!BT) {
+    if (p.stats) {                     // (as igemm_v4_body: statistics of the rounded rows this workgroup stores)
+      const int st_live = p.n_live ? *p.n_live : 0x7fffffff;
+      __syncthreads();                 // every wave has left its last phase: the weight buffers are free
+      wg_bn_stats<COUT, CPL, MB, NW, (BF16 ? 2 : 1)>(acc, grow, st_live, reinterpret_cast<float *>(smem),
+                                                     p.stats + static_cast<size_t>(blockIdx.x) * 3 * COUT);
+    }
+  }
 }
 
 template <int NW, int G, int D, bool BF16, bool BT>
-int launch_ws_one(const WsArgs &a, hipStream_t s) {
+int launch_ws_one(const WsArgs &a, hipStream_t s, int *grid_out) {
   constexpr size_t lds = 2 * static_cast<size_t>(G) * 64 * kRowBytes;
   auto kern = igemm_ws_kernel<NW, G, D, BF16, BT>;
   static std::atomic<uint64_t> attr_done{0};      // one bit per device (common.h: ensure_dynamic_lds)
@@ -392,6 +402,7 @@ int launch_ws_one(const WsArgs &a, hipStream_t s) {
   q.ntiles = div_up(a.n_dst, NW * 32);
   count_launch(kFamWs);
   hipLaunchKernelGGL(kern, dim3(q.ntiles), dim3(NW * 64), lds, s, q);
+  if (grid_out) *grid_out = q.stats ? q.ntiles : 0;
   SPX_LAUNCH_CHECK();
   return 0;
 }
@@ -437,8 +448,12 @@ int launch_gather_gemm_ws(const GemmParams &p, int dtype, hipStream_t s) {
   a.act_alpha = p.act_alpha;
   const bool bt = p.strideD != 1;
   const bool bf = dtype == SPX_BF16;
-  if (bt) return bf ? launch_ws_one<16, 9, 2, true, true>(a, s) : launch_ws_one<16, 9, 2, false, true>(a, s);
-  return bf ? launch_ws_one<16, 9, 2, true, false>(a, s) : launch_ws_one<16, 9, 2, false, false>(a, s);
+  a.stats = bt ? nullptr : p.stats;
+  a.n_live = p.n_live;
+  if (bt) return bf ? launch_ws_one<16, 9, 2, true, true>(a, s, p.grid_out)
+                    : launch_ws_one<16, 9, 2, false, true>(a, s, p.grid_out);
+  return bf ? launch_ws_one<16, 9, 2, true, false>(a, s, p.grid_out)
+            : launch_ws_one<16, 9, 2, false, false>(a, s, p.grid_out);
 }
 
 }  // namespace spx

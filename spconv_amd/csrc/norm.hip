@@ -486,11 +486,12 @@ size_t spx_batchnorm_ws_bytes(int n, int C) {
   return align_up((static_cast<size_t>(bn_blocks(n)) * 3 + 2) * (C > 0 ? C : 1) * sizeof(float), 256) + 256;
 }
 
-int spx_batchnorm_fwd(const void *x, void *y, int n, int C, int dtype, const void *weight,
-                      const void *bias, void *running_mean, void *running_var,
-                      long long *num_batches_tracked, int param_dtype, int training, float momentum,
-                      float eps, int relu, float *save_mean, float *save_invstd, void *ws,
-                      size_t ws_bytes, const int32_t *n_live, spx_stream_t stream) {
+static int batchnorm_fwd_impl(const void *x, void *y, int n, int C, int dtype, const void *weight,
+                              const void *bias, void *running_mean, void *running_var,
+                              long long *num_batches_tracked, int param_dtype, int training, float momentum,
+                              float eps, int relu, float *save_mean, float *save_invstd, void *ws,
+                              size_t ws_bytes, const int32_t *n_live, spx_stream_t stream,
+                              const float *ext_partial, int ext_G) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   SPX_CHECK(bn_shape_ok(C, dtype), "batchnorm: C = %d must be a multiple of %d (<= 256), dtype f16/bf16/f32", C,
             dtype == SPX_F32 ? 4 : 8);
@@ -502,13 +503,18 @@ int spx_batchnorm_fwd(const void *x, void *y, int n, int C, int dtype, const voi
   const u32x4 *xv = static_cast<const u32x4 *>(x);
   u32x4 *yv = static_cast<u32x4 *>(y);
   if (training) {
-    SPX_CHECK(save_mean && save_invstd && ws && ws_bytes >= spx_batchnorm_ws_bytes(n, C),
+    SPX_CHECK(save_mean && save_invstd && (ext_partial || (ws && ws_bytes >= spx_batchnorm_ws_bytes(n, C))),
               "training needs save_mean / save_invstd and the workspace");
-    const int G = bn_blocks(n);
-    float *partial = static_cast<float *>(ws);
-#define SPX_BN_PARTIAL(D) hipLaunchKernelGGL(bn_partial_kernel<D>, dim3(G), dim3(kT), 0, s, xv, n, C, partial, n_live)
-    SPX_BN_DISPATCH(dtype, SPX_BN_PARTIAL);
+    // statistics records {rows, mean, M2} per channel: from the producing convolution's epilogue (spx_igemm_fwd_stats:
+    // one per workgroup of that launch), or from a pass over the rows here
+    const int G = ext_partial ? ext_G : bn_blocks(n);
+    const float *partial = ext_partial ? ext_partial : static_cast<const float *>(ws);
+    if (!ext_partial) {
+#define SPX_BN_PARTIAL(D) \
+  hipLaunchKernelGGL(bn_partial_kernel<D>, dim3(G), dim3(kT), 0, s, xv, n, C, static_cast<float *>(ws), n_live)
+      SPX_BN_DISPATCH(dtype, SPX_BN_PARTIAL);
 #undef SPX_BN_PARTIAL
+    }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(kT), 0, s, partial, G, C, eps, momentum, save_mean,
                        save_invstd, running_mean, running_var, param_dtype, num_batches_tracked);
 #define SPX_BN_APPLY(D)                                                                                    \
@@ -528,6 +534,27 @@ int spx_batchnorm_fwd(const void *x, void *y, int n, int C, int dtype, const voi
   }
   SPX_LAUNCH_CHECK();
   return 0;
+}
+
+int spx_batchnorm_fwd(const void *x, void *y, int n, int C, int dtype, const void *weight,
+                      const void *bias, void *running_mean, void *running_var,
+                      long long *num_batches_tracked, int param_dtype, int training, float momentum,
+                      float eps, int relu, float *save_mean, float *save_invstd, void *ws,
+                      size_t ws_bytes, const int32_t *n_live, spx_stream_t stream) {
+  return batchnorm_fwd_impl(x, y, n, C, dtype, weight, bias, running_mean, running_var, num_batches_tracked,
+                            param_dtype, training, momentum, eps, relu, save_mean, save_invstd, ws, ws_bytes, n_live,
+                            stream, nullptr, 0);
+}
+
+int spx_batchnorm_fwd_stats(const void *x, void *y, int n, int C, int dtype, const void *weight,
+                            const void *bias, void *running_mean, void *running_var,
+                            long long *num_batches_tracked, int param_dtype, float momentum, float eps, int relu,
+                            float *save_mean, float *save_invstd, const float *stats, int stats_records,
+                            const int32_t *n_live, spx_stream_t stream) {
+  SPX_CHECK(stats && stats_records > 0, "statistics records required (spx_igemm_fwd_stats)");
+  return batchnorm_fwd_impl(x, y, n, C, dtype, weight, bias, running_mean, running_var, num_batches_tracked,
+                            param_dtype, 1, momentum, eps, relu, save_mean, save_invstd, nullptr, 0, n_live, stream,
+                            stats, stats_records);
 }
 
 int spx_batchnorm_bwd(const void *x, const void *dy, void *dx, int n, int C, int dtype,

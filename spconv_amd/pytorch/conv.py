@@ -370,6 +370,10 @@ class SparseConvolution(SparseModule):
             t = time.time()
 
         num_out = outids.shape[0]
+        sink = ops.current_stats_sink()
+        if sink is not None:       # (BatchNorm statistics out of this layer's epilogue: the live rows of ITS output)
+            sink.n_live = (rb.in_n_live_dev if self.inverse else
+                           getattr(input, "n_live_dev", None) if self.subm else rb.out_n_live_dev)
         with _timed(input, sparse_unique_name or name, "forward"):
             out_features = self._run_kernels(grad_path, is_int8, input, features, weight, rb, num_out, algo,
                                              bias_for_infer, act_type, act_alpha, act_beta, output_scale,

@@ -87,14 +87,27 @@ class SparseSequential(SparseModule):
     def _run(self, mods, input):
         from spconv_amd.pytorch import norm, ops
         i = 0
+        conv_stats = None       # BatchNorm statistics the convolution just before a normalisation layer left (or None)
         while i < len(mods):
             module = mods[i]
             i += 1
             if is_spconv_module(module):
                 nxt = mods[i] if i < len(mods) else None
+                conv_stats = None
                 if isinstance(nxt, nn.modules.batchnorm._BatchNorm):
+                    # a training-mode BatchNorm1d on the fused path behind a bias-free convolution: its statistics
+                    # come out of the convolution's epilogue (ops.collect_bn_stats), it starts at the merge step
+                    fuse_stats = (ops.BN_EPILOGUE and norm.ENABLED and type(nxt) is nn.BatchNorm1d
+                                  and (nxt.training or nxt.running_mean is None) and is_sparse_conv(module)
+                                  and getattr(module, "bias", None) is None and module.training
+                                  and not module._forward_hooks and not nxt._forward_hooks
+                                  and not nxt._forward_pre_hooks)
                     with ops.output_stays_cached():     # the normalisation reads the rows next (ops._OUT_CACHED)
-                        input = module(input)
+                        if fuse_stats:
+                            with ops.collect_bn_stats() as conv_stats:
+                                input = module(input)
+                        else:
+                            input = module(input)
                 else:
                     input = module(input)
             elif isinstance(input, SparseConvTensor):
@@ -108,7 +121,9 @@ class SparseSequential(SparseModule):
                                 and not mods[i]._forward_pre_hooks and not mods[i]._backward_hooks
                                 and not getattr(mods[i], "_backward_pre_hooks", None))
                         input = input.replace_feature(norm.batch_norm(input.features, module, relu=fuse,
-                                                                      n_live=getattr(input, "n_live_dev", None)))
+                                                                      n_live=getattr(input, "n_live_dev", None),
+                                                                      stats=conv_stats))
+                        conv_stats = None
                         i += 1 if fuse else 0
                     else:
                         if (getattr(input, "n_live_dev", None) is not None and getattr(module, "training", False)

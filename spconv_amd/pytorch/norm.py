@@ -50,7 +50,7 @@ def _param_dtype(*tensors) -> Optional[torch.dtype]:
 class _BatchNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu, nbt=None,
-                n_live=None, differentiable=True):
+                n_live=None, differentiable=True, records=None, n_records=0):
         # differentiable: the caller's grad mode AND an input that requires grad (decided outside: inside forward the
         # grad mode is always off, and ctx.needs_input_grad reports requires_grad whatever the mode -- an inference
         # pass under no_grad over a model whose parameters still require grad must not pay for a snapshot)
@@ -61,8 +61,21 @@ class _BatchNormFn(torch.autograd.Function):
         y = torch.empty_like(x)
         pdt = _param_dtype(weight, bias, running_mean, running_var)
         stats = torch.empty((2, C), dtype=torch.float32, device=dev)
-        ws = torch.empty((max(L.spx_batchnorm_ws_bytes(n, C), 16),), dtype=torch.uint8, device=dev)
         p = lambda t: None if t is None else t.data_ptr()
+        if records is not None and training:
+            # the statistics pass has happened already: in the epilogue of the convolution that produced x
+            # (spx_igemm_fwd_stats left one {rows, mean, M2} record per workgroup) -- merge + apply, two launches
+            with torch.cuda.device(dev):
+                _lib.check(L.spx_batchnorm_fwd_stats(x.data_ptr(), y.data_ptr(), n, C, _DT[x.dtype], p(weight), p(bias),
+                                                     p(running_mean), p(running_var), p(nbt), _DT[pdt], float(momentum),
+                                                     float(eps), int(relu), stats[0].data_ptr(), stats[1].data_ptr(),
+                                                     records.data_ptr(), int(n_records), p(n_live),
+                                                     torch._C._cuda_getCurrentRawStream(dev.index)))
+            ctx.snap = False
+            ctx.save_for_backward(x, weight, bias, stats[0], stats[1])
+            ctx.training, ctx.relu, ctx.pdt, ctx.n_live, ctx.eps = True, bool(relu), pdt, n_live, float(eps)
+            return y
+        ws = torch.empty((max(L.spx_batchnorm_ws_bytes(n, C), 16),), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             _lib.check(L.spx_batchnorm_fwd(x.data_ptr(), y.data_ptr(), n, C, _DT[x.dtype], p(weight), p(bias),
                                            p(running_mean), p(running_var), p(nbt), _DT[pdt], int(training), float(momentum),
@@ -105,14 +118,16 @@ class _BatchNormFn(torch.autograd.Function):
                                            p(bias), _DT[ctx.pdt], mean.data_ptr(), invstd.data_ptr(),
                                            int(ctx.training), int(ctx.relu), p(dw), p(db), ws.data_ptr(), ws.numel(),
                                            p(ctx.n_live), torch._C._cuda_getCurrentRawStream(dev.index)))
-        return dx, dw, db, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
 
 
 def batch_norm(features: torch.Tensor, bn: nn.BatchNorm1d, relu: bool = False,
-               n_live: Optional[torch.Tensor] = None) -> torch.Tensor:
+               n_live: Optional[torch.Tensor] = None, stats=None) -> torch.Tensor:
     """``relu(bn(features))`` (relu optional) with torch.nn.BatchNorm1d's bookkeeping.  n_live: device
     int32 scalar of a static-shape tensor (spconv_amd/pytorch/static.py) -- statistics over the first
-    n_live rows, the padding rows come out as zeros in both directions."""
+    n_live rows, the padding rows come out as zeros in both directions.  stats: an ``ops.StatsSink`` the convolution
+    that produced `features` filled from its epilogue (per-workgroup {rows, mean, M2} records of exactly these rows);
+    the statistics pass over the rows is then skipped."""
     momentum = 0.0 if bn.momentum is None else bn.momentum
     nbt = None
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
@@ -127,6 +142,10 @@ def batch_norm(features: torch.Tensor, bn: nn.BatchNorm1d, relu: bool = False,
     update = bn.training and bn.track_running_stats
     differentiable = torch.is_grad_enabled() and any(t is not None and t.requires_grad
                                                      for t in (features, bn.weight, bn.bias))
+    records, n_records = None, 0
+    if (stats is not None and stats.records is not None and use_batch and stats.rows == features.shape[0]
+            and stats.channels == features.shape[1] and stats.n_live is n_live):
+        records, n_records = stats.records, stats.count
     return _BatchNormFn.apply(features, bn.weight, bn.bias, bn.running_mean if (update or not use_batch) else None,
                               bn.running_var if (update or not use_batch) else None, use_batch, momentum, bn.eps,
-                              relu, nbt, n_live, differentiable)
+                              relu, nbt, n_live, differentiable, records, n_records)

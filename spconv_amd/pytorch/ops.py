@@ -133,6 +133,37 @@ def output_stays_cached():
         _out_policy.cached = prev
 
 
+# BatchNorm statistics out of the convolution's epilogue (include/spconv_amd.h: spx_igemm_fwd_stats).  SparseSequential
+# opens `collect_bn_stats()` around a training-mode convolution that a plain BatchNorm1d follows; the first plain
+# igemm_fwd inside it (no bias, no activation, kernel volume <= 32, MFMA shapes) leaves the per-workgroup {rows, mean, M2}
+# records in the sink, and norm.batch_norm starts at its merge step.  Anything else leaves the sink empty and the
+# normalisation layer runs its own statistics pass.  SPCONV_AMD_BN_EPILOGUE=0 switches it off.
+BN_EPILOGUE = os.environ.get("SPCONV_AMD_BN_EPILOGUE", "1") != "0"
+_stats_req = threading.local()
+
+
+class StatsSink:
+    __slots__ = ("n_live", "records", "count", "rows", "channels")
+
+    def __init__(self):
+        self.n_live, self.records, self.count, self.rows, self.channels = None, None, 0, 0, 0
+
+
+@contextlib.contextmanager
+def collect_bn_stats():
+    sink = StatsSink()
+    prev = getattr(_stats_req, "sink", None)
+    _stats_req.sink = sink
+    try:
+        yield sink
+    finally:
+        _stats_req.sink = prev
+
+
+def current_stats_sink() -> Optional[StatsSink]:
+    return getattr(_stats_req, "sink", None)
+
+
 def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=device)
 
@@ -839,6 +870,21 @@ def igemm_fwd(features: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
     if bias is not None:
         bias = bias.to(features.dtype).contiguous()
     ws = _ws(L.spx_igemm_acc_bytes(n_out, K, kv), features.device) if kv > 32 else None   # fp32 partial sums
+    sink = getattr(_stats_req, "sink", None)
+    if (sink is not None and sink.records is None and bias is None and int(act_type) == Activation.None_
+            and K == K0 and kv <= 32 and n_out > 0):
+        slots = int(L.spx_igemm_fwd_stats_slots(n_out))
+        records = torch.empty((slots, 3, K), dtype=torch.float32, device=features.device)
+        used = ctypes.c_int(0)
+        _lib.check(L.spx_igemm_fwd_stats(features.data_ptr(), filters.data_ptr(), out.data_ptr(),
+                                         _ptr(pair), _ptr(mask), _ptr(argsort), _with_dense_hint(int(tile_order), argsort),
+                                         features.shape[0], n_out, C, K, kv, _dtype_code(features), identity_k, None,
+                                         int(act_type) | (_OUT_CACHED if getattr(_out_policy, "cached", False) else 0),
+                                         float(act_alpha), None, 0, records.data_ptr(), slots, _ptr(sink.n_live),
+                                         ctypes.byref(used), _stream(features)))
+        if used.value > 0:
+            sink.records, sink.count, sink.rows, sink.channels = records, int(used.value), n_out, K
+        return out
     _lib.check(L.spx_igemm_fwd(features.data_ptr(), filters.data_ptr(), out.data_ptr(),
                                _ptr(pair), _ptr(mask), _ptr(argsort), _with_dense_hint(int(tile_order), argsort),
                                features.shape[0], n_out, C, K, kv, _dtype_code(features), identity_k, _ptr(bias),

@@ -170,3 +170,142 @@ def test_batchnorm_over_the_live_rows_of_a_static_tensor(cuda, dtype, tol, n, li
     for a, b in ((bn.weight.grad, ref.weight.grad), (bn.bias.grad, ref.bias.grad),
                  (bn.running_mean, ref.running_mean), (bn.running_var, ref.running_var)):
         assert float((a.float() - b.float()).abs().max()) <= 1e-3 * max(float(b.float().abs().max()), 1.0)
+
+
+def _conv_bn(spconv, cin, cout, dev, dtype, subm=True):
+    torch.manual_seed(cin * 1000 + cout)
+    conv = (spconv.SubMConv3d(cin, cout, 3, bias=False, indice_key="k") if subm
+            else spconv.SparseConv3d(cin, cout, 3, 2, 1, bias=False, indice_key="d"))
+    net = spconv.SparseSequential(conv, nn.BatchNorm1d(cout, eps=1e-3, momentum=0.01), nn.ReLU()).to(dev)
+    with torch.no_grad():
+        net[1].weight.uniform_(0.5, 1.5)
+        net[1].bias.uniform_(-0.5, 0.5)
+    return net.to(dtype).train()
+
+
+@pytest.mark.parametrize("cin,cout,n_per,shape,subm,dtype,tol", [
+    (16, 16, 6000, [24, 40, 40], True, torch.float16, 2e-3),       # igemm_v4_kernel<16>: dense-ish neighbourhoods
+    (16, 32, 6000, [24, 40, 40], False, torch.float16, 2e-3),      # strided layer (its own output rows)
+    (32, 32, 50_000, [40, 400, 400], True, torch.float16, 2e-3),   # 100 k uniform rows: rows layout, appendix workgroups
+    (64, 64, 50_000, [40, 400, 400], True, torch.bfloat16, 1.6e-2),
+    (64, 128, 4000, [24, 40, 40], True, torch.float16, 2e-3),      # 128 output channels (64-row tiles)
+    (8, 16, 5000, [24, 40, 40], True, torch.float32, 5e-5),        # fp32 MFMA path
+])
+def test_conv_epilogue_statistics_feed_the_batchnorm(cuda, monkeypatch, cin, cout, n_per, shape, subm, dtype, tol):
+    """BatchNorm statistics out of the producing convolution's epilogue (spx_igemm_fwd_stats ->
+    spx_batchnorm_fwd_stats).  The reference hands `.features` to torch's BatchNorm1d (spconv/pytorch/modules.py:127-168),
+    which is the oracle here: y, every gradient and the running estimates against nn.BatchNorm1d in fp32 over the
+    convolution's (rounded) output, with the statistics taken (a) from the epilogue records and (b) -- the same numbers
+    up to summation order -- from the normalisation layer's own pass (SPCONV_AMD_BN_EPILOGUE=0)."""
+    import spconv_amd.pytorch as spconv
+    from spconv_amd.pytorch import norm, ops
+    from util import scene
+    bs = 2
+    idx = torch.from_numpy(scene(shape, n_per, bs, seed=cin + cout)).to(cuda)
+    n = idx.shape[0]
+    f = (torch.randn(n, cin, device=cuda) * 0.7).to(dtype)
+    net = _conv_bn(spconv, cin, cout, cuda, dtype, subm)
+    used = []
+    real = norm._BatchNormFn.apply
+
+    def spy(*a):
+        used.append(a[12] is not None)
+        return real(*a)
+    monkeypatch.setattr(norm._BatchNormFn, "apply", spy)
+
+    def run(model, on):
+        monkeypatch.setattr(ops, "BN_EPILOGUE", on)
+        model.zero_grad(set_to_none=True)
+        fe = f.clone().requires_grad_(True)
+        y = model(spconv.SparseConvTensor(fe, idx, shape, bs))
+        g = torch.ones_like(y.features) * 0.01 + (torch.arange(y.features.shape[1], device=cuda) % 3).to(dtype) * 0.01
+        y.features.backward(g)
+        torch.cuda.synchronize()
+        return y.features.detach().float(), fe.grad.float(), g
+
+    ref_net = copy.deepcopy(net)
+    y_on, din_on, g = run(net, True)
+    y_off, din_off, _ = run(ref_net, False)
+    assert used == [True, False]
+    # both against torch's BatchNorm1d in fp32 on the convolution's own output
+    with torch.no_grad():
+        conv_out = net[0](spconv.SparseConvTensor(f, idx, shape, bs)).features.float()
+    bn32 = nn.BatchNorm1d(cout, eps=1e-3, momentum=0.01).to(cuda).train()
+    with torch.no_grad():
+        bn32.weight.copy_(ref_net[1].weight.float())
+        bn32.bias.copy_(ref_net[1].bias.float())
+    y_ref = torch.relu(bn32(conv_out)).detach()
+    scale = float(y_ref.abs().max())
+    assert float((y_on - y_ref).abs().max()) <= tol * scale
+    assert float((y_off - y_ref).abs().max()) <= tol * scale
+    assert float((y_on - y_off).abs().max()) <= tol * scale
+    assert float((din_on - din_off).abs().max()) <= 2 * tol * float(din_off.abs().max())
+    for a, b in zip(net.parameters(), ref_net.parameters()):
+        assert float((a.grad.float() - b.grad.float()).norm()) <= 2 * tol * float(b.grad.float().norm()) + 1e-7
+    for name in ("running_mean", "running_var"):
+        a, b = getattr(net[1], name).float(), getattr(bn32, name)
+        assert torch.allclose(a, b, rtol=max(tol, 1e-3), atol=max(tol, 1e-3) * 0.1), name
+    assert int(net[1].num_batches_tracked) == 1
+
+
+def test_conv_epilogue_statistics_over_the_live_rows_of_a_static_tensor(cuda, monkeypatch):
+    """Static shapes: padding rows (batch -1) behind the scene are dead rows of the convolution (zero output) and must
+    not be counted -- the records' row counts follow `n_live`; a captured training step equals the eager one."""
+    import spconv_amd.pytorch as spconv
+    from spconv_amd.pytorch import ops
+    from spconv_amd.pytorch.static import StaticTrainingStep
+    from util import scene
+    shape, bs = [24, 40, 40], 2
+    torch.manual_seed(2)
+    net = spconv.SparseSequential(
+        spconv.SubMConv3d(8, 16, 3, bias=False, indice_key="s"), nn.BatchNorm1d(16), nn.ReLU(),
+        spconv.SparseConv3d(16, 32, 3, 2, 1, bias=False, indice_key="d"), nn.BatchNorm1d(32), nn.ReLU(),
+        spconv.SubMConv3d(32, 32, 3, bias=False, indice_key="s2"), nn.BatchNorm1d(32)).to(cuda).float().train()
+    eager = copy.deepcopy(net)
+    idx = torch.from_numpy(scene(shape, 3000, bs, seed=4)).to(cuda)
+    n = idx.shape[0]
+    f = torch.randn(n, 8, device=cuda)
+    ye = eager(spconv.SparseConvTensor(f.clone().requires_grad_(True), idx, shape, bs))
+    g = torch.randn(ye.features.shape[0] + 700, 32, device=cuda) * 0.1
+    ye.features.backward(g[:ye.features.shape[0]])
+    step = StaticTrainingStep(net, n + 900, 8, shape, bs, torch.float32, bounds={"3": ye.features.shape[0] + 700},
+                              out_grad=g, example=(f, idx))
+    out = step(f, idx)
+    k = ye.features.shape[0]
+    assert int(out.n_live_dev) == k
+    assert float((out.features[:k] - ye.features).abs().max()) <= 2e-5 * float(ye.features.abs().max())
+    assert bool((out.features[k:] == 0).all())
+    for (name, a), b in zip(net.named_parameters(), eager.parameters()):
+        assert float((a.grad - b.grad).norm()) <= 5e-4 * float(b.grad.norm()) + 1e-8, name
+    for a, b in zip(net.buffers(), eager.buffers()):
+        if a.dtype.is_floating_point:
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+
+
+def test_conv_epilogue_statistics_from_the_weight_stationary_kernel(cuda, monkeypatch):
+    """Dense C = K = 64 layers take igemm_ws_kernel (512-row workgroups): its epilogue leaves the same records.  Forced
+    with SPX_WS=1; the outputs of the two-launch normalisation equal the three-launch one within the rounding of y."""
+    import spconv_amd.pytorch as spconv
+    from spconv_amd import _lib
+    from spconv_amd.pytorch import ops
+    from util import scene
+    L = _lib.load()
+    shape, bs = [24, 64, 64], 1
+    idx = torch.from_numpy(scene(shape, 40_001, bs, seed=3)).to(cuda)
+    n = idx.shape[0]
+    f = (torch.randn(n, 64, device=cuda) * 0.5).half()
+    net = _conv_bn(spconv, 64, 64, cuda, torch.float16)
+    ref = copy.deepcopy(net)
+    before = L.spx_launch_count(b"igemm_ws")
+    L.spx_set_option(b"SPX_WS", 1)
+    try:
+        monkeypatch.setattr(ops, "BN_EPILOGUE", True)
+        y_on = net(spconv.SparseConvTensor(f, idx, shape, bs)).features
+        monkeypatch.setattr(ops, "BN_EPILOGUE", False)
+        y_off = ref(spconv.SparseConvTensor(f, idx, shape, bs)).features
+        torch.cuda.synchronize()
+    finally:
+        L.spx_set_option(b"SPX_WS", -1)
+    assert L.spx_launch_count(b"igemm_ws") - before == 2
+    assert float((y_on.float() - y_off.float()).abs().max()) <= 2e-3 * float(y_off.float().abs().max())
+    assert torch.allclose(net[1].running_var, ref[1].running_var, rtol=1e-3, atol=1e-4)

@@ -282,9 +282,11 @@ def test_static_training_step_fp32_is_a_bound_not_a_noise_floor(cuda):
 def test_config4_network_captured_step_equals_eager_in_fp32(cuda):
     """The BASELINE config-4 network itself (spconv_amd.utils.nets.second_backbone: 12 sparse convolutions, 12
     BatchNorm1d + ReLU, the p = (0, 1, 1) and (3, 1, 1) / (2, 1, 1) layers) as ONE captured training step against the
-    eager, unbounded step -- in fp32, where the comparison is a bound and not a noise floor (bench.py
-    accepts the fp16 step against a self-permutation floor).  Output 1e-5, every parameter gradient 5e-4 (twelve
-    normalisation layers deep; summation orders of the statistics and of the weight-gradient ranges differ)."""
+    eager step -- in fp32, where the comparison is a bound and not a noise floor (bench.py accepts the
+    fp16 step against a self-permutation floor).  Two references: (a) the same static-shape pass run eagerly -- every
+    gradient BIT FOR BIT; (b) the eager UNBOUNDED step -- output 1e-5, gradients within the bound of one flipped ReLU
+    mask (see the comment at (b): round 6 found the former 5e-4 bar to hold only while no pre-ReLU value of the ~1 M in
+    the network sits within 1e-6 of zero, which depends on how the two passes tile their BatchNorm statistics)."""
     import spconv_amd.pytorch as spconv
     from spconv_amd.pytorch.static import StaticTrainingStep, strided_layers
     from spconv_amd.utils import nets
@@ -313,11 +315,29 @@ def test_config4_network_captured_step_equals_eager_in_fp32(cuda):
     n_out = ye.features.shape[0]
     assert n_out == n_last and int(out.n_live_dev) == n_out and torch.equal(out.indices[:n_out], ye.indices)
     ye.features.backward(g[:n_out])
-    err = float((out.features[:n_out] - ye.features).abs().max() / ye.features.abs().max())
+    err = float((out.features[:n_out] - ye.features).abs().max() / ye.features.detach().abs().max())
     assert err < 1e-5, err
+    # (a) the captured step against the SAME static-shape pass run eagerly (padded input, frozen bounds, live-row
+    # counts on the device): the same launches on the same rows -- every gradient bit for bit
+    twin = copy.deepcopy(net)                      # (carries the frozen bounds; its own .grad tensors)
+    twin.zero_grad(set_to_none=True)
+    xs = spconv.SparseConvTensor(step.features.detach().clone(), step.indices.clone(), shape, bs)
+    xs.n_live_dev = step.n_live
+    ys = twin(xs)
+    ys.features.backward(g)
+    torch.cuda.synchronize()
+    assert torch.equal(ys.features, out.features)
+    for (name, pa), pb in zip(net.named_parameters(), twin.parameters()):
+        assert torch.equal(pa.grad, pb.grad), name
+    # (b) against the eager UNBOUNDED step.  The two passes tile the rows differently (padding rows, bounded levels), so
+    # their BatchNorm statistics differ in the last bit (merge order) and every activation by ~1e-6: outputs agree to
+    # 1e-5 (above).  Gradients are smooth in that EXCEPT where a pre-ReLU value sits within 1e-6 of zero and its mask
+    # flips: one flipped element of ~1 M moves the sums behind it -- sums of a zero-mean gradient through twelve
+    # normalisation layers, small against their terms -- by ~1 % (measured: 1 flip of 84 480 elements at |y| = 1.8e-6
+    # -> 0.8 % in 0.weight; without a flip 3e-6).  Hence the bound here is the flip bound, and (a) is the sharp one.
     for (name, pa), pb in zip(net.named_parameters(), eager.parameters()):
         rel = float((pa.grad - pb.grad).norm() / pb.grad.norm().clamp_min(1e-20))
-        assert rel < 5e-4, (name, rel)
+        assert rel < 3e-2, (name, rel)
 
 
 @pytest.mark.parametrize("pool", [False, True])
