@@ -75,6 +75,12 @@ int spx_set_option(const char *name_h, int value);
  * when the choice depends on an asynchronously read density class.  Host only. */
 long long spx_launch_count(const char *family_h);
 
+/* dst[r] = src[r] followed by zeros: rows of src_row_bytes bytes widened to dst_row_bytes (both even), one launch.  The
+ * channel padding of layers whose widths the MFMA kernels are not instantiated for (the 3-5 channel first layer of a
+ * voxel backbone: the reference pads nothing and tunes a kernel per shape, csrc/sparse/convops.py:919-1466). */
+int spx_pad_rows(const void *src, void *dst, long long rows, int src_row_bytes, int dst_row_bytes,
+                 spx_stream_t stream);
+
 /* ops.get_conv_output_size / get_deconv_output_size (pytorch/ops.py:73-96). Host only. */
 int spx_conv_out_shape(int ndim, const int *in_shape, const int *ksize, const int *stride,
                        const int *padding, const int *dilation, const int *out_padding,

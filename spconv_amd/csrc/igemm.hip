@@ -804,6 +804,22 @@ GemmParams dgrad_params(const void *dout, const void *weight, void *din, const i
 
 using namespace spx;
 
+namespace spx {
+namespace {
+// rows of `sw` 16-bit words copied into rows of `dw` >= sw words, the tail zero-filled: the channel padding of a layer
+// whose width the MFMA kernels are not instantiated for (a backbone's 3-5 channel first layer) in ONE launch -- torch's
+// pad is a fill and a copy
+__global__ void __launch_bounds__(kThreads)
+pad_rows_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, long long total, int sw, int dw) {
+  const long long i = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x;
+  if (i >= total) return;
+  const long long r = i / dw;
+  const int c = static_cast<int>(i - r * dw);
+  dst[i] = c < sw ? src[r * sw + c] : static_cast<uint16_t>(0);
+}
+}  // namespace
+}  // namespace spx
+
 extern "C" {
 
 size_t spx_igemm_acc_bytes(int n_dst, int cout, int kv) {
@@ -1218,6 +1234,20 @@ int spx_bias_act_inplace(void *out, const void *bias, int n, int K, int dtype, i
                        static_cast<const b16 *>(bias), total, K, act, act_alpha);
   else
     SPX_CHECK(false, "unsupported dtype %d", dtype);
+  SPX_LAUNCH_CHECK();
+  return 0;
+}
+
+int spx_pad_rows(const void *src, void *dst, long long rows, int src_row_bytes, int dst_row_bytes,
+                 spx_stream_t stream) {
+  SPX_CHECK(src_row_bytes > 0 && dst_row_bytes >= src_row_bytes && src_row_bytes % 2 == 0 && dst_row_bytes % 2 == 0,
+            "row sizes must be even, destination rows at least as long as source rows");
+  if (rows <= 0) return 0;
+  SPX_CHECK(src && dst, "null tensor pointer");
+  const long long total = rows * (dst_row_bytes / 2);
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(static_cast<unsigned>((total + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const uint16_t *>(src), static_cast<uint16_t *>(dst),
+                     total, src_row_bytes / 2, dst_row_bytes / 2);
   SPX_LAUNCH_CHECK();
   return 0;
 }

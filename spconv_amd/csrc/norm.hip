@@ -233,12 +233,16 @@ bn_partial_kernel(const u32x4 *__restrict__ x, int n, int C, float *__restrict__
   }
 }
 
-// one block per channel: Chan merge of the G partials; mean / invstd out, running estimates updated
-__global__ void __launch_bounds__(kT)
+// one block per channel: Chan merge of the G partials; mean / invstd out, running estimates updated.  T threads: 256
+// for the normalisation layer's own statistics pass (G <= 1024 records), 1024 for the records a convolution's epilogue
+// leaves (one per workgroup of that launch: ~3900 at 400 k rows -- four trips per thread instead of sixteen)
+template <int T>
+__global__ void __launch_bounds__(T)
 bn_finalize_kernel(const float *__restrict__ partial, int G, int C, float eps, float momentum,
                    float *__restrict__ mean_out, float *__restrict__ invstd_out,
                    void *__restrict__ running_mean, void *__restrict__ running_var, int pdt,
                    long long *__restrict__ num_batches_tracked) {
+  constexpr int kT = T;
   __shared__ float ln[kT], lm[kT], l2[kT];
   const int c = blockIdx.x;
   if (num_batches_tracked && c == 0 && threadIdx.x == 0) *num_batches_tracked += 1;   // (no launch of its own)
@@ -515,8 +519,12 @@ static int batchnorm_fwd_impl(const void *x, void *y, int n, int C, int dtype, c
       SPX_BN_DISPATCH(dtype, SPX_BN_PARTIAL);
 #undef SPX_BN_PARTIAL
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(kT), 0, s, partial, G, C, eps, momentum, save_mean,
-                       save_invstd, running_mean, running_var, param_dtype, num_batches_tracked);
+    if (G > 1024)
+      hipLaunchKernelGGL(bn_finalize_kernel<1024>, dim3(C), dim3(1024), 0, s, partial, G, C, eps, momentum, save_mean,
+                         save_invstd, running_mean, running_var, param_dtype, num_batches_tracked);
+    else
+      hipLaunchKernelGGL(bn_finalize_kernel<kT>, dim3(C), dim3(kT), 0, s, partial, G, C, eps, momentum, save_mean,
+                         save_invstd, running_mean, running_var, param_dtype, num_batches_tracked);
 #define SPX_BN_APPLY(D)                                                                                    \
   hipLaunchKernelGGL(bn_apply_kernel<D>, dim3(stream_grid(pieces)), dim3(kT), 0, s, xv, yv, pieces, C,     \
                      static_cast<const void *>(save_mean), static_cast<const void *>(save_invstd), weight,  \

@@ -829,7 +829,20 @@ def _round_cout(c: int) -> int:
 
 
 def _pad_last(t: torch.Tensor, to: int) -> torch.Tensor:
-    return t if t.shape[-1] == to else torch.nn.functional.pad(t, (0, to - t.shape[-1]))
+    """Last dimension zero-padded to `to` entries: one launch of spx_pad_rows for contiguous CUDA tensors of 2- / 4-byte
+    elements outside autograd (torch's pad is a fill + a copy: 4 of the ~190 launches of a backbone step went there)."""
+    if t.shape[-1] == to:
+        return t
+    if (t.is_cuda and t.is_contiguous() and t.element_size() in (2, 4) and t.numel() > 0
+            and not (torch.is_grad_enabled() and t.requires_grad)
+            and not t.is_quantized):
+        out = torch.empty(t.shape[:-1] + (to,), dtype=t.dtype, device=t.device)
+        es = t.element_size()
+        with torch.cuda.device(t.device):
+            _lib.check(_lib.load().spx_pad_rows(t.data_ptr(), out.data_ptr(), t.numel() // t.shape[-1],
+                                                t.shape[-1] * es, to * es, _stream(t)))
+        return out
+    return torch.nn.functional.pad(t, (0, to - t.shape[-1]))
 
 
 def _pad_first(t: torch.Tensor, to: int) -> torch.Tensor:
