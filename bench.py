@@ -841,9 +841,14 @@ def run_layer(args, D: Dist):
     # step.  With the engine single-threaded (torch.autograd.set_multithreading_enabled(False): backward on the calling
     # thread) six of six processes ran 76-77 us; pinning the process to two cores does the same
     # (profiles/r05_experiments.md section 8).  Both figures: the recipe's, and the default engine's (median of three).
+    # Round 6: importing spconv_amd.pytorch puts the engine on the calling thread in a process that drives ONE GPU
+    # (spconv_amd/pytorch/__init__.py: AUTOGRAD_ENGINE) -- the "default engine" runs below are what a drop-in user gets
+    # after the import; torch's own multi-threaded engine is measured explicitly beside it.
     with torch.autograd.set_multithreading_enabled(False):
         eager_runs_st = [event_time_ms(compute_eager, iters=200, warm=30) for _ in range(3)]
     eager_runs = [event_time_ms(compute_eager, iters=200, warm=30) for _ in range(3)]
+    with torch.autograd.set_multithreading_enabled(True):
+        eager_runs_mt = [event_time_ms(compute_eager, iters=200, warm=30) for _ in range(2)]
     t_eager = sorted(eager_runs_st)[1]
     del net_e, eager
     t_sort_dev = None
@@ -924,6 +929,8 @@ def run_layer(args, D: Dist):
                                          "median of three windows; default engine beside it",
         "eager_device_ms_per_step_runs": [round(v, 5) for v in eager_runs_st],
         "eager_device_ms_per_step_default_engine_runs": [round(v, 5) for v in eager_runs],
+        "eager_autograd_engine_after_import": spconv.AUTOGRAD_ENGINE,
+        "eager_device_ms_per_step_torch_multithreaded_engine_runs": [round(v, 5) for v in eager_runs_mt],
         "ms_per_step_one_step_per_replay": None if single_replay_ms is None else round(single_replay_ms, 5),
         "rulebook_ms": round(statistics.median(rule_ms), 4),
         "rulebook_device_ms": round(t_rule_dev, 4),

@@ -233,9 +233,7 @@ bn_partial_kernel(const u32x4 *__restrict__ x, int n, int C, float *__restrict__
   }
 }
 
-// one block per channel: Chan merge of the G partials; mean / invstd out, running estimates updated.  T threads: 256
-// for the normalisation layer's own statistics pass (G <= 1024 records), 1024 for the records a convolution's epilogue
-// leaves (one per workgroup of that launch: ~3900 at 400 k rows -- four trips per thread instead of sixteen)
+// one block per channel: Chan merge of the G partials; mean / invstd out, running estimates updated
 template <int T>
 __global__ void __launch_bounds__(T)
 bn_finalize_kernel(const float *__restrict__ partial, int G, int C, float eps, float momentum,
@@ -247,15 +245,28 @@ bn_finalize_kernel(const float *__restrict__ partial, int G, int C, float eps, f
   const int c = blockIdx.x;
   if (num_batches_tracked && c == 0 && threadIdx.x == 0) *num_batches_tracked += 1;   // (no launch of its own)
   float n = 0.f, m = 0.f, M2 = 0.f;
-  for (int b = threadIdx.x; b < G; b += kT) {
-    const float nb = partial[static_cast<size_t>(b) * 3 * C + c];
-    const float mb = partial[static_cast<size_t>(b) * 3 * C + C + c];
-    const float Mb = partial[static_cast<size_t>(b) * 3 * C + 2 * C + c];
-    if (nb > 0.f) {
-      const float tot = n + nb, d = mb - m;
-      m += d * (nb / tot);
-      M2 += Mb + d * d * (n * nb / tot);
-      n = tot;
+  // eight records per trip: their 24 loads leave together, the merges follow (the records a convolution's epilogue
+  // leaves come one per workgroup of that launch -- ~3900 at 400 k rows: sixteen dependent trips per thread otherwise)
+  constexpr int U = 8;
+  for (int b0 = threadIdx.x; b0 < G; b0 += kT * U) {
+    float nb[U], mb[U], Mb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int b = b0 + u * kT;
+      const bool ok = b < G;
+      const size_t at = static_cast<size_t>(ok ? b : 0) * 3 * C + c;
+      nb[u] = ok ? partial[at] : 0.f;
+      mb[u] = ok ? partial[at + C] : 0.f;
+      Mb[u] = ok ? partial[at + 2 * C] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (nb[u] > 0.f) {
+        const float tot = n + nb[u], d = mb[u] - m;
+        m += d * (nb[u] / tot);
+        M2 += Mb[u] + d * d * (n * nb[u] / tot);
+        n = tot;
+      }
     }
   }
   ln[threadIdx.x] = n;
@@ -519,12 +530,8 @@ static int batchnorm_fwd_impl(const void *x, void *y, int n, int C, int dtype, c
       SPX_BN_DISPATCH(dtype, SPX_BN_PARTIAL);
 #undef SPX_BN_PARTIAL
     }
-    if (G > 1024)
-      hipLaunchKernelGGL(bn_finalize_kernel<1024>, dim3(C), dim3(1024), 0, s, partial, G, C, eps, momentum, save_mean,
-                         save_invstd, running_mean, running_var, param_dtype, num_batches_tracked);
-    else
-      hipLaunchKernelGGL(bn_finalize_kernel<kT>, dim3(C), dim3(kT), 0, s, partial, G, C, eps, momentum, save_mean,
-                         save_invstd, running_mean, running_var, param_dtype, num_batches_tracked);
+    hipLaunchKernelGGL(bn_finalize_kernel<kT>, dim3(C), dim3(kT), 0, s, partial, G, C, eps, momentum, save_mean,
+                       save_invstd, running_mean, running_var, param_dtype, num_batches_tracked);
 #define SPX_BN_APPLY(D)                                                                                    \
   hipLaunchKernelGGL(bn_apply_kernel<D>, dim3(stream_grid(pieces)), dim3(kT), 0, s, xv, yv, pieces, C,     \
                      static_cast<const void *>(save_mean), static_cast<const void *>(save_invstd), weight,  \

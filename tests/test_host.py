@@ -530,3 +530,30 @@ def test_sort_voxels_by_coordinate():
     assert i2.tolist() == [[0, 0, 0, 7], [0, 5, 1, 1], [1, 0, 2, 2], [1, 0, 2, 3]]
     assert f2.view(-1).tolist() == [2.0, 1.0, 3.0, 0.0] and order.tolist() == [2, 1, 3, 0]
     assert torch.equal(ind[order], i2)
+
+
+def test_autograd_engine_rule_of_the_package_import(monkeypatch):
+    """after `import spconv_amd.pytorch` a process that drives one GPU (or runs under a launcher) has
+    its autograd backward on the calling thread -- the fast eager state is the default, not a recipe --, a process that
+    sees several GPUs keeps torch's engine and is told once, and SPCONV_AMD_AUTOGRAD_THREADS=keep never touches it."""
+    import warnings
+    import torch
+    import spconv_amd.pytorch as spconv
+    calls = []
+    monkeypatch.setattr(torch.autograd, "set_multithreading_enabled", lambda v: calls.append(v))
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+    monkeypatch.delenv("SPCONV_AMD_AUTOGRAD_THREADS", raising=False)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    assert spconv._autograd_on_the_calling_thread() == "calling thread" and calls == [False]
+    calls.clear()
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert spconv._autograd_on_the_calling_thread() == "kept" and calls == []
+    assert len(w) == 1 and "set_multithreading_enabled" in str(w[0].message)
+    monkeypatch.setenv("LOCAL_RANK", "3")                     # torchrun: one process per GPU
+    assert spconv._autograd_on_the_calling_thread() == "calling thread" and calls == [False]
+    calls.clear()
+    monkeypatch.setenv("SPCONV_AMD_AUTOGRAD_THREADS", "keep")
+    assert spconv._autograd_on_the_calling_thread() == "kept" and calls == []

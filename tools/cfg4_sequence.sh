@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 mkdir -p $O
 for cfg in 4 4i; do
-  (cd /tmp && SPCONV_AMD_PREFETCH=${PREFETCH:-0} timeout 300 rocprofv3 --kernel-trace --output-format csv -d $R/$O/seq_${T}_cfg$cfg -o bench -- python $R/bench.py --config $cfg --steps 12 --warmup 4 --no-cpu-baseline > $R/$O/${T}_cfg${cfg}_seq.log 2>&1)
+  (cd /tmp && SPCONV_AMD_PREFETCH=${PREFETCH:-0} timeout 300 rocprofv3 --kernel-trace --output-format csv -d $R/$O/seq_${T}_cfg$cfg -o bench -- python $R/bench.py --config $cfg --steps 12 --warmup 4 --no-cpu-baseline ${BENCH_EXTRA} > $R/$O/${T}_cfg${cfg}_seq.log 2>&1)
   f=$(find $O/seq_${T}_cfg$cfg -name "*kernel_trace.csv" | head -1)
   [ -n "$f" ] && { echo "# tree: $(cat BUILD_STAMP 2>/dev/null || echo unknown: run through tools/grun.sh)"; python tools/step_sequence.py "$f"; } > $O/${T}_cfg${cfg}_sequence.txt 2>&1
   find $O/seq_${T}_cfg$cfg -name "*.csv" -delete
