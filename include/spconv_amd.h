@@ -240,6 +240,10 @@ int spx_subm_rulebook_ranked(const int32_t *indices, int n, int ndim, int batch_
 size_t spx_mask_argsort_ws_bytes(int n);
 int spx_mask_argsort(const uint32_t *mask, int n, int words, int32_t *argsort,
                      void *ws, size_t ws_bytes, spx_stream_t stream);
+/* The same sort when the caller knows the kernel volume: only the low kv bits of a mask word can be set, so the sort
+ * runs ceil(kv / 9) or ceil(kv / 8) digit passes instead of four (27 offsets: three). */
+int spx_mask_argsort_kv(const uint32_t *mask, int n, int kv, int32_t *argsort, void *ws, size_t ws_bytes,
+                        spx_stream_t stream);
 
 /* Layout conversions for callers that hold only one of the two rulebook forms
  * (the reference's public ops take either the Native lists, pytorch/ops.py:811-988,

@@ -74,6 +74,7 @@ SIGNATURES = {
                                          vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_size_t, vp, vp]),
     "spx_mask_argsort_ws_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "spx_mask_argsort": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_size_t, vp]),
+    "spx_mask_argsort_kv": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_size_t, vp]),
     "spx_native_to_table": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 5 + [vp, vp, vp]),
     "spx_table_to_native_ws_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "spx_table_to_native": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp,

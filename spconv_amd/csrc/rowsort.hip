@@ -9,19 +9,27 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kSortItems = 512;               // entries per block of a radix pass (>= 256 blocks at 128 k rows)
-constexpr int kRadixBits = 8, kRadix = 1 << kRadixBits;
 
-__global__ void __launch_bounds__(kBlock)
+// Digits of BITS = 8 or 9 bits, R = 2^BITS bins, R threads per workgroup.  Round 6: 9-bit digits where they save a
+// pass -- the mask words of a 3x3x3 kernel carry 27 bits: three passes (nine launches) instead of four (twelve); at
+// 100-125 k keys a launch of this sort sits at its ~3 us floor, so the sort goes 37-39 -> 28-30 us.  (A one-launch-per-
+// pass form -- tiles handing their digit counts to each other through {status, value} words, decoupled look-back -- was
+// built and measured at 39-43 us: on this chip a cross-workgroup hand-over inside a launch goes through memory-side
+// atomics at ~1 us per hop, which costs more than the kernel boundaries it removes; profiles/r06_experiments.md.)
+template <int BITS>
+__global__ void __launch_bounds__(1 << BITS)
 radix_count_kernel(const uint32_t *__restrict__ keys, int n, int shift, int nblk,
-                        int32_t *__restrict__ hist /*[kRadix][nblk]*/) {
-  __shared__ int lds_hist[kRadix];
+                   int32_t *__restrict__ hist /*[R][nblk]*/) {
+  constexpr int R = 1 << BITS, T = R;
+  __shared__ int lds_hist[R];
   lds_hist[threadIdx.x] = 0;
   __syncthreads();
   const int begin = blockIdx.x * kSortItems;
 #pragma unroll
-  for (int it = 0; it < kSortItems / kBlock; ++it) {
-    const int e = begin + it * kBlock + threadIdx.x;
-    if (e < n) atomicAdd(&lds_hist[(keys[e] >> shift) & (kRadix - 1)], 1);
+  for (int it = 0; it < (kSortItems + T - 1) / T; ++it) {
+    const int e = begin + it * T + threadIdx.x;
+    if (e < n && it * T + static_cast<int>(threadIdx.x) < kSortItems)
+      atomicAdd(&lds_hist[(keys[e] >> shift) & (R - 1)], 1);
   }
   __syncthreads();
   hist[static_cast<size_t>(threadIdx.x) * nblk + blockIdx.x] = lds_hist[threadIdx.x];
@@ -62,18 +70,20 @@ radix_scan_kernel(const int32_t *__restrict__ hist, int32_t *__restrict__ off, i
 }
 
 // stable scatter of one pass; the base of a digit = (entries of smaller digits) + (entries of this
-// digit in earlier blocks); inside a 256-entry group the rank among equal digits comes from a
+// digit in earlier blocks); inside a T-entry group the rank among equal digits comes from a
 // bitwise match over wave ballots
-__global__ void __launch_bounds__(kBlock)
+template <int BITS>
+__global__ void __launch_bounds__(1 << BITS)
 radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const int32_t *__restrict__ vals_in,
-                          int n, int shift, int nblk, const int32_t *__restrict__ hist_off,
-                          const int32_t *__restrict__ totals, uint32_t *__restrict__ keys_out,
-                          int32_t *__restrict__ vals_out) {
-  __shared__ int lds_base[kRadix];
-  __shared__ int lds_cnt[kBlock / 64][kRadix];
-  __shared__ int lds_wave[kBlock / 64];
+                     int n, int shift, int nblk, const int32_t *__restrict__ hist_off,
+                     const int32_t *__restrict__ totals, uint32_t *__restrict__ keys_out,
+                     int32_t *__restrict__ vals_out) {
+  constexpr int R = 1 << BITS, T = R, NW = T / 64;
+  __shared__ int lds_base[R];
+  __shared__ int lds_cnt[NW][R];
+  __shared__ int lds_wave[NW];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  {   // exclusive scan of the 256 digit totals
+  {   // exclusive scan of the R digit totals
     const int v = totals[threadIdx.x];
     int incl = v;
 #pragma unroll
@@ -85,23 +95,23 @@ radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const int32_t *__rest
     __syncthreads();
     int prefix = 0;
 #pragma unroll
-    for (int w = 0; w < kBlock / 64; ++w)
+    for (int w = 0; w < NW; ++w)
       if (w < wave) prefix += lds_wave[w];
     lds_base[threadIdx.x] = prefix + incl - v + hist_off[static_cast<size_t>(threadIdx.x) * nblk + blockIdx.x];
   }
   const int begin = blockIdx.x * kSortItems;
-  for (int it = 0; it < kSortItems / kBlock; ++it) {
+  for (int it = 0; it < (kSortItems + T - 1) / T; ++it) {
 #pragma unroll
-    for (int w = 0; w < kBlock / 64; ++w) lds_cnt[w][threadIdx.x] = 0;
+    for (int w = 0; w < NW; ++w) lds_cnt[w][threadIdx.x] = 0;
     __syncthreads();
-    const int e = begin + it * kBlock + threadIdx.x;
-    const bool valid = e < n;
+    const int e = begin + it * T + threadIdx.x;
+    const bool valid = e < n && it * T + static_cast<int>(threadIdx.x) < kSortItems;
     const uint32_t key = valid ? keys_in[e] : 0u;
     const int val = valid ? (vals_in ? vals_in[e] : e) : 0;
-    const int digit = valid ? static_cast<int>((key >> shift) & (kRadix - 1)) : -1;
+    const int digit = valid ? static_cast<int>((key >> shift) & (R - 1)) : -1;
     unsigned long long same = __ballot(valid);
 #pragma unroll
-    for (int bit = 0; bit < kRadixBits; ++bit) {
+    for (int bit = 0; bit < BITS; ++bit) {
       const unsigned long long bal = __ballot((digit >> bit) & 1);
       same &= ((digit >> bit) & 1) ? bal : ~bal;
     }
@@ -111,7 +121,7 @@ radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const int32_t *__rest
     if (valid) {
       int prior = 0;
 #pragma unroll
-      for (int w = 0; w < kBlock / 64; ++w)
+      for (int w = 0; w < NW; ++w)
         if (w < wave) prior += lds_cnt[w][digit];
       const int dst = lds_base[digit] + prior + rank_in_wave;
       keys_out[dst] = key;
@@ -121,7 +131,7 @@ radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const int32_t *__rest
     {
       int sum = 0;
 #pragma unroll
-      for (int w = 0; w < kBlock / 64; ++w) sum += lds_cnt[w][threadIdx.x];
+      for (int w = 0; w < NW; ++w) sum += lds_cnt[w][threadIdx.x];
       lds_base[threadIdx.x] += sum;
     }
     __syncthreads();
@@ -148,35 +158,47 @@ permute_tables_kernel(const int32_t *__restrict__ pair, const uint32_t *__restri
 size_t radix_argsort_ws_bytes(int n_in) {
   const size_t n = n_in > 0 ? n_in : 1;
   const size_t nblk = (n + kSortItems - 1) / kSortItems;
-  return 2 * align_up(n * 4, 256) + 2 * align_up(n * 4, 256) + 2 * align_up(kRadix * nblk * 4, 256) +
-         align_up(kRadix * 4, 256) + 256;
+  return 2 * align_up(n * 4, 256) + 2 * align_up(n * 4, 256) + 2 * align_up(512 * nblk * 4, 256) +
+         align_up(512 * 4, 256) + 256;
 }
 
+namespace {
+template <int BITS>
+void radix_pass(const uint32_t *kin, const int32_t *vin, int n, int shift, int nblk, int32_t *hist, int32_t *hist_off,
+                int32_t *totals, uint32_t *kout, int32_t *vout, hipStream_t s) {
+  constexpr int R = 1 << BITS;
+  hipLaunchKernelGGL(radix_count_kernel<BITS>, dim3(nblk), dim3(R), 0, s, kin, n, shift, nblk, hist);
+  hipLaunchKernelGGL(radix_scan_kernel, dim3(R), dim3(kBlock), 0, s, hist, hist_off, nblk, totals);
+  hipLaunchKernelGGL(radix_scatter_kernel<BITS>, dim3(nblk), dim3(R), 0, s, kin, vin, n, shift, nblk, hist_off, totals,
+                     kout, vout);
+}
+}  // namespace
+
 // Stable LSD radix argsort of n 32-bit keys on their low `nbits` bits: order_out[t] = index of the
-// t-th smallest key.  8-bit digits, three launches per pass (count, per-digit scan, scatter), all
-// of them wide (>= n / 512 workgroups).  `keys` is not modified.
+// t-th smallest key.  Three launches per pass (count, per-digit scan, scatter), all of them wide (>= n / 512
+// workgroups); 9-bit digits when that saves a pass (nbits = 27: three passes), 8-bit otherwise.  `keys` is not modified.
 int radix_argsort(const uint32_t *keys, int n, int nbits, int32_t *order_out, void *ws, hipStream_t s) {
   if (n <= 0) return 0;
+  if (nbits < 1) nbits = 1;
+  if (nbits > 32) nbits = 32;
+  const int bits = (nbits + 8) / 9 < (nbits + 7) / 8 ? 9 : 8;
   const int nblk = div_up(n, kSortItems);
   Carver cv(ws);
   uint32_t *kA = cv.take<uint32_t>(n), *kB = cv.take<uint32_t>(n);
   int32_t *vA = cv.take<int32_t>(n), *vB = cv.take<int32_t>(n);
   (void)vB;
-  int32_t *hist = cv.take<int32_t>(static_cast<size_t>(kRadix) * nblk);
-  int32_t *hist_off = cv.take<int32_t>(static_cast<size_t>(kRadix) * nblk);
-  int32_t *totals = cv.take<int32_t>(kRadix);
-  const int passes = div_up(nbits > 0 ? nbits : 1, kRadixBits);
+  int32_t *hist = cv.take<int32_t>(static_cast<size_t>(512) * nblk);
+  int32_t *hist_off = cv.take<int32_t>(static_cast<size_t>(512) * nblk);
+  int32_t *totals = cv.take<int32_t>(512);
+  const int passes = div_up(nbits, bits);
   const uint32_t *kin = keys;
   const int32_t *vin = nullptr;
   for (int pass = 0; pass < passes; ++pass) {
-    const int shift = pass * kRadixBits;
     // value buffers alternate so that the LAST pass writes order_out
     int32_t *vout = ((passes - 1 - pass) & 1) ? vA : order_out;
     uint32_t *kout = (pass & 1) ? kA : kB;
-    hipLaunchKernelGGL(radix_count_kernel, dim3(nblk), dim3(kBlock), 0, s, kin, n, shift, nblk, hist);
-    hipLaunchKernelGGL(radix_scan_kernel, dim3(kRadix), dim3(kBlock), 0, s, hist, hist_off, nblk, totals);
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk), dim3(kBlock), 0, s, kin, vin, n, shift, nblk,
-                       hist_off, totals, kout, vout);
+    if (bits == 9) radix_pass<9>(kin, vin, n, pass * bits, nblk, hist, hist_off, totals, kout, vout, s);
+    else radix_pass<8>(kin, vin, n, pass * bits, nblk, hist, hist_off, totals, kout, vout, s);
     kin = kout;
     vin = vout;
   }

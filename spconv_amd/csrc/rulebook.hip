@@ -3118,6 +3118,15 @@ int spx_mask_argsort(const uint32_t *mask, int n, int words, int32_t *argsort, v
   return radix_argsort(mask, n, 32, argsort, ws, static_cast<hipStream_t>(stream));
 }
 
+int spx_mask_argsort_kv(const uint32_t *mask, int n, int kv, int32_t *argsort, void *ws, size_t ws_bytes,
+                        spx_stream_t stream) {
+  SPX_CHECK(kv >= 1 && kv <= 32, "mask_argsort supports kernel volume <= 32, got %d", kv);
+  SPX_CHECK(ws_bytes >= spx_mask_argsort_ws_bytes(n), "workspace too small");
+  if (n == 0) return 0;
+  // the mask words of a kernel volume kv carry kv bits: 27 bits are three 9-bit passes instead of four 8-bit ones
+  return radix_argsort(mask, n, kv, argsort, ws, static_cast<hipStream_t>(stream));
+}
+
 int spx_native_to_table(const int32_t *pair_native, const int32_t *num_per_loc, int n_in,
                         int n_dst, int kv, int subm, int inverse, int32_t *table,
                         uint32_t *mask, spx_stream_t stream) {

@@ -637,7 +637,7 @@ def sort_rulebook(rb: Rulebook) -> None:
         pair, mask = (rb.pair_fwd, rb.mask_fwd) if which == "fwd" else (rb.pair_bwd, rb.mask_bwd)
         if pair is None or mask is None or mask.shape[1] != 1 or pair.shape[1] == 0:
             continue
-        order = mask_argsort(mask)
+        order = mask_argsort(mask, rb.kv)
         pair_t, mask_t = torch.empty_like(pair), torch.empty_like(mask)
         _lib.check(L.spx_permute_tables(pair.data_ptr(), mask.data_ptr(), order.data_ptr(), pair.shape[0],
                                         pair.shape[1], mask.shape[1], pair_t.data_ptr(), mask_t.data_ptr(),
@@ -672,14 +672,19 @@ def tables_of(rb: Rulebook, which: str, cout: int = 64):
 
 
 @_on_device
-def mask_argsort(mask: torch.Tensor) -> torch.Tensor:
-    """SpconvOps.sort_1d_by_key_allocator (all.py:935-991): argsort of the mask words."""
+def mask_argsort(mask: torch.Tensor, kv: int = 0) -> torch.Tensor:
+    """SpconvOps.sort_1d_by_key_allocator (all.py:935-991): stable argsort of the mask words.  kv (1..32): the kernel
+    volume the words belong to -- only their low kv bits can be set, the sort runs fewer digit passes."""
     L = _lib.load()
     n, words = mask.shape
     out = torch.empty((n,), dtype=torch.int32, device=mask.device)
     ws = _ws(L.spx_mask_argsort_ws_bytes(n), mask.device)
-    _lib.check(L.spx_mask_argsort(mask.data_ptr(), n, words, out.data_ptr(), ws.data_ptr(),
-                                  ws.numel(), _stream(mask)))
+    if 1 <= int(kv) <= 32 and words == 1:
+        _lib.check(L.spx_mask_argsort_kv(mask.data_ptr(), n, int(kv), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                         _stream(mask)))
+    else:
+        _lib.check(L.spx_mask_argsort(mask.data_ptr(), n, words, out.data_ptr(), ws.data_ptr(),
+                                      ws.numel(), _stream(mask)))
     return out
 
 

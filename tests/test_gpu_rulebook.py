@@ -145,15 +145,26 @@ def test_subm_even_kernel_raises(cuda):
 
 
 def test_mask_argsort_is_stable_sort(cuda):
+    """spx_mask_argsort / spx_mask_argsort_kv (the reference: thrust's stable sort_by_key, all.py:935-991) against
+    numpy's stable argsort: sizes around the 2048-key tiles of the one-launch-per-pass sort (single tile, many tiles,
+    enough tiles that the look-back walks over several predecessors), full 32-bit keys (four 8-bit passes), 27-bit mask
+    words (three 9-bit passes), narrow kernel volumes, heavy duplication."""
     from spconv_amd.pytorch import ops
     rng = np.random.default_rng(0)
-    for n in (1, 63, 2048, 2049, 50_000):
-        m = rng.integers(0, 1 << 27, size=(n, 1), dtype=np.int64).astype(np.uint32)
-        m[rng.random(n) < 0.6] = 1 << 13                          # many equal keys
-        t = torch.from_numpy(m.view(np.int32)).to(cuda)
-        perm = to_np(ops.mask_argsort(t)).astype(np.int64)
-        expect = np.argsort(m[:, 0], kind="stable")
-        np.testing.assert_array_equal(perm, expect)
+    for n in (1, 63, 2048, 2049, 50_000, 1_000_003):
+        for bits, kv in ((27, 0), (27, 27), (32, 0), (9, 9), (3, 3), (16, 16), (32, 32)):
+            m = rng.integers(0, 1 << bits, size=(n, 1), dtype=np.int64).astype(np.uint32)
+            m[rng.random(n) < 0.6] = 1 << min(13, bits - 1)                # many equal keys
+            t = torch.from_numpy(m.view(np.int32)).to(cuda)
+            perm = to_np(ops.mask_argsort(t, kv)).astype(np.int64)
+            expect = np.argsort(m[:, 0], kind="stable")
+            np.testing.assert_array_equal(perm, expect, err_msg=f"n={n} bits={bits} kv={kv}")
+    # twice on the same stream without a synchronisation in between (the control block is zeroed by the call itself)
+    m = rng.integers(0, 1 << 27, size=(300_000, 1), dtype=np.int64).astype(np.uint32)
+    t = torch.from_numpy(m.view(np.int32)).to(cuda)
+    a, b = ops.mask_argsort(t, 27), ops.mask_argsort(t, 27)
+    assert torch.equal(a, b)
+    np.testing.assert_array_equal(to_np(a).astype(np.int64), np.argsort(m[:, 0], kind="stable"))
 
 
 def test_layout_conversions_round_trip(cuda):

@@ -52,6 +52,30 @@ def main():
         rb = subm(True, "layout")(0)[0]
         if rb.layout is not None:
             row["layout_class"], row["rows_with_a_neighbour"] = rb.layout[:2].cpu().tolist()
+        # round 6: the mask argsort alone (one launch per digit pass; 27 mask bits = three 9-bit passes, 32 = four 8-bit
+        # ones) and the explicit sort of a rulebook (SPCONV_DO_SORT=1: argsort + table copies)
+        row["mask_argsort_kv27_us"] = round(bench.event_time_ms(lambda i: ops.mask_argsort(rb.mask_fwd, 27), iters=40, span=4) * 1e3, 1)
+        row["mask_argsort_32bit_us"] = round(bench.event_time_ms(lambda i: ops.mask_argsort(rb.mask_fwd), iters=40, span=4) * 1e3, 1)
+        row["sort_rulebook_us"] = round(bench.event_time_ms(lambda i: ops.sort_rulebook(rb), iters=40, span=4) * 1e3, 1)
+        # round 6: the same scene handed over in coordinate-key order (utils.sort_voxels_by_coordinate): level 1 from a
+        # rank map built from the rows themselves (ops.attach_rank_map) instead of a hash table
+        from spconv_amd.pytorch.utils import sort_voxels_by_coordinate
+        ind_s = sort_voxels_by_coordinate(ind, shape, batch_size=bs, rank_map=False)[0]
+
+        def keyed(sort):
+            def fn(i):
+                ops.attach_rank_map(ind_s, bs, shape, check=False)
+                return ops.build_rulebook(ind_s, bs, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True,
+                                          need_native=False, do_sort=sort)
+            return fn
+        if ops.attach_rank_map(ind_s, bs, shape, check=True):
+            row["key_ordered_rank_map_us"] = round(bench.event_time_ms(
+                lambda i: ops.attach_rank_map(ind_s, bs, shape, check=False), iters=40, span=4) * 1e3, 1)
+            row["key_ordered_subm_tables_us"] = round(bench.event_time_ms(keyed(False), iters=40, span=4) * 1e3, 1)
+            row["key_ordered_subm_tables_layout_us"] = round(bench.event_time_ms(keyed("layout"), iters=40, span=4) * 1e3, 1)
+            ind_s._spx_rankmap = None
+            hash_rb = ops.build_rulebook(ind_s, bs, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True, need_native=False)[0]
+            row["key_ordered_equals_hash_build"] = bool(torch.equal(keyed(False)(0)[0].pair_fwd, hash_rb.pair_fwd))
         for name, k, s, p in (() if os.environ.get("RB_ONLY_SUBM") == "1" else (("conv_k3s2", 3, 2, 1), ("conv_k2s2", 2, 2, 0))):
             rb, _ = ops.build_rulebook(ind, bs, shape, [k] * 3, [s] * 3, [p] * 3, [1] * 3, [0] * 3, False)
             cap = rb.n_out + 1024
