@@ -70,6 +70,65 @@ def main():
     for name, fn in (("small_only", small_chain), ("big_only", big_chain), ("serial", serial), ("forked", forked)):
         g = capture(fn)
         res[f"graph_{name}_us"] = timeit(g.replay)
+    # (c) two LINEAR graphs replayed on two streams at once (no dependency between them)
+    g_small, g_big = capture(small_chain), capture(big_chain)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def two_graphs():
+        cur = torch.cuda.current_stream()
+        sa.wait_stream(cur)
+        sb.wait_stream(cur)
+        with torch.cuda.stream(sa):
+            g_small.replay()
+        with torch.cuda.stream(sb):
+            g_big.replay()
+        cur.wait_stream(sa)
+        cur.wait_stream(sb)
+
+    res["two_linear_graphs_two_streams_us"] = timeit(two_graphs)
+
+    # (d) the same with a dependency in the middle through an EXTERNAL event (event-record / event-wait graph nodes instead
+    # of a fork): the big chain's second half waits for the small chain's first half
+    try:
+        ev = torch.cuda.Event(external=True)
+
+        def small_with_record():
+            for i in range(n_small):
+                small[i % 4].add_(1.0)
+                if i == n_small // 2:
+                    ev.record()
+
+        def big_with_wait():
+            for i in range(n_big):
+                if i == n_big // 2:
+                    torch.cuda.current_stream().wait_event(ev)
+                big_b.copy_(big_a)
+                big_a.add_(1)
+
+        ev.record()
+        torch.cuda.synchronize()
+        g_s2, g_b2 = capture(small_with_record), capture(big_with_wait)
+
+        def two_graphs_ev():
+            cur = torch.cuda.current_stream()
+            sa.wait_stream(cur)
+            sb.wait_stream(cur)
+            with torch.cuda.stream(sa):
+                g_s2.replay()
+            with torch.cuda.stream(sb):
+                g_b2.replay()
+            cur.wait_stream(sa)
+            cur.wait_stream(sb)
+
+        res["two_linear_graphs_external_event_us"] = timeit(two_graphs_ev)
+    except Exception as e:      # noqa: BLE001
+        res["two_linear_graphs_external_event_us"] = "unsupported: %r" % (e,)
+
+    # (e) launch floor of a linear graph: 240 tiny kernels
+    def tiny():
+        for i in range(240):
+            small[i % 4].add_(1.0)
+    res["graph_240_tiny_us"] = timeit(capture(tiny).replay)
     print(json.dumps(res, indent=1))
 
 
