@@ -123,35 +123,45 @@ __device__ __forceinline__ RowSplit row_split(int n, int P, int nblocks) {
 }
 
 // Sums a[], b[] over the threads of the block that hold the same piece (threads piece + P * lane_row);
-// on return threads 0 .. C-1 hold the totals of channel threadIdx.x in (ra, rb).  P dividing 64: wave
-// butterflies + four wave totals through LDS; other P: a short serial loop.
+// on return threads 0 .. C-1 hold the totals of channel threadIdx.x in (ra, rb).  P dividing 64: the lanes of a 16-lane
+// row that hold the same piece are summed with DPP row rotations (plain VALU: no trip through the LDS crossbar per
+// step, which the ds_bpermute form of a wave butterfly pays 2 * VPL times per step), the 16 row totals of the block
+// through LDS; other P: a short serial loop.
+template <int D>
+__device__ __forceinline__ float row_ror_add(float x) {
+  return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + D, 0xf, 0xf, false));
+}
+
 template <int VPL>
 __device__ __forceinline__ void piece_reduce(float (&a)[VPL], float (&b)[VPL], int P, int C, int rows_per_sweep,
                                              float (*lds)[kT][VPL + 1], float &ra, float &rb) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
   ra = rb = 0.f;
   if (64 % P == 0) {
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
-      for (int d = P; d < 64; d <<= 1) {
-        a[i] += __shfl_xor(a[i], d, 64);
-        b[i] += __shfl_xor(b[i], d, 64);
-      }
+      if (P <= 8) { a[i] = row_ror_add<8>(a[i]); b[i] = row_ror_add<8>(b[i]); }
+      if (P <= 4) { a[i] = row_ror_add<4>(a[i]); b[i] = row_ror_add<4>(b[i]); }
+      if (P <= 2) { a[i] = row_ror_add<2>(a[i]); b[i] = row_ror_add<2>(b[i]); }
+      if (P <= 1) { a[i] = row_ror_add<1>(a[i]); b[i] = row_ror_add<1>(b[i]); }
     }
-    if (lane < P) {
+    // lane j of a row now holds the row's total of piece (16 * row + j) % P, for j < min(P, 16)
+    const int j = lane & 15, slot = threadIdx.x >> 4, per_row = P < 16 ? P : 16;
+    if (j < per_row) {
 #pragma unroll
       for (int i = 0; i < VPL; ++i) {
-        lds[0][wave * P + lane][i] = a[i];
-        lds[1][wave * P + lane][i] = b[i];
+        lds[0][slot * 16 + j][i] = a[i];
+        lds[1][slot * 16 + j][i] = b[i];
       }
     }
     __syncthreads();
     if (threadIdx.x < C) {
       const int piece = threadIdx.x / VPL, e = threadIdx.x % VPL;
-#pragma unroll
-      for (int w = 0; w < kT / 64; ++w) {
-        ra += lds[0][w * P + piece][e];
-        rb += lds[1][w * P + piece][e];
+      // the rows (of 16 lanes) that hold this piece: every one for P <= 16, every (P / 16)-th from piece / 16 on otherwise
+      const int step = P <= 16 ? 1 : P / 16, first = P <= 16 ? 0 : piece / 16, jj = piece % 16;
+      for (int r = first; r < kT / 16; r += step) {
+        ra += lds[0][r * 16 + jj][e];
+        rb += lds[1][r * 16 + jj][e];
       }
     }
     return;
@@ -185,17 +195,18 @@ bn_partial_kernel(const u32x4 *__restrict__ x, int n, int C, float *__restrict__
   for (int i = 0; i < VPL; ++i) shift[i] = sum[i] = sq[i] = 0.f;
   if (s.active && s.r0 < s.r1) Vec<DT>::unpack(x[static_cast<size_t>(s.r0) * P + s.piece], shift);
   if (s.active) {
-    // four rows of loads in flight per thread (a block owns ~390 rows: without this a thread's 3-4 loads were a
-    // chain of memory round trips); rows past the block's end are predicated, not branched around
-    for (int r = s.r0 + s.lane_row; r < s.r1; r += 4 * s.rows_per_sweep) {
-      u32x4 v[4];
+    // eight rows of loads in flight per thread (a block owns 64-390 rows: one trip; without this a thread's loads were
+    // a chain of memory round trips); rows past the block's end are predicated, not branched around
+    constexpr int U = 8;
+    for (int r = s.r0 + s.lane_row; r < s.r1; r += U * s.rows_per_sweep) {
+      u32x4 v[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {
         const int ru = r + u * s.rows_per_sweep;
         v[u] = ru < s.r1 ? x[static_cast<size_t>(ru) * P + s.piece] : u32x4{0u, 0u, 0u, 0u};
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {
         if (r + u * s.rows_per_sweep < s.r1) {
           float f[VPL];
           Vec<DT>::unpack(v[u], f);
@@ -309,6 +320,10 @@ bn_apply_kernel(const u32x4 *__restrict__ x, u32x4 *__restrict__ y, long long pi
                 int stat_is_var, int relu, const int32_t *__restrict__ n_live, int n) {
   constexpr int VPL = Vec<DT>::VPL;
   __shared__ __attribute__((aligned(16))) float l_sc[kT], l_sh[kT];
+  // the first piece of this thread is asked for BEFORE the coefficients are put together: its latency runs under the
+  // prologue's (parameter loads -> LDS -> barrier), not behind it
+  long long i = static_cast<long long>(blockIdx.x) * kT + threadIdx.x;
+  u32x4 v = i < pieces ? x[i] : u32x4{0u, 0u, 0u, 0u};
   if (threadIdx.x < C) {
     const int c = threadIdx.x;
     const float mean = stat_is_var ? ldp(stat1, pdt, c) : static_cast<const float *>(stat1)[c];
@@ -320,22 +335,31 @@ bn_apply_kernel(const u32x4 *__restrict__ x, u32x4 *__restrict__ y, long long pi
   __syncthreads();
   const int P = C / VPL;
   const long long live = static_cast<long long>(live_rows(n_live, n)) * P;
-  for (long long i = static_cast<long long>(blockIdx.x) * kT + threadIdx.x; i < pieces;
-       i += static_cast<long long>(gridDim.x) * kT) {
+  const long long stride = static_cast<long long>(gridDim.x) * kT;
+  while (i < pieces) {
+    const long long nxt = i + stride;
+    const u32x4 vn = nxt < pieces ? x[nxt] : u32x4{0u, 0u, 0u, 0u};
     const int c0 = static_cast<int>(i % P) * VPL;
     float f[VPL];
-    Vec<DT>::unpack(x[i], f);
+    Vec<DT>::unpack(v, f);
 #pragma unroll
     for (int e = 0; e < VPL; ++e) {
-      float v = f[e] * l_sc[c0 + e] + l_sh[c0 + e];
-      if (relu) v = v > 0.f ? v : 0.f;
-      f[e] = i < live ? v : 0.f;
+      float r = f[e] * l_sc[c0 + e] + l_sh[c0 + e];
+      if (relu) r = r > 0.f ? r : 0.f;
+      f[e] = i < live ? r : 0.f;
     }
     __builtin_nontemporal_store(Vec<DT>::pack(f), &y[i]);      // (not read again by this launch)
+    v = vn;
+    i = nxt;
   }
 }
 
-// partial[b][0][c] = sum dy, [1][c] = sum dy * xhat over the block's rows (dy masked by y > 0 with ReLU)
+// partial[b][0][c] = sum dy, [1][c] = sum dy * xhat over the block's rows (dy masked by y > 0 with ReLU).  The first
+// kBwdBatch rows of a thread (all of them up to 8 rows per thread: 1 M rows at 16 channels) are asked for before anything
+// else; the per-channel coefficients come through LDS (threads < C load them once per block -- 4 * VPL loads per
+// thread were as many requests as the rows themselves on a small level).
+constexpr int kBwdBatch = 8;
+
 template <int DT>
 __global__ void __launch_bounds__(kT)
 bn_bwd_partial_kernel(const u32x4 *__restrict__ x, const u32x4 *__restrict__ dy, int n, int C,
@@ -344,41 +368,63 @@ bn_bwd_partial_kernel(const u32x4 *__restrict__ x, const u32x4 *__restrict__ dy,
                       float *__restrict__ partial, const int32_t *__restrict__ n_live) {
   constexpr int VPL = Vec<DT>::VPL;
   __shared__ float lds[2][kT][VPL + 1];
+  __shared__ __attribute__((aligned(16))) float l_a[kT], l_b[kT], l_w[kT], l_bias[kT];
   const int P = C / VPL;
   const RowSplit s = row_split(live_rows(n_live, n), P, gridDim.x);
-  float s1[VPL], s2[VPL], mu[VPL], is[VPL], w[VPL], bb[VPL];
+  constexpr int U = kBwdBatch;
+  u32x4 vx[U], vg[U];
+  int r = s.r0 + s.lane_row;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int ru = r + u * s.rows_per_sweep;
+    const bool ok = s.active && ru < s.r1;
+    vx[u] = ok ? x[static_cast<size_t>(ru) * P + s.piece] : u32x4{0u, 0u, 0u, 0u};
+    vg[u] = ok ? dy[static_cast<size_t>(ru) * P + s.piece] : u32x4{0u, 0u, 0u, 0u};
+  }
+  if (threadIdx.x < C) {
+    const int c = threadIdx.x;
+    const float is = invstd[c];
+    l_a[c] = is;
+    l_b[c] = -mean[c] * is;
+    l_w[c] = weight ? ldp(weight, pdt, c) : 1.f;
+    l_bias[c] = bias ? ldp(bias, pdt, c) : 0.f;
+  }
+  __syncthreads();
+  float s1[VPL], s2[VPL], ca[VPL], cb[VPL], w[VPL], bb[VPL];
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     s1[i] = s2[i] = 0.f;
-    const int c = s.piece * VPL + i;
-    mu[i] = s.active ? mean[c] : 0.f;
-    is[i] = s.active ? invstd[c] : 0.f;
-    w[i] = (s.active && weight) ? ldp(weight, pdt, c) : 1.f;
-    bb[i] = (s.active && bias) ? ldp(bias, pdt, c) : 0.f;
+    const int c = s.active ? s.piece * VPL + i : 0;
+    ca[i] = l_a[c];
+    cb[i] = l_b[c];
+    w[i] = l_w[c];
+    bb[i] = l_bias[c];
   }
   if (s.active) {
-    for (int r = s.r0 + s.lane_row; r < s.r1; r += 4 * s.rows_per_sweep) {      // (as bn_partial_kernel)
-      u32x4 vx[4], vg[4];
+    while (r < s.r1) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int ru = r + u * s.rows_per_sweep;
-        const bool ok = ru < s.r1;
-        vx[u] = ok ? x[static_cast<size_t>(ru) * P + s.piece] : u32x4{0u, 0u, 0u, 0u};
-        vg[u] = ok ? dy[static_cast<size_t>(ru) * P + s.piece] : u32x4{0u, 0u, 0u, 0u};
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {
         if (r + u * s.rows_per_sweep < s.r1) {
           float f[VPL], g[VPL];
           Vec<DT>::unpack(vx[u], f);
           Vec<DT>::unpack(vg[u], g);
 #pragma unroll
           for (int i = 0; i < VPL; ++i) {
-            const float xh = (f[i] - mu[i]) * is[i];
+            const float xh = f[i] * ca[i] + cb[i];
             const float gg = (relu && xh * w[i] + bb[i] <= 0.f) ? 0.f : g[i];
             s1[i] += gg;
             s2[i] += gg * xh;
           }
+        }
+      }
+      r += U * s.rows_per_sweep;
+      if (r < s.r1) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int ru = r + u * s.rows_per_sweep;
+          const bool ok = ru < s.r1;
+          vx[u] = ok ? x[static_cast<size_t>(ru) * P + s.piece] : u32x4{0u, 0u, 0u, 0u};
+          vg[u] = ok ? dy[static_cast<size_t>(ru) * P + s.piece] : u32x4{0u, 0u, 0u, 0u};
         }
       }
     }
@@ -467,7 +513,9 @@ bn_bwd_apply_kernel(const u32x4 *__restrict__ x, const u32x4 *__restrict__ dy, u
 }
 
 int bn_blocks(int n) {
-  int g = div_up(n > 0 ? n : 1, 384);      // ~384 rows per block, at most 1024 blocks
+  // at most 1024 blocks (~390 rows each at 400 k rows), at least 64 rows per block: a 20 k-row level still puts a block
+  // on every CU (53 blocks of 384 rows left four CUs in five idle and took 12 us for 5 MB)
+  int g = div_up(n > 0 ? n : 1, 64);
   return g < 1 ? 1 : (g > 1024 ? 1024 : g);
 }
 
@@ -486,6 +534,17 @@ unsigned stream_grid(long long pieces) {
 }  // namespace spx
 
 using namespace spx;
+
+// measurement builds only (-DSPX_BN_PROBE, tools/bn_probe.py): which launches of a call are issued -- bit 0 = statistics
+// pass, 1 = merge, 2 = apply -- so that each can be timed alone; the library always issues all three
+#ifdef SPX_BN_PROBE
+static int bn_phases() {
+  static const int v = [] { const char *e = getenv("SPX_BN_PHASES"); return e ? atoi(e) : 7; }();
+  return v;
+}
+#else
+static constexpr int bn_phases() { return 7; }
+#endif
 
 #define SPX_BN_DISPATCH(dtype, CALL)                         \
   do {                                                       \
@@ -524,14 +583,16 @@ static int batchnorm_fwd_impl(const void *x, void *y, int n, int C, int dtype, c
     // one per workgroup of that launch), or from a pass over the rows here
     const int G = ext_partial ? ext_G : bn_blocks(n);
     const float *partial = ext_partial ? ext_partial : static_cast<const float *>(ws);
-    if (!ext_partial) {
+    if (!ext_partial && (bn_phases() & 1)) {
 #define SPX_BN_PARTIAL(D) \
   hipLaunchKernelGGL(bn_partial_kernel<D>, dim3(G), dim3(kT), 0, s, xv, n, C, static_cast<float *>(ws), n_live)
       SPX_BN_DISPATCH(dtype, SPX_BN_PARTIAL);
 #undef SPX_BN_PARTIAL
     }
+    if (bn_phases() & 2)
     hipLaunchKernelGGL(bn_finalize_kernel<kT>, dim3(C), dim3(kT), 0, s, partial, G, C, eps, momentum, save_mean,
                        save_invstd, running_mean, running_var, param_dtype, num_batches_tracked);
+    if (!(bn_phases() & 4)) return 0;
 #define SPX_BN_APPLY(D)                                                                                    \
   hipLaunchKernelGGL(bn_apply_kernel<D>, dim3(stream_grid(pieces)), dim3(kT), 0, s, xv, yv, pieces, C,     \
                      static_cast<const void *>(save_mean), static_cast<const void *>(save_invstd), weight,  \
@@ -596,15 +657,16 @@ int spx_batchnorm_bwd(const void *x, const void *dy, void *dx, int n, int C, int
 #define SPX_BN_BP(D)                                                                                        \
   hipLaunchKernelGGL(bn_bwd_partial_kernel<D>, dim3(G), dim3(kT), 0, s, xv, gv, n, C, mean, invstd, weight, \
                      bias, param_dtype, relu, partial, n_live)
-  SPX_BN_DISPATCH(dtype, SPX_BN_BP);
+  if (bn_phases() & 1) SPX_BN_DISPATCH(dtype, SPX_BN_BP);
 #undef SPX_BN_BP
+  if (bn_phases() & 2)
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(kT), 0, s, partial, G, C, sums, dweight, dbias,
                      param_dtype);
 #define SPX_BN_BA(D)                                                                                        \
   hipLaunchKernelGGL(bn_bwd_apply_kernel<D>, dim3(stream_grid(pieces)), dim3(kT), 0, s, xv, gv,             \
                      static_cast<u32x4 *>(dx), pieces, n, C, mean, invstd, weight, bias, param_dtype, sums,  \
                      relu, use_batch_stats, n_live)
-  SPX_BN_DISPATCH(dtype, SPX_BN_BA);
+  if (bn_phases() & 4) SPX_BN_DISPATCH(dtype, SPX_BN_BA);
 #undef SPX_BN_BA
   SPX_LAUNCH_CHECK();
   return 0;

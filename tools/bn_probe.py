@@ -2,7 +2,9 @@
 """Device time of one fused BatchNorm1d + ReLU forward and backward (csrc/norm.hip, through the C ABI on preallocated
 buffers, hipGraph replays of 20 calls) at the level shapes of the config-4 backbone, next to the time the
 passes' bytes would take at 6 TB/s (tools/experiments/bn_two_launch.patch: the two-launch forms this tool compared).
-    python tools/bn_probe.py            -> one JSON line per shape"""
+    python tools/bn_probe.py            -> one JSON line per shape
+Each launch alone: csrc/build_bn_probe.sh, then SPX_LIB=.../libspconv_amd_bnprobe.so SPX_BN_PHASES=1|2|4 (statistics pass |
+merge | apply).  fwd_from_conv_records_us: merge + apply over the records a convolution's epilogue leaves (one per 128 rows)."""
 import json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -56,7 +58,19 @@ for n, C in SHAPES:
                                        stats[0].data_ptr(), stats[1].data_ptr(), 1, 1, dw.data_ptr(), db.data_ptr(),
                                        ws.data_ptr(), ws.numel(), None, raw))
 
-    out = {"n": n, "C": C, "tensor_MB": round(n * C * 2 / 1e6, 1)}
+    Gc = (n + 127) // 128                      # records a convolution's epilogue leaves: one per 128-row tile
+    recs = torch.zeros(Gc + 32, 3, C, device=dev)      # (+ 32 records of merge scratch, as spx_igemm_fwd_stats_slots sizes it)
+    recs[:Gc, 0] = 128.0
+    recs[:Gc, 1] = torch.randn(Gc, C, device=dev) * 0.1
+    recs[:Gc, 2] = 128.0 + torch.rand(Gc, C, device=dev)
+
+    def fwd_stats():
+        _lib.check(L.spx_batchnorm_fwd_stats(x.data_ptr(), y.data_ptr(), n, C, F16, w.data_ptr(), b.data_ptr(), rm.data_ptr(),
+                                             rv.data_ptr(), None, F32, 0.01, 1e-3, 1, stats[0].data_ptr(),
+                                             stats[1].data_ptr(), recs.data_ptr(), Gc, None, raw))
+
+    out = {"n": n, "C": C, "tensor_MB": round(n * C * 2 / 1e6, 1), "phases": os.environ.get("SPX_BN_PHASES", "7")}
+    out["fwd_from_conv_records_us"] = round(timed(fwd_stats, s), 2)
     res = {}
     out["three_launches"] = {"fwd_us": round(timed(fwd, s), 2), "bwd_us": round(timed(bwd, s), 2)}
     out["ideal_us_at_6TBps"] = {"fwd": round(3 * n * C * 2 / 6e6, 2), "bwd": round(5 * n * C * 2 / 6e6, 2)}
