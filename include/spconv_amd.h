@@ -284,7 +284,8 @@ int spx_igemm_fwd(const void *feat, const void *weight, void *out, const int32_t
                   spx_stream_t stream);
 
 /* The same launch, and the BatchNorm statistics of the rows it stores on the way out: workgroup b of the launch leaves
- * {rows, mean, M2 = sum of squared deviations} of every output channel at stats[b][3][K] (fp32; statistics of the
+ * {rows, mean, M2 = sum of squared deviations} of every output channel at stats[field][channel][b], i.e. float
+ * (field * K + channel) * records + b with records = *slots_used_h (fp32, field 0 rows / 1 mean / 2 M2; statistics of the
  * ROUNDED output values, i.e. of what a normalisation layer behind the convolution reads), rows >= *n_live (device,
  * static-shape tensors; NULL = every row) not counted.  *slots_used_h (host) = number of records written = the
  * launch's workgroup count, or 0 when the kernel that was dispatched leaves none (bias / activation in the epilogue,
@@ -538,7 +539,7 @@ int spx_batchnorm_fwd(const void *x, void *y, int n, int C, int dtype, const voi
                       float eps, int relu, float *save_mean, float *save_invstd, void *ws,
                       size_t ws_bytes, const int32_t *n_live, spx_stream_t stream);
 /* Training-mode forward whose statistics pass has already happened: `stats` = the {rows, mean, M2} records
- * (stats_records of them, [3][C] fp32 each) that spx_igemm_fwd_stats left behind the convolution producing x.  Two
+ * (stats_records of them, laid out [3][C][stats_records] fp32) that spx_igemm_fwd_stats left behind the convolution producing x.  Two
  * launches (merge, apply) instead of three; semantics as spx_batchnorm_fwd with training = 1. */
 int spx_batchnorm_fwd_stats(const void *x, void *y, int n, int C, int dtype, const void *weight,
                             const void *bias, void *running_mean, void *running_var,

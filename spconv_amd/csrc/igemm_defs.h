@@ -68,8 +68,8 @@ struct GemmParams {
   int dense_hint;         // the caller knows the neighbourhoods are dense (SPX_DENSE_HINT in tile_order): forward and
                           // dgrad take the weight-stationary kernel (igemm_ws.hip) where its shape limits allow
   // BatchNorm statistics of the rows the launch stores (spx_igemm_fwd_stats): workgroup b leaves {rows, mean, M2} of
-  // every output channel at stats[b][3][COUT] -- the layout bn_partial_kernel writes (norm.hip), so the normalisation
-  // layer behind the convolution starts at its merge step.  n_live: device row count of a static-shape tensor (rows
+  // every output channel at stats[field][channel][b] (bn_record_store below) -- the layout bn_partial_kernel writes
+  // (norm.hip), so the normalisation layer behind the convolution starts at its merge step.  n_live: device row count of a static-shape tensor (rows
   // beyond it are padding: not counted), or null.  grid_out (host): receives the launch's workgroup count, 0 when the
   // kernel that was dispatched leaves no statistics.
   float *stats;
@@ -148,7 +148,8 @@ struct GemmRest {
 // rows, nrows its valid rows (counted on g == 0 lanes only).  The 16 lanes of a group are reduced with DPP row
 // rotations, the waves of the workgroup through LDS (`lds`: NWAVES * (2 * COUT + 1) floats, free at this point -- the
 // caller has put a barrier behind its last read of the weight stages), and thread c < COUT writes channel c's
-// {rows, mean, M2} to dst[0 / COUT / 2 COUT + c]: bn_partial_kernel's record (norm.hip), merged by bn_finalize_kernel.
+// {rows, mean, M2} as record `rec` of `nrec` (bn_record_store): bn_partial_kernel's record (norm.hip), merged by
+// bn_finalize_kernel.
 __device__ __forceinline__ float row16_sum(float x) {
   x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));
   x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xf, 0xf, false));
@@ -164,6 +165,20 @@ __device__ __forceinline__ float row16_sum(float x) {
 // and the waves are merged with Chan's update: no sum-of-squares cancellation however far a channel's mean is from
 // zero -- through twelve normalisation layers in fp32 a plain sum(x^2) - sum(x)^2 / n per tile showed as 0.8 % in the
 // first layer's weight gradient between two tilings of the same rows.
+// Record layout: FIELD-major, then channel, then record -- stats[(f * COUT + c) * nrec + rec], f = 0 rows, 1 mean, 2 M2,
+// nrec = the launch's workgroup count.  The merge (norm.hip bn_finalize_kernel: one block per channel) then reads every
+// field of its channel as ONE contiguous run of nrec floats; record-major (one [3][COUT] block per workgroup, what this
+// was) made each of its loads a 4-byte pick out of a different 64-byte sector: 9.1 us for 3125 records at 16 channels.
+// The stores below are 3 scattered dwords per thread, COUT threads per workgroup: fire and forget.
+template <int COUT>
+__device__ __forceinline__ void bn_record_store(float *__restrict__ stats, int rec, int nrec, int c, float n, float m,
+                                                float m2) {
+  const size_t g = static_cast<size_t>(nrec);
+  stats[static_cast<size_t>(c) * g + rec] = n;
+  stats[(static_cast<size_t>(COUT) + c) * g + rec] = m;
+  stats[(2 * static_cast<size_t>(COUT) + c) * g + rec] = m2;
+}
+
 template <int ROUND>
 __device__ __forceinline__ float bn_rounded(float v) {
   if constexpr (ROUND == 1) v = static_cast<float>(static_cast<_Float16>(v));
@@ -177,7 +192,7 @@ __device__ __forceinline__ float bn_rounded(float v) {
 
 template <int COUT, int CPL, int MB, int NWAVES, int ROUND, typename Acc>
 __device__ __forceinline__ void wg_bn_stats(const Acc (&acc)[CPL / 4][MB], const int (&grow)[MB], int n_live,
-                                            float *lds, float *__restrict__ dst) {
+                                            float *lds, float *__restrict__ stats, int rec, int nrec) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 15, lgrp = lane >> 4;
   constexpr int W = 2 * COUT + 1;
   bool ok[MB];
@@ -223,20 +238,14 @@ __device__ __forceinline__ void wg_bn_stats(const Acc (&acc)[CPL / 4][MB], const
         n = tot;
       }
     }
-    dst[tid] = n;
-    dst[COUT + tid] = m;
-    dst[2 * COUT + tid] = m2;
+    bn_record_store<COUT>(stats, rec, nrec, tid, n, m, m2);
   }
 }
 
 // a workgroup that leaves without rows (appendix workgroups of a dense rulebook, ...): an empty record
 template <int COUT>
-__device__ __forceinline__ void wg_bn_stats_empty(float *__restrict__ dst) {
-  if (threadIdx.x < COUT) {
-    dst[threadIdx.x] = 0.f;
-    dst[COUT + threadIdx.x] = 0.f;
-    dst[2 * COUT + threadIdx.x] = 0.f;
-  }
+__device__ __forceinline__ void wg_bn_stats_empty(float *__restrict__ stats, int rec, int nrec) {
+  if (threadIdx.x < COUT) bn_record_store<COUT>(stats, rec, nrec, threadIdx.x, 0.f, 0.f, 0.f);
 }
 
 // balanced-segment weight gradient (igemm_bwd.h: wgrad_tr_body / wgrad_f32_body; plan: wgrad_plan2_kernel in igemm.hip)

@@ -257,7 +257,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
     const int cls = *(cptr_t)(p.cls);
     app_m = *(cptr_t)(p.cls + 1);
     if (!cls) {
-      if constexpr (!I8 && !BT) if (p.stats) wg_bn_stats_empty<COUT>(p.stats + static_cast<size_t>(block) * 3 * COUT);
+      if constexpr (!I8 && !BT) if (p.stats) wg_bn_stats_empty<COUT>(p.stats, block, static_cast<int>(gridDim.x));
       return;
     }
     // The M rows of the appendix are dealt to the launch's napp appendix workgroups in whole 16-row blocks, h rows
@@ -269,7 +269,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
     const int groups = p.app_budget > 0 ? min(napp, p.app_budget) : napp;
     const int h = min(TM, (((app_m + groups - 1) / groups) + 15) & ~15);
     if (block * h >= app_m) {
-      if constexpr (!I8 && !BT) if (p.stats) wg_bn_stats_empty<COUT>(p.stats + static_cast<size_t>(block) * 3 * COUT);
+      if constexpr (!I8 && !BT) if (p.stats) wg_bn_stats_empty<COUT>(p.stats, block, static_cast<int>(gridDim.x));
       return;
     }
 #pragma unroll
@@ -701,7 +701,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
         const int st_live = p.n_live ? *p.n_live : 0x7fffffff;
         __syncthreads();      // every wave is past its last read of the weight stages: the LDS is free
         wg_bn_stats<COUT, CPL, MB, kThreads / 64, (F32 ? 0 : (BF16 ? 2 : 1))>(
-            acc, grow, st_live, reinterpret_cast<float *>(smem), p.stats + static_cast<size_t>(block) * 3 * COUT);
+            acc, grow, st_live, reinterpret_cast<float *>(smem), p.stats, block, static_cast<int>(gridDim.x));
       }
     }
   } else {

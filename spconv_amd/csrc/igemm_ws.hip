@@ -386,8 +386,8 @@ igemm_ws_kernel(WsArgs p) {
     if (p.stats) {                     // (as igemm_v4_body: statistics of the rounded rows this workgroup stores)
       const int st_live = p.n_live ? *p.n_live : 0x7fffffff;
       __syncthreads();                 // every wave has left its last phase: the weight buffers are free
-      wg_bn_stats<COUT, CPL, MB, NW, (BF16 ? 2 : 1)>(acc, grow, st_live, reinterpret_cast<float *>(smem),
-                                                     p.stats + static_cast<size_t>(blockIdx.x) * 3 * COUT);
+      wg_bn_stats<COUT, CPL, MB, NW, (BF16 ? 2 : 1)>(acc, grow, st_live, reinterpret_cast<float *>(smem), p.stats,
+                                                     static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
     }
   }
 }

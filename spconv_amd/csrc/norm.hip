@@ -181,7 +181,8 @@ __device__ __forceinline__ void piece_reduce(float (&a)[VPL], float (&b)[VPL], i
   }
 }
 
-// partial[b][0][c] = rows of block b, [1] = mean, [2] = M2 (sum of squared deviations)
+// partial[0][c][b] = rows of block b, [1][c][b] = mean, [2][c][b] = M2 (sum of squared deviations): field-major, then
+// channel, then block -- the merge reads each field of a channel as one contiguous run (igemm_defs.h bn_record_store)
 template <int DT>
 __global__ void __launch_bounds__(kT)
 bn_partial_kernel(const u32x4 *__restrict__ x, int n, int C, float *__restrict__ partial,
@@ -237,10 +238,10 @@ bn_partial_kernel(const u32x4 *__restrict__ x, int n, int C, float *__restrict__
       Vec<DT>::unpack(x[static_cast<size_t>(s.r0) * P + piece], f);
       sh = f[e];
     }
-    float *dst = partial + static_cast<size_t>(blockIdx.x) * 3 * C;
-    dst[threadIdx.x] = cnt;
-    dst[C + threadIdx.x] = cnt > 0.f ? sh + a / cnt : 0.f;
-    dst[2 * C + threadIdx.x] = cnt > 0.f ? b - a * a / cnt : 0.f;
+    const size_t G = gridDim.x, c = threadIdx.x;
+    partial[c * G + blockIdx.x] = cnt;
+    partial[(C + c) * G + blockIdx.x] = cnt > 0.f ? sh + a / cnt : 0.f;
+    partial[(2 * static_cast<size_t>(C) + c) * G + blockIdx.x] = cnt > 0.f ? b - a * a / cnt : 0.f;
   }
 }
 
@@ -265,10 +266,10 @@ bn_finalize_kernel(const float *__restrict__ partial, int G, int C, float eps, f
     for (int u = 0; u < U; ++u) {
       const int b = b0 + u * kT;
       const bool ok = b < G;
-      const size_t at = static_cast<size_t>(ok ? b : 0) * 3 * C + c;
+      const size_t at = static_cast<size_t>(c) * G + (ok ? b : 0), fs = static_cast<size_t>(C) * G;      // (field stride)
       nb[u] = ok ? partial[at] : 0.f;
-      mb[u] = ok ? partial[at + C] : 0.f;
-      Mb[u] = ok ? partial[at + 2 * C] : 0.f;
+      mb[u] = ok ? partial[at + fs] : 0.f;
+      Mb[u] = ok ? partial[at + 2 * fs] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {

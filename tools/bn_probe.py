@@ -59,10 +59,10 @@ for n, C in SHAPES:
                                        ws.data_ptr(), ws.numel(), None, raw))
 
     Gc = (n + 127) // 128                      # records a convolution's epilogue leaves: one per 128-row tile
-    recs = torch.zeros(Gc + 32, 3, C, device=dev)      # (+ 32 records of merge scratch, as spx_igemm_fwd_stats_slots sizes it)
-    recs[:Gc, 0] = 128.0
-    recs[:Gc, 1] = torch.randn(Gc, C, device=dev) * 0.1
-    recs[:Gc, 2] = 128.0 + torch.rand(Gc, C, device=dev)
+    recs = torch.zeros(3, C, Gc, device=dev)      # [field][channel][record]
+    recs[0] = 128.0
+    recs[1] = torch.randn(C, Gc, device=dev) * 0.1
+    recs[2] = 128.0 + torch.rand(C, Gc, device=dev)
 
     def fwd_stats():
         _lib.check(L.spx_batchnorm_fwd_stats(x.data_ptr(), y.data_ptr(), n, C, F16, w.data_ptr(), b.data_ptr(), rm.data_ptr(),
