@@ -509,6 +509,8 @@ def run_layer(args, D: Dist):
     for si in range(S):
         sc = Scene()
         sc.idx_np, sc.shape = make_scene(kind, voxels, seed=rank * S + si)
+        if getattr(args, "key_order", False):      # rows in ascending coordinate key (utils.sort_voxels_by_coordinate)
+            sc.idx_np = key_sorted(sc.idx_np, sc.shape)
         sc.n = sc.idx_np.shape[0]
         sc.indices = torch.from_numpy(sc.idx_np).to(dev)
         g = torch.Generator(device="cpu").manual_seed(1234 + rank * S + si)

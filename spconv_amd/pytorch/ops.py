@@ -892,7 +892,8 @@ def igemm_fwd(features: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
     if (sink is not None and sink.records is None and bias is None and int(act_type) == Activation.None_
             and K == K0 and kv <= 32 and n_out > 0):
         slots = int(L.spx_igemm_fwd_stats_slots(n_out))
-        records = torch.empty((slots, 3, K), dtype=torch.float32, device=features.device)
+        # [field][channel][workgroup] over the `used` workgroups of the launch (igemm_defs.h bn_record_store): a flat buffer
+        records = torch.empty((3 * K * slots,), dtype=torch.float32, device=features.device)
         used = ctypes.c_int(0)
         _lib.check(L.spx_igemm_fwd_stats(features.data_ptr(), filters.data_ptr(), out.data_ptr(),
                                          _ptr(pair), _ptr(mask), _ptr(argsort), _with_dense_hint(int(tile_order), argsort),
