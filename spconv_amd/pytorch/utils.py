@@ -39,7 +39,12 @@ class PointToVoxel(object):
 
     def __init__(self, vsize_xyz: List[float], coors_range_xyz: List[float], num_point_features: int,
                  max_num_voxels: int, max_num_points_per_voxel: int,
-                 device: torch.device = torch.device("cuda:0")):
+                 device: torch.device = torch.device("cuda:0"), key_order: bool = False):
+        # key_order (not in the reference, pytorch/utils.py:23-160, whose voxels come out in point / hash-slot order):
+        # voxels numbered by ascending (z, y, x) key instead of by their first point -- the order the first level of a
+        # backbone wants (sort_voxels_by_coordinate below; DESIGN.md sections 3.15 / 3.17).  Scenes concatenated in
+        # batch order stay in key order; pc_voxel_id follows the renumbering.
+        self.key_order = bool(key_order)
         self.ndim = len(vsize_xyz)
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -89,6 +94,17 @@ class PointToVoxel(object):
                 self.num_per_voxel.data_ptr(), pc_voxel_id.data_ptr(), ctypes.byref(nv), ws.data_ptr(),
                 ws.numel(), torch.cuda.current_stream(pc.device).cuda_stream))
             num_voxels = int(nv.value)
+            if self.key_order and num_voxels > 1:
+                idx = self.indices[:num_voxels]
+                key = idx[:, 0].to(torch.int64)
+                for d in range(1, self.ndim):          # (indices and grid_size are both in zyx order)
+                    key = key * int(self.grid_size[d]) + idx[:, d].to(torch.int64)
+                order = torch.argsort(key)
+                rank = torch.empty_like(order)
+                rank[order] = torch.arange(num_voxels, device=order.device)
+                pc_voxel_id = torch.where(pc_voxel_id >= 0, rank[pc_voxel_id.clamp_min(0)], pc_voxel_id)
+                return (self.voxels[:num_voxels][order].contiguous(), idx[order].contiguous(),
+                        self.num_per_voxel[:num_voxels][order].contiguous(), pc_voxel_id)
             return (self.voxels[:num_voxels].clone(), self.indices[:num_voxels].clone(),
                     self.num_per_voxel[:num_voxels].clone(), pc_voxel_id)
 

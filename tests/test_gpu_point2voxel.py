@@ -98,3 +98,35 @@ def test_point2voxel_equals_the_reference_code_executed(cuda, tag, monkeypatch):
     np.testing.assert_array_equal(pid2.cpu().numpy(), d[f"{tag}_pid"])
     stored = (np.arange(mp)[None, :] < d[f"{tag}_num"][:, None])
     np.testing.assert_array_equal(v2.cpu().numpy()[stored], d[f"{tag}_voxels"][stored])
+
+
+def test_point2voxel_key_order_is_the_first_seen_result_renumbered(cuda):
+    """PointToVoxel(..., key_order=True) (not in the reference, whose voxels come out in point / hash-slot order:
+    pytorch/utils.py:23-160): the same voxels, numbered by ascending (z, y, x) key; pc_voxel_id follows; two scenes
+    concatenated in batch order are in coordinate-key order, and a first-level SubM rulebook built from their rank map
+    (ops.attach_rank_map: no hash table) equals the hash build bit for bit."""
+    import spconv_amd.pytorch as spconv
+    from spconv_amd.pytorch import ops
+    from spconv_amd.pytorch.utils import PointToVoxel
+    args = ([0.2, 0.2, 0.4], [0, -4, -2, 8, 4, 2], 4, 20000, 4)
+    ref_gen, gen = PointToVoxel(*args, device=cuda), PointToVoxel(*args, device=cuda, key_order=True)
+    scenes = []
+    for seed in (2, 3):
+        pts = torch.from_numpy(_cloud(8000, seed)).to(cuda)
+        v0, c0, n0, p0 = ref_gen.generate_voxel_with_id(pts, empty_mean=True)
+        v1, c1, n1, p1 = gen.generate_voxel_with_id(pts, empty_mean=True)
+        Z, Y, X = gen.grid_size
+        k0 = (c0[:, 0].long() * Y + c0[:, 1].long()) * X + c0[:, 2].long()
+        k1 = (c1[:, 0].long() * Y + c1[:, 1].long()) * X + c1[:, 2].long()
+        assert bool((k1[1:] > k1[:-1]).all())                      # ascending, unique
+        order = torch.argsort(k0)
+        assert torch.equal(c1, c0[order]) and torch.equal(v1, v0[order]) and torch.equal(n1, n0[order])
+        assert torch.equal(p1 < 0, p0 < 0)
+        inside = p0 >= 0
+        assert torch.equal(c1[p1[inside]], c0[p0[inside]])         # every point still lands in its voxel
+        scenes.append(c1)
+    idx = torch.cat([torch.cat([torch.full_like(c[:, :1], b), c], dim=1) for b, c in enumerate(scenes)]).contiguous()
+    rb_hash, _ = ops.build_rulebook(idx.clone(), 2, gen.grid_size, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True)
+    assert ops.attach_rank_map(idx, 2, gen.grid_size, check=True)
+    rb_rank, _ = ops.build_rulebook(idx, 2, gen.grid_size, [3] * 3, [1] * 3, [1] * 3, [1] * 3, [0] * 3, True)
+    assert torch.equal(rb_rank.pair_fwd, rb_hash.pair_fwd) and torch.equal(rb_rank.mask_fwd, rb_hash.mask_fwd)
