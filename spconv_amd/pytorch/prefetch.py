@@ -155,11 +155,12 @@ def start(mods, input) -> Optional[Chain]:
             from spconv_amd.pytorch import ops
             indices, shape, bs = input.indices, list(input.spatial_shape), input.batch_size
             n_live = getattr(input, "n_live_dev", None)
+            late = []
             with torch.cuda.stream(side):
                 for m in todo:
                     rb = m._build_rulebook(indices, bs, shape, feats.dtype, n_live)
                     if rb.has_native and torch.is_grad_enabled():
-                        ops._plan_of(rb)         # the weight-gradient range plan: off the backward's critical path
+                        late.append(rb)
                     p = _Prefetched()
                     p.rb, p.indices, p.batch_size, p.spatial_shape = rb, indices, bs, list(shape)
                     p.event = torch.cuda.Event()
@@ -169,6 +170,13 @@ def start(mods, input) -> Optional[Chain]:
                     m.__dict__[_ATTR] = p
                     if not m.subm:
                         indices, shape, n_live = rb.out_indices, list(rb.out_shape), rb.out_n_live_dev
+                # the weight-gradient range plans -- read by the BACKWARD pass only -- behind the tables of every level:
+                # off the backward's critical path, and no layer of the forward pass waits for them either (built right
+                # behind each rulebook they delayed every later hand-over by ~10 us: config 4 2.397 -> 2.386 ms)
+                for rb in late:
+                    plan = ops._plan_of(rb)
+                    if plan is not None:
+                        plan.record_stream(main)
         except Exception:
             chain.finish()
             raise
