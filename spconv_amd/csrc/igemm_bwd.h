@@ -341,7 +341,7 @@ __device__ __forceinline__ void wgrad_f32_body(const Wgrad2Params &p, int block)
 // is latency-bound with idle issue slots and idle HBM bandwidth, so running them side by side
 // on the same CUs costs little more than the slower one -- and one kernel boundary (~1.7 us)
 // disappears.  (Two HIP streams were tried first: the fork/join costs more than it buys.)
-template <int COUT, int MB, int DT, int NKS = 2>
+template <int COUT, int MB, int DT, int NKS = 2, int PK = 1>
 __global__ void __launch_bounds__(kThreads, COUT <= 64 ? 4 : 2)   // 4 waves/SIMD: 1024 resident workgroups
 igemm_bwd_kernel(const void *argA, const void *argB, const uint32_t *arg_mask,
                  const int32_t *arg_argsort, const int32_t *arg_pair, int n_dst, int n_src, int CIN,
@@ -357,7 +357,7 @@ igemm_bwd_kernel(const void *argA, const void *argB, const uint32_t *arg_mask,
                      identity_k, b_reverse, rest);
     p.xcd_rot = (rest.dbg & 0x100) ? 0 : (nw & 7);      // (SPX_V4_DBG=256: A/B switch)
     p.app_budget = kAppBudget;
-    igemm_v4_body<COUT, MB, DT, true, NKS>(p, n_dgrad < 0 ? b - nw : b);
+    igemm_v4_body<COUT, MB, DT, true, NKS, PK>(p, n_dgrad < 0 ? b - nw : b);
   } else {
     if constexpr (DT == 3) wgrad_f32_body(wp, n_dgrad < 0 ? b : b - n_dgrad);
     else wgrad_tr_body<DT == 1, 1>(wp, n_dgrad < 0 ? b : b - n_dgrad);
@@ -383,16 +383,22 @@ int launch_bwd(const GemmParams &p, const Wgrad2Params &q, int n_wgrad_blocks, h
   GemmParams pl = p;
   pl.lpt = p.tile_order && n_dgrad + n_wgrad_blocks > 1024;           // (see launch_v4)
   count_launch(kFamBwdFused);
-  if (p.CIN * (DT == 3 ? 4 : 2) <= 64)     // dgrad's reduction rows (dout channels) fit half a piece
-    hipLaunchKernelGGL((igemm_bwd_kernel<COUT, MB, DT, 1>), dim3(n_dgrad + n_wgrad_blocks), dim3(kThreads),
-                       (bwd_smem_bytes<COUT, MB, DT>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,
-                       p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(pl), rr,
-                       wgrad_first ? ~n_wgrad_blocks : n_dgrad, q);
-  else
-    hipLaunchKernelGGL((igemm_bwd_kernel<COUT, MB, DT, 2>), dim3(n_dgrad + n_wgrad_blocks), dim3(kThreads),
-                       (bwd_smem_bytes<COUT, MB, DT>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,
-                       p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(pl), rr,
-                       wgrad_first ? ~n_wgrad_blocks : n_dgrad, q);
+#define SPX_LAUNCH_BWD(NKSV, PKV)                                                                                  \
+  hipLaunchKernelGGL((igemm_bwd_kernel<COUT, MB, DT, NKSV, PKV>), dim3(n_dgrad + n_wgrad_blocks), dim3(kThreads),  \
+                     (bwd_smem_bytes<COUT, MB, DT>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,           \
+                     p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(pl), rr,                                        \
+                     wgrad_first ? ~n_wgrad_blocks : n_dgrad, q)
+  const int pk = v4_pack(p, DT, DT == 3 ? 4 : 2);   // dgrad's reduction rows are the dout channels
+  if constexpr (DT == 0 || DT == 1) {
+    if (pk == 4) SPX_LAUNCH_BWD(1, 4);
+    else if (pk == 2) SPX_LAUNCH_BWD(1, 2);
+    else if (p.CIN * 2 <= 64) SPX_LAUNCH_BWD(1, 1);     // ... fit half a piece
+    else SPX_LAUNCH_BWD(2, 1);
+  } else {
+    if (p.CIN * (DT == 3 ? 4 : 2) <= 64) SPX_LAUNCH_BWD(1, 1);
+    else SPX_LAUNCH_BWD(2, 1);
+  }
+#undef SPX_LAUNCH_BWD
   SPX_LAUNCH_CHECK();
   return 0;
 }

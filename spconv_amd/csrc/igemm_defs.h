@@ -405,16 +405,44 @@ struct StepIt {
   int k;           // -1 = end
   int chunk;
   uint32_t rest;   // offsets still to visit after k
+  // narrow reduction rows (<= 32 bytes: 16 channels of a 16-bit type, or 8): up to three MORE offsets ride in the same
+  // step -- the offset of group g in the 16 (8) reduction positions of lane group(s) g of the MFMA, next to k in group 0
+  // (igemm_v4_body, PK); packed into ONE word -- byte g - 1 = the offset of group g, 0xff = none -- so that an iterator
+  // stays four scalars (three iterators are live in the step loop; separate fields pushed the PK = 4 kernels into scratch).
+  uint32_t kx;
 };
 
+// offset of group g (1 .. 3) of a step, or -1
+__device__ __forceinline__ int step_k(const StepIt &it, int g) {
+  const uint32_t v = (it.kx >> (8 * (g - 1))) & 0xffu;
+  return v == 0xffu ? -1 : static_cast<int>(v);
+}
+
+template <int PK = 1>
+__device__ __forceinline__ void step_pack(StepIt &it) {
+  it.kx = 0xffffffffu;
+  if constexpr (PK > 1) {
+#pragma unroll
+    for (int g = 1; g < PK; ++g) {
+      if (it.k >= 0 && it.rest) {
+        it.kx = (it.kx & ~(0xffu << (8 * (g - 1)))) | (static_cast<uint32_t>(__builtin_ctz(it.rest)) << (8 * (g - 1)));
+        it.rest &= it.rest - 1;
+      }
+    }
+  }
+}
+
+template <int PK = 1>
 __device__ __forceinline__ StepIt step_begin(uint32_t bits) {
   StepIt it;
   it.chunk = 0;
   it.k = bits ? __builtin_ctz(bits) : -1;
   it.rest = bits ? (bits & (bits - 1)) : 0u;
+  step_pack<PK>(it);
   return it;
 }
 
+template <int PK = 1>
 __device__ __forceinline__ StepIt step_next(StepIt it, int nchunk) {
   if (it.k < 0) return it;
   if (it.chunk + 1 < nchunk) {
@@ -424,6 +452,7 @@ __device__ __forceinline__ StepIt step_next(StepIt it, int nchunk) {
   it.chunk = 0;
   it.k = it.rest ? __builtin_ctz(it.rest) : -1;
   it.rest = it.rest ? (it.rest & (it.rest - 1)) : 0u;
+  step_pack<PK>(it);
   return it;
 }
 

@@ -42,7 +42,7 @@ __device__ unsigned long long g_timeline[kTlMaxWg * kTlSlots];
 
 
 
-template <int COUT, int MB, int DT, bool BT, int NKS = 2>
+template <int COUT, int MB, int DT, bool BT, int NKS = 2, int PK = 1>
 __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block);
 __device__ __forceinline__ void unpack_gemm_args(GemmParams &p, const void *argA, const void *argB,
                                                  const uint32_t *arg_mask, const int32_t *arg_argsort,
@@ -54,7 +54,7 @@ __device__ __forceinline__ void unpack_gemm_args(GemmParams &p, const void *argA
 // piece is empty, so its loads and MFMAs are not emitted at all -- the dense-scene kernels are
 // bound by vector-memory INSTRUCTIONS (16 clocks each in the address unit, whatever the lanes
 // fetch), and a dead load costs as much as a live one.
-template <int COUT, int MB, int DT, bool BT, int NKS = 2>
+template <int COUT, int MB, int DT, bool BT, int NKS = 2, int PK = 1>
 __global__ void __launch_bounds__(kThreads)
 igemm_v4_kernel(const void *argA, const void *argB, const uint32_t *arg_mask,
                 const int32_t *arg_argsort, const int32_t *arg_pair, int n_dst, int n_src, int CIN,
@@ -62,7 +62,7 @@ igemm_v4_kernel(const void *argA, const void *argB, const uint32_t *arg_mask,
   GemmParams p;
   unpack_gemm_args(p, argA, argB, arg_mask, arg_argsort, arg_pair, n_dst, n_src, CIN, kv, identity_k,
                    b_reverse, rest);
-  igemm_v4_body<COUT, MB, DT, BT, NKS>(p, blockIdx.x);
+  igemm_v4_body<COUT, MB, DT, BT, NKS, PK>(p, blockIdx.x);
 }
 
 __device__ __forceinline__ void unpack_gemm_args(GemmParams &p, const void *argA, const void *argB,
@@ -206,9 +206,17 @@ __device__ __forceinline__ void i8_epilogue(const GemmParams &p, i32x4 (&acc)[CO
 
 }
 
-template <int COUT, int MB, int DT, bool BT, int NKS>
+// PK (narrow reduction rows of a 16-bit type, one 64-byte MFMA piece per row: NKS = 1): 2 for rows of <= 32 bytes (16
+// channels), 4 for <= 16 bytes (8 channels) -- a step then carries PK offsets, offset g of the step in the reduction
+// positions of lane group(s) g of v_mfma_f32_16x16x32: the lanes that used to multiply zeros (reduction positions past
+// the row's end) gather the row of ANOTHER offset and read that offset's weights, and a tile that meets all 27 offsets
+// walks 14 (or 8) steps instead of 27 -- the same number of load instructions per step, half (a quarter of) the steps,
+// barriers and pair-word trips.  The identity step stays alone (it runs ahead of the mask exchange).  Sums of a row
+// associate differently than with one offset per step: the same values to fp32 rounding, not bit for bit.
+template <int COUT, int MB, int DT, bool BT, int NKS, int PK>
 __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   constexpr bool BF16 = DT == 1, I8 = DT == 2, F32 = DT == 3;
+  static_assert(PK == 1 || (NKS == 1 && !I8 && !F32), "offset packing: 16-bit operands, rows within one 64-byte piece");
   constexpr int ES = I8 ? 1 : (F32 ? 4 : 2);            // bytes per element
   static_assert(!(I8 && BT), "int8 is forward only");
   constexpr int NB = COUT / 16;
@@ -296,6 +304,9 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   const int tbl_rows = app ? mcap : p.n_dst;                       // row stride of the pair table in use
   const int lrow = lane & 15, lgrp = lane >> 4;
   const int slot = tid & 7, r0 = tid >> 3;
+  // offset packing: the step's offset this LANE gathers for (A operand) -- group ga = lgrp / (4 / PK)
+  constexpr int GL = 4 / PK;                            // lane groups (16-byte reduction slots) per packed offset
+  const int ga = PK == 1 ? 0 : lgrp / GL;
   // Output-channel permutation: MFMA row (g = i >> 2, e = i & 3) of channel block nb carries
   // channel g * CPL + nb * 4 + e, so a lane ends up with CPL CONSECUTIVE channels of its voxel
   // row and stores them straight from registers (no LDS transpose in the epilogue).  The
@@ -354,18 +365,23 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   uint32_t aoff[AK], aoff_tail[AK];
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
-    const int c = ks * 64 + lgrp * 16;                  // byte inside the 128-byte piece
+    const int c = PK == 1 ? ks * 64 + lgrp * 16        // byte inside the 128-byte piece
+                          : (lgrp % GL) * 16;           // ... inside the (<= 32-byte) row of this lane's offset
     aoff[ks] = static_cast<uint32_t>(c);
     aoff_tail[ks] = c < ctail ? 0u : kOob;
   }
   uint32_t boff[BA], boff_tail[BA];
+  int bgrp[BA];           // offset packing: which of the step's offsets this thread's weight vector j belongs to
   if constexpr (!BT) {
 #pragma unroll
     for (int j = 0; j < BROWS; ++j) {
       const int n = r0 + 32 * j;
-      const uint32_t o = static_cast<uint32_t>(n) * static_cast<uint32_t>(p.strideN) * ES + slot * 16u;
-      boff[j] = n < COUT ? o : kOob;
-      boff_tail[j] = slot * 16 < ctail ? 0u : kOob;
+      // PK: 16-byte slot `slot` of the stage row holds slot % GL of the row of offset slot / GL (slots 4 .. 7: nothing)
+      const int sl = PK == 1 ? slot : slot % GL;
+      const uint32_t o = static_cast<uint32_t>(n) * static_cast<uint32_t>(p.strideN) * ES + sl * 16u;
+      bgrp[j] = PK == 1 ? 0 : slot / GL;
+      boff[j] = (n < COUT && (PK == 1 || slot < 4)) ? o : kOob;
+      boff_tail[j] = sl * 16 < ctail ? 0u : kOob;
     }
   } else {
 #pragma unroll
@@ -373,9 +389,12 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
       // reduction row inside the chunk, first of the 16 / ES channels of this vector
       const int d = F32 ? r0 : 2 * r0 + (j & 1);
       const int n = F32 ? j * 32 + slot * 4 : (j >> 1) * 64 + slot * 8;
-      const uint32_t o = (static_cast<uint32_t>(d) * static_cast<uint32_t>(p.strideD) + n) * ES;
-      boff[j] = n < COUT ? o : kOob;
-      boff_tail[j] = d * ES < ctail ? 0u : kOob;
+      // PK: reduction position d of the stage = position d % (8 GL) of the row of offset d / (8 GL) (d >= 32: nothing)
+      const int dl = PK == 1 ? d : d % (8 * GL);
+      const uint32_t o = (static_cast<uint32_t>(dl) * static_cast<uint32_t>(p.strideD) + n) * ES;
+      bgrp[j] = PK == 1 ? 0 : (d / (8 * GL)) & 3;
+      boff[j] = (n < COUT && (PK == 1 || d < 32)) ? o : kOob;
+      boff_tail[j] = dl * ES < ctail ? 0u : kOob;
     }
   }
 
@@ -392,28 +411,51 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   // Straight-line on purpose (no branch around a load): the compiler's s_waitcnt counts stay
   // exact only when every path issues the same loads.  A step that does not exist (k < 0)
   // reads through a zero-sized resource: every lane is out of range, nothing is fetched.
+  // offset packing: the offset of step `it` that this lane's group gathers for (-1: none)
+  auto lane_k = [&](const StepIt &it) __attribute__((always_inline)) {
+    int km = it.k;
+    if constexpr (PK > 1) {
+      const int kg = step_k(it, ga < 1 ? 1 : ga);     // (a per-lane shift of the packed word)
+      km = ga == 0 ? km : kg;
+    }
+    return km;
+  };
   auto load_idx = [&](const StepIt &it, auto SET) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
-    const int k = it.k < 0 ? 0 : it.k;
-    const __amdgpu_buffer_rsrc_t rP = make_rsrc(pairp + static_cast<size_t>(k) * tbl_rows,
-                                                (pairp && it.k >= 0) ? pair_bytes : 0u);
     // the identity select happens where the words are consumed (load_a): selecting here would
     // make the loop-carried value depend on the load and park the wave on it at the loop end
     identr[S] = it.k == p.identity_k ? 0xffffffffu : 0u;
+    if constexpr (PK == 1) {
+      const int k = it.k < 0 ? 0 : it.k;
+      const __amdgpu_buffer_rsrc_t rP = make_rsrc(pairp + static_cast<size_t>(k) * tbl_rows,
+                                                  (pairp && it.k >= 0) ? pair_bytes : 0u);
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-      idxr[S][mb] = SPX_ABL(p, 5) ? grow[mb] : static_cast<int>(__builtin_amdgcn_raw_buffer_load_b32(rP, goff[mb], 0, SPX_AUX_TABLE));
+      for (int mb = 0; mb < MB; ++mb)
+        idxr[S][mb] = SPX_ABL(p, 5) ? grow[mb] : static_cast<int>(__builtin_amdgcn_raw_buffer_load_b32(rP, goff[mb], 0, SPX_AUX_TABLE));
+    } else {
+      // every lane reads the pair word of ITS offset of the step: one resource over the whole table, the table row in
+      // the lane's offset (an absent offset: out of range, the word comes back as 0 and is never used -- load_a drops
+      // the lane's rows the same way)
+      const int km = lane_k(it);
+      const __amdgpu_buffer_rsrc_t rP = make_rsrc(pairp, (pairp && it.k >= 0) ? pair_bytes * static_cast<uint32_t>(p.kv - p.kbase > 32 ? 32 : p.kv - p.kbase) : 0u);
+      const uint32_t kb = km < 0 ? kOob : static_cast<uint32_t>(km) * pair_bytes;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+        idxr[S][mb] = static_cast<int>(__builtin_amdgcn_raw_buffer_load_b32(rP, min(kb + goff[mb], kOob) | ((kb | goff[mb]) & kOob), 0, SPX_AUX_TABLE));
+    }
   };
   auto load_a = [&](const StepIt &it, auto SET) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
     const uint32_t tail = (!cfull && it.chunk == nchunk - 1) ? 0xffffffffu : 0u;
     const uint32_t so = static_cast<uint32_t>(it.chunk) * kRowBytes;
     const __amdgpu_buffer_rsrc_t r = make_rsrc(p.A, it.k >= 0 ? a_bytes : 0u);
+    // offset packing: a lane whose group has no offset in this step contributes nothing (the identity step, an odd tail)
+    const uint32_t dead = (PK > 1 && lane_k(it) < 0) ? kOob : 0u;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
       const uint32_t idx = (static_cast<uint32_t>(grow[mb]) & identr[S]) |
                            (static_cast<uint32_t>(idxr[S][mb]) & ~identr[S]);
-      const uint32_t rbase = idx * rowB;                                   // -1 -> >= kOob
+      const uint32_t rbase = (idx * rowB) | dead;                          // -1 -> >= kOob
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         const uint32_t lo = aoff[ks] | (aoff_tail[ks] & tail);
@@ -426,15 +468,30 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   auto load_b = [&](const StepIt &it, auto WSET) __attribute__((always_inline)) {
     constexpr int WS = decltype(WSET)::value;
     const uint32_t tail = (!cfull && it.chunk == nchunk - 1) ? 0xffffffffu : 0u;
-    const int k = (it.k < 0 ? 0 : it.k) + p.kbase;
-    const int kb = p.b_reverse ? p.kv - 1 - k : k;
-    uint32_t so = static_cast<uint32_t>(kb) * static_cast<uint32_t>(p.strideK) * ES;
-    if constexpr (!BT) so += static_cast<uint32_t>(it.chunk) * kRowBytes;
-    else so += static_cast<uint32_t>(it.chunk) * (kRowBytes / ES) * static_cast<uint32_t>(p.strideD) * ES;
     const __amdgpu_buffer_rsrc_t r = make_rsrc(p.B, it.k >= 0 ? w_bytes : 0u);
+    if constexpr (PK == 1) {
+      const int k = (it.k < 0 ? 0 : it.k) + p.kbase;
+      const int kb = p.b_reverse ? p.kv - 1 - k : k;
+      uint32_t so = static_cast<uint32_t>(kb) * static_cast<uint32_t>(p.strideK) * ES;
+      if constexpr (!BT) so += static_cast<uint32_t>(it.chunk) * kRowBytes;
+      else so += static_cast<uint32_t>(it.chunk) * (kRowBytes / ES) * static_cast<uint32_t>(p.strideD) * ES;
 #pragma unroll
-    for (int j = 0; j < BROWS; ++j)
-      breg[WS][j] = __builtin_amdgcn_raw_buffer_load_b128(r, boff[j] | (boff_tail[j] & tail), so, 0);
+      for (int j = 0; j < BROWS; ++j)
+        breg[WS][j] = __builtin_amdgcn_raw_buffer_load_b128(r, boff[j] | (boff_tail[j] & tail), so, 0);
+    } else {
+      // the weight slice of the offset this vector's stage position belongs to (rows are one chunk: it.chunk == 0);
+      // no offset there: out of range -> zeros in the stage
+#pragma unroll
+      for (int j = 0; j < BROWS; ++j) {
+        const int kg = step_k(it, bgrp[j] < 1 ? 1 : bgrp[j]);
+        const int km = bgrp[j] == 0 ? it.k : kg;
+        const int k = (km < 0 ? 0 : km) + p.kbase;
+        const int kb = p.b_reverse ? p.kv - 1 - k : k;
+        const uint32_t so = static_cast<uint32_t>(kb) * static_cast<uint32_t>(p.strideK) * ES;
+        const uint32_t vo = boff[j] | (boff_tail[j] & tail) | (km < 0 ? kOob : 0u);
+        breg[WS][j] = __builtin_amdgcn_raw_buffer_load_b128(r, min(vo + so, kOob) | (vo & kOob), 0, 0);
+      }
+    }
   };
   auto store_b = [&](char *ldsB, auto WSET) __attribute__((always_inline)) {
     constexpr int WS = decltype(WSET)::value;
@@ -481,6 +538,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   it0.k = p.identity_k;
   it0.chunk = 0;
   it0.rest = 0;
+  it0.kx = 0xffffffffu;
   __builtin_amdgcn_sched_barrier(0);
   // identity step: start its loads before the mask words arrive.  Unconditional (a regular
   // conv has it0.k == -1 here and reads zero-sized resources) so that the wait for the mask
@@ -527,15 +585,15 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   if (spec) {
     it0.rest = tilemask & ~(1u << p.identity_k);
   } else {
-    it0 = step_begin(tilemask);
+    it0 = step_begin<PK>(tilemask);
     load_b(it0, Set0{});
     load_idx(it0, Set0{});
     load_a(it0, Set0{});
     store_b(smem, Set0{});
     __syncthreads();          // regular conv: the first step's weights could not be staged earlier
   }
-  StepIt it1 = step_next(it0, nchunk);
-  StepIt it2 = step_next(it1, nchunk);
+  StepIt it1 = step_next<PK>(it0, nchunk);
+  StepIt it2 = step_next<PK>(it1, nchunk);
 
   using acc_t = typename std::conditional<I8, i32x4, f32x4>::type;
   acc_t acc[NB][MB];
@@ -548,7 +606,15 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   // offset k (or the step does not exist): skipped.
   auto compute = [&](const StepIt &it, auto SET) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
-    if (it.k >= 0 && ((wavemask >> it.k) & 1u)) {
+    uint32_t stepbits = it.k >= 0 ? 1u << it.k : 0u;      // the offsets of this step (one, or up to PK)
+    if constexpr (PK > 1) {
+#pragma unroll
+      for (int g = 1; g < PK; ++g) {
+        const int kg = step_k(it, g);
+        stepbits |= kg >= 0 ? 1u << kg : 0u;
+      }
+    }
+    if (wavemask & stepbits) {
       const char *cur = smem + S * B_BYTES;
       const int ksteps = (min(kRowBytes, static_cast<int>(rowB) - it.chunk * kRowBytes) + 63) >> 6;  // 1 or 2
 #pragma unroll
@@ -585,7 +651,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   load_a(it1, Set1{});
   store_b(smem + B_BYTES, WSetA{});      // weights of step 1 -> stage 1 (published by step 1's barrier)
   {
-    const StepIt it3 = step_next(it2, nchunk);
+    const StepIt it3 = step_next<PK>(it2, nchunk);
     load_b(it2, Set0{});
     if constexpr (WD == 2) load_b(it3, Set1{});   // step 3's weights: in flight two steps before their LDS write
     __builtin_amdgcn_sched_barrier(0);
@@ -609,7 +675,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
     using WSetN = std::integral_constant<int, (WD == 2 ? 1 - S : 0)>;
     if (!SPX_ABL(p, 1) && !SPX_ABL(p, 2)) store_b(smem + (1 - S) * B_BYTES, WSetN{});
     compute(it0, SET);
-    const StepIt it3 = step_next(it2, nchunk);
+    const StepIt it3 = step_next<PK>(it2, nchunk);
     if (!SPX_ABL(p, 1) && !SPX_ABL(p, 2)) {
       if constexpr (WD == 2) load_b(it3, WSetN{});
       else load_b(it2, WSetN{});
@@ -739,6 +805,15 @@ template <int COUT, int MB, int DT>
 int launch_v4(const GemmParams &p, hipStream_t s);
 GemmRest rest_of(const GemmParams &p);
 
+// offsets per step of a launch (igemm_v4_body, PK): 4 / 2 for reduction rows of <= 16 / 32 bytes of a 16-bit type whose
+// pair table fits one buffer resource (32 table rows), else 1.  SPX_PK = 0 switches the packing off (A/B runs, tests).
+inline int v4_pack(const GemmParams &p, int DT, int es) {
+  if ((DT != 0 && DT != 1) || !p.pair || option_int("SPX_PK", 1) == 0) return 1;
+  if (static_cast<unsigned long long>(p.n_dst) * 4ull * 32ull >= 0x7fff0000ull) return 1;
+  const int rb = p.CIN * es;
+  return rb <= 16 ? 4 : (rb <= 32 ? 2 : 1);
+}
+
 template <int COUT, int MB, int DT>
 int launch_v4(const GemmParams &p, hipStream_t s) {
   const int ntiles = div_up(p.n_dst, 64 * MB);
@@ -752,18 +827,33 @@ int launch_v4(const GemmParams &p, hipStream_t s) {
   r.napp = p.cls ? napp : -1;
   constexpr int es = DT == 2 ? 1 : (DT == 3 ? 4 : 2);
   const bool half = p.CIN * es <= 64;        // narrow rows: only the first 64 bytes of a piece exist
+  const int pk = v4_pack(p, DT, es);         // ... <= 32 / 16 bytes: 2 / 4 offsets per step (igemm_v4_body, PK)
   count_launch(kFamV4);
-#define SPX_LAUNCH_V4(BTV, NKSV)                                                                     \
-  hipLaunchKernelGGL((igemm_v4_kernel<COUT, MB, DT, BTV, NKSV>), dim3(napp + ntiles), dim3(kThreads),   \
+#define SPX_LAUNCH_V4(BTV, NKSV, PKV)                                                                \
+  hipLaunchKernelGGL((igemm_v4_kernel<COUT, MB, DT, BTV, NKSV, PKV>), dim3(napp + ntiles), dim3(kThreads),   \
                      (v4_smem_bytes<COUT, MB, DT>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,  \
                      p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(q), r)
   if (p.grid_out) *p.grid_out = (p.stats && DT != 2 && p.strideD == 1 && !p.acc_mode) ? napp + ntiles : 0;
   if (DT == 2 || p.strideD == 1) {
-    if (half) SPX_LAUNCH_V4(false, 1);
-    else SPX_LAUNCH_V4(false, 2);
+    if constexpr (DT == 0 || DT == 1) {
+      if (pk == 4) SPX_LAUNCH_V4(false, 1, 4);
+      else if (pk == 2) SPX_LAUNCH_V4(false, 1, 2);
+      else if (half) SPX_LAUNCH_V4(false, 1, 1);
+      else SPX_LAUNCH_V4(false, 2, 1);
+    } else {
+      if (half) SPX_LAUNCH_V4(false, 1, 1);
+      else SPX_LAUNCH_V4(false, 2, 1);
+    }
   } else if constexpr (DT != 2) {
-    if (half) SPX_LAUNCH_V4(true, 1);
-    else SPX_LAUNCH_V4(true, 2);
+    if constexpr (DT == 0 || DT == 1) {
+      if (pk == 4) SPX_LAUNCH_V4(true, 1, 4);
+      else if (pk == 2) SPX_LAUNCH_V4(true, 1, 2);
+      else if (half) SPX_LAUNCH_V4(true, 1, 1);
+      else SPX_LAUNCH_V4(true, 2, 1);
+    } else {
+      if (half) SPX_LAUNCH_V4(true, 1, 1);
+      else SPX_LAUNCH_V4(true, 2, 1);
+    }
   }
 #undef SPX_LAUNCH_V4
   SPX_LAUNCH_CHECK();

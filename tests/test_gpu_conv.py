@@ -543,3 +543,45 @@ def test_backward_is_bit_reproducible(cuda, scene_kind):
         else:
             for a, b in zip(ref, cur):
                 assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("C,K,ksize,stride,pad,subm,n", [
+    (8, 16, [3] * 3, [1] * 3, [1] * 3, True, 6000),        # 16-byte rows: four offsets per step forward
+    (16, 16, [3] * 3, [1] * 3, [1] * 3, True, 6000),       # 32-byte rows: two per step, forward and dgrad
+    (16, 32, [3] * 3, [2] * 3, [1] * 3, False, 6000),      # strided layer, narrow forward
+    (32, 16, [3] * 3, [2] * 3, [1] * 3, False, 6000),      # ... narrow dgrad (16 dout channels)
+    (16, 16, [2] * 3, [2] * 3, [0] * 3, False, 6000),      # kernel volume 8: an even count, no identity offset
+    (8, 8, [3, 1, 1], [1] * 3, [1, 0, 0], True, 3000),     # kernel volume 3: identity + one packed step with a hole
+    (16, 64, [3] * 3, [1] * 3, [1] * 3, True, 40_000),     # rows layout territory (> 32 k rows)
+])
+def test_packed_offsets_for_narrow_rows(cuda, C, K, ksize, stride, pad, subm, n, dtype):
+    """igemm_v4_body, PK: reduction rows of <= 32 / 16 bytes carry 2 / 4 offsets per MFMA step (the lanes that used to
+    multiply the zeros behind the row's end gather another offset's row).  Against the oracle with the sharp bars, and
+    against the one-offset-per-step walk (SPX_PK = 0) of the same library -- the same values up to fp32 association."""
+    from spconv_amd import _lib
+    shape = [40, 64, 64] if n > 10_000 else [24, 24, 24]
+    idx, ref, f, w, dout = _case(shape, n, 2, C, K, ksize, stride, pad, [1] * 3, subm, dtype)
+    out_ref = oracle.indice_conv(f, w, ref["pair"], ref["num"], ref["n_out"], subm=subm)
+    din_ref, dw_ref = oracle.indice_conv_backward(f, w, dout, ref["pair"], ref["num"], subm=subm)
+    L = _lib.load()
+    res = {}
+    try:
+        for pk in (1, 0):
+            L.spx_set_option(b"SPX_PK", pk)
+            _, out, din, dw = _run_gpu(cuda, idx, 2, shape, ksize, stride, pad, [1] * 3, subm, False, f, w, dout, dtype)
+            res[pk] = (out, din, dw)
+    finally:
+        L.spx_set_option(b"SPX_PK", 1)
+    tol = TOL[dtype]
+    for pk in (1, 0):
+        out, din, dw = res[pk]
+        _check("out", out, out_ref, tol)
+        _check("din", din, din_ref, tol)
+        _check("dw", dw, dw_ref, tol)
+        _check_abs((out, din, dw), (out_ref, din_ref, dw_ref), f, w, dout, ref, subm, dtype)
+    # the two walks against each other: one rounding of the stored dtype apart at most, nearly everywhere equal
+    for a, b in zip(res[1][:2], res[0][:2]):
+        a, b = a.float(), b.float()
+        assert float((a - b).abs().max()) <= 2 * tol * float(b.abs().max()) + 1e-6
+        assert float((a != b).float().mean()) < 0.2
