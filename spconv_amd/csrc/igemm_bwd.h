@@ -388,9 +388,12 @@ int launch_bwd(const GemmParams &p, const Wgrad2Params &q, int n_wgrad_blocks, h
                      (bwd_smem_bytes<COUT, MB, DT>()), s, p.A, p.B, p.mask, p.argsort, p.pair, p.n_dst,           \
                      p.n_src, p.CIN, p.kv, p.identity_k, v4_flags(pl), rr,                                        \
                      wgrad_first ? ~n_wgrad_blocks : n_dgrad, q)
-  const int pk = v4_pack(p, DT, DT == 3 ? 4 : 2);   // dgrad's reduction rows are the dout channels
+  const int pk = v4_pack(p, DT, DT == 3 ? 4 : 2, true);   // dgrad's reduction rows are the dout channels
   if constexpr (DT == 0 || DT == 1) {
-    if (pk == 4) SPX_LAUNCH_BWD(1, 4);
+    if (pk == 32) SPX_LAUNCH_BWD(2, 32);
+    else if (pk == 16) SPX_LAUNCH_BWD(2, 16);
+    else if (pk == 8) SPX_LAUNCH_BWD(2, 8);
+    else if (pk == 4) SPX_LAUNCH_BWD(1, 4);
     else if (pk == 2) SPX_LAUNCH_BWD(1, 2);
     else if (p.CIN * 2 <= 64) SPX_LAUNCH_BWD(1, 1);     // ... fit half a piece
     else SPX_LAUNCH_BWD(2, 1);

@@ -407,25 +407,28 @@ struct StepIt {
   uint32_t rest;   // offsets still to visit after k
   // narrow reduction rows (<= 32 bytes: 16 channels of a 16-bit type, or 8): up to three MORE offsets ride in the same
   // step -- the offset of group g in the 16 (8) reduction positions of lane group(s) g of the MFMA, next to k in group 0
-  // (igemm_v4_body, PK); packed into ONE word -- byte g - 1 = the offset of group g, 0xff = none -- so that an iterator
-  // stays four scalars (three iterators are live in the step loop; separate fields pushed the PK = 4 kernels into scratch).
-  uint32_t kx;
+  // (igemm_v4_body, PK); packed into ONE 64-bit word -- byte g - 1 = the offset of group g (up to seven more: eight
+  // offsets per step when both 64-byte pieces of a step are packed), 0xff = none -- so that an iterator stays a handful
+  // of scalars (three iterators are live in the step loop; separate fields pushed the kernels into scratch).
+  unsigned long long kx;
 };
 
-// offset of group g (1 .. 3) of a step, or -1
+// offset of group g (1 .. 7) of a step, or -1
 __device__ __forceinline__ int step_k(const StepIt &it, int g) {
-  const uint32_t v = (it.kx >> (8 * (g - 1))) & 0xffu;
+  const uint32_t v = static_cast<uint32_t>(it.kx >> (8 * (g - 1))) & 0xffu;
   return v == 0xffu ? -1 : static_cast<int>(v);
 }
 
-template <int PK = 1>
+// T = offsets per step
+template <int T = 1>
 __device__ __forceinline__ void step_pack(StepIt &it) {
-  it.kx = 0xffffffffu;
-  if constexpr (PK > 1) {
+  it.kx = ~0ull;
+  if constexpr (T > 1) {
 #pragma unroll
-    for (int g = 1; g < PK; ++g) {
+    for (int g = 1; g < T; ++g) {
       if (it.k >= 0 && it.rest) {
-        it.kx = (it.kx & ~(0xffu << (8 * (g - 1)))) | (static_cast<uint32_t>(__builtin_ctz(it.rest)) << (8 * (g - 1)));
+        it.kx = (it.kx & ~(0xffull << (8 * (g - 1)))) |
+                (static_cast<unsigned long long>(__builtin_ctz(it.rest)) << (8 * (g - 1)));
         it.rest &= it.rest - 1;
       }
     }

@@ -206,17 +206,27 @@ __device__ __forceinline__ void i8_epilogue(const GemmParams &p, i32x4 (&acc)[CO
 
 }
 
-// PK (narrow reduction rows of a 16-bit type, one 64-byte MFMA piece per row: NKS = 1): 2 for rows of <= 32 bytes (16
-// channels), 4 for <= 16 bytes (8 channels) -- a step then carries PK offsets, offset g of the step in the reduction
-// positions of lane group(s) g of v_mfma_f32_16x16x32: the lanes that used to multiply zeros (reduction positions past
-// the row's end) gather the row of ANOTHER offset and read that offset's weights, and a tile that meets all 27 offsets
-// walks 14 (or 8) steps instead of 27 -- the same number of load instructions per step, half (a quarter of) the steps,
-// barriers and pair-word trips.  The identity step stays alone (it runs ahead of the mask exchange).  Sums of a row
-// associate differently than with one offset per step: the same values to fp32 rounding, not bit for bit.
+// PK -- offset packing for narrow reduction rows of a 16-bit type.  A step feeds v_mfma_f32_16x16x32 64-byte pieces of
+// a row (NKS of them); a row of 32 bytes (16 channels) fills half a piece, one of 16 bytes (8 channels: a 4-channel input
+// layer padded) a quarter, and the lanes behind the row's end loaded out-of-range zeros and multiplied them.  With PK they
+// gather the row of ANOTHER offset of the tile (every lane reads the pair word of its own offset through one resource
+// over the whole table) and read that offset's weights (the stage row holds the slices side by side; forward layout and
+// the transposing dgrad layout alike):
+//   PK = 2 / 4, NKS = 1   2 / 4 offsets in the one piece of a step (rows <= 32 / 16 bytes)
+//   PK = 8 / 16 / 32, NKS = 2   BOTH pieces of a step packed, 1 / 2 / 4 offsets each (rows <= 64 / 32 / 16 bytes):
+//                               2 / 4 / 8 offsets per step, two pair words and two rows per lane and m-block
+// A tile that meets all 27 offsets walks 1 + 13 / 7 / 4 steps instead of 27 (the identity step stays alone: it runs
+// ahead of the mask exchange) -- the same load instructions per offset, a fraction of the steps, barriers and pair-word
+// trips (~1 us of kernel time per step and launch on the 400 k-row level of config 4).  Sums of a row associate
+// differently than with one offset per step: the same values to fp32 rounding, not bit for bit.
 template <int COUT, int MB, int DT, bool BT, int NKS, int PK>
 __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   constexpr bool BF16 = DT == 1, I8 = DT == 2, F32 = DT == 3;
-  static_assert(PK == 1 || (NKS == 1 && !I8 && !F32), "offset packing: 16-bit operands, rows within one 64-byte piece");
+  constexpr bool XK = PK >= 8;                          // both pieces of a step packed
+  constexpr int PP = XK ? PK / 8 : PK;                  // offsets per 64-byte piece
+  constexpr int T = PP * (XK ? 2 : 1);                  // offsets per step
+  static_assert(PK == 1 || (!I8 && !F32 && (XK ? NKS == 2 : NKS == 1)), "offset packing: 16-bit operands");
+  static_assert(PP == 1 || PP == 2 || PP == 4, "offsets per piece");
   constexpr int ES = I8 ? 1 : (F32 ? 4 : 2);            // bytes per element
   static_assert(!(I8 && BT), "int8 is forward only");
   constexpr int NB = COUT / 16;
@@ -304,9 +314,9 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   const int tbl_rows = app ? mcap : p.n_dst;                       // row stride of the pair table in use
   const int lrow = lane & 15, lgrp = lane >> 4;
   const int slot = tid & 7, r0 = tid >> 3;
-  // offset packing: the step's offset this LANE gathers for (A operand) -- group ga = lgrp / (4 / PK)
-  constexpr int GL = 4 / PK;                            // lane groups (16-byte reduction slots) per packed offset
-  const int ga = PK == 1 ? 0 : lgrp / GL;
+  // offset packing: 16-byte reduction slot (ks, lgrp) of a step belongs to offset group (ks * 4 + lgrp) / GL
+  constexpr int GL = 4 / PP;                            // lane groups (16-byte reduction slots) per packed offset
+  const int ga = lgrp / GL;                             // this lane's group inside a piece
   // Output-channel permutation: MFMA row (g = i >> 2, e = i & 3) of channel block nb carries
   // channel g * CPL + nb * 4 + e, so a lane ends up with CPL CONSECUTIVE channels of its voxel
   // row and stores them straight from registers (no LDS transpose in the epilogue).  The
@@ -365,8 +375,8 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   uint32_t aoff[AK], aoff_tail[AK];
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
-    const int c = PK == 1 ? ks * 64 + lgrp * 16        // byte inside the 128-byte piece
-                          : (lgrp % GL) * 16;           // ... inside the (<= 32-byte) row of this lane's offset
+    const int c = T == 1 ? ks * 64 + lgrp * 16         // byte inside the 128-byte piece
+                         : (lgrp % GL) * 16;            // ... inside the (<= 64-byte) row of this lane's offset
     aoff[ks] = static_cast<uint32_t>(c);
     aoff_tail[ks] = c < ctail ? 0u : kOob;
   }
@@ -377,10 +387,10 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
     for (int j = 0; j < BROWS; ++j) {
       const int n = r0 + 32 * j;
       // PK: 16-byte slot `slot` of the stage row holds slot % GL of the row of offset slot / GL (slots 4 .. 7: nothing)
-      const int sl = PK == 1 ? slot : slot % GL;
+      const int sl = T == 1 ? slot : slot % GL;
       const uint32_t o = static_cast<uint32_t>(n) * static_cast<uint32_t>(p.strideN) * ES + sl * 16u;
-      bgrp[j] = PK == 1 ? 0 : slot / GL;
-      boff[j] = (n < COUT && (PK == 1 || slot < 4)) ? o : kOob;
+      bgrp[j] = T == 1 ? 0 : slot / GL;
+      boff[j] = (n < COUT && (T == 1 || XK || slot < 4)) ? o : kOob;
       boff_tail[j] = sl * 16 < ctail ? 0u : kOob;
     }
   } else {
@@ -390,15 +400,15 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
       const int d = F32 ? r0 : 2 * r0 + (j & 1);
       const int n = F32 ? j * 32 + slot * 4 : (j >> 1) * 64 + slot * 8;
       // PK: reduction position d of the stage = position d % (8 GL) of the row of offset d / (8 GL) (d >= 32: nothing)
-      const int dl = PK == 1 ? d : d % (8 * GL);
+      const int dl = T == 1 ? d : d % (8 * GL);
       const uint32_t o = (static_cast<uint32_t>(dl) * static_cast<uint32_t>(p.strideD) + n) * ES;
-      bgrp[j] = PK == 1 ? 0 : (d / (8 * GL)) & 3;
-      boff[j] = (n < COUT && (PK == 1 || d < 32)) ? o : kOob;
+      bgrp[j] = T == 1 ? 0 : (d / (8 * GL)) & 7;
+      boff[j] = (n < COUT && (T == 1 || XK || d < 32)) ? o : kOob;
       boff_tail[j] = dl * ES < ctail ? 0u : kOob;
     }
   }
 
-  int idxr[2][MB];
+  int idxr[2][MB][AK];    // pair words of a step ([.][.][1]: the second piece's offset, XK only)
   uint32_t identr[2] = {0u, 0u};   // wave-uniform: idxr[S] stands for the identity offset
   u32x4 areg[2][MB][AK];
   // WD = 2: two weight register sets -- a slice is requested THREE steps before its MFMAs (two before it
@@ -412,11 +422,12 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   // exact only when every path issues the same loads.  A step that does not exist (k < 0)
   // reads through a zero-sized resource: every lane is out of range, nothing is fetched.
   // offset packing: the offset of step `it` that this lane's group gathers for (-1: none)
-  auto lane_k = [&](const StepIt &it) __attribute__((always_inline)) {
+  auto lane_k = [&](const StepIt &it, int ks) __attribute__((always_inline)) {
     int km = it.k;
-    if constexpr (PK > 1) {
-      const int kg = step_k(it, ga < 1 ? 1 : ga);     // (a per-lane shift of the packed word)
-      km = ga == 0 ? km : kg;
+    if constexpr (T > 1) {
+      const int g = (XK ? ks * PP : 0) + ga;
+      const int kg = step_k(it, g < 1 ? 1 : g);       // (a per-lane shift of the packed word)
+      km = g == 0 ? km : kg;
     }
     return km;
   };
@@ -425,23 +436,26 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
     // the identity select happens where the words are consumed (load_a): selecting here would
     // make the loop-carried value depend on the load and park the wave on it at the loop end
     identr[S] = it.k == p.identity_k ? 0xffffffffu : 0u;
-    if constexpr (PK == 1) {
+    if constexpr (T == 1) {
       const int k = it.k < 0 ? 0 : it.k;
       const __amdgpu_buffer_rsrc_t rP = make_rsrc(pairp + static_cast<size_t>(k) * tbl_rows,
                                                   (pairp && it.k >= 0) ? pair_bytes : 0u);
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
-        idxr[S][mb] = SPX_ABL(p, 5) ? grow[mb] : static_cast<int>(__builtin_amdgcn_raw_buffer_load_b32(rP, goff[mb], 0, SPX_AUX_TABLE));
+        idxr[S][mb][0] = SPX_ABL(p, 5) ? grow[mb] : static_cast<int>(__builtin_amdgcn_raw_buffer_load_b32(rP, goff[mb], 0, SPX_AUX_TABLE));
     } else {
-      // every lane reads the pair word of ITS offset of the step: one resource over the whole table, the table row in
-      // the lane's offset (an absent offset: out of range, the word comes back as 0 and is never used -- load_a drops
-      // the lane's rows the same way)
-      const int km = lane_k(it);
+      // every lane reads the pair word of ITS offset of the step (XK: of its two offsets): one resource over the whole
+      // table, the table row in the lane's offset (an absent offset: out of range, the word comes back as 0 and is never
+      // used -- load_a drops the lane's rows the same way)
       const __amdgpu_buffer_rsrc_t rP = make_rsrc(pairp, (pairp && it.k >= 0) ? pair_bytes * static_cast<uint32_t>(p.kv - p.kbase > 32 ? 32 : p.kv - p.kbase) : 0u);
-      const uint32_t kb = km < 0 ? kOob : static_cast<uint32_t>(km) * pair_bytes;
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-        idxr[S][mb] = static_cast<int>(__builtin_amdgcn_raw_buffer_load_b32(rP, min(kb + goff[mb], kOob) | ((kb | goff[mb]) & kOob), 0, SPX_AUX_TABLE));
+      for (int ks = 0; ks < (XK ? 2 : 1); ++ks) {
+        const int km = lane_k(it, ks);
+        const uint32_t kb = km < 0 ? kOob : static_cast<uint32_t>(km) * pair_bytes;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+          idxr[S][mb][ks] = static_cast<int>(__builtin_amdgcn_raw_buffer_load_b32(rP, min(kb + goff[mb], kOob) | ((kb | goff[mb]) & kOob), 0, SPX_AUX_TABLE));
+      }
     }
   };
   auto load_a = [&](const StepIt &it, auto SET) __attribute__((always_inline)) {
@@ -450,14 +464,16 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
     const uint32_t so = static_cast<uint32_t>(it.chunk) * kRowBytes;
     const __amdgpu_buffer_rsrc_t r = make_rsrc(p.A, it.k >= 0 ? a_bytes : 0u);
     // offset packing: a lane whose group has no offset in this step contributes nothing (the identity step, an odd tail)
-    const uint32_t dead = (PK > 1 && lane_k(it) < 0) ? kOob : 0u;
+    uint32_t dead[AK];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) dead[ks] = (T > 1 && lane_k(it, ks) < 0) ? kOob : 0u;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
-      const uint32_t idx = (static_cast<uint32_t>(grow[mb]) & identr[S]) |
-                           (static_cast<uint32_t>(idxr[S][mb]) & ~identr[S]);
-      const uint32_t rbase = (idx * rowB) | dead;                          // -1 -> >= kOob
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
+        const uint32_t idx = (static_cast<uint32_t>(grow[mb]) & identr[S]) |
+                             (static_cast<uint32_t>(idxr[S][mb][XK ? ks : 0]) & ~identr[S]);
+        const uint32_t rbase = (idx * rowB) | dead[ks];                    // -1 -> >= kOob
         const uint32_t lo = aoff[ks] | (aoff_tail[ks] & tail);
         const uint32_t vo = min(rbase + lo, kOob) | (lo & kOob);
         if (SPX_ABL(p, 4)) areg[S][mb][ks] = u32x4{vo, vo, vo, vo};
@@ -469,7 +485,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
     constexpr int WS = decltype(WSET)::value;
     const uint32_t tail = (!cfull && it.chunk == nchunk - 1) ? 0xffffffffu : 0u;
     const __amdgpu_buffer_rsrc_t r = make_rsrc(p.B, it.k >= 0 ? w_bytes : 0u);
-    if constexpr (PK == 1) {
+    if constexpr (T == 1) {
       const int k = (it.k < 0 ? 0 : it.k) + p.kbase;
       const int kb = p.b_reverse ? p.kv - 1 - k : k;
       uint32_t so = static_cast<uint32_t>(kb) * static_cast<uint32_t>(p.strideK) * ES;
@@ -538,7 +554,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   it0.k = p.identity_k;
   it0.chunk = 0;
   it0.rest = 0;
-  it0.kx = 0xffffffffu;
+  it0.kx = ~0ull;
   __builtin_amdgcn_sched_barrier(0);
   // identity step: start its loads before the mask words arrive.  Unconditional (a regular
   // conv has it0.k == -1 here and reads zero-sized resources) so that the wait for the mask
@@ -546,7 +562,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   load_b(it0, Set0{});
   identr[0] = 0xffffffffu;
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) idxr[0][mb] = 0;
+  for (int mb = 0; mb < MB; ++mb) idxr[0][mb][0] = idxr[0][mb][1] = 0;
   load_a(it0, Set0{});
   __builtin_amdgcn_sched_barrier(0);
   SPX_STAMP(1);   // identity-step loads issued
@@ -585,15 +601,15 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   if (spec) {
     it0.rest = tilemask & ~(1u << p.identity_k);
   } else {
-    it0 = step_begin<PK>(tilemask);
+    it0 = step_begin<T>(tilemask);
     load_b(it0, Set0{});
     load_idx(it0, Set0{});
     load_a(it0, Set0{});
     store_b(smem, Set0{});
     __syncthreads();          // regular conv: the first step's weights could not be staged earlier
   }
-  StepIt it1 = step_next<PK>(it0, nchunk);
-  StepIt it2 = step_next<PK>(it1, nchunk);
+  StepIt it1 = step_next<T>(it0, nchunk);
+  StepIt it2 = step_next<T>(it1, nchunk);
 
   using acc_t = typename std::conditional<I8, i32x4, f32x4>::type;
   acc_t acc[NB][MB];
@@ -607,16 +623,16 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   auto compute = [&](const StepIt &it, auto SET) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
     uint32_t stepbits = it.k >= 0 ? 1u << it.k : 0u;      // the offsets of this step (one, or up to PK)
-    if constexpr (PK > 1) {
+    if constexpr (T > 1) {
 #pragma unroll
-      for (int g = 1; g < PK; ++g) {
+      for (int g = 1; g < T; ++g) {
         const int kg = step_k(it, g);
         stepbits |= kg >= 0 ? 1u << kg : 0u;
       }
     }
     if (wavemask & stepbits) {
       const char *cur = smem + S * B_BYTES;
-      const int ksteps = (min(kRowBytes, static_cast<int>(rowB) - it.chunk * kRowBytes) + 63) >> 6;  // 1 or 2
+      const int ksteps = XK ? 2 : (min(kRowBytes, static_cast<int>(rowB) - it.chunk * kRowBytes) + 63) >> 6;  // 1 or 2
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         if (ks < ksteps) {
@@ -651,7 +667,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
   load_a(it1, Set1{});
   store_b(smem + B_BYTES, WSetA{});      // weights of step 1 -> stage 1 (published by step 1's barrier)
   {
-    const StepIt it3 = step_next<PK>(it2, nchunk);
+    const StepIt it3 = step_next<T>(it2, nchunk);
     load_b(it2, Set0{});
     if constexpr (WD == 2) load_b(it3, Set1{});   // step 3's weights: in flight two steps before their LDS write
     __builtin_amdgcn_sched_barrier(0);
@@ -675,7 +691,7 @@ __device__ __forceinline__ void igemm_v4_body(const GemmParams &p, int block) {
     using WSetN = std::integral_constant<int, (WD == 2 ? 1 - S : 0)>;
     if (!SPX_ABL(p, 1) && !SPX_ABL(p, 2)) store_b(smem + (1 - S) * B_BYTES, WSetN{});
     compute(it0, SET);
-    const StepIt it3 = step_next<PK>(it2, nchunk);
+    const StepIt it3 = step_next<T>(it2, nchunk);
     if (!SPX_ABL(p, 1) && !SPX_ABL(p, 2)) {
       if constexpr (WD == 2) load_b(it3, WSetN{});
       else load_b(it2, WSetN{});
@@ -805,12 +821,21 @@ template <int COUT, int MB, int DT>
 int launch_v4(const GemmParams &p, hipStream_t s);
 GemmRest rest_of(const GemmParams &p);
 
-// offsets per step of a launch (igemm_v4_body, PK): 4 / 2 for reduction rows of <= 16 / 32 bytes of a 16-bit type whose
-// pair table fits one buffer resource (32 table rows), else 1.  SPX_PK = 0 switches the packing off (A/B runs, tests).
-inline int v4_pack(const GemmParams &p, int DT, int es) {
-  if ((DT != 0 && DT != 1) || !p.pair || option_int("SPX_PK", 1) == 0) return 1;
+// the PK code of a launch (igemm_v4_body) for reduction rows of a 16-bit type whose pair table fits one buffer resource
+// (32 table rows): ONE piece per step packed -- 4 / 2 offsets for rows of <= 16 / 32 bytes -- in the forward / dgrad
+// launches; BOTH pieces (32 / 16 / 8 for rows of <= 16 / 32 / 64 bytes) in the fused backward.  Measured on the levels of
+// config 4 (profiles/r06_experiments.md section 8): these kernels are bound by vector-memory INSTRUCTIONS, and packing
+// one piece halves them (the lanes behind a row's end issued dead loads); packing both pieces only halves the barriers
+// -- level with one piece or slower forward (55.5 -> 55.6 us at 32 channels, 39.6 -> 43.4 at 16: three waves per SIMD
+// less), 3-7 us faster in the fused backward (97.6 -> 90.7, 79.4 -> 76.4), whose occupancy the wgrad half sets anyway.
+// SPX_PK = 0: no packing; 2: one piece everywhere; 3: both pieces everywhere (A/B runs, tests).
+inline int v4_pack(const GemmParams &p, int DT, int es, bool fused_bwd = false) {
+  const int mode = option_int("SPX_PK", 1);
+  if ((DT != 0 && DT != 1) || !p.pair || mode == 0) return 1;
   if (static_cast<unsigned long long>(p.n_dst) * 4ull * 32ull >= 0x7fff0000ull) return 1;
   const int rb = p.CIN * es;
+  const bool both = mode == 3 || (mode == 1 && fused_bwd);
+  if (both) return rb <= 16 ? 32 : (rb <= 32 ? 16 : (rb <= 64 ? 8 : 1));
   return rb <= 16 ? 4 : (rb <= 32 ? 2 : 1);
 }
 
@@ -836,7 +861,10 @@ int launch_v4(const GemmParams &p, hipStream_t s) {
   if (p.grid_out) *p.grid_out = (p.stats && DT != 2 && p.strideD == 1 && !p.acc_mode) ? napp + ntiles : 0;
   if (DT == 2 || p.strideD == 1) {
     if constexpr (DT == 0 || DT == 1) {
-      if (pk == 4) SPX_LAUNCH_V4(false, 1, 4);
+      if (pk == 32) SPX_LAUNCH_V4(false, 2, 32);
+      else if (pk == 16) SPX_LAUNCH_V4(false, 2, 16);
+      else if (pk == 8) SPX_LAUNCH_V4(false, 2, 8);
+      else if (pk == 4) SPX_LAUNCH_V4(false, 1, 4);
       else if (pk == 2) SPX_LAUNCH_V4(false, 1, 2);
       else if (half) SPX_LAUNCH_V4(false, 1, 1);
       else SPX_LAUNCH_V4(false, 2, 1);
@@ -846,7 +874,10 @@ int launch_v4(const GemmParams &p, hipStream_t s) {
     }
   } else if constexpr (DT != 2) {
     if constexpr (DT == 0 || DT == 1) {
-      if (pk == 4) SPX_LAUNCH_V4(true, 1, 4);
+      if (pk == 32) SPX_LAUNCH_V4(true, 2, 32);
+      else if (pk == 16) SPX_LAUNCH_V4(true, 2, 16);
+      else if (pk == 8) SPX_LAUNCH_V4(true, 2, 8);
+      else if (pk == 4) SPX_LAUNCH_V4(true, 1, 4);
       else if (pk == 2) SPX_LAUNCH_V4(true, 1, 2);
       else if (half) SPX_LAUNCH_V4(true, 1, 1);
       else SPX_LAUNCH_V4(true, 2, 1);

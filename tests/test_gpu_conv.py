@@ -554,6 +554,7 @@ def test_backward_is_bit_reproducible(cuda, scene_kind):
     (16, 16, [2] * 3, [2] * 3, [0] * 3, False, 6000),      # kernel volume 8: an even count, no identity offset
     (8, 8, [3, 1, 1], [1] * 3, [1, 0, 0], True, 3000),     # kernel volume 3: identity + one packed step with a hole
     (16, 64, [3] * 3, [1] * 3, [1] * 3, True, 40_000),     # rows layout territory (> 32 k rows)
+    (32, 32, [3] * 3, [1] * 3, [1] * 3, True, 6000),       # 64-byte rows: packed only across the two pieces of a step
 ])
 def test_packed_offsets_for_narrow_rows(cuda, C, K, ksize, stride, pad, subm, n, dtype):
     """igemm_v4_body, PK: reduction rows of <= 32 / 16 bytes carry 2 / 4 offsets per MFMA step (the lanes that used to
@@ -567,21 +568,22 @@ def test_packed_offsets_for_narrow_rows(cuda, C, K, ksize, stride, pad, subm, n,
     L = _lib.load()
     res = {}
     try:
-        for pk in (1, 0):
+        for pk in (1, 3, 0):          # the rule | both pieces of a step packed everywhere | one offset per step
             L.spx_set_option(b"SPX_PK", pk)
             _, out, din, dw = _run_gpu(cuda, idx, 2, shape, ksize, stride, pad, [1] * 3, subm, False, f, w, dout, dtype)
             res[pk] = (out, din, dw)
     finally:
         L.spx_set_option(b"SPX_PK", 1)
     tol = TOL[dtype]
-    for pk in (1, 0):
+    for pk in (1, 3, 0):
         out, din, dw = res[pk]
         _check("out", out, out_ref, tol)
         _check("din", din, din_ref, tol)
         _check("dw", dw, dw_ref, tol)
         _check_abs((out, din, dw), (out_ref, din_ref, dw_ref), f, w, dout, ref, subm, dtype)
     # the two walks against each other: one rounding of the stored dtype apart at most, nearly everywhere equal
-    for a, b in zip(res[1][:2], res[0][:2]):
-        a, b = a.float(), b.float()
-        assert float((a - b).abs().max()) <= 2 * tol * float(b.abs().max()) + 1e-6
-        assert float((a != b).float().mean()) < 0.2
+    for pk in (1, 3):
+        for a, b in zip(res[pk][:2], res[0][:2]):
+            a, b = a.float(), b.float()
+            assert float((a - b).abs().max()) <= 2 * tol * float(b.abs().max()) + 1e-6
+            assert float((a != b).float().mean()) < 0.2
