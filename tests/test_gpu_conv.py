@@ -555,6 +555,7 @@ def test_backward_is_bit_reproducible(cuda, scene_kind):
     (8, 8, [3, 1, 1], [1] * 3, [1, 0, 0], True, 3000),     # kernel volume 3: identity + one packed step with a hole
     (16, 64, [3] * 3, [1] * 3, [1] * 3, True, 40_000),     # rows layout territory (> 32 k rows)
     (32, 32, [3] * 3, [1] * 3, [1] * 3, True, 6000),       # 64-byte rows: packed only across the two pieces of a step
+    (16, 16, [5, 3, 3], [1] * 3, [2, 1, 1], True, 3000),   # kernel volume 45: two groups of offsets (two mask words)
 ])
 def test_packed_offsets_for_narrow_rows(cuda, C, K, ksize, stride, pad, subm, n, dtype):
     """igemm_v4_body, PK: reduction rows of <= 32 / 16 bytes carry 2 / 4 offsets per MFMA step (the lanes that used to
