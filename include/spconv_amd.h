@@ -225,6 +225,23 @@ int spx_conv_rulebook_static_sorted(const int32_t *indices, int n_in, int ndim, 
  * csrc/sparse/indices.py:723-741,806-874. */
 int spx_rankmap_from_sorted(const int32_t *indices, int n, int ndim, int batch_size, const int *spatial_shape,
                             void *rankmap, size_t rankmap_bytes, int32_t *violation, spx_stream_t stream);
+/* Rows in key order when the caller's are not: order[t] = the row with the t-th smallest linear coordinate key
+ * (batch-major, last axis fastest), rows that are dead (batch -1) or out of range behind every live row in their own
+ * order; `indices_sorted` (or NULL) receives indices[order[t]] (dead rows: -1s).  The keys of a level are unique, so
+ * this is four launches: one stable radix pass on the upper key bits (<= 511 buckets of 2^sh consecutive keys,
+ * sh <= 20), then a workgroup per bucket ranks its rows through an occupancy bit per key in LDS -- nothing is compared.
+ * A coordinate that occurs twice still yields a permutation (its extra rows land behind their bucket's distinct keys);
+ * spx_rankmap_from_sorted raises its flag on such a result.  Nothing is read back (hipGraph-safe): a captured pass
+ * sorts its scene at the entry (StaticInference / StaticTrainingStep entry_sort), hands spx_rankmap_from_sorted the
+ * result and runs every level in key order.  With `rankmap` (spx_rankmap_bytes() bytes, or NULL) the bucket pass leaves
+ * the rank map of indices_sorted behind as well -- what spx_rankmap_from_sorted would build from it; its fill rides
+ * in the sort's first launch: no pass of its own -- and `violation` (device int32 [1] or NULL: cleared by the first launch) is
+ * raised when a coordinate occurs twice.  Needs batch x grid <= 0xffe00000.  The reference sorts keys where it
+ * wants this order (thrust sort + unique of the output keys, csrc/sparse/all.py:1533-1552). */
+size_t spx_key_argsort_ws_bytes(int n);
+int spx_key_argsort(const int32_t *indices, int n, int ndim, int batch_size, const int *spatial_shape, int32_t *order,
+                    int32_t *indices_sorted, void *rankmap, size_t rankmap_bytes, int32_t *violation, void *ws,
+                    size_t ws_bytes, spx_stream_t stream);
 /* SubM rulebook (outputs as spx_subm_rulebook, bit for bit) of a level whose rows are in key order and whose
  * rank map a sorted-order build left behind: `indices` must be that build's out_indices (rows past its count:
  * batch -1). */

@@ -370,12 +370,14 @@ _RANKMAP_MAX_CELLS_PER_ROW = float(os.environ.get("SPCONV_AMD_RANKMAP_MAX_CELLS_
 
 
 @_on_device
-def attach_rank_map(indices: torch.Tensor, batch_size: int, spatial_shape, check: bool = True) -> bool:
+def attach_rank_map(indices: torch.Tensor, batch_size: int, spatial_shape, check: bool = True,
+                    violation: Optional[torch.Tensor] = None) -> bool:
     """Declares `indices` [n, ndim + 1] (int32, batch index first) to be in ascending, unique coordinate-key order
     (batch-major, last axis fastest; rows with batch index -1 -- static shapes -- trail) and attaches the level's rank
     map to the tensor.  check=True reads the device-side verdict back (ONE synchronisation; a data loader's place): a
     tensor that breaks the contract is left untouched and False is returned.  check=False (inside a stream capture;
-    the caller vouches for the order) never synchronises.  Returns whether a map was attached."""
+    the caller vouches for the order) never synchronises; `violation` (int32 [1] on the device) then receives the
+    verdict for whoever wants to read it later (1 = the rows break the contract).  Returns whether a map was attached."""
     _require_gpu(indices, "indices")
     assert indices.dtype == torch.int32 and indices.ndim == 2 and indices.is_contiguous()
     L = _lib.load()
@@ -389,7 +391,7 @@ def attach_rank_map(indices: torch.Tensor, batch_size: int, spatial_shape, check
         return False
     i32 = dict(dtype=torch.int32, device=indices.device)
     cells_t = torch.empty((nbytes // 4,), **i32)
-    bad = torch.empty((1,), **i32) if check else None
+    bad = torch.empty((1,), **i32) if check else violation
     _lib.check(L.spx_rankmap_from_sorted(indices.data_ptr(), n, ndim, batch_size, _lib.ints(spatial_shape),
                                          cells_t.data_ptr(), nbytes, _ptr(bad), _stream(indices)))
     if check and int(bad.item()) != 0:
@@ -397,6 +399,44 @@ def attach_rank_map(indices: torch.Tensor, batch_size: int, spatial_shape, check
     indices._spx_rankmap = (cells_t, batch_size, tuple(int(v) for v in spatial_shape), n,
                             indices._version, indices.data_ptr())
     return True
+
+
+@_on_device
+def key_argsort(indices: torch.Tensor, batch_size: int, spatial_shape, want_indices: bool = True,
+                rank_map: bool = False, violation: Optional[torch.Tensor] = None):
+    """(order, indices[order]) with order[t] = the row of the t-th smallest coordinate key (batch-major, last axis
+    fastest); dead rows (batch index -1) trail in their own order and come out as -1 in every column.  One C-ABI call
+    (spx_key_argsort: four launches -- one stable radix pass on the upper key bits, then workgroups per bucket rank
+    their rows through an occupancy map in LDS; the keys of a level are unique), nothing read back, so it can sit inside
+    a stream capture -- the static runners sort their scene at the entry with it (static.py entry_sort).
+    rank_map=True: the sorted index tensor leaves with the level's rank map attached, written by the same bucket pass
+    (what attach_rank_map would build from it; same size gates -- beyond them the tensor stays untagged); `violation`
+    (int32 [1] on the device) is raised when a coordinate occurs twice.  Returns None when the key space of
+    batch x grid does not fit 32 bits."""
+    _require_gpu(indices, "indices")
+    assert indices.dtype == torch.int32 and indices.ndim == 2 and indices.is_contiguous()
+    cells = int(batch_size)
+    for d in spatial_shape:
+        cells *= int(d)
+    if cells > 0xffe00000:
+        return None
+    L = _lib.load()
+    n, ndim = indices.shape[0], indices.shape[1] - 1
+    order = torch.empty((n,), dtype=torch.int32, device=indices.device)
+    out = torch.empty_like(indices) if (want_indices or rank_map) else None
+    cells_t = None
+    if rank_map and n > 0:
+        nbytes = int(L.spx_rankmap_bytes(ndim, batch_size, _lib.ints(spatial_shape)))
+        if not (nbytes == 0 or nbytes > _SORTED_MAX_SCRATCH
+                or (_RANKMAP_MAX_CELLS_PER_ROW > 0 and cells > _RANKMAP_MAX_CELLS_PER_ROW * n)):
+            cells_t = torch.empty((nbytes // 4,), dtype=torch.int32, device=indices.device)
+    ws = _ws(L.spx_key_argsort_ws_bytes(n), indices.device)
+    _lib.check(L.spx_key_argsort(indices.data_ptr(), n, ndim, int(batch_size), _lib.ints(spatial_shape),
+                                 order.data_ptr(), _ptr(out), _ptr(cells_t), 0 if cells_t is None else cells_t.numel() * 4,
+                                 _ptr(violation), ws.data_ptr(), ws.numel(), _stream(indices)))
+    if cells_t is not None:
+        out._spx_rankmap = (cells_t, batch_size, tuple(int(v) for v in spatial_shape), n, out._version, out.data_ptr())
+    return order, out
 
 
 def _build_sorted(L, indices, batch_size, spatial_shape, out_shape, ksize, stride, padding, dilation, args,

@@ -31,6 +31,7 @@ input FEATURES are zero, and either the loss has zero gradient on dead rows or t
 normalisation layer.  bench.py (`static_training_steps`) captures the whole training step of BASELINE
 configs 3 and 4 this way and checks it against the eager step before timing it.
 """
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -98,7 +99,78 @@ def _declare_key_order(runner) -> None:
     (ops.attach_rank_map)."""
     if getattr(runner, "key_ordered_input", False):
         from spconv_amd.pytorch import ops
-        ops.attach_rank_map(runner.indices, runner.batch_size, runner.spatial_shape, check=False)
+        ops.attach_rank_map(runner.indices, runner.batch_size, runner.spatial_shape, check=False,
+                            violation=runner._order_flag)
+
+
+class _GatherRows(torch.autograd.Function):
+    """rows[order] with the gradient scattered back (order is a permutation: every row receives exactly one term)."""
+
+    @staticmethod
+    def forward(ctx, rows, order):
+        ctx.save_for_backward(order)
+        return rows.index_select(0, order)
+
+    @staticmethod
+    def backward(ctx, g):
+        (order,) = ctx.saved_tensors
+        return torch.empty_like(g).index_copy_(0, order.long(), g), None
+
+
+def _entry_sort_default() -> bool:
+    return os.environ.get("SPCONV_AMD_ENTRY_SORT", "1") != "0"
+
+
+def _entry(runner):
+    """(features, indices) the network sees.  entry_sort (default; SPCONV_AMD_ENTRY_SORT=0 or entry_sort=False turns
+    it off): the scene is sorted by coordinate key at the head of every pass, inside the captured graph
+    (ops.key_argsort: four launches that also leave the level's rank map behind, nothing read back), and declared in key order, so level 1
+    runs like the levels behind a strided layer do -- rulebooks from a rank map instead of a hash table, x-neighbours in
+    adjacent rows for every gather.  What changes for the caller: tensors of the FIRST level come out in key order
+    (`runner.order[t]` = the input row behind row t; their `indices` say the same); levels behind a strided layer
+    are in key order with or without it.  The coordinates of a scene must be unique (a voxeliser's are):
+    `runner.input_order_violation()` reads the device-side verdict."""
+    if runner.key_ordered_input or not runner.entry_sort:
+        _declare_key_order(runner)
+        return runner.features, runner.indices
+    from spconv_amd.pytorch import ops
+    res = ops.key_argsort(runner.indices, runner.batch_size, runner.spatial_shape, rank_map=True,
+                          violation=runner._order_flag)
+    if res is None:                                   # (key space beyond 32 bits)
+        runner.entry_sort = False
+        return runner.features, runner.indices
+    runner.order, idx = res
+    return _GatherRows.apply(runner.features, runner.order), idx
+
+
+class _ScatterRows(torch.autograd.Function):
+    """out[order[t]] = rows[t] (the inverse of _GatherRows)."""
+
+    @staticmethod
+    def forward(ctx, rows, order):
+        ctx.save_for_backward(order)
+        return torch.empty_like(rows).index_copy_(0, order.long(), rows)
+
+    @staticmethod
+    def backward(ctx, g):
+        (order,) = ctx.saved_tensors
+        return g.index_select(0, order), None
+
+
+def _exit(runner, out, idx_seen):
+    """A result that lives on the INPUT's rows (a SubM-only stack, a decoder that returns onto them through inverse
+    convolutions) goes back into the caller's row order: entry_sort is then invisible in what the runner returns."""
+    if (idx_seen is not runner.indices and isinstance(out, SparseConvTensor) and out.indices is idx_seen):
+        back = out._like(_ScatterRows.apply(out.features, runner.order), {})
+        back.indices = runner.indices
+        return back
+    return out
+
+
+def _input_order_violation(runner) -> bool:
+    """True when the last replay's scene broke the entry sort's / key_ordered_input's contract (a coordinate twice, a
+    live row behind a dead one): its first-level rulebooks are then not the reference's.  One synchronisation."""
+    return bool(int(runner._order_flag.item()) != 0)
 
 
 class StaticInference:
@@ -120,10 +192,12 @@ class StaticInference:
                  spatial_shape: Sequence[int], batch_size: int, dtype: torch.dtype = torch.float16,
                  bounds: Optional[Dict[str, int]] = None, margin: float = 1.25,
                  device: Optional[torch.device] = None, warmup: int = 2, capture_error_mode: str = "global",
-                 key_ordered_input: bool = False):
+                 key_ordered_input: bool = False, entry_sort: Optional[bool] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("StaticInference needs the GPU (there is no CPU path)")
         self.key_ordered_input = bool(key_ordered_input)
+        self.entry_sort = _entry_sort_default() if entry_sort is None else bool(entry_sort)
+        self.order = None
         self.net = net.eval()
         self.device = torch.device(device if device is not None else "cuda")
         self.max_voxels = int(max_voxels)
@@ -135,6 +209,7 @@ class StaticInference:
         self.features = torch.zeros((self.max_voxels, in_channels), dtype=dtype, device=self.device)
         self.indices = torch.full((self.max_voxels, nd + 1), -1, dtype=torch.int32, device=self.device)
         self.n_live = torch.zeros((1,), dtype=torch.int32, device=self.device)   # rows of the current scene
+        self._order_flag = torch.zeros((1,), dtype=torch.int32, device=self.device)
         self._live = 0
         self.graph = None
         self.out = None
@@ -157,10 +232,10 @@ class StaticInference:
                           if getattr(m, "_static_n_out_dev", None) is not None}
 
     def _forward(self):
-        _declare_key_order(self)
-        x = SparseConvTensor(self.features, self.indices, self.spatial_shape, self.batch_size)
+        feats, idx = _entry(self)
+        x = SparseConvTensor(feats, idx, self.spatial_shape, self.batch_size)
         x.n_live_dev = self.n_live          # (normalisation layers write zeros into the padding rows)
-        return self.net(x)
+        return _exit(self, self.net(x), idx)
 
     def load(self, features: torch.Tensor, indices: torch.Tensor) -> None:
         """Copies one scene into the static input buffers (stream-ordered, no synchronisation)."""
@@ -195,6 +270,8 @@ class StaticInference:
         {layer: outputs found}.  Empty = every live row is exact."""
         return {k: c for k, (c, ovf) in self.counts().items() if c > self.bounds[k] or ovf}
 
+    input_order_violation = _input_order_violation
+
     def release_bounds(self) -> None:
         """Clears the frozen bounds of the network's strided layers (eager passes are unbounded again; the
         captured graph keeps working, its shapes are baked in)."""
@@ -223,10 +300,13 @@ class StaticTrainingStep:
                  batch_size: int, dtype: torch.dtype = torch.float16, bounds: Optional[Dict[str, int]] = None,
                  margin: float = 1.25, backward=None, out_grad: Optional[torch.Tensor] = None,
                  input_grad: bool = False, device: Optional[torch.device] = None, warmup: int = 2,
-                 example=None, capture_error_mode: str = "global", key_ordered_input: bool = False):
+                 example=None, capture_error_mode: str = "global", key_ordered_input: bool = False,
+                 entry_sort: Optional[bool] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("StaticTrainingStep needs the GPU (there is no CPU path)")
         self.key_ordered_input = bool(key_ordered_input)
+        self.entry_sort = _entry_sort_default() if entry_sort is None else bool(entry_sort)
+        self.order = None
         if (backward is None) == (out_grad is None):
             raise ValueError("give exactly one of `backward` (callable on the output tensor) and `out_grad`")
         self.net = net.train()
@@ -240,6 +320,7 @@ class StaticTrainingStep:
                                     device=self.device).requires_grad_(input_grad)
         self.indices = torch.full((self.max_voxels, nd + 1), -1, dtype=torch.int32, device=self.device)
         self.n_live = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        self._order_flag = torch.zeros((1,), dtype=torch.int32, device=self.device)
         self._live = 0
         self.out = None
         with torch.cuda.device(self.device):
@@ -266,10 +347,10 @@ class StaticTrainingStep:
     def _compute(self):
         self.net.zero_grad(set_to_none=True)
         self.features.grad = None
-        _declare_key_order(self)
-        x = SparseConvTensor(self.features, self.indices, self.spatial_shape, self.batch_size)
+        feats, idx = _entry(self)
+        x = SparseConvTensor(feats, idx, self.spatial_shape, self.batch_size)
         x.n_live_dev = self.n_live
-        self.out = self.net(x)
+        self.out = _exit(self, self.net(x), idx)
         self._backward(self.out)
 
     def load(self, features: torch.Tensor, indices: torch.Tensor) -> None:
@@ -293,5 +374,6 @@ class StaticTrainingStep:
         return self.out
 
     counts = StaticInference.counts
+    input_order_violation = _input_order_violation
     overflowed = StaticInference.overflowed
     release_bounds = StaticInference.release_bounds

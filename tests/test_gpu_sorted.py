@@ -362,3 +362,129 @@ def test_captured_pass_over_key_ordered_input_equals_eager(cuda):
         k = want.indices.shape[0]
         assert torch.equal(got.indices[:k], want.indices) and torch.equal(got.features[:k], want.features)
     runner.release_bounds()
+
+
+@pytest.mark.parametrize("shape,n,bs,dead", [([19, 18, 17], 1500, 2, 0), ([41, 400, 352], 60000, 4, 777),
+                                             ([60, 50], 900, 2, 5), ([1600, 1280, 40], 20000, 1, 0),
+                                             ([2000, 2000, 400], 30000, 1, 100),      # 31 key bits: two radix passes
+                                             ([41, 1600, 1408], 110000, 4, 20000),    # BASELINE config 4's grid
+                                             ([64, 64, 64], 100000, 1, 0)])           # crowded buckets (38 % occupied)
+def test_key_argsort_is_the_stable_sort_by_coordinate_key(cuda, shape, n, bs, dead):
+    """spx_key_argsort (the entry sort of the static runners): order = stable argsort of the linear coordinate keys,
+    dead rows (batch -1) behind every live row in their own order; the gathered index rows ride along."""
+    from spconv_amd.pytorch import ops
+    ind = scene(shape, n, bs, seed=4)
+    rng = np.random.default_rng(1)
+    ind = ind[rng.permutation(ind.shape[0])]
+    if dead:                                    # dead rows anywhere (the runners' trail, the sort does not need that)
+        pos = rng.choice(ind.shape[0], dead, replace=False)
+        ind[pos, 0] = -1
+    key = _keys(ind, shape)
+    key[ind[:, 0] < 0] = np.iinfo(np.int64).max
+    want = np.argsort(key, kind="stable")
+    order, rows = ops.key_argsort(torch.from_numpy(ind).to(cuda), bs, shape)
+    assert np.array_equal(to_np(order), want.astype(np.int32))
+    want_rows = ind[want]
+    want_rows[want_rows[:, 0] < 0] = -1         # (dead rows come out as -1 in every column)
+    assert np.array_equal(to_np(rows), want_rows)
+    assert ops.key_argsort(torch.from_numpy(ind).to(cuda), 1 << 12, [1 << 10, 1 << 10]) is None     # > 32 key bits
+    # rank_map=True: the bucket pass leaves the map spx_rankmap_from_sorted would build from the sorted rows, word for word
+    flag = torch.ones((1,), dtype=torch.int32, device=cuda)
+    order_m, rows_m = ops.key_argsort(torch.from_numpy(ind).to(cuda), bs, shape, rank_map=True, violation=flag)
+    assert torch.equal(order_m, order) and torch.equal(rows_m, rows) and int(flag.item()) == 0
+    ref = rows.clone()
+    if ops.attach_rank_map(ref, bs, shape, check=True):
+        got_map, want_map = rows_m._spx_rankmap[0], ref._spx_rankmap[0]
+        W = (bs * int(np.prod(shape)) + 31) // 32
+        off = ((W * 8 + 255) // 256) * 256 // 4
+        assert torch.equal(got_map[:2 * W], want_map[:2 * W])
+        assert torch.equal(got_map[off:off + (W + 2047) // 2048], want_map[off:off + (W + 2047) // 2048])
+        assert rows_m._spx_rankmap[1:4] == ref._spx_rankmap[1:4]
+    else:
+        assert getattr(rows_m, "_spx_rankmap", None) is None           # (the same size gates)
+    # a coordinate twice breaks the contract (the rank-map pass behind the sort raises its flag): still a permutation,
+    # and every row outside the buckets of the doubled keys is where the sort puts it
+    live = np.flatnonzero(ind[:, 0] >= 0)
+    ind2 = ind.copy()
+    ind2[live[3]] = ind2[live[-7]]
+    ind2[live[11]] = ind2[live[-7]]
+    t2 = torch.from_numpy(ind2).to(cuda)
+    order2, rows2 = ops.key_argsort(t2, bs, shape)
+    o2 = to_np(order2)
+    assert np.array_equal(np.sort(o2), np.arange(ind2.shape[0]))
+    want_rows = ind2[o2]
+    want_rows[want_rows[:, 0] < 0] = -1
+    assert np.array_equal(to_np(rows2), want_rows)
+    assert not ops.attach_rank_map(rows2, bs, shape, check=True)
+    ops.key_argsort(t2, bs, shape, rank_map=True, violation=flag)
+    assert int(flag.item()) == 1 or getattr(rows_m, "_spx_rankmap", None) is None
+
+
+def test_entry_sort_of_the_static_runners(cuda):
+    """entry_sort (default): a captured pass sorts its scene by coordinate key at the entry and runs level 1 over a rank
+    map.  (a) a backbone's output (behind a strided layer: key order either way) equals the pass without the sort bit
+    for bit; (b) a SubM-only stack's output comes back in the CALLER's row order; (c) the gradient of the input features
+    of a captured training step arrives in the caller's order; (d) a scene with a coordinate twice raises the flag."""
+    import copy
+    import spconv_amd.pytorch as spconv
+    from spconv_amd.pytorch.static import StaticInference, StaticTrainingStep, strided_layers
+    from torch import nn
+    shape, bs = [32, 40, 40], 2
+    torch.manual_seed(5)
+    net = spconv.SparseSequential(
+        spconv.SubMConv3d(8, 16, 3, bias=False, indice_key="s0"), nn.ReLU(),
+        spconv.SubMConv3d(16, 16, 3, bias=False, indice_key="s0"), nn.ReLU(),
+        spconv.SparseConv3d(16, 32, 3, 2, 1, bias=False, indice_key="d1"), nn.ReLU(),
+        spconv.SubMConv3d(32, 32, 3, bias=False, indice_key="s1")).to(cuda).half().eval()
+    name = list(strided_layers(net))[0]
+    mk = lambda es: StaticInference(copy.deepcopy(net), max_voxels=12_000, in_channels=8, spatial_shape=shape,
+                                    batch_size=bs, dtype=torch.float16, bounds={name: 13_000}, entry_sort=es)
+    on, off = mk(None), mk(False)
+    assert on.entry_sort and not off.entry_sort
+    flat = spconv.SparseSequential(
+        spconv.SubMConv3d(8, 16, 3, bias=False, indice_key="s0"), nn.ReLU(),
+        spconv.SubMConv3d(16, 16, 3, bias=True, indice_key="s0")).to(cuda).half().eval()
+    fon = StaticInference(copy.deepcopy(flat), 12_000, 8, shape, bs, torch.float16, bounds={})
+    for n, seed in ((4500, 1), (2001, 2), (5999, 3)):
+        idx = torch.from_numpy(scene(shape, n, bs, seed)).to(cuda)
+        idx = idx[torch.randperm(idx.shape[0], device=cuda)].contiguous()
+        f = (torch.rand((idx.shape[0], 8), device=cuda) - 0.5).half()
+        a, b = on(f, idx), off(f, idx)
+        assert not on.input_order_violation()
+        assert torch.equal(a.indices, b.indices) and torch.equal(a.features, b.features)             # (a)
+        k = idx.shape[0]
+        key = _keys(to_np(idx), shape)
+        assert np.array_equal(to_np(on.order)[:k], np.argsort(key, kind="stable"))
+        with torch.no_grad():
+            want = flat(spconv.SparseConvTensor(f, idx, shape, bs))
+        got = fon(f, idx)                                                                               # (b)
+        assert torch.equal(got.indices[:k], idx) and torch.equal(got.features[:k], want.features)
+        assert bool((got.indices[k:, 0] < 0).all())
+    # (c)
+    tnet = copy.deepcopy(flat).train()
+    eager = copy.deepcopy(tnet)
+    idx = torch.from_numpy(scene(shape, 3000, bs, 7)).to(cuda)
+    idx = idx[torch.randperm(idx.shape[0], device=cuda)].contiguous()
+    k = idx.shape[0]
+    f = (torch.rand((k, 8), device=cuda) - 0.5).half()
+    g = ((torch.rand((k + 100, 16), device=cuda) - 0.5) * 0.2).half()
+    g[k:] = 0
+    step = StaticTrainingStep(tnet, k + 100, 8, shape, bs, torch.float16, bounds={}, out_grad=g, input_grad=True,
+                              example=(f, idx))
+    assert step.entry_sort
+    out = step(f, idx)
+    fe = f.clone().requires_grad_(True)
+    ye = eager(spconv.SparseConvTensor(fe, idx, shape, bs))
+    ye.features.backward(g[:k])
+    assert torch.equal(out.indices[:k], idx) and torch.equal(out.features[:k], ye.features)
+    assert torch.equal(step.features.grad[:k], fe.grad)                  # (dgrad: a row's sum does not see the row order)
+    for pa, pb in zip(tnet.parameters(), eager.parameters()):
+        rel = float((pa.grad.float() - pb.grad.float()).norm() / pb.grad.float().norm().clamp_min(1e-12))
+        assert rel < 2e-3, rel
+    # (d)
+    dup = idx.clone()
+    dup[5] = dup[900]
+    step(f, dup)
+    assert step.input_order_violation()
+    step(f, idx)
+    assert not step.input_order_violation()

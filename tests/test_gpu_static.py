@@ -321,7 +321,10 @@ def test_config4_network_captured_step_equals_eager_in_fp32(cuda):
     # counts on the device): the same launches on the same rows -- every gradient bit for bit
     twin = copy.deepcopy(net)                      # (carries the frozen bounds; its own .grad tensors)
     twin.zero_grad(set_to_none=True)
-    xs = spconv.SparseConvTensor(step.features.detach().clone(), step.indices.clone(), shape, bs)
+    # (the runner sorts its scene by coordinate key at the entry -- static.py entry_sort --: the twin gets those rows)
+    assert step.entry_sort
+    o = step.order.long()
+    xs = spconv.SparseConvTensor(step.features.detach()[o].clone(), step.indices[o].clone(), shape, bs)
     xs.n_live_dev = step.n_live
     ys = twin(xs)
     ys.features.backward(g)
