@@ -1145,7 +1145,10 @@ def run_net(args, D: Dist):
                       "static_shapes": static_info, "parallelism": f"dp{world}", "ranks_seen": ranks_seen,
                       "conv_output_order": __import__("spconv_amd.constants", fromlist=["x"]).CONV_OUTPUT_ORDER,
                       "input_row_order": "ascending coordinate key, declared (key_ordered_input)" if key_order
-                                         else "generator order (shuffled in space)",
+                                         else "generator order (shuffled in space)" +
+                                         ("; sorted by coordinate key at the head of the captured step (entry_sort: "
+                                          "spx_key_argsort inside the graph and the timed region)"
+                                          if (static_info or {}).get("entry_sort") and eager_ms is not None else ""),
                       "dist_backend": D.backend if D.multi else None},
            "roofline": roofline_obj("step", total, ms, "whole step: rulebook builders + igemm_v4 / igemm_bwd / "
                                     "wgrad_reduce2 of every layer (+ the bn_* BatchNorm+ReLU kernels at config 4)", None,
@@ -1255,7 +1258,8 @@ def static_training_steps(net, data, bs, cin, shape, steps, warm, D: Dist, input
     elapsed = timed_region(D, run_steps, warm, steps)
     over = runner.overflowed()
     runner.release_bounds()
-    return elapsed, {"bounds": bounds, "padded_input_rows": n_max, "dw_rel_diff_vs_eager": worst, "dw_rel_diff_noise_floor": floor, "out_rel_diff_vs_eager": out_diff,
+    return elapsed, {"bounds": bounds, "padded_input_rows": n_max, "entry_sort": bool(runner.entry_sort and not key_ordered),
+                     "input_order_violation": runner.input_order_violation(), "dw_rel_diff_vs_eager": worst, "dw_rel_diff_noise_floor": floor, "out_rel_diff_vs_eager": out_diff,
                      "dw_rel_diff_worst_params": sorted(per_param, reverse=True)[:4],
                      "din_rel_diff_vs_eager": din, "overflowed": over}
 
@@ -1383,7 +1387,11 @@ def run_infer(args, D: Dist):
                        "launch": "hipGraph replay (rulebooks + convolutions), one graph for every scene",
                        "conv_output_order": __import__("spconv_amd.constants", fromlist=["x"]).CONV_OUTPUT_ORDER,
                        "input_row_order": "ascending coordinate key, declared (key_ordered_input)"
-                                          if getattr(args, "key_order", False) else "generator order (shuffled in space)",
+                                          if getattr(args, "key_order", False) else "generator order (shuffled in space)" +
+                                          ("; sorted by coordinate key at the head of the captured pass (entry_sort: "
+                                           "spx_key_argsort inside the graph and the timed region)"
+                                           if runner.entry_sort else ""),
+                       "entry_sort": bool(runner.entry_sort and not getattr(args, "key_order", False)),
                        "parallelism": f"dp{world}", "ranks_seen": ranks_seen}}
 
 
@@ -1439,6 +1447,21 @@ def also_block(args, D: Dist):
                     c["first_seen_order_ms_per_step"] = f"{type(e).__name__}: {e}"[:200]
                 finally:
                     _c.CONV_OUTPUT_ORDER = keep
+        if cfg in ("4", "4i") and not getattr(a, "key_order", False) and os.environ.get("SPCONV_AMD_ENTRY_SORT", "auto") != "0":
+            # the same captured pass WITHOUT the entry sort (static.py entry_sort: level 1 in the caller's row order, its
+            # rulebooks from a hash table) -- what the sort at the head of the pass buys, sort included
+            keep_es = os.environ.get("SPCONV_AMD_ENTRY_SORT")
+            try:
+                os.environ["SPCONV_AMD_ENTRY_SORT"] = "0"
+                r4 = run_infer(a, D) if cfg == "4i" else run_net(a, D)
+                c["entry_sort_off_ms_per_step"] = round(r4["ms_per_step"], 5)
+                del r4
+            except Exception as e:
+                c["entry_sort_off_ms_per_step"] = f"{type(e).__name__}: {e}"[:200]
+            finally:
+                os.environ.pop("SPCONV_AMD_ENTRY_SORT", None)
+                if keep_es is not None:
+                    os.environ["SPCONV_AMD_ENTRY_SORT"] = keep_es
         if cfg in ("4", "4i") and not getattr(a, "key_order", False):
             # the same network with the scenes handed over in coordinate-key order (a data loader that sorts once:
             # utils.sort_voxels_by_coordinate) and the captured pass told so: level 1 without a hash table

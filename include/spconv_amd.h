@@ -450,6 +450,31 @@ int spx_igemm_bwd(const void *feat, const void *dout, const void *weight, void *
                   int n_in, int n_out, int C, int K, int kv, int dtype, int subm, void *ws,
                   size_t ws_bytes, spx_stream_t stream);
 
+/* The weight gradient's SECOND STAGE deferred.  spx_igemm_bwd / spx_igemm_wgrad end with a small launch that reduces
+ * the per-range partial tiles (fp32, in `ws`) into dw; nothing in a backward pass waits for a layer's dw, and a
+ * dependent 4-9 us launch per layer is what a captured training step of a backbone is made of.  The *_deferred forms
+ * run everything BUT that launch and write its description into `stage2_job` (SPX_STAGE2_JOB_BYTES bytes of host
+ * memory, opaque); spx_wgrad_stage2_batch then reduces the partial tiles of up to 16 layers per launch (jobs:
+ * `njobs` consecutive records, any mix of dtypes).  Between the two calls the caller keeps `ws`, the plan and dw
+ * alive and must not read dw.  A call whose shapes take a path without a second stage (empty scene, odd channel counts)
+ * completes dw at once and leaves an empty record, which the batch call skips.  Results are bit-identical to the
+ * undeferred calls (same kernel body, same summation order).  The reference returns din and dw from one blocking
+ * call (pytorch/ops.py:1667-1896); its split-K reduction is part of that call. */
+#define SPX_STAGE2_JOB_BYTES 64
+int spx_igemm_bwd_deferred(const void *feat, const void *dout, const void *weight, void *din, void *dw,
+                           const int32_t *pair, const uint32_t *mask, const int32_t *argsort, int tile_order,
+                           const int32_t *pair_native, const int32_t *num_per_loc, const int32_t *plan,
+                           int n_in, int n_out, int C, int K, int kv, int dtype, int subm, void *ws,
+                           size_t ws_bytes, spx_stream_t stream, void *stage2_job);
+int spx_igemm_wgrad_deferred(const void *feat, const void *dout, void *dw, const int32_t *pair_native,
+                             const int32_t *num_per_loc, const int32_t *plan, int n_in, int n_out, int C,
+                             int K, int kv, int dtype, int subm, void *ws, size_t ws_bytes,
+                             spx_stream_t stream, void *stage2_job);
+int spx_wgrad_stage2_batch(const void *jobs, int njobs, spx_stream_t stream);
+/* Points a pending record at another destination of the same shape and dtype (an autograd engine may have moved the
+ * gradient it was handed into a tensor of its own); returns 1, or 0 for an empty record. */
+int spx_stage2_job_retarget(void *stage2_job, void *dw);
+
 /* In-place epilogues for callers that keep bias/activation separate
  * (InferenceOps.bias_add_act_inplace etc., csrc/sparse/inference.py:26-146). */
 int spx_bias_act_inplace(void *out, const void *bias, int n, int K, int dtype, int act,

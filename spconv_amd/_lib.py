@@ -97,6 +97,11 @@ SIGNATURES = {
     "spx_igemm_wgrad": (ctypes.c_int, [vp] * 6 + [ctypes.c_int] * 7 + [vp, ctypes.c_size_t, vp]),
     "spx_igemm_bwd": (ctypes.c_int, [vp] * 8 + [ctypes.c_int] + [vp] * 3 + [ctypes.c_int] * 7
                       + [vp, ctypes.c_size_t, vp]),
+    "spx_igemm_wgrad_deferred": (ctypes.c_int, [vp] * 6 + [ctypes.c_int] * 7 + [vp, ctypes.c_size_t, vp, vp]),
+    "spx_igemm_bwd_deferred": (ctypes.c_int, [vp] * 8 + [ctypes.c_int] + [vp] * 3 + [ctypes.c_int] * 7
+                               + [vp, ctypes.c_size_t, vp, vp]),
+    "spx_wgrad_stage2_batch": (ctypes.c_int, [vp, ctypes.c_int, vp]),
+    "spx_stage2_job_retarget": (ctypes.c_int, [vp, vp]),
     "spx_permute_tables": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]),
     "spx_maxpool_fwd": (ctypes.c_int, [vp] * 4 + [ctypes.c_int] * 5 + [vp]),
     "spx_maxpool_bwd": (ctypes.c_int, [vp] * 6 + [ctypes.c_int] * 4 + [vp]),

@@ -62,7 +62,7 @@ const char *spx_last_error(void) { return spx::g_error.c_str(); }
 
 long long spx_launch_count(const char *family_h) {
   static const char *names[spx::kFamCount] = {"igemm_v4", "igemm_ws", "igemm_bwd", "igemm_bwd_rows", "igemm_i8_stream",
-                                              "generic"};
+                                              "generic", "wgrad_stage2", "wgrad_stage2_batch"};
   if (!family_h) return -1;
   for (int i = 0; i < spx::kFamCount; ++i)
     if (strcmp(names[i], family_h) == 0) return spx::g_launches[i].load(std::memory_order_relaxed);

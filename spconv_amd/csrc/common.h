@@ -114,7 +114,7 @@ inline Geom make_geom(int ndim, int batch, const int *in_dims, const int *out_di
 
 // ---- launch counters (diagnostics: which kernel family a call dispatched; spx_launch_count) --------
 namespace spx {
-enum LaunchFamily { kFamV4 = 0, kFamWs, kFamBwdFused, kFamBwdRows, kFamI8Stream, kFamGeneric, kFamCount };
+enum LaunchFamily { kFamV4 = 0, kFamWs, kFamBwdFused, kFamBwdRows, kFamI8Stream, kFamGeneric, kFamStage2, kFamStage2Batch, kFamCount };
 extern std::atomic<long long> g_launches[kFamCount];
 inline void count_launch(LaunchFamily f) { g_launches[f].fetch_add(1, std::memory_order_relaxed); }
 }  // namespace spx

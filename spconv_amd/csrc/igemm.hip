@@ -19,6 +19,7 @@
 // 2.5 GFLOP, so the design spends its effort on coalesced 128-byte row
 // gathers, mask-predicated rulebook reads and single-pass outputs, not on MFMA
 // utilisation.
+#include <cstring>
 #include "igemm_bwd.h"
 
 namespace spx {
@@ -540,15 +541,20 @@ wgrad_f32_kernel(Wgrad2Params p) {
 // every offset a block shape that fits its segment count -- 16 elements x 128 segment groups
 // for long lists, 128 x 4 or 512 x 1 for short ones -- so a SubM rulebook with one long and
 // 26 short lists runs ~460 blocks of useful work instead of 27 x 128 mostly idle ones.
+// (one layer's second stage: the job of a workgroup column `tile`; shared by the one-layer launch and the batched one)
+struct Wgrad2Job {
+  const float *partial;    // [segment][tile][64*64]
+  const int32_t *plan2;
+  void *dw;
+  int G, kv, tiles_k, tiles_c, K, C;
+};
+
 template <typename T>
-__global__ void __launch_bounds__(kRedThreads)
-wgrad_reduce2_kernel(Wgrad2Params p, T *__restrict__ dw) {
-  __shared__ float red[kRedThreads];
+__device__ __forceinline__ void wgrad_reduce2_body(const Wgrad2Job &p, T *__restrict__ dw, const int tile, float *red) {
   const int32_t *__restrict__ rl = p.plan2 + plan2_red(p.G, p.kv);
   const int nitems = rl[0];
   const int ntile = p.tiles_k * p.tiles_c;
   const size_t stride = static_cast<size_t>(ntile) * (kWT * kWT);
-  const int tile = blockIdx.y;
   for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
     const int4 item = *reinterpret_cast<const int4 *>(rl + 4 + 4 * it);    // uniform: one s_load_dwordx4
     const int k = item.x & 0xff, mode = item.x >> 8, e0 = item.y, first = item.z, nseg = item.w;
@@ -616,6 +622,35 @@ wgrad_reduce2_kernel(Wgrad2Params p, T *__restrict__ dw) {
     }
     if (S > 1) __syncthreads();   // red[] is reused by the next item
   }
+}
+
+
+template <typename T>
+__global__ void __launch_bounds__(kRedThreads)
+wgrad_reduce2_kernel(Wgrad2Params p, T *__restrict__ dw) {
+  __shared__ float red[kRedThreads];
+  const Wgrad2Job j{p.partial, p.plan2, dw, p.G, p.kv, p.tiles_k, p.tiles_c, p.K, p.C};
+  wgrad_reduce2_body<T>(j, dw, static_cast<int>(blockIdx.y), red);
+}
+
+// The second stages of SEVERAL layers in one launch (spx_wgrad_stage2_batch): a backward pass of a network reduces
+// every layer's partial tiles at its end instead of behind each layer -- a 4-9 us launch per layer leaves the chain.
+// blockIdx.y = tile columns of job 0, then of job 1, ...; blockIdx.x strides over a job's work list as above.
+constexpr int kStage2MaxJobs = 16;
+struct Wgrad2Batch {
+  int n;
+  int ybase[kStage2MaxJobs + 1];
+  Wgrad2Job job[kStage2MaxJobs];
+};
+
+template <typename T>
+__global__ void __launch_bounds__(kRedThreads)
+wgrad_reduce2_batch_kernel(Wgrad2Batch b) {
+  __shared__ float red[kRedThreads];
+  int j = 0;
+  while (j + 1 < b.n && static_cast<int>(blockIdx.y) >= b.ybase[j + 1]) ++j;      // (uniform: scalar compares)
+  const Wgrad2Job job = b.job[j];
+  wgrad_reduce2_body<T>(job, static_cast<T *>(job.dw), static_cast<int>(blockIdx.y) - b.ybase[j], red);
 }
 
 template <typename T>
@@ -751,6 +786,34 @@ int wgrad_groups(int n_in, int subm) {
 int reduce2_blocks(int kv) {
   constexpr int cap = 512;
   return kv * 256 < cap ? kv * 256 : cap;
+}
+
+// host form of a deferred second stage (include/spconv_amd.h SPX_STAGE2_JOB_BYTES: opaque to the caller)
+struct Stage2JobH {
+  const float *partial;
+  const int32_t *plan2;
+  void *dw;
+  int G, kv, tiles_k, tiles_c, K, C, dtype, valid;
+};
+static_assert(sizeof(Stage2JobH) <= SPX_STAGE2_JOB_BYTES, "job record");
+
+// the second stage of one layer: launched here, or -- `defer` -- written down for spx_wgrad_stage2_batch
+int launch_reduce2(const Wgrad2Params &q, void *dw, int dtype, int ntile, hipStream_t s, void *defer) {
+  if (defer) {
+    Stage2JobH j{q.partial, q.plan2, dw, q.G, q.kv, q.tiles_k, q.tiles_c, q.K, q.C, dtype, 1};
+    memcpy(defer, &j, sizeof(j));
+    return 0;
+  }
+  const dim3 rgrid2(reduce2_blocks(q.kv), ntile);   // block-stride over the work list
+  count_launch(kFamStage2);
+  if (dtype == SPX_F32)
+    hipLaunchKernelGGL(wgrad_reduce2_kernel<float>, rgrid2, dim3(kRedThreads), 0, s, q, static_cast<float *>(dw));
+  else if (dtype == SPX_F16)
+    hipLaunchKernelGGL(wgrad_reduce2_kernel<h16>, rgrid2, dim3(kRedThreads), 0, s, q, static_cast<h16 *>(dw));
+  else
+    hipLaunchKernelGGL(wgrad_reduce2_kernel<b16>, rgrid2, dim3(kRedThreads), 0, s, q, static_cast<b16 *>(dw));
+  SPX_LAUNCH_CHECK();
+  return 0;
 }
 
 int wgrad_xcd_order() {
@@ -1000,10 +1063,10 @@ size_t spx_igemm_wgrad_ws_bytes(int n_in, int C, int K, int kv) {
   return align_up(parts * tiles * kWT * kWT * sizeof(float), 256) + spx_wgrad_plan_bytes(n_in, kv);
 }
 
-int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t *pair_native,
-                    const int32_t *num_per_loc, const int32_t *plan, int n_in, int n_out, int C,
-                    int K, int kv, int dtype, int subm, void *ws, size_t ws_bytes,
-                    spx_stream_t stream) {
+static int igemm_wgrad_impl(const void *feat, const void *dout, void *dw, const int32_t *pair_native,
+                            const int32_t *num_per_loc, const int32_t *plan, int n_in, int n_out, int C,
+                            int K, int kv, int dtype, int subm, void *ws, size_t ws_bytes,
+                            spx_stream_t stream, void *stage2_job) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   SPX_CHECK(dw && C > 0 && K > 0, "null tensor pointer");
   SPX_CHECK(kv >= 1 && kv <= 128, "kernel volume %d not supported by wgrad (max 128)", kv);
@@ -1080,18 +1143,7 @@ int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t 
       else if (sl == 4) hipLaunchKernelGGL((wgrad_tr_kernel<true, 4>), grid, dim3(kThreads), lds, s, q);
       else hipLaunchKernelGGL((wgrad_tr_kernel<true, 8>), grid, dim3(kThreads), lds, s, q);
     }
-    const dim3 rgrid2(reduce2_blocks(kv), ntile);   // block-stride over the work list
-    if (dtype == SPX_F32)
-      hipLaunchKernelGGL(wgrad_reduce2_kernel<float>, rgrid2, dim3(kRedThreads), 0, s, q,
-                         static_cast<float *>(dw));
-    else if (dtype == SPX_F16)
-      hipLaunchKernelGGL(wgrad_reduce2_kernel<h16>, rgrid2, dim3(kRedThreads), 0, s, q,
-                         static_cast<h16 *>(dw));
-    else
-      hipLaunchKernelGGL(wgrad_reduce2_kernel<b16>, rgrid2, dim3(kRedThreads), 0, s, q,
-                         static_cast<b16 *>(dw));
-    SPX_LAUNCH_CHECK();
-    return 0;
+    return launch_reduce2(q, dw, dtype, ntile, s, stage2_job);
   }
   {
     // fallback kernels (odd channel counts, tensors beyond 32-bit offsets): their item list is
@@ -1138,11 +1190,11 @@ int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t 
   return 0;
 }
 
-int spx_igemm_bwd(const void *feat, const void *dout, const void *weight, void *din, void *dw,
-                  const int32_t *pair, const uint32_t *mask, const int32_t *argsort, int tile_order,
-                  const int32_t *pair_native, const int32_t *num_per_loc, const int32_t *plan,
-                  int n_in, int n_out, int C, int K, int kv, int dtype, int subm, void *ws,
-                  size_t ws_bytes, spx_stream_t stream) {
+static int igemm_bwd_impl(const void *feat, const void *dout, const void *weight, void *din, void *dw,
+                          const int32_t *pair, const uint32_t *mask, const int32_t *argsort, int tile_order,
+                          const int32_t *pair_native, const int32_t *num_per_loc, const int32_t *plan,
+                          int n_in, int n_out, int C, int K, int kv, int dtype, int subm, void *ws,
+                          size_t ws_bytes, spx_stream_t stream, void *stage2_job) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (n_in == 0 || n_out == 0) {                              // empty scene: din empty / zero, dW zero
     SPX_CHECK(dw && C > 0 && K > 0 && kv > 0, "null tensor pointer");
@@ -1175,8 +1227,8 @@ int spx_igemm_bwd(const void *feat, const void *dout, const void *weight, void *
     if (spx_igemm_dgrad(dout, weight, din, pair, mask, argsort, tile_order, n_out, n_in, C, K, kv, dtype, subm,
                         nullptr, 0, stream))
       return -2;
-    return spx_igemm_wgrad(feat, dout, dw, pair_native, num_per_loc, plan, n_in, n_out, C, K, kv, dtype,
-                           subm, ws, ws_bytes, stream);
+    return igemm_wgrad_impl(feat, dout, dw, pair_native, num_per_loc, plan, n_in, n_out, C, K, kv, dtype,
+                            subm, ws, ws_bytes, stream, stage2_job);
   }
   if (!plan) {  // caller did not cache a plan: build it behind the partials
     int32_t *own = reinterpret_cast<int32_t *>(static_cast<char *>(ws) + ws_bytes -
@@ -1206,14 +1258,94 @@ int spx_igemm_bwd(const void *feat, const void *dout, const void *weight, void *
                                   : (dtype == SPX_BF16 ? dispatch_bwd_bf16(p, q, q.G * ntile, s)
                                                        : dispatch_bwd<0>(p, q, q.G * ntile, s));
   if (rc) return rc;
-  const dim3 rgrid2(reduce2_blocks(kv), ntile);   // block-stride over the work list
-  if (dtype == SPX_F32)
-    hipLaunchKernelGGL(wgrad_reduce2_kernel<float>, rgrid2, dim3(kRedThreads), 0, s, q, static_cast<float *>(dw));
-  else if (dtype == SPX_F16)
-    hipLaunchKernelGGL(wgrad_reduce2_kernel<h16>, rgrid2, dim3(kRedThreads), 0, s, q, static_cast<h16 *>(dw));
-  else
-    hipLaunchKernelGGL(wgrad_reduce2_kernel<b16>, rgrid2, dim3(kRedThreads), 0, s, q, static_cast<b16 *>(dw));
-  SPX_LAUNCH_CHECK();
+  return launch_reduce2(q, dw, dtype, ntile, s, stage2_job);
+}
+
+int spx_igemm_wgrad(const void *feat, const void *dout, void *dw, const int32_t *pair_native,
+                    const int32_t *num_per_loc, const int32_t *plan, int n_in, int n_out, int C,
+                    int K, int kv, int dtype, int subm, void *ws, size_t ws_bytes,
+                    spx_stream_t stream) {
+  return igemm_wgrad_impl(feat, dout, dw, pair_native, num_per_loc, plan, n_in, n_out, C, K, kv, dtype, subm, ws,
+                          ws_bytes, stream, nullptr);
+}
+
+int spx_igemm_bwd(const void *feat, const void *dout, const void *weight, void *din, void *dw,
+                  const int32_t *pair, const uint32_t *mask, const int32_t *argsort, int tile_order,
+                  const int32_t *pair_native, const int32_t *num_per_loc, const int32_t *plan,
+                  int n_in, int n_out, int C, int K, int kv, int dtype, int subm, void *ws,
+                  size_t ws_bytes, spx_stream_t stream) {
+  return igemm_bwd_impl(feat, dout, weight, din, dw, pair, mask, argsort, tile_order, pair_native, num_per_loc, plan, n_in,
+                        n_out, C, K, kv, dtype, subm, ws, ws_bytes, stream, nullptr);
+}
+
+int spx_igemm_wgrad_deferred(const void *feat, const void *dout, void *dw, const int32_t *pair_native,
+                             const int32_t *num_per_loc, const int32_t *plan, int n_in, int n_out, int C,
+                             int K, int kv, int dtype, int subm, void *ws, size_t ws_bytes,
+                             spx_stream_t stream, void *stage2_job) {
+  SPX_CHECK(stage2_job, "stage2_job is required");
+  memset(stage2_job, 0, SPX_STAGE2_JOB_BYTES);
+  return igemm_wgrad_impl(feat, dout, dw, pair_native, num_per_loc, plan, n_in, n_out, C, K, kv, dtype, subm, ws,
+                          ws_bytes, stream, stage2_job);
+}
+
+int spx_igemm_bwd_deferred(const void *feat, const void *dout, const void *weight, void *din, void *dw,
+                           const int32_t *pair, const uint32_t *mask, const int32_t *argsort, int tile_order,
+                           const int32_t *pair_native, const int32_t *num_per_loc, const int32_t *plan,
+                           int n_in, int n_out, int C, int K, int kv, int dtype, int subm, void *ws,
+                           size_t ws_bytes, spx_stream_t stream, void *stage2_job) {
+  SPX_CHECK(stage2_job, "stage2_job is required");
+  memset(stage2_job, 0, SPX_STAGE2_JOB_BYTES);
+  return igemm_bwd_impl(feat, dout, weight, din, dw, pair, mask, argsort, tile_order, pair_native, num_per_loc, plan, n_in,
+                        n_out, C, K, kv, dtype, subm, ws, ws_bytes, stream, stage2_job);
+}
+
+int spx_stage2_job_retarget(void *stage2_job, void *dw) {
+  SPX_CHECK(stage2_job && dw, "null pointer");
+  Stage2JobH j;
+  memcpy(&j, stage2_job, sizeof(j));
+  if (j.valid) {
+    j.dw = dw;
+    memcpy(stage2_job, &j, sizeof(j));
+  }
+  return j.valid;
+}
+
+int spx_wgrad_stage2_batch(const void *jobs, int njobs, spx_stream_t stream) {
+  SPX_CHECK(njobs >= 0 && (jobs || njobs == 0), "jobs required");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const char *base = static_cast<const char *>(jobs);
+  for (int dtype : {SPX_F16, SPX_BF16, SPX_F32}) {
+    Wgrad2Batch b{};
+    int kvmax = 0;
+    auto flush = [&]() -> int {
+      if (b.n == 0) return 0;
+      // ~2048 workgroups over all jobs -- one resident round: with a layer's own 512 per tile column a batch of ten
+      // layers ran six rounds (34 us measured); a workgroup walks its few items one behind the other instead
+      int gx = 2048 / (b.ybase[b.n] > 0 ? b.ybase[b.n] : 1);
+      gx = gx < 32 ? 32 : gx;
+      gx = gx > reduce2_blocks(kvmax) ? reduce2_blocks(kvmax) : gx;
+      const dim3 grid(gx, b.ybase[b.n]);
+      count_launch(kFamStage2Batch);
+      if (dtype == SPX_F32) hipLaunchKernelGGL(wgrad_reduce2_batch_kernel<float>, grid, dim3(kRedThreads), 0, s, b);
+      else if (dtype == SPX_F16) hipLaunchKernelGGL(wgrad_reduce2_batch_kernel<h16>, grid, dim3(kRedThreads), 0, s, b);
+      else hipLaunchKernelGGL(wgrad_reduce2_batch_kernel<b16>, grid, dim3(kRedThreads), 0, s, b);
+      SPX_LAUNCH_CHECK();
+      b = Wgrad2Batch{};
+      kvmax = 0;
+      return 0;
+    };
+    for (int i = 0; i < njobs; ++i) {
+      Stage2JobH j;
+      memcpy(&j, base + static_cast<size_t>(i) * SPX_STAGE2_JOB_BYTES, sizeof(j));
+      if (!j.valid || j.dtype != dtype) continue;
+      SPX_CHECK(j.partial && j.plan2 && j.dw, "job %d: null pointer (was it filled by spx_igemm_*_deferred?)", i);
+      b.job[b.n] = Wgrad2Job{j.partial, j.plan2, j.dw, j.G, j.kv, j.tiles_k, j.tiles_c, j.K, j.C};
+      b.ybase[b.n + 1] = b.ybase[b.n] + j.tiles_k * j.tiles_c;
+      kvmax = j.kv > kvmax ? j.kv : kvmax;
+      if (++b.n == kStage2MaxJobs && flush()) return -1;
+    }
+    if (flush()) return -1;
+  }
   return 0;
 }
 

@@ -1043,6 +1043,83 @@ def igemm_wgrad(features: torch.Tensor, out_bp: torch.Tensor, filters_shape, nat
     return dw if (C == C0 and K == K0) else dw[:K0, ..., :C0].contiguous()
 
 
+# The weight gradient's second stage, deferred to the END of a backward pass (include/spconv_amd.h: spx_igemm_bwd_deferred
+# / spx_wgrad_stage2_batch).  Nothing inside a pass waits for a layer's dW when the weight is a leaf whose .grad is empty
+# (AccumulateGrad then just keeps the tensor it is handed): the reductions of the partial tiles -- a dependent 4-9 us
+# launch per layer -- leave the chain and run as ONE launch per sixteen layers from the autograd engine's final callback.
+# Only inside `deferred_wgrad()` -- the static training runner opens it around its backward call; eager passes never
+# defer -- and not for weights that are not leaves (a cast in front: its backward READS dW), that already hold a gradient
+# (accumulation reads it), that carry hooks, or whose shapes take a path without a second stage.  A weight that shows up a
+# second time in a pass flushes what is pending first (the engine adds the two gradients).
+# SPCONV_AMD_WGRAD_DEFER=0 turns it off.
+_WGRAD_DEFER = os.environ.get("SPCONV_AMD_WGRAD_DEFER", "1") != "0"
+_STAGE2_JOB_BYTES = 64     # SPX_STAGE2_JOB_BYTES
+_defer_depth = [0]
+_defer_passes = {}         # autograd graph-task id -> {"jobs": [...], "seen": {weight address}}
+_defer_lock = threading.Lock()
+
+
+class deferred_wgrad:
+    """Context of a backward pass whose caller reads no weight gradient before the pass has ended."""
+
+    def __enter__(self):
+        _defer_depth[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _defer_depth[0] -= 1
+        return False
+
+
+def _flush_deferred(task_id: int) -> None:
+    with _defer_lock:
+        st = _defer_passes.pop(task_id, None)
+    if not st or not st["jobs"]:
+        return
+    L = _lib.load()
+    by_dev = {}
+    for job, param, _keep in st["jobs"]:
+        g = param.grad
+        if g is not None:                   # (the engine kept the tensor it was handed, or made one of its own)
+            if not (g.is_contiguous() and g.shape == param.shape and g.dtype == param.dtype):
+                raise RuntimeError("deferred weight gradient: .grad of a weight has another layout than the weight")
+            L.spx_stage2_job_retarget(job, g.data_ptr())
+        by_dev.setdefault(param.device, []).append(job)
+    for dev, jobs in by_dev.items():
+        blob = b"".join(j.raw for j in jobs)
+        with torch.cuda.device(dev):
+            _lib.check(L.spx_wgrad_stage2_batch(blob, len(jobs), torch._C._cuda_getCurrentRawStream(dev.index)))
+
+
+def _defer_state(filters: torch.Tensor):
+    """The pending list of the backward pass this call belongs to, or None (see above)."""
+    if not (_WGRAD_DEFER and _defer_depth[0] > 0 and filters.is_cuda):
+        return None
+    if not (filters.is_leaf and filters.requires_grad and filters.grad is None and filters.is_contiguous()):
+        return None
+    if filters._backward_hooks or getattr(filters, "_post_accumulate_grad_hooks", None):
+        return None
+    task = torch._C._current_graph_task_id()
+    if task < 0:
+        return None
+    with _defer_lock:
+        st = _defer_passes.get(task)
+        if st is None:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(lambda t=task: _flush_deferred(t))
+            except RuntimeError:            # not inside a backward pass
+                return None
+            st = _defer_passes[task] = {"jobs": [], "seen": set()}
+        key = filters.data_ptr()
+        again = key in st["seen"]
+        st["seen"].add(key)
+    if again:
+        # a second use of this weight in the pass: every pending gradient is completed before the engine adds the two
+        _flush_deferred(task)
+        return None
+    return st
+
+
 @_on_device
 def igemm_bwd(features: torch.Tensor, out_bp: torch.Tensor, filters: torch.Tensor,
               table: torch.Tensor, mask: Optional[torch.Tensor], argsort: Optional[torch.Tensor],
@@ -1073,6 +1150,8 @@ def igemm_bwd(features: torch.Tensor, out_bp: torch.Tensor, filters: torch.Tenso
     L = _lib.load()
     features = features.contiguous()
     out_bp = out_bp.contiguous()
+    st = _defer_state(filters)
+    filters_leaf = filters
     filters = filters.contiguous()
     K, C = filters.shape[0], filters.shape[-1]
     kv = filters.numel() // (K * C)
@@ -1080,6 +1159,16 @@ def igemm_bwd(features: torch.Tensor, out_bp: torch.Tensor, filters: torch.Tenso
     din = torch.empty((n_in, C), dtype=out_bp.dtype, device=out_bp.device)
     dw = torch.empty_like(filters)
     ws = _ws(L.spx_igemm_wgrad_ws_bytes(native.shape[2], C, K, kv), features.device)
+    if st is not None:
+        job = ctypes.create_string_buffer(_STAGE2_JOB_BYTES)
+        _lib.check(L.spx_igemm_bwd_deferred(features.data_ptr(), out_bp.data_ptr(), filters.data_ptr(),
+                                            din.data_ptr(), dw.data_ptr(), _ptr(table), _ptr(mask), _ptr(argsort),
+                                            int(tile_order), native.data_ptr(), num_per_loc.data_ptr(), _ptr(plan), n_in,
+                                            out_bp.shape[0], C, K, kv, _dtype_code(out_bp), int(subm),
+                                            ws.data_ptr(), ws.numel(), _stream(out_bp), job))
+        with _defer_lock:       # (ws, plan and the lists live until the batch launch; dw is the engine's from here on)
+            st["jobs"].append((job, filters_leaf, (ws, plan, native, num_per_loc)))
+        return din, dw
     _lib.check(L.spx_igemm_bwd(features.data_ptr(), out_bp.data_ptr(), filters.data_ptr(),
                                din.data_ptr(), dw.data_ptr(), _ptr(table), _ptr(mask), _ptr(argsort),
                                int(tile_order), native.data_ptr(), num_per_loc.data_ptr(), _ptr(plan), n_in,

@@ -117,13 +117,26 @@ class _GatherRows(torch.autograd.Function):
         return torch.empty_like(g).index_copy_(0, order.long(), g), None
 
 
-def _entry_sort_default() -> bool:
-    return os.environ.get("SPCONV_AMD_ENTRY_SORT", "1") != "0"
+def _entry_sort_default(net: torch.nn.Module) -> bool:
+    """entry_sort=None: on when the network's first sparse layer (definition order) is a submanifold convolution -- its
+    rulebook, and that of every SubM layer of the first level, then comes from the rank map the sort leaves behind
+    instead of a hash table, which is where the sort earns more than it costs (BASELINE config 4: 2.27 -> 2.10 ms; a
+    network that opens with a strided layer -- config 3 -- only gains gather locality in that one layer and loses 80 us
+    to the sort).  SPCONV_AMD_ENTRY_SORT=1 / 0 forces it."""
+    env = os.environ.get("SPCONV_AMD_ENTRY_SORT", "auto")
+    if env in ("0", "1"):
+        return env == "1"
+    for m in net.modules():
+        if isinstance(m, SparseConvolution):
+            return bool(m.subm)
+        if isinstance(m, SparseMaxPool):
+            return False
+    return False
 
 
 def _entry(runner):
-    """(features, indices) the network sees.  entry_sort (default; SPCONV_AMD_ENTRY_SORT=0 or entry_sort=False turns
-    it off): the scene is sorted by coordinate key at the head of every pass, inside the captured graph
+    """(features, indices) the network sees.  entry_sort (default for networks that open with a SubM layer, see
+    _entry_sort_default; SPCONV_AMD_ENTRY_SORT=0 or entry_sort=False turns it off): the scene is sorted by coordinate key at the head of every pass, inside the captured graph
     (ops.key_argsort: four launches that also leave the level's rank map behind, nothing read back), and declared in key order, so level 1
     runs like the levels behind a strided layer do -- rulebooks from a rank map instead of a hash table, x-neighbours in
     adjacent rows for every gather.  What changes for the caller: tensors of the FIRST level come out in key order
@@ -196,7 +209,7 @@ class StaticInference:
         if not torch.cuda.is_available():
             raise RuntimeError("StaticInference needs the GPU (there is no CPU path)")
         self.key_ordered_input = bool(key_ordered_input)
-        self.entry_sort = _entry_sort_default() if entry_sort is None else bool(entry_sort)
+        self.entry_sort = _entry_sort_default(net) if entry_sort is None else bool(entry_sort)
         self.order = None
         self.net = net.eval()
         self.device = torch.device(device if device is not None else "cuda")
@@ -305,7 +318,7 @@ class StaticTrainingStep:
         if not torch.cuda.is_available():
             raise RuntimeError("StaticTrainingStep needs the GPU (there is no CPU path)")
         self.key_ordered_input = bool(key_ordered_input)
-        self.entry_sort = _entry_sort_default() if entry_sort is None else bool(entry_sort)
+        self.entry_sort = _entry_sort_default(net) if entry_sort is None else bool(entry_sort)
         self.order = None
         if (backward is None) == (out_grad is None):
             raise ValueError("give exactly one of `backward` (callable on the output tensor) and `out_grad`")
@@ -315,6 +328,8 @@ class StaticTrainingStep:
         self.bounds = freeze_bounds(net, bounds, margin)
         self._layers = strided_layers(net)
         self._backward = backward if backward is not None else (lambda out: out.features.backward(out_grad))
+        ddp = torch.nn.parallel.DistributedDataParallel
+        self._defer_wgrad = not any(isinstance(m, ddp) for m in net.modules())     # (its bucket hooks read gradients as they arrive)
         nd = len(self.spatial_shape)
         self.features = torch.zeros((self.max_voxels, in_channels), dtype=dtype,
                                     device=self.device).requires_grad_(input_grad)
@@ -351,7 +366,14 @@ class StaticTrainingStep:
         x = SparseConvTensor(feats, idx, self.spatial_shape, self.batch_size)
         x.n_live_dev = self.n_live
         self.out = _exit(self, self.net(x), idx)
-        self._backward(self.out)
+        if self._defer_wgrad:
+            # nothing reads a weight gradient before the pass has ended: the second stages of every layer's weight
+            # gradient run as one launch behind it (ops.deferred_wgrad)
+            from spconv_amd.pytorch import ops
+            with ops.deferred_wgrad():
+                self._backward(self.out)
+        else:
+            self._backward(self.out)
 
     def load(self, features: torch.Tensor, indices: torch.Tensor) -> None:
         n = features.shape[0]

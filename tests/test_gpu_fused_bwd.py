@@ -287,3 +287,87 @@ def test_wgrad_plan_fits_its_buffer_at_small_kernel_volumes(cuda, ksize):
     L = _lib.load()
     kv = int(np.prod(ksize))
     assert L.spx_wgrad_plan_bytes(n, kv) >= 4 * (8 + 8 * 384 + kv + 1 + 3 * (384 + kv))
+
+
+def test_deferred_second_stage_is_bit_identical_and_one_launch(cuda):
+    """spx_igemm_bwd_deferred + spx_wgrad_stage2_batch (ops.deferred_wgrad: the static training runner's backward): the
+    reductions of every layer's partial weight-gradient tiles run as ONE launch when the pass ends, from the autograd
+    engine's final callback.  Same kernel body, same summation order: every gradient bit-identical to the pass that
+    reduces behind each layer (the reference returns din and dw from one blocking call, pytorch/ops.py:1667-1896) -- with a
+    weight used twice in the pass (what is pending is flushed before the engine adds the two gradients), with a weight
+    that already holds a gradient (not deferred), eagerly and inside a capture."""
+    import spconv_amd.pytorch as spconv
+    from spconv_amd import _lib
+    from spconv_amd.pytorch import ops
+    from util import scene
+    L = _lib.load()
+    shape, bs = [24, 48, 48], 2
+    idx = torch.from_numpy(scene(shape, 9000, bs, seed=11)).to(cuda)
+    n = idx.shape[0]
+    torch.manual_seed(5)
+    f = (torch.randn(n, 64, device=cuda) * 0.5).half()
+    shared = spconv.SubMConv3d(64, 64, 3, bias=False, indice_key="a")
+    net = spconv.SparseSequential(spconv.SubMConv3d(64, 32, 3, bias=False, indice_key="a"),
+                                  spconv.SubMConv3d(32, 64, 3, bias=False, indice_key="a"), shared,
+                                  spconv.SubMConv3d(64, 64, 3, bias=False, indice_key="a"), shared).to(cuda).half().train()
+    g = ((torch.rand(n, 64, device=cuda) - 0.5) * 0.1).half()
+    fin = f.clone().requires_grad_(True)
+
+    def step(defer):
+        net.zero_grad(set_to_none=True)
+        fin.grad = None
+        y = net(spconv.SparseConvTensor(fin, idx, shape, bs)).features
+        if defer:
+            with ops.deferred_wgrad():
+                y.backward(g)
+        else:
+            y.backward(g)
+
+    def counts():
+        return [int(L.spx_launch_count(k)) for k in (b"wgrad_stage2", b"wgrad_stage2_batch", b"igemm_bwd")]
+
+    step(False)
+    torch.cuda.synchronize()
+    want = [p.grad.clone() for p in net.parameters()] + [fin.grad.clone()]
+    c0 = counts()
+    step(False)
+    c1 = counts()
+    per_pass = c1[0] - c0[0]
+    assert per_pass >= 5 and c1[1] == c0[1] and c1[2] - c0[2] >= 3      # a second stage behind every layer
+    step(True)
+    torch.cuda.synchronize()
+    c2 = counts()
+    got = [p.grad.clone() for p in net.parameters()] + [fin.grad.clone()]
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    # deferred: the fused layers' second stages ran as batches (one at the shared weight's second use, one at the end)
+    assert c2[0] - c1[0] < per_pass and 1 <= c2[1] - c1[1] <= 2, (c0, c1, c2)
+    assert not ops._defer_passes
+    # a weight that already holds a gradient accumulates: not deferred, still right
+    for p in net.parameters():
+        p.grad = torch.zeros_like(p)
+    fin.grad = None
+    with ops.deferred_wgrad():
+        net(spconv.SparseConvTensor(fin, idx, shape, bs)).features.backward(g)
+    torch.cuda.synchronize()
+    for p, w in zip(net.parameters(), want):
+        assert torch.equal(p.grad, w)
+    # captured
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step(True)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step(True)
+    for p in net.parameters():
+        p.grad.zero_()
+    fin.grad.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    got = [p.grad.clone() for p in net.parameters()] + [fin.grad.clone()]
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    assert not ops._defer_passes
