@@ -122,6 +122,13 @@ def gather_features_by_pc_voxel_id(seg_res_features: torch.Tensor, pc_voxel_id: 
     return torch.where(inside.view(shape), rows, fill)
 
 
+def _row_keys(indices: torch.Tensor, spatial_shape) -> torch.Tensor:
+    key = indices[:, 0].to(torch.int64)
+    for d, s in enumerate(spatial_shape):
+        key = key * int(s) + indices[:, 1 + d].to(torch.int64)
+    return key
+
+
 def sort_voxels_by_coordinate(indices: torch.Tensor, spatial_shape: List[int], *row_tensors: torch.Tensor,
                               batch_size: int = 0, rank_map: bool = True):
     """Rows in ascending coordinate-key order (batch-major, last axis fastest): ``(indices, *row_tensors, order)``.
@@ -138,6 +145,21 @@ def sort_voxels_by_coordinate(indices: torch.Tensor, spatial_shape: List[int], *
     level build their rulebook without a hash table, like the levels behind a strided layer do.  Coordinates that occur
     twice are detected on the device (one synchronisation, here in the data loader) and leave the tensor untagged."""
     assert indices.dim() == 2 and indices.shape[1] == len(spatial_shape) + 1
+    if (batch_size > 0 and indices.is_cuda and indices.dtype == torch.int32 and indices.is_contiguous()
+            and indices.shape[0] > 0):
+        # the library's own sort (spx_key_argsort: four launches, the rank map written by the same pass -- ~60 us for
+        # 420 k rows where torch.argsort of the keys takes 160); a coordinate that occurs twice (one read of the
+        # device-side verdict, here in the data loader) takes the general path below
+        from spconv_amd.pytorch import ops
+        flag = torch.zeros((1,), dtype=torch.int32, device=indices.device)
+        res = ops.key_argsort(indices, int(batch_size), [int(v) for v in spatial_shape], rank_map=rank_map, violation=flag)
+        if res is not None:
+            order32, out = res
+            tagged = getattr(out, "_spx_rankmap", None) is not None
+            unique = bool(int(flag.item()) == 0) if tagged else bool((_row_keys(out, spatial_shape).diff() > 0).all())
+            if unique:
+                order = order32.long()
+                return (out, *[t.index_select(0, order) for t in row_tensors], order)
     key = indices[:, 0].to(torch.int64)
     for d, s in enumerate(spatial_shape):
         key = key * int(s) + indices[:, 1 + d].to(torch.int64)

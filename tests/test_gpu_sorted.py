@@ -488,3 +488,23 @@ def test_entry_sort_of_the_static_runners(cuda):
     assert step.input_order_violation()
     step(f, idx)
     assert not step.input_order_violation()
+
+
+def test_sort_voxels_by_coordinate_native_sort_equals_the_torch_path(cuda):
+    """utils.sort_voxels_by_coordinate on CUDA int32 rows with a batch size takes spx_key_argsort (rank map written by the
+    same pass); without one, or with a coordinate twice, torch.argsort -- same rows, same carried tensors, same order."""
+    from spconv_amd.pytorch.utils import sort_voxels_by_coordinate
+    shape, bs = [41, 400, 352], 4
+    idx = torch.from_numpy(scene(shape, 30000, bs, seed=9)).to(cuda)
+    idx = idx[torch.randperm(idx.shape[0], device=cuda)].contiguous()
+    f = torch.randn(idx.shape[0], 5, device=cuda)
+    a_idx, a_f, a_order = sort_voxels_by_coordinate(idx, shape, f, batch_size=bs)
+    b_idx, b_f, b_order = sort_voxels_by_coordinate(idx, shape, f)                 # (no batch size: the general path)
+    assert torch.equal(a_idx, b_idx) and torch.equal(a_f, b_f) and torch.equal(a_order, b_order)
+    assert getattr(a_idx, "_spx_rankmap", None) is not None and getattr(b_idx, "_spx_rankmap", None) is None
+    dup = idx.clone()
+    dup[7] = dup[20000]
+    c_idx, c_f, c_order = sort_voxels_by_coordinate(dup, shape, f, batch_size=bs)
+    d_idx, d_f, d_order = sort_voxels_by_coordinate(dup, shape, f)
+    assert torch.equal(c_idx, d_idx) and getattr(c_idx, "_spx_rankmap", None) is None
+    assert torch.equal(c_f, f[c_order])
