@@ -122,10 +122,16 @@ def _entry_sort_default(net: torch.nn.Module) -> bool:
     rulebook, and that of every SubM layer of the first level, then comes from the rank map the sort leaves behind
     instead of a hash table, which is where the sort earns more than it costs (BASELINE config 4: 2.27 -> 2.10 ms; a
     network that opens with a strided layer -- config 3 -- only gains gather locality in that one layer and loses 80 us
-    to the sort).  SPCONV_AMD_ENTRY_SORT=1 / 0 forces it."""
+    to the sort), and only with the default output order of the strided layers (SPCONV_AMD_CONV_ORDER=sorted).
+    SPCONV_AMD_ENTRY_SORT=1 / 0 forces it."""
     env = os.environ.get("SPCONV_AMD_ENTRY_SORT", "auto")
     if env in ("0", "1"):
         return env == "1"
+    from spconv_amd import constants
+    if constants.CONV_OUTPUT_ORDER != "sorted":
+        # first-seen numbering of a strided layer's outputs FOLLOWS the input's row order: with sorted input rows the
+        # levels behind would be numbered differently from the eager pass of the same scene
+        return False
     for m in net.modules():
         if isinstance(m, SparseConvolution):
             return bool(m.subm)
