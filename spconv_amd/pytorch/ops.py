@@ -1068,6 +1068,10 @@ class deferred_wgrad:
 
     def __exit__(self, *exc):
         _defer_depth[0] -= 1
+        if _defer_depth[0] == 0 and _defer_passes:
+            # (a pass that ended in an exception never reached its final callback: what it left pending is dropped)
+            with _defer_lock:
+                _defer_passes.clear()
         return False
 
 

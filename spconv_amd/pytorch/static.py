@@ -142,13 +142,14 @@ def _entry_sort_default(net: torch.nn.Module) -> bool:
 
 def _entry(runner):
     """(features, indices) the network sees.  entry_sort (default for networks that open with a SubM layer, see
-    _entry_sort_default; SPCONV_AMD_ENTRY_SORT=0 or entry_sort=False turns it off): the scene is sorted by coordinate key at the head of every pass, inside the captured graph
-    (ops.key_argsort: four launches that also leave the level's rank map behind, nothing read back), and declared in key order, so level 1
-    runs like the levels behind a strided layer do -- rulebooks from a rank map instead of a hash table, x-neighbours in
-    adjacent rows for every gather.  What changes for the caller: tensors of the FIRST level come out in key order
-    (`runner.order[t]` = the input row behind row t; their `indices` say the same); levels behind a strided layer
-    are in key order with or without it.  The coordinates of a scene must be unique (a voxeliser's are):
-    `runner.input_order_violation()` reads the device-side verdict."""
+    _entry_sort_default; SPCONV_AMD_ENTRY_SORT=0 or entry_sort=False turns it off): the scene is sorted by coordinate
+    key at the head of every pass, inside the captured graph (ops.key_argsort: four launches that also leave the level's
+    rank map behind, nothing read back), so level 1 runs like the levels behind a strided layer do -- rulebooks from a
+    rank map instead of a hash table, x-neighbours in adjacent rows for every gather.  What the caller sees: nothing --
+    a result that lives on the input's rows goes back into the caller's order before the runner returns it (_exit), levels
+    behind a strided layer are in key order with or without the sort; `runner.order[t]` = the input row behind sorted
+    row t, for code that looks at tensors INSIDE the network.  The coordinates of a scene must be unique (a voxeliser's
+    are): `runner.input_order_violation()` reads the device-side verdict."""
     if runner.key_ordered_input or not runner.entry_sort:
         _declare_key_order(runner)
         return runner.features, runner.indices
