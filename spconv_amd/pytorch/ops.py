@@ -318,7 +318,16 @@ def build_rulebook(indices: torch.Tensor, batch_size: int, spatial_shape: List[i
         # read back).  Strided layers keep their row order (dense by construction: every output has
         # several inputs), small rulebooks are launch-bound either way.
         if subm and 1 < kv <= 32 and n_in >= _LAYOUT_MIN_ROWS:
-            rows_layout(rb)
+            if (_LAYOUT_SKIP and torch.cuda.is_current_stream_capturing()
+                    and bool(getattr(pred_key, _CLS0_ATTR, False))):
+                # Inside a capture the class of this module's rulebooks is what the warm-up passes saw.  Class 0 (most
+                # rows have a neighbour: every level of a LiDAR backbone) uses nothing of a layout but its class word:
+                # the three launches that make it are left out, the gather-GEMMs walk the row-order tables as they do for
+                # small rulebooks, with the density hint the prediction gives (a scene of the other class still computes
+                # the same values, on the slower walk).
+                rb.mask_fwd._spx_dense = _pred_get(pred_key)
+            else:
+                rows_layout(rb)
     elif do_sort and words == 1:
         sort_rulebook(rb)
     return rb, out_shape
@@ -536,6 +545,8 @@ _WS_MIN_ROWS = 98304          # one 512-row workgroup per CU: below ~3/4 of 256 
 _CLASS_SLOTS = 1024
 _class_ring = {}              # device index -> [pinned int32 [_CLASS_SLOTS, 2], next slot, owner tokens]
 _PRED_ATTR = "_spx_dense_pred"     # on the owning module (rb.pred_key): the rulebook built for it last time was dense
+_CLS0_ATTR = "_spx_class0_pred"    # ... and its rows layout was of class 0 (no appendix)
+_LAYOUT_SKIP = os.environ.get("SPCONV_AMD_LAYOUT_SKIP", "1") != "0"
 
 
 def _pred_get(key) -> bool:
@@ -569,6 +580,11 @@ class _ClassRequest:
         self.done = True
         dense = (not cls) and self.n >= _WS_MIN_ROWS and 4 * heavy >= 3 * self.n
         _pred_set(self.key, dense)
+        if self.key is not None and heavy > 0:      # (no row with a neighbour -- the empty scene a runner warms up on -- says nothing)
+            try:
+                object.__setattr__(self.key, _CLS0_ATTR, (not cls) and 4 * heavy >= self.n)
+            except (AttributeError, TypeError):
+                pass
         rb = self.rb()
         if rb is not None and rb.layout is not None:
             rb.sparse_class, rb.heavy_rows = bool(cls), heavy
@@ -624,9 +640,11 @@ def poll_class(rb: Optional[Rulebook]) -> None:
         rb._class_req = None
 
 
-def _with_dense_hint(tile_order: int, argsort) -> int:
+def _with_dense_hint(tile_order: int, argsort, mask=None) -> int:
     if tile_order == _ROWS_LAYOUT and getattr(argsort, "_spx_dense", False):
         return tile_order | _DENSE_HINT
+    if tile_order == 0 and argsort is None and getattr(mask, "_spx_dense", False):
+        return _DENSE_HINT               # (a rulebook whose layout was left out: build_rulebook)
     return tile_order
 
 
@@ -936,7 +954,7 @@ def igemm_fwd(features: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
         records = torch.empty((3 * K * slots,), dtype=torch.float32, device=features.device)
         used = ctypes.c_int(0)
         _lib.check(L.spx_igemm_fwd_stats(features.data_ptr(), filters.data_ptr(), out.data_ptr(),
-                                         _ptr(pair), _ptr(mask), _ptr(argsort), _with_dense_hint(int(tile_order), argsort),
+                                         _ptr(pair), _ptr(mask), _ptr(argsort), _with_dense_hint(int(tile_order), argsort, mask),
                                          features.shape[0], n_out, C, K, kv, _dtype_code(features), identity_k, None,
                                          int(act_type) | (_OUT_CACHED if getattr(_out_policy, "cached", False) else 0),
                                          float(act_alpha), None, 0, records.data_ptr(), slots, _ptr(sink.n_live),
@@ -945,7 +963,7 @@ def igemm_fwd(features: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
             sink.records, sink.count, sink.rows, sink.channels = records, int(used.value), n_out, K
         return out
     _lib.check(L.spx_igemm_fwd(features.data_ptr(), filters.data_ptr(), out.data_ptr(),
-                               _ptr(pair), _ptr(mask), _ptr(argsort), _with_dense_hint(int(tile_order), argsort),
+                               _ptr(pair), _ptr(mask), _ptr(argsort), _with_dense_hint(int(tile_order), argsort, mask),
                                features.shape[0], n_out, C, K, kv, _dtype_code(features), identity_k, _ptr(bias),
                                int(act_type) | (_OUT_CACHED if getattr(_out_policy, "cached", False) else 0),
                                float(act_alpha), _ptr(ws), 0 if ws is None else ws.numel(),
@@ -976,7 +994,7 @@ def igemm_dgrad(out_bp: torch.Tensor, filters: torch.Tensor, pair: torch.Tensor,
     code = _dtype_code(out_bp)
     ws = _ws(max(L.spx_igemm_dgrad_ws_bytes(C, K, kv, code), L.spx_igemm_acc_bytes(n_in, C, kv)), out_bp.device)
     _lib.check(L.spx_igemm_dgrad(out_bp.data_ptr(), filters.data_ptr(), din.data_ptr(), _ptr(pair),
-                                 _ptr(mask), _ptr(argsort), _with_dense_hint(int(tile_order), argsort), out_bp.shape[0],
+                                 _ptr(mask), _ptr(argsort), _with_dense_hint(int(tile_order), argsort, mask), out_bp.shape[0],
                                  n_in, C, K, kv, code,
                                  int(subm), ws.data_ptr(), ws.numel(), _stream(out_bp)))
     return din if C == C0 else din[:, :C0].contiguous()

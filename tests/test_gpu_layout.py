@@ -261,3 +261,45 @@ def test_layout_build_sits_in_a_graph(cuda):
         ref = run()
         assert torch.equal(y.features, ref.features)
     assert classes == [1, 0], classes
+
+
+def test_capture_leaves_out_the_layout_of_class_0_rulebooks(cuda):
+    """Inside a capture a SubM module whose rulebooks were of class 0 in the passes before (every level of a LiDAR
+    backbone) builds no rows layout -- three launches per rulebook -- and its convolutions walk the row-order tables with the
+    density hint the same passes left; a module that saw class 1 (sparse: config 2) keeps its layout.  Values are those
+    of the pass with the layout, bit for bit (no normalisation layer in between: the per-row sums do not see the tiling)."""
+    import copy
+    import spconv_amd.pytorch as spconv
+    from golden import lidar_scene
+    from spconv_amd.pytorch import ops
+    from spconv_amd.pytorch.static import StaticInference
+    from util import scene
+    from torch import nn
+    for kind in ("dense", "sparse"):
+        if kind == "dense":
+            idx, shape = lidar_scene()
+        else:
+            shape = [40, 1600, 1280]
+            idx = scene(shape, 100_000, 1, 3)
+        ind = torch.from_numpy(idx).to(cuda)
+        torch.manual_seed(2)
+        net = spconv.SparseSequential(spconv.SubMConv3d(64, 64, 3, bias=False, indice_key="a"), nn.ReLU(),
+                                      spconv.SubMConv3d(64, 64, 3, bias=False, indice_key="a")).to(cuda).half().eval()
+        f = (torch.rand((ind.shape[0], 64), device=cuda) - 0.5).half()
+        with torch.no_grad():
+            for _ in range(3):                              # eager passes: the class word arrives, the module learns it
+                want = net(spconv.SparseConvTensor(f, ind, shape, 1)).features
+                torch.cuda.synchronize()
+        assert bool(getattr(net[0], ops._CLS0_ATTR, False)) == (kind == "dense")
+        built = []
+        keep = ops.rows_layout
+        ops.rows_layout = lambda rb: (built.append(rb.n_out), keep(rb))[1]
+        try:
+            runner = StaticInference(copy.deepcopy(net), ind.shape[0], 64, shape, 1, torch.float16, bounds={},
+                                     entry_sort=False, warmup=1)
+        finally:
+            ops.rows_layout = keep
+        # warm-up pass (eager) builds one; the captured pass builds one only for the sparse module
+        assert len(built) == (1 if kind == "dense" else 2), (kind, built)
+        got = runner(f, ind).features
+        assert torch.equal(got, want)

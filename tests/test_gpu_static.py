@@ -279,7 +279,7 @@ def test_static_training_step_fp32_is_a_bound_not_a_noise_floor(cuda):
     assert rel < 2e-4, rel
 
 
-def test_config4_network_captured_step_equals_eager_in_fp32(cuda):
+def test_config4_network_captured_step_equals_eager_in_fp32(cuda, monkeypatch):
     """The BASELINE config-4 network itself (spconv_amd.utils.nets.second_backbone: 12 sparse convolutions, 12
     BatchNorm1d + ReLU, the p = (0, 1, 1) and (3, 1, 1) / (2, 1, 1) layers) as ONE captured training step against the
     eager step -- in fp32, where the comparison is a bound and not a noise floor (bench.py accepts the
@@ -288,8 +288,13 @@ def test_config4_network_captured_step_equals_eager_in_fp32(cuda):
     mask (see the comment at (b): round 6 found the former 5e-4 bar to hold only while no pre-ReLU value of the ~1 M in
     the network sits within 1e-6 of zero, which depends on how the two passes tile their BatchNorm statistics)."""
     import spconv_amd.pytorch as spconv
+    from spconv_amd.pytorch import ops
     from spconv_amd.pytorch.static import StaticTrainingStep, strided_layers
     from spconv_amd.utils import nets
+    # (a) below wants the SAME launches captured and eager: a capture leaves out the rows layout of a module whose
+    # rulebooks were of class 0 so far (ops.build_rulebook; an eager pass keeps building it to keep learning the class),
+    # which changes the tiling of the convolutions' statistics records and with it the last bit of every BatchNorm
+    monkeypatch.setattr(ops, "_LAYOUT_SKIP", False)
     shape, bs, C = [41, 96, 88], 2, 4
     torch.manual_seed(3)
     net = nets.second_backbone(C).to(cuda).train()
