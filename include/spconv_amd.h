@@ -236,12 +236,14 @@ int spx_rankmap_from_sorted(const int32_t *indices, int n, int ndim, int batch_s
  * result and runs every level in key order.  With `rankmap` (spx_rankmap_bytes() bytes, or NULL) the bucket pass leaves
  * the rank map of indices_sorted behind as well -- what spx_rankmap_from_sorted would build from it; its fill rides
  * in the sort's first launch: no pass of its own -- and `violation` (device int32 [1] or NULL: cleared by the first launch) is
- * raised when a coordinate occurs twice.  Needs batch x grid <= 0xffe00000.  The reference sorts keys where it
+ * raised when a coordinate occurs twice.  `rows` / `rows_sorted` (or NULL; row_bytes a multiple of 4): rows that travel with
+ * the sort -- the level's features -- rows_sorted[t] = rows[order[t]], written by the same bucket pass (no gather launch).
+ * Needs batch x grid <= 0xffe00000.  The reference sorts keys where it
  * wants this order (thrust sort + unique of the output keys, csrc/sparse/all.py:1533-1552). */
 size_t spx_key_argsort_ws_bytes(int n);
 int spx_key_argsort(const int32_t *indices, int n, int ndim, int batch_size, const int *spatial_shape, int32_t *order,
-                    int32_t *indices_sorted, void *rankmap, size_t rankmap_bytes, int32_t *violation, void *ws,
-                    size_t ws_bytes, spx_stream_t stream);
+                    int32_t *indices_sorted, void *rankmap, size_t rankmap_bytes, int32_t *violation, const void *rows,
+                    void *rows_sorted, int row_bytes, void *ws, size_t ws_bytes, spx_stream_t stream);
 /* SubM rulebook (outputs as spx_subm_rulebook, bit for bit) of a level whose rows are in key order and whose
  * rank map a sorted-order build left behind: `indices` must be that build's out_indices (rows past its count:
  * batch -1). */

@@ -126,7 +126,7 @@ SIGNATURES = {
                                                ctypes.c_size_t, vp, vp]),
     "spx_key_argsort_ws_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "spx_key_argsort": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_int_p, vp, vp, vp,
-                                       ctypes.c_size_t, vp, vp, ctypes.c_size_t, vp]),
+                                       ctypes.c_size_t, vp, vp, vp, ctypes.c_int, vp, ctypes.c_size_t, vp]),
     "spx_pad_rows": (ctypes.c_int, [vp, vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp]),
     "spx_launch_count": (ctypes.c_longlong, [ctypes.c_char_p]),
     "spx_bias_act_inplace": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -235,7 +235,24 @@ struct RankMapOut {        // the level's rank map (csrc/rulebook.hip rank_of: {
   uint2 *cells;            // null: not wanted.  Zero-filled by key_count_kernel: only occupied words are written
   unsigned long long words;
   int32_t *violation;
+  // rows that travel with the sort (a level's features): rows_out[t] = rows_in[order[t]], row_bytes a multiple of 4
+  const char *rows_in;
+  char *rows_out;
+  int row_bytes;
 };
+
+__device__ __forceinline__ void carry_row(const RankMapOut &rm, int dst, int src) {
+  if (!rm.rows_out) return;
+  const char *s = rm.rows_in + static_cast<size_t>(src) * rm.row_bytes;
+  char *d = rm.rows_out + static_cast<size_t>(dst) * rm.row_bytes;
+  if (rm.row_bytes == 8) {
+    *reinterpret_cast<uint2 *>(d) = *reinterpret_cast<const uint2 *>(s);
+  } else if ((rm.row_bytes & 15) == 0) {
+    for (int o = 0; o < rm.row_bytes; o += 16) *reinterpret_cast<uint4 *>(d + o) = *reinterpret_cast<const uint4 *>(s + o);
+  } else {
+    for (int o = 0; o < rm.row_bytes; o += 4) *reinterpret_cast<uint32_t *>(d + o) = *reinterpret_cast<const uint32_t *>(s + o);
+  }
+}
 
 // A JOB = (bucket b, part): the rows of bucket b -- a run of the bucket-sorted arrays -- to their ranks.  Every part
 // workgroup of a bucket builds the bucket's whole occupancy map (LDS atomics are cheap, the keys come out of the L2) and
@@ -308,6 +325,7 @@ key_bucket_kernel(const uint32_t *__restrict__ keys, const int32_t *__restrict__
     for (int i = c0 + tid; i < c1; i += kBucketThreads) {
       order[i] = vals[i];
       if (idx_out) store_index_row(idx_out, i, 0u, g, true);
+      carry_row(rm, i, vals[i]);
     }
     return;
   }
@@ -403,6 +421,7 @@ key_bucket_kernel(const uint32_t *__restrict__ keys, const int32_t *__restrict__
     if (!dup) {
       order[beg + r] = val;
       if (idx_out) store_index_row(idx_out, beg + r, key, g, false);
+      carry_row(rm, beg + r, val);
     } else {
       tmp[beg + i] = r;
     }
@@ -428,6 +447,7 @@ key_bucket_kernel(const uint32_t *__restrict__ keys, const int32_t *__restrict__
     const int r = (old & bit) ? tmp[beg + i] : carry + atomicAdd(&s_extra, 1);
     order[beg + r] = vals[beg + i];
     if (idx_out) store_index_row(idx_out, beg + r, key, g, false);
+    carry_row(rm, beg + r, vals[beg + i]);
   }
 }
 
@@ -517,7 +537,8 @@ static void key_split(unsigned long long cells, int *sh_out, int *nb_live_out) {
 }
 
 int key_argsort(const int32_t *indices, int n, int ndim, int batch_size, const int *spatial_shape, int32_t *order,
-                int32_t *indices_sorted, void *rankmap, int32_t *violation, void *ws, hipStream_t s) {
+                int32_t *indices_sorted, void *rankmap, int32_t *violation, const void *rows, void *rows_sorted,
+                int row_bytes, void *ws, hipStream_t s) {
   KeyGeom g{};
   g.ndim = ndim;
   g.batch = batch_size;
@@ -539,6 +560,9 @@ int key_argsort(const int32_t *indices, int n, int ndim, int batch_size, const i
   int32_t *totals = cv.take<int32_t>(512);
   RankMapOut rm{};
   rm.violation = violation;
+  rm.rows_in = static_cast<const char *>(rows);
+  rm.rows_out = static_cast<char *>(rows_sorted);
+  rm.row_bytes = row_bytes;
   unsigned long long zero_units = 0;               // 16-byte units of the rank map (cells, padding, block offsets)
   if (rankmap) {                                   // layout: csrc/rulebook.hip rank_bytes (cells, then one int per 2048 words)
     rm.words = (cells + 31ull) / 32ull;
@@ -594,8 +618,9 @@ int spx_permute_tables(const int32_t *pair, const uint32_t *mask, const int32_t 
 size_t spx_key_argsort_ws_bytes(int n) { return key_argsort_ws_bytes(n); }
 
 int spx_key_argsort(const int32_t *indices, int n, int ndim, int batch_size, const int *spatial_shape, int32_t *order,
-                    int32_t *indices_sorted, void *rankmap, size_t rankmap_bytes, int32_t *violation, void *ws,
-                    size_t ws_bytes, spx_stream_t stream) {
+                    int32_t *indices_sorted, void *rankmap, size_t rankmap_bytes, int32_t *violation, const void *rows,
+                    void *rows_sorted, int row_bytes, void *ws, size_t ws_bytes, spx_stream_t stream) {
+  SPX_CHECK(!rows_sorted || (rows && row_bytes > 0 && row_bytes % 4 == 0), "rows to carry: rows, rows_sorted and a row size that is a multiple of 4");
   SPX_CHECK(ndim >= 1 && ndim <= 4, "ndim must be in [1,4], got %d", ndim);
   SPX_CHECK(n >= 0 && (n == 0 || (indices && order)), "indices and order are required");
   SPX_CHECK(batch_size >= 1, "batch_size must be >= 1, got %d", batch_size);
@@ -615,8 +640,8 @@ int spx_key_argsort(const int32_t *indices, int n, int ndim, int batch_size, con
     SPX_CHECK(!rankmap, "a rank map of no rows: use spx_rankmap_from_sorted");
     return 0;
   }
-  return key_argsort(indices, n, ndim, batch_size, spatial_shape, order, indices_sorted, rankmap, violation, ws,
-                     static_cast<hipStream_t>(stream));
+  return key_argsort(indices, n, ndim, batch_size, spatial_shape, order, indices_sorted, rankmap, violation, rows,
+                     rows_sorted, row_bytes, ws, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

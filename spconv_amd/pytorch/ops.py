@@ -412,7 +412,7 @@ def attach_rank_map(indices: torch.Tensor, batch_size: int, spatial_shape, check
 
 @_on_device
 def key_argsort(indices: torch.Tensor, batch_size: int, spatial_shape, want_indices: bool = True,
-                rank_map: bool = False, violation: Optional[torch.Tensor] = None):
+                rank_map: bool = False, violation: Optional[torch.Tensor] = None, rows: Optional[torch.Tensor] = None):
     """(order, indices[order]) with order[t] = the row of the t-th smallest coordinate key (batch-major, last axis
     fastest); dead rows (batch index -1) trail in their own order and come out as -1 in every column.  One C-ABI call
     (spx_key_argsort: four launches -- one stable radix pass on the upper key bits, then workgroups per bucket rank
@@ -420,8 +420,9 @@ def key_argsort(indices: torch.Tensor, batch_size: int, spatial_shape, want_indi
     a stream capture -- the static runners sort their scene at the entry with it (static.py entry_sort).
     rank_map=True: the sorted index tensor leaves with the level's rank map attached, written by the same bucket pass
     (what attach_rank_map would build from it; same size gates -- beyond them the tensor stays untagged); `violation`
-    (int32 [1] on the device) is raised when a coordinate occurs twice.  Returns None when the key space of
-    batch x grid does not fit 32 bits."""
+    (int32 [1] on the device) is raised when a coordinate occurs twice.  `rows` ([n, ...] contiguous, row size a
+    multiple of 4 bytes: the level's features): a third result, rows[order], written by the same bucket pass.  Returns
+    None when the key space of batch x grid does not fit 32 bits."""
     _require_gpu(indices, "indices")
     assert indices.dtype == torch.int32 and indices.ndim == 2 and indices.is_contiguous()
     cells = int(batch_size)
@@ -440,12 +441,19 @@ def key_argsort(indices: torch.Tensor, batch_size: int, spatial_shape, want_indi
                 or (_RANKMAP_MAX_CELLS_PER_ROW > 0 and cells > _RANKMAP_MAX_CELLS_PER_ROW * n)):
             cells_t = torch.empty((nbytes // 4,), dtype=torch.int32, device=indices.device)
     ws = _ws(L.spx_key_argsort_ws_bytes(n), indices.device)
+    rows_sorted, row_bytes = None, 0
+    if rows is not None:
+        assert rows.is_cuda and rows.is_contiguous() and rows.shape[0] == n
+        row_bytes = (rows.numel() // max(n, 1)) * rows.element_size()
+        assert row_bytes % 4 == 0, "rows carried by the sort: row size must be a multiple of 4 bytes"
+        rows_sorted = torch.empty_like(rows)
     _lib.check(L.spx_key_argsort(indices.data_ptr(), n, ndim, int(batch_size), _lib.ints(spatial_shape),
                                  order.data_ptr(), _ptr(out), _ptr(cells_t), 0 if cells_t is None else cells_t.numel() * 4,
-                                 _ptr(violation), ws.data_ptr(), ws.numel(), _stream(indices)))
+                                 _ptr(violation), _ptr(rows), _ptr(rows_sorted), row_bytes,
+                                 ws.data_ptr(), ws.numel(), _stream(indices)))
     if cells_t is not None:
         out._spx_rankmap = (cells_t, batch_size, tuple(int(v) for v in spatial_shape), n, out._version, out.data_ptr())
-    return order, out
+    return (order, out) if rows is None else (order, out, rows_sorted)
 
 
 def _build_sorted(L, indices, batch_size, spatial_shape, out_shape, ksize, stride, padding, dilation, args,

@@ -117,6 +117,25 @@ class _GatherRows(torch.autograd.Function):
         return torch.empty_like(g).index_copy_(0, order.long(), g), None
 
 
+class _EntrySort(torch.autograd.Function):
+    """features[order] out of the sort itself (ops.key_argsort carries the rows: no gather launch); leaves the
+    permutation and the sorted, rank-mapped index tensor on the runner.  Gradient: scattered back through the permutation."""
+
+    @staticmethod
+    def forward(ctx, feats, runner):
+        from spconv_amd.pytorch import ops
+        order, idx, rows = ops.key_argsort(runner.indices, runner.batch_size, runner.spatial_shape, rank_map=True,
+                                           violation=runner._order_flag, rows=feats.detach())
+        runner.order, runner._idx_sorted = order, idx
+        ctx.save_for_backward(order)
+        return rows
+
+    @staticmethod
+    def backward(ctx, g):
+        (order,) = ctx.saved_tensors
+        return torch.empty_like(g).index_copy_(0, order.long(), g.contiguous()), None
+
+
 def _entry_sort_default(net: torch.nn.Module) -> bool:
     """entry_sort=None: on when the network's first sparse layer (definition order) is a submanifold convolution -- its
     rulebook, and that of every SubM layer of the first level, then comes from the rank map the sort leaves behind
@@ -153,14 +172,20 @@ def _entry(runner):
     if runner.key_ordered_input or not runner.entry_sort:
         _declare_key_order(runner)
         return runner.features, runner.indices
-    from spconv_amd.pytorch import ops
-    res = ops.key_argsort(runner.indices, runner.batch_size, runner.spatial_shape, rank_map=True,
-                          violation=runner._order_flag)
-    if res is None:                                   # (key space beyond 32 bits)
+    cells = int(runner.batch_size)
+    for d in runner.spatial_shape:
+        cells *= int(d)
+    feats = runner.features
+    if cells > 0xffe00000:                            # (key space beyond 32 bits)
         runner.entry_sort = False
-        return runner.features, runner.indices
-    runner.order, idx = res
-    return _GatherRows.apply(runner.features, runner.order), idx
+        return feats, runner.indices
+    row_bytes = (feats.numel() // max(feats.shape[0], 1)) * feats.element_size()
+    if row_bytes % 4 == 0 and feats.is_contiguous():
+        return _EntrySort.apply(feats, runner), runner._idx_sorted     # (features ride in the sort's bucket pass)
+    from spconv_amd.pytorch import ops
+    runner.order, idx = ops.key_argsort(runner.indices, runner.batch_size, runner.spatial_shape, rank_map=True,
+                                        violation=runner._order_flag)
+    return _GatherRows.apply(feats, runner.order), idx
 
 
 class _ScatterRows(torch.autograd.Function):

@@ -390,6 +390,11 @@ def test_key_argsort_is_the_stable_sort_by_coordinate_key(cuda, shape, n, bs, de
     want_rows[want_rows[:, 0] < 0] = -1         # (dead rows come out as -1 in every column)
     assert np.array_equal(to_np(rows), want_rows)
     assert ops.key_argsort(torch.from_numpy(ind).to(cuda), 1 << 12, [1 << 10, 1 << 10]) is None     # > 32 key bits
+    # rows that travel with the sort (a level's features: 8-byte, 16-byte-multiple and odd row sizes)
+    for width, dt in ((4, torch.float16), (16, torch.float32), (6, torch.float16)):
+        feats = torch.randn(ind.shape[0], width, device=cuda).to(dt)
+        o3, r3, f3 = ops.key_argsort(torch.from_numpy(ind).to(cuda), bs, shape, rows=feats)
+        assert torch.equal(o3, order) and torch.equal(r3, rows) and torch.equal(f3, feats[order.long()])
     # rank_map=True: the bucket pass leaves the map spx_rankmap_from_sorted would build from the sorted rows, word for word
     flag = torch.ones((1,), dtype=torch.int32, device=cuda)
     order_m, rows_m = ops.key_argsort(torch.from_numpy(ind).to(cuda), bs, shape, rank_map=True, violation=flag)
